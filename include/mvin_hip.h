@@ -1,0 +1,135 @@
+/*
+ * mvin_hip.h -- C ABI of libmvin_hip.so: the MI355X (gfx950) implementation of the MVIN
+ * K-hop neighbor-attention aggregation + embedding-propagation scoring path.
+ *
+ * The reference (johnnyjana730/MVIN) is pure Python on TensorFlow 1.x and has no FFI of
+ * its own; its boundary is the Python class surface `MVIN` / `SumAggregator_urh_matrix`
+ * (src/model/MVIN/model.py:6-444, aggregators.py:17-152).  Every entry point below
+ * replaces one stock-TF op sequence of that graph and cites it.  mvin_amd/model.py and
+ * mvin_amd/aggregators.py bind these through ctypes and keep the reference's call surface.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (torch allocates; the library
+ *    holds no state except a per-thread last-error string);
+ *  - tensors are dense row-major; ids are int32 (the reference's int64 ids are accepted
+ *    only at mvin_expand_ids, model.py:50-51); tables are fp32;
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launches
+ *    are asynchronous on it; the library never synchronises;
+ *  - return 0 on success, <0 for argument/shape errors, >0 = hipError_t of the launch.
+ *    mvin_last_error() describes the last failure on the calling thread;
+ *  - B = pairs in the batch, K = neighbor_sample_size, D = dim, N = nodes per pair at the
+ *    level being aggregated, T = B*N "node tasks".
+ */
+#ifndef MVIN_HIP_H
+#define MVIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVIN_ABI_VERSION 1
+#define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
+#define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
+
+int mvin_abi_version(void);
+const char* mvin_last_error(void);
+
+/* Number of int32 elements of the flattened id lists mvin_expand_ids writes:
+ * entities levels 0..levels (B * sum_{e<=levels} K^e) and relations levels 0..levels-1
+ * (B * sum_{1<=e<=levels} K^e).  Level e of `ent_out` starts at B*sum_{i<e}K^i and is
+ * [B, K^e]; level e of `rel_out` starts at B*sum_{1<=i<=e}K^i and is [B, K^(e+1)]. */
+size_t mvin_ent_elems(int B, int K, int levels);
+size_t mvin_rel_elems(int B, int K, int levels);
+
+/* MVIN.get_neighbors (model.py:243-256): level-by-level expansion of the fixed-fan-out
+ * adjacency.  entities[0] = items; entities[e+1][b, j*K+k] = adj_entity[entities[e][b,j], k];
+ * relations[e][b, j*K+k] = adj_relation[entities[e][b,j], k].  `levels` expansions.
+ * items are int64 (items_i64) or int32 (items_i32); exactly one must be non-NULL. */
+int mvin_expand_ids(const int32_t* adj_entity, const int32_t* adj_relation,
+                    const int64_t* items_i64, const int32_t* items_i32,
+                    int B, int K, int levels, int n_entity,
+                    int32_t* ent_out, int32_t* rel_out, void* stream);
+
+/* Attention logits of SumAggregator_urh_matrix._mix_neighbor_vectors_urh
+ * (aggregators.py:118-139) reduced to their k-dependent term:
+ * score[b,n,k] = [user; rel_k; self] . urh_weights = const(b,n) + rel_emb[r_k] . urh_w[D:2D];
+ * the constant cancels in softmax_k, so t[r] = rel_emb[r,:] . urh_weights[D:2D] is all
+ * the kernels need.  t_out is [nR]. */
+int mvin_rel_score(const float* relation_emb, const float* urh_weights, int nR, int D,
+                   float* t_out, void* stream);
+
+/* Generic "rows x small dense" operator behind the stock tf.matmul sites of the path:
+ *   out[z][r, :] = act( concat_s(X_s[r, :]) . W[z] + bias[z] + rowbias[r / rows_per_group, :] )
+ * X_s is either dense rows (ids[s]==NULL: X_s[r] = src[s] + r*Dsrc) or a table gather
+ * (X_s[r] = src[s] + ids[s][r]*Dsrc; tf.nn.embedding_lookup).  W is [nsrc*Dsrc, Dout]
+ * (NULL = identity copy; needs nsrc==1, Dsrc==Dout).  nz batches share the sources and
+ * step W/bias/out by the given element strides.  Optional fused scoring epilogue
+ * (model.py:158-159): score[r] = sum_j out[r,j]*score_u[r,j]; sigmoid[r] = 1/(1+exp(-score)).
+ * Covers: user-oriented projection (model.py:270-283), mix-hop combiner (:310-315),
+ * user MLP (:232-236), the per-relation item projection of _key_addressing (:211-220). */
+typedef struct {
+    const float* src[MVIN_MAX_SRC];
+    const int32_t* ids[MVIN_MAX_SRC];
+    int nsrc;
+    int Dsrc;
+    int Dout;
+    int64_t rows;
+    const float* W;
+    const float* bias;         /* [Dout] or NULL */
+    const float* rowbias;      /* [ceil(rows/rows_per_group), Dout] or NULL */
+    int rows_per_group;
+    int relu;
+    float* out;
+    int64_t ldo;                 /* out row stride in elements (>= Dout) */
+    int nz;
+    int64_t w_zstride, bias_zstride, out_zstride;
+    const float* score_u;      /* [rows, Dout] or NULL */
+    float* score_out;          /* [rows] or NULL */
+    float* sigmoid_out;        /* [rows] or NULL */
+} mvin_linear_args;
+int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
+
+/* Deepest hop of MVIN.aggregate_delta_whole (model.py:267-283 + :295-305 at hop = L-1,
+ * i = 0, n = 0) fused with SumAggregator_urh_matrix._call (aggregators.py:98-146):
+ * for node task t = (b, n) with entity x = node_ids[t]:
+ *     y_k = adj_entity[x,k], r_k = adj_relation[x,k]                 (tf.gather, model.py:251-252)
+ *     p   = softmax_k(rel_score[r_k])   (or p_k = 1 when rel_score == NULL: aggregators.py:148-152)
+ *     S   = sum_k p_k * table[y_k, :]                                (embedding_lookup + weighted sum)
+ *     agg = (S . Wc + (sum_k p_k) * c_child[b, :]) / K   (Wc == NULL: agg = S / K)
+ *           == reduce_mean_k(p_k * ((table[y_k]+q_b) . W_L + b_L)) by linearity, c_child = q_b.W_L + b_L
+ *     out[t, :] = relu((self_vec[t, :] + agg) . Wagg + bagg)
+ * The K^L child rows are never materialised.  probs ([T, K]) is optional (model.py:294,304). */
+int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                         const int32_t* node_ids, const float* rel_score,
+                         const float* self_vec, const float* Wc, const float* c_child,
+                         const float* Wagg, const float* bagg,
+                         int B, int N, int K, int D, int n_entity,
+                         float* out, float* probs, void* stream);
+
+/* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
+ * other than the deepest hop; aggregators.py:98-152, model.py:295-305):
+ *     p = softmax_k(rel_score[rel_ids[t*K+k]])  (or 1), agg = (1/K) sum_k p_k * neigh[t*K+k, :]
+ *     out[t, :] = relu((self_vec[t, :] + agg) . Wagg + bagg)
+ * rel_ids == NULL with rel_score != NULL: rel_score holds one logit per child ([T*K]), the form
+ * Aggregator.__call__ needs when it is handed relation VECTORS (aggregators.py:29-31). */
+int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids,
+                 const float* rel_score, const float* Wagg, const float* bagg,
+                 int B, int N, int K, int D, float* out, float* probs, void* stream);
+
+/* One attention read over a user's ripple set (MVIN._key_addressing, model.py:161-240):
+ *   mode 0 (hop loop, :210-230): s_m = E[score_ids[b,m]] . V[b, rel_ids[b,m], :] where
+ *          V[b,r,:] = E[item_b] . R_KGE[r]  (== (R_KGE[r] . h_m) . item_b, :214-220);
+ *   mode 1 (soft_attention_h_set, :162-197): s_m = E[score_ids[b,m]] . w[0:D]
+ *          (the user term and the bias are constant over m and cancel in the softmax);
+ *   o[b, :] = sum_m softmax_m(s)_m * E[value_ids[b,m], :]  written at out + b*ldo. */
+int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+                         const int32_t* value_ids, const float* V, const float* w, int mode,
+                         int B, int Nm, int D, int nR, float* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVIN_HIP_H */

@@ -1,0 +1,99 @@
+"""ctypes binding of libmvin_hip.so (include/mvin_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared
+object is missing or fails to load, importing a compute entry point raises immediately.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+MAX_SRC = 8
+
+_c_f32p = C.c_void_p
+_c_i32p = C.c_void_p
+
+
+class LinearArgs(C.Structure):
+    """mvin_linear_args (include/mvin_hip.h)."""
+    _fields_ = [
+        ("src", C.c_void_p * MAX_SRC),
+        ("ids", C.c_void_p * MAX_SRC),
+        ("nsrc", C.c_int),
+        ("Dsrc", C.c_int),
+        ("Dout", C.c_int),
+        ("rows", C.c_int64),
+        ("W", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p),
+        ("rows_per_group", C.c_int),
+        ("relu", C.c_int),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("nz", C.c_int),
+        ("w_zstride", C.c_int64),
+        ("bias_zstride", C.c_int64),
+        ("out_zstride", C.c_int64),
+        ("score_u", C.c_void_p),
+        ("score_out", C.c_void_p),
+        ("sigmoid_out", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
+SIGNATURES = {
+    "mvin_abi_version": (C.c_int, []),
+    "mvin_last_error": (C.c_char_p, []),
+    "mvin_ent_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mvin_rel_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mvin_expand_ids": (C.c_int, [_c_i32p, _c_i32p, C.c_void_p, _c_i32p, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _c_i32p, _c_i32p, C.c_void_p]),
+    "mvin_rel_score": (C.c_int, [_c_f32p, _c_f32p, C.c_int, C.c_int, _c_f32p, C.c_void_p]),
+    "mvin_linear_fwd": (C.c_int, [C.POINTER(LinearArgs), C.c_void_p]),
+    "mvin_gather_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
+                                       _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_agg_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
+                               C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
+                                       C.c_void_p]),
+}
+
+_lib = None
+
+
+class MvinHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise loudly when the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MvinHipError(
+            f"{path} is missing: build it with `python -m mvin_amd.build` (hipcc, gfx950). "
+            "mvin_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.mvin_abi_version()
+    if ver != 1:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mvin_last_error().decode(errors="replace")
+        raise MvinHipError(f"{what or 'mvin call'} failed (rc={rc}): {msg}")

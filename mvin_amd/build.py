@@ -1,0 +1,76 @@
+"""Build libmvin_hip.so in-tree with hipcc for gfx950 (no JIT cache, no pip install).
+
+    python -m mvin_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container too.
+The .so is git-ignored but travels to the GPU box with the repo snapshot.
+"""
+import argparse
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
+LIB_PATH = os.path.join(PKG_DIR, "libmvin_hip.so")
+STAMP_PATH = LIB_PATH + ".stamp"
+SOURCES = ["mvin_kernels.hip", "mvin_fused.hip", "mvin_abi.hip"]
+HEADERS = ["mvin_common.h", "mvin_kernels.h"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def _existing(names, base):
+    return [os.path.join(base, n) for n in names if os.path.exists(os.path.join(base, n))]
+
+
+def _digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in _existing(SOURCES + HEADERS, CSRC) + [os.path.join(INCLUDE, "mvin_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(path.encode())
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
+        return True
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != _digest()
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source into one shared library.  Returns the library path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    srcs = _existing(SOURCES, CSRC)
+    cmd = [_hipcc()] + FLAGS + [f"-I{INCLUDE}", f"-I{CSRC}"] + srcs + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    if verbose and res.stderr:
+        print(res.stderr, file=sys.stderr)
+    with open(STAMP_PATH, "w") as f:
+        f.write(_digest())
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(force=a.force, verbose=a.verbose))

@@ -1,0 +1,181 @@
+// extern "C" boundary of libmvin_hip.so (see include/mvin_hip.h).  Argument validation,
+// per-thread error string, kernel launches.  No allocation, no synchronisation, no state.
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "mvin_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+bool bad_dim(int D) { return D < 4 || D > MVIN_MAX_DIM || (D & 3) != 0; }
+
+size_t geom_sum(int B, int K, int from, int to) {  // B * sum_{e=from..to} K^e
+    size_t s = 0, p = 1;
+    for (int e = 0; e <= to; ++e) {
+        if (e >= from) s += p;
+        p *= (size_t)K;
+    }
+    return s * (size_t)B;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvin_abi_version(void) { return MVIN_ABI_VERSION; }
+
+const char* mvin_last_error(void) { return g_last_error.c_str(); }
+
+size_t mvin_ent_elems(int B, int K, int levels) { return geom_sum(B, K, 0, levels); }
+
+size_t mvin_rel_elems(int B, int K, int levels) { return levels > 0 ? geom_sum(B, K, 1, levels) : 0; }
+
+int mvin_expand_ids(const int32_t* adj_entity, const int32_t* adj_relation, const int64_t* items_i64,
+                    const int32_t* items_i32, int B, int K, int levels, int n_entity,
+                    int32_t* ent_out, int32_t* rel_out, void* stream) {
+    if (!ent_out || (!items_i64 && !items_i32) || (items_i64 && items_i32))
+        return fail(-1, "mvin_expand_ids: need ent_out and exactly one of items_i64/items_i32");
+    if (levels > 0 && (!adj_entity || !adj_relation || !rel_out))
+        return fail(-1, "mvin_expand_ids: null adjacency/rel_out with levels=%d", levels);
+    if (B <= 0 || K <= 0 || levels < 0 || n_entity <= 0)
+        return fail(-2, "mvin_expand_ids: bad sizes B=%d K=%d levels=%d n_entity=%d", B, K, levels, n_entity);
+    return hip_result(mvin::launch_expand(adj_entity, adj_relation, items_i64, items_i32, B, K, levels,
+                                          n_entity, ent_out, rel_out, (hipStream_t)stream),
+                      "mvin_expand_ids");
+}
+
+int mvin_rel_score(const float* relation_emb, const float* urh_weights, int nR, int D, float* t_out,
+                   void* stream) {
+    if (!relation_emb || !urh_weights || !t_out) return fail(-1, "mvin_rel_score: null pointer");
+    if (nR <= 0 || D <= 0) return fail(-2, "mvin_rel_score: bad sizes nR=%d D=%d", nR, D);
+    return hip_result(mvin::launch_rel_score(relation_emb, urh_weights, nR, D, t_out, (hipStream_t)stream),
+                      "mvin_rel_score");
+}
+
+int mvin_linear_fwd(const mvin_linear_args* a, void* stream) {
+    if (!a) return fail(-1, "mvin_linear_fwd: null args");
+    if (a->nsrc < 1 || a->nsrc > MVIN_MAX_SRC) return fail(-2, "mvin_linear_fwd: nsrc=%d", a->nsrc);
+    if (a->Dsrc < 4 || (a->Dsrc & 3) || a->Dout < 1 || a->Dout > MVIN_MAX_DIM)
+        return fail(-2, "mvin_linear_fwd: Dsrc=%d (need %%4==0) Dout=%d (need 1..%d)", a->Dsrc, a->Dout,
+                    MVIN_MAX_DIM);
+    if ((size_t)a->nsrc * a->Dsrc > 4096) return fail(-2, "mvin_linear_fwd: nsrc*Dsrc > 4096");
+    if (a->rows < 0) return fail(-2, "mvin_linear_fwd: rows < 0");
+    if (!a->out) return fail(-1, "mvin_linear_fwd: null out");
+    for (int s = 0; s < a->nsrc; ++s)
+        if (!a->src[s]) return fail(-1, "mvin_linear_fwd: null src[%d]", s);
+    if (!a->W && (a->nsrc != 1 || a->Dsrc != a->Dout))
+        return fail(-2, "mvin_linear_fwd: identity (W=NULL) needs nsrc==1 and Dsrc==Dout");
+    if (a->ldo < a->Dout) return fail(-2, "mvin_linear_fwd: ldo < Dout");
+    if (a->rowbias && a->rows_per_group < 1) return fail(-2, "mvin_linear_fwd: rows_per_group < 1");
+    if (a->score_u && a->Dout > a->nsrc * a->Dsrc + 4)
+        return fail(-2, "mvin_linear_fwd: fused score needs Dout <= nsrc*Dsrc + 4");
+    if (a->rows == 0) return 0;
+    return hip_result(mvin::launch_linear(*a, (hipStream_t)stream), "mvin_linear_fwd");
+}
+
+static int agg_common(mvin::GatherAttnArgs& g, int B, int N, int K, int D, const char* who) {
+    if (B <= 0 || N <= 0 || K <= 0) return fail(-2, "%s: bad sizes B=%d N=%d K=%d", who, B, N, K);
+    if (bad_dim(D)) return fail(-2, "%s: D=%d (need %%4==0, 4..%d)", who, D, MVIN_MAX_DIM);
+    if (K > 4096) return fail(-2, "%s: K=%d > 4096", who, K);
+    if (!g.self_vec || !g.Wagg || !g.out) return fail(-1, "%s: null self_vec/Wagg/out", who);
+    g.T = (int64_t)B * N;
+    g.N = N;
+    g.K = K;
+    g.D = D;
+    g.lpr_log2 = mvin::lpr_log2_for(D);
+    return 0;
+}
+
+int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                         const int32_t* node_ids, const float* rel_score, const float* self_vec,
+                         const float* Wc, const float* c_child, const float* Wagg, const float* bagg, int B,
+                         int N, int K, int D, int n_entity, float* out, float* probs, void* stream) {
+    mvin::GatherAttnArgs g{};
+    g.gather = 1;
+    g.table = table;
+    g.adj_e = adj_entity;
+    g.adj_r = adj_relation;
+    g.node_ids = node_ids;
+    g.rel_score = rel_score;
+    g.self_vec = self_vec;
+    g.Wc = Wc;
+    g.c_child = c_child;
+    g.Wagg = Wagg;
+    g.bagg = bagg;
+    g.out = out;
+    g.probs = probs;
+    if (!table || !adj_entity || !node_ids || (rel_score && !adj_relation))
+        return fail(-1, "mvin_gather_attn_fwd: null table/adjacency/node_ids");
+    if (n_entity <= 0) return fail(-2, "mvin_gather_attn_fwd: n_entity=%d", n_entity);
+    if (probs && !rel_score) return fail(-2, "mvin_gather_attn_fwd: probs requested without rel_score");
+    if (int rc = agg_common(g, B, N, K, D, "mvin_gather_attn_fwd")) return rc;
+    return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_gather_attn_fwd");
+}
+
+int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
+                 const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
+                 void* stream) {
+    mvin::GatherAttnArgs g{};
+    g.gather = 0;
+    g.neigh = neigh;
+    g.rel_ids = rel_ids;
+    g.rel_score = rel_score;
+    g.self_vec = self_vec;
+    g.Wagg = Wagg;
+    g.bagg = bagg;
+    g.out = out;
+    g.probs = probs;
+    if (!neigh) return fail(-1, "mvin_agg_fwd: null neigh");
+    if (probs && !rel_score) return fail(-2, "mvin_agg_fwd: probs requested without rel_score");
+    if (int rc = agg_common(g, B, N, K, D, "mvin_agg_fwd")) return rc;
+    return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_agg_fwd");
+}
+
+int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+                         const int32_t* value_ids, const float* V, const float* w, int mode, int B, int Nm,
+                         int D, int nR, float* out, int64_t ldo, void* stream) {
+    if (!entity_emb || !score_ids || !value_ids || !out) return fail(-1, "mvin_ripple_attn_fwd: null pointer");
+    if (mode != 0 && mode != 1) return fail(-2, "mvin_ripple_attn_fwd: mode=%d", mode);
+    if (mode == 0 && (!V || !rel_ids || nR <= 0)) return fail(-1, "mvin_ripple_attn_fwd: mode 0 needs V, rel_ids, nR");
+    if (mode == 1 && !w) return fail(-1, "mvin_ripple_attn_fwd: mode 1 needs w");
+    if (B <= 0 || Nm <= 0 || Nm > 8192) return fail(-2, "mvin_ripple_attn_fwd: bad sizes B=%d Nm=%d", B, Nm);
+    if (bad_dim(D)) return fail(-2, "mvin_ripple_attn_fwd: D=%d (need %%4==0, 4..%d)", D, MVIN_MAX_DIM);
+    if (ldo < D || (ldo & 3)) return fail(-2, "mvin_ripple_attn_fwd: ldo=%lld (need >= D, %%4==0)", (long long)ldo);
+    mvin::RippleArgs r{};
+    r.E = entity_emb;
+    r.score_ids = score_ids;
+    r.rel_ids = rel_ids;
+    r.value_ids = value_ids;
+    r.V = V;
+    r.w = w;
+    r.out = out;
+    r.ldo = ldo;
+    r.B = B;
+    r.mode = mode;
+    r.Nm = Nm;
+    r.D = D;
+    r.nR = nR;
+    r.lpr_log2 = mvin::lpr_log2_for(D);
+    return hip_result(mvin::launch_ripple(r, (hipStream_t)stream), "mvin_ripple_attn_fwd");
+}
+
+}  // extern "C"

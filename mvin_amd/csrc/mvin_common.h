@@ -1,0 +1,68 @@
+// Device-side helpers shared by the MVIN gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mvin {
+
+constexpr int kWave = 64;    // CDNA wavefront
+constexpr int kBlock = 256;  // 4 waves per workgroup
+constexpr int kTM = 32;      // node tasks (rows) per workgroup tile
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
+    a.x = fmaf(s, v.x, a.x);
+    a.y = fmaf(s, v.y, a.y);
+    a.z = fmaf(s, v.z, a.z);
+    a.w = fmaf(s, v.w, a.w);
+    return a;
+}
+
+// Sum a float4 over the lane groups of a wave: lanes l and l^off for off = lpr, 2*lpr, ... < 64.
+__device__ __forceinline__ float4 group_xor_sum(float4 a, int lpr) {
+    for (int o = lpr; o < kWave; o <<= 1) {
+        a.x += __shfl_xor(a.x, o, kWave);
+        a.y += __shfl_xor(a.y, o, kWave);
+        a.z += __shfl_xor(a.z, o, kWave);
+        a.w += __shfl_xor(a.w, o, kWave);
+    }
+    return a;
+}
+
+// acc[i] += sum_k sX[(rg + RP*i)*ldx + k] * W[k*Dout + j], i < NR, RP = kTM / NR.
+// sX rows are read as broadcast float4 (every lane of a row group reads the same address);
+// W columns are read coalesced across j from global memory (L1/L2 resident, <= 256 KB).
+template <int NR>
+__device__ __forceinline__ void tile_matvec(const float* __restrict__ sX, int ldx, int Din,
+                                            const float* __restrict__ W, int Dout, int j, int rg,
+                                            float (&acc)[NR]) {
+    constexpr int RP = kTM / NR;
+    const float* wp = W + j;
+    for (int k = 0; k < Din; k += 4) {
+        const float w0 = wp[(size_t)(k + 0) * Dout];
+        const float w1 = wp[(size_t)(k + 1) * Dout];
+        const float w2 = wp[(size_t)(k + 2) * Dout];
+        const float w3 = wp[(size_t)(k + 3) * Dout];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(sX + (rg + RP * i) * ldx + k);
+            acc[i] = fmaf(x.x, w0, acc[i]);
+            acc[i] = fmaf(x.y, w1, acc[i]);
+            acc[i] = fmaf(x.z, w2, acc[i]);
+            acc[i] = fmaf(x.w, w3, acc[i]);
+        }
+    }
+}
+
+}  // namespace mvin

@@ -1,0 +1,59 @@
+// Internal kernel-argument structs and launchers (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvin_hip.h"
+#include "mvin_common.h"
+
+namespace mvin {
+
+struct GatherAttnArgs {
+    int gather;               // 1: children through adjacency + table; 0: dense neigh rows
+    const float* table;       // [nE, D]
+    const int32_t* adj_e;     // [nE, K]
+    const int32_t* adj_r;     // [nE, K]
+    const int32_t* node_ids;  // [T]
+    const float* neigh;       // [T*K, D]
+    const int32_t* rel_ids;   // [T*K]
+    const float* rel_score;   // [nR] or NULL (uniform weights)
+    const float* self_vec;    // [T, D]
+    const float* Wc;          // [D, D] or NULL
+    const float* c_child;     // [B, D] or NULL
+    const float* Wagg;        // [D, D]
+    const float* bagg;        // [D] or NULL
+    float* out;               // [T, D]
+    float* probs;             // [T, K] or NULL
+    int64_t T;
+    int N, K, D, lpr_log2;
+};
+
+struct RippleArgs {
+    const float* E;
+    const int32_t* score_ids;
+    const int32_t* rel_ids;
+    const int32_t* value_ids;
+    const float* V;
+    const float* w;
+    float* out;
+    int64_t ldo;
+    int64_t B;
+    int mode, Nm, D, nR, lpr_log2;
+};
+
+inline int lpr_log2_for(int D) {
+    int l = 0;
+    while ((4 << l) < D) ++l;
+    return l;  // 2^l lanes x 4 floats >= D
+}
+
+hipError_t launch_expand(const int32_t* adj_e, const int32_t* adj_r, const int64_t* items64,
+                         const int32_t* items32, int B, int K, int levels, int n_entity,
+                         int32_t* ent_out, int32_t* rel_out, hipStream_t st);
+hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D, float* t,
+                            hipStream_t st);
+hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st);
+hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st);
+hipError_t launch_ripple(const RippleArgs& a, hipStream_t st);
+
+}  // namespace mvin

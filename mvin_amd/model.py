@@ -1,0 +1,414 @@
+"""MVIN model -- the reference's call surface (src/model/MVIN/model.py:6-444) on top of
+libmvin_hip.so.  Host code in Python on PyTorch-ROCm (device memory + stream only); every
+op of the scoring path is a hand-written gfx950 kernel reached through the C ABI.
+
+    model = MVIN(args, n_user, n_entity, n_relation, adj_entity, adj_relation)
+    model.get_scores(sess, feed_dict) -> (item_indices, sigmoid_scores)     model.py:443-444
+    model.eval(sess, feed_dict)       -> (auc, acc, f1)                      model.py:419-426
+    model.eval_case_study(sess, feed) -> 7-tuple                             model.py:428-441
+    model.train(sess, feed_dict)      -> NotImplementedError (backward + Adam is a later row)
+
+``sess`` is accepted and ignored (there is no TF session); feed keys are the placeholder
+sentinels ``model.user_indices / item_indices / labels / memories_{h,r,t}[i]``
+(train.py:113-120, util.py:209-230).  Unlike the reference graph, whose static reshapes
+bake ``batch_size`` in (model.py:251,281,296), any batch length is accepted.
+
+How the forward is arranged (see DESIGN.md for the data layout and the kernel roofline):
+  * ids of levels 0..L-1 are expanded on device (mvin_expand_ids); level L is never
+    materialised -- the deepest aggregator hop reads the adjacency rows itself and gathers
+    the K^L entity rows straight into a wave-level softmax / weighted sum
+    (mvin_gather_attn_fwd);
+  * the user-oriented projection (model.py:270-283) is applied AFTER the weighted sum on
+    the deepest level ((sum_k p_k E[y_k]).W + c == sum_k p_k (E[y_k].W + c) as sum_k p_k = 1)
+    and per row on the small upper levels (mvin_linear_fwd with a gathered source);
+  * attention logits use the nR-entry table t[r] = Rel[r].urh_w[D:2D]: the user and self
+    terms of aggregators.py:130-133 are constant over k and cancel in the softmax;
+  * key addressing (model.py:161-240) uses (R h).v == h.(v R): V[b,r,:] = E[item_b].R_KGE[r]
+    is computed once per pair, then each memory needs one D-long dot product.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import ops
+from .aggregators import SumAggregator_urh_matrix
+from .params import aggregator_keys, init_params
+
+
+class Placeholder(object):
+    """Hashable stand-in for a tf.placeholder used as a feed_dict key (model.py:49-64)."""
+
+    def __init__(self, name, dtype, shape):
+        self.name, self.dtype, self.shape = name, dtype, shape
+
+    def __repr__(self):
+        return f"<Placeholder {self.name} {self.dtype} {self.shape}>"
+
+
+class MVIN(object):
+    def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
+                 params=None, device=None, seed=0):
+        self.device = torch.device(device or "cuda")
+        self._parse_args(args, adj_entity, adj_relation)
+        self._build_inputs()
+        self._build_model(n_user, n_entity, n_relation, params, seed)
+        self._build_train()
+
+    # ------------------------------------------------------------------ construction
+    def _parse_args(self, args, adj_entity, adj_relation):
+        """model.py:17-47."""
+        self.dataset = getattr(args, "dataset", None)
+        self.load_pretrain_emb = getattr(args, "load_pretrain_emb", False)
+        self.h_hop = args.h_hop
+        self.batch_size = args.batch_size
+        self.n_neighbor = args.neighbor_sample_size
+        self.p_hop = args.p_hop
+        self.dim = args.dim
+        self.l2_weight = getattr(args, "l2_weight", 0.0)
+        self.l2_agg_weight = getattr(args, "l2_agg_weight", 0.0)
+        self.kge_weight = getattr(args, "kge_weight", 0.0)
+        self.lr = getattr(args, "lr", 0.0)
+        self.save_model_name = getattr(args, "save_model_name", "model1")
+        self.n_mix_hop = args.n_mix_hop
+        self.n_memory = args.n_memory
+        self.update_item_emb = getattr(args, "update_item_emb", None)
+        self.h0_att = getattr(args, "h0_att", None)
+        self.path = getattr(args, "path", None)
+        self.User_orient_rela = bool(args.User_orient_rela)
+        self.args = args
+        self.aggregator_class = SumAggregator_urh_matrix
+        self.agg_fun = self.aggregate_delta_whole if args.wide_deep else self.aggregate
+        if self.dim % 4 != 0 or not (4 <= self.dim <= 256):
+            raise ValueError("dim must be a multiple of 4 in [4, 256] (16-byte row loads)")
+        adj_entity = np.asarray(adj_entity)
+        adj_relation = np.asarray(adj_relation)
+        if adj_entity.shape != adj_relation.shape or adj_entity.shape[1] != self.n_neighbor:
+            raise ValueError("adj_entity/adj_relation must both be [n_entity, neighbor_sample_size]")
+        # ids are int64 in the reference (data_loader_user_set.py:377-378); int32 on device
+        # halves the id traffic (n_entity < 2^31).
+        self.adj_entity = torch.from_numpy(adj_entity.astype(np.int32)).to(self.device).contiguous()
+        self.adj_relation = torch.from_numpy(adj_relation.astype(np.int32)).to(self.device).contiguous()
+
+    def _build_inputs(self):
+        """model.py:49-64."""
+        self.user_indices = Placeholder("user_indices", "int64", [None])
+        self.item_indices = Placeholder("item_indices", "int64", [None])
+        self.labels = Placeholder("labels", "float32", [None])
+        self.memories_h, self.memories_r, self.memories_t = [], [], []
+        for hop in range(max(1, self.p_hop)):
+            self.memories_h.append(Placeholder(f"memories_h_{hop}", "int32", [None, self.n_memory]))
+            self.memories_r.append(Placeholder(f"memories_r_{hop}", "int32", [None, self.n_memory]))
+            self.memories_t.append(Placeholder(f"memories_t_{hop}", "int32", [None, self.n_memory]))
+
+    def _build_model(self, n_user, n_entity, n_relation, params, seed):
+        """model.py:69-122 (parameters).  The graph body (:125-159) runs in ``forward_device``."""
+        a = self.args
+        self.n_user, self.n_entity, self.n_relation = n_user, n_entity, n_relation
+        if params is None:
+            params = init_params(a, n_user, n_entity, n_relation, seed=seed)
+        D, H, M = self.dim, self.h_hop, self.n_mix_hop
+        L = M * H
+
+        def dev(x):
+            return torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.device).contiguous()
+
+        self.user_emb_matrix = dev(params["user_emb_matrix"])
+        self.entity_emb_matrix = dev(params["entity_emb_matrix"])
+        self.relation_emb_matrix = dev(params["relation_emb_matrix"])
+        self.relation_emb_KGE_matrix = dev(params["relation_emb_KGE_matrix"])
+        for t, shape in ((self.user_emb_matrix, (n_user, D)), (self.entity_emb_matrix, (n_entity, D)),
+                         (self.relation_emb_matrix, (n_relation, D)),
+                         (self.relation_emb_KGE_matrix, (n_relation, D, D))):
+            if tuple(t.shape) != shape:
+                raise ValueError(f"parameter shape {tuple(t.shape)} != {shape}")
+        self.enti_transfer_matrix_list = [dev(params[f"enti_transfer_matrix_{n}"]) for n in range(M)]
+        self.enti_transfer_bias_list = [dev(params[f"enti_transfer_bias_{n}"]) for n in range(M)]
+        self.user_mlp_matrix = dev(params["user_mlp_matrix"])
+        self.user_mlp_bias = dev(params["user_mlp_bias"])
+        # the L+1 projection matrices live in one stack so q.W_e + b_e for every level is one launch
+        self._transfer_W = dev(np.stack([params[f"transfer_matrix_{e}"] for e in range(L + 1)]))
+        self._transfer_b = dev(np.stack([params[f"transfer_bias_{e}"] for e in range(L + 1)]))
+        self.transfer_matrix_list = [self._transfer_W[e] for e in range(L + 1)]
+        self.transfer_matrix_bias = [self._transfer_b[e] for e in range(L + 1)]
+        self.transform_matrix, self.transform_bias = self.transfer_matrix_list[-1], self.transfer_matrix_bias[-1]
+        self.h_emb_item_mlp_matrix = dev(params["h_emb_item_mlp_matrix"])
+        self.h_emb_item_mlp_bias = dev(params["h_emb_item_mlp_bias"])
+        # aggregators (model.py:290 / :359)
+        self._agg = {}
+        self.aggregators = []
+        if not a.PS_only:
+            for (i, n) in aggregator_keys(a):
+                tag = f"agg_{i}_{n}_"
+                name = (str(i) + "_" + str(n)) if a.wide_deep else i
+                agg = self.aggregator_class(
+                    self.save_model_name, self.batch_size, D, name=name,
+                    User_orient_rela=(self.User_orient_rela if a.wide_deep else True),
+                    weights=params[tag + "weights"], bias=params[tag + "bias"],
+                    urh_weights=params[tag + "urh_weights"], urh_bias=params[tag + "urh_bias"],
+                    relation_emb=self.relation_emb_matrix, device=self.device)
+                self._agg[(i, n)] = agg
+                self.aggregators.append(agg)
+        self._profile = None
+
+    def _build_train(self):
+        """model.py:378-414 (loss + Adam): the backward path is a later row of the scope
+        table; nothing is built here yet."""
+        self.optimizer = None
+
+    def parameters_dict(self):
+        """All parameters as numpy arrays under the names of mvin_amd/params.py."""
+        L = self.n_mix_hop * self.h_hop
+        p = {k: getattr(self, k).cpu().numpy() for k in
+             ("user_emb_matrix", "entity_emb_matrix", "relation_emb_matrix", "relation_emb_KGE_matrix",
+              "user_mlp_matrix", "user_mlp_bias", "h_emb_item_mlp_matrix", "h_emb_item_mlp_bias")}
+        for n in range(self.n_mix_hop):
+            p[f"enti_transfer_matrix_{n}"] = self.enti_transfer_matrix_list[n].cpu().numpy()
+            p[f"enti_transfer_bias_{n}"] = self.enti_transfer_bias_list[n].cpu().numpy()
+        for e in range(L + 1):
+            p[f"transfer_matrix_{e}"] = self.transfer_matrix_list[e].cpu().numpy()
+            p[f"transfer_bias_{e}"] = self.transfer_matrix_bias[e].cpu().numpy()
+        for (i, n), agg in self._agg.items():
+            tag = f"agg_{i}_{n}_"
+            for nm in ("weights", "bias", "urh_weights", "urh_bias"):
+                p[tag + nm] = getattr(agg, nm).cpu().numpy()
+        return p
+
+    # ------------------------------------------------------------------ stage-wise tables
+    _STWS = ("user_emb_matrix", "entity_emb_matrix", "relation_emb_matrix", "relation_emb_KGE_matrix")
+
+    def _emb_path(self):
+        if self.path is None or getattr(self.path, "emb", None) is None:
+            raise ValueError("args.path.emb is not set")
+        return f"{self.path.emb}_sw_para_{self.save_model_name}_parameter.npz"
+
+    def save_pretrain_emb_fuc(self, sess=None, saver=None):
+        """model.py:66-67 / train.py:43-51: persist the four ``STWS`` embedding tables."""
+        np.savez(self._emb_path(), **{k: getattr(self, k).cpu().numpy() for k in self._STWS})
+
+    def restore_pretrain_emb(self):
+        """train.py:53-54 counterpart."""
+        with np.load(self._emb_path()) as z:
+            for k in self._STWS:
+                getattr(self, k).copy_(torch.from_numpy(z[k]).to(self.device))
+        for agg in self.aggregators:
+            agg.invalidate()
+
+    # ------------------------------------------------------------------ graph pieces
+    def get_neighbors(self, seeds, levels=None):
+        """model.py:243-256 on device.  Returns (entities, relations) int32 id lists."""
+        L = self.n_mix_hop * self.h_hop if levels is None else levels
+        return ops.expand_ids(self.adj_entity, self.adj_relation, seeds, self.n_neighbor, L, self.n_entity)
+
+    def _lookup(self, table, ids32):
+        """tf.nn.embedding_lookup of [B] ids -> [B, D]."""
+        return ops.linear([table], None, table.shape[-1], ids=[ids32])
+
+    def _key_addressing(self, user32, item32, mem_h, mem_r, mem_t):
+        """model.py:161-240 -> user_o [B,D]."""
+        a, D, P = self.args, self.dim, self.p_hop
+        B = item32.shape[0]
+        nR = self.n_relation
+        n_o = P + 1 if a.PS_O_ft else P
+        o_cat = torch.empty((B, n_o * D), dtype=torch.float32, device=self.device)
+        slot = 0
+        if a.PS_O_ft:  # :162-197, :204-206
+            w_h = self.h_emb_item_mlp_matrix.view(-1)  # first D entries multiply h (concat order [h, user], :171)
+            ops.ripple_attn(self.entity_emb_matrix, mem_h[0], None, mem_h[0], None, w_h, 1,
+                            o_cat, 0, n_o * D, nR)
+            slot = 1
+        if P > 0:
+            # V[b,r,:] = E[item_b] . R_KGE[r]   ((R h).v == h.(v R), :214-220)
+            V = torch.empty((B, nR, D), dtype=torch.float32, device=self.device)
+            ops.linear([self.entity_emb_matrix], self.relation_emb_KGE_matrix, D, ids=[item32], rows=B,
+                       out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
+            for hop in range(P):  # :210-230
+                ops.ripple_attn(self.entity_emb_matrix, mem_h[hop], mem_r[hop], mem_t[hop], V, None, 0,
+                                o_cat, (slot + hop) * D, n_o * D, nR)
+        # :232-236
+        return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
+
+    def _project_levels(self, ents, q, top):
+        """model.py:267-283 for levels 0..top-1 (level ``top`` is fused into the deepest hop).
+        Returns (ev list, c) with c[e] = q.W_e + b_e for every level ([L+1, B, D]) or None."""
+        a, D, K = self.args, self.dim, self.n_neighbor
+        B = ents[0].shape[0]
+        E = self.entity_emb_matrix
+        if a.User_orient:
+            nlev = self._transfer_W.shape[0]
+            c = ops.linear([q], self._transfer_W, D, bias=self._transfer_b, nz=nlev, w_zstride=D * D,
+                           bias_zstride=D)
+            ev = [ops.linear([E], self.transfer_matrix_list[e], D, ids=[ents[e].view(-1)], rowbias=c[e],
+                             rows_per_group=K ** e).view(B, -1, D) for e in range(top)]
+            return ev, c
+        ev = [ops.linear([E], None, D, ids=[ents[e].view(-1)]).view(B, -1, D) for e in range(top)]
+        return ev, None
+
+    def _apply(self, agg, ev, ents, rels, hop, c, fused_level, want_probs):
+        """One aggregator application at one hop (model.py:296-305)."""
+        a, D, K = self.args, self.dim, self.n_neighbor
+        B = ev[hop].shape[0]
+        N = K ** hop
+        t = agg.relation_scores() if agg.User_orient_rela else None
+        wp = want_probs and agg.User_orient_rela
+        if fused_level is not None:
+            Wc = self.transfer_matrix_list[fused_level] if a.User_orient else None
+            cc = c[fused_level] if a.User_orient else None
+            if self._profile is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            res = ops.gather_attn(self.entity_emb_matrix, self.adj_entity, self.adj_relation,
+                                  ents[hop].view(-1), t, ev[hop].view(B * N, D), Wc, cc, agg.weights,
+                                  agg.bias, B, N, K, D, want_probs=wp)
+            if self._profile is not None:
+                ev1.record()
+                self._profile.append((ev0, ev1))
+            return res
+        return ops.agg(ev[hop].view(B * N, D), ev[hop + 1].view(B * N * K, D), rels[hop].view(-1), t,
+                       agg.weights, agg.bias, B, N, K, D, want_probs=wp)
+
+    def aggregate_delta_whole(self, ents, rels, q, user_o, want_probs=False):
+        """model.py:259-324 -> (item_embeddings [B,D], scores, sigmoid, importance_list)."""
+        D, K, H, M = self.dim, self.n_neighbor, self.h_hop, self.n_mix_hop
+        L = M * H
+        ev, c = self._project_levels(ents, q, L)
+        importance = []
+        out = None
+        for n in range(M):
+            stages = [ev]
+            for i in range(H):
+                agg = self._agg[(i, n)]
+                nxt, probs = [], []
+                for hop in range(L - (H * n + i)):
+                    fused = L if (n == 0 and i == 0 and hop == L - 1) else None
+                    o, p = self._apply(agg, ev, ents, rels, hop, c, fused, want_probs and i == 0)
+                    nxt.append(o)
+                    probs.append(p)
+                if i == 0:
+                    importance = probs
+                ev = nxt
+                stages.append(ev)
+            keep = (M - n - 1) * H + 1
+            last = n == M - 1
+            new = []
+            for e in range(keep):  # :310-315
+                res = ops.linear([st[e].view(-1, D) for st in stages], self.enti_transfer_matrix_list[n], D,
+                                 bias=self.enti_transfer_bias_list[n], score_u=user_o if last else None)
+                if last:
+                    out = res
+                else:
+                    new.append(res.view(ev[0].shape[0], -1, D))
+            ev = new
+        item_emb, scores, sig = out
+        return item_emb, scores, sig, importance
+
+    def aggregate(self, ents, rels, q, user_o, want_probs=False):
+        """model.py:327-376 (wide_deep=False).  The reference revision cannot run this path
+        (it treats the aggregator's tuple as a tensor, :366-374); the evident intent --
+        element [0] -- is implemented.  Untested by the reference."""
+        D, H = self.dim, self.h_hop
+        ev, c = self._project_levels(ents, q, H)
+        for i in range(H):
+            agg = self._agg[(i, 0)]
+            nxt = []
+            for hop in range(H - i):
+                fused = H if (i == 0 and hop == H - 1) else None
+                o, _ = self._apply(agg, ev, ents, rels, hop, c, fused, False)
+                nxt.append(o)
+            ev = nxt
+        item_emb, scores, sig = ops.linear([ev[0].view(-1, D)], None, D, score_u=user_o)
+        return item_emb, scores, sig, []
+
+    # ------------------------------------------------------------------ forward
+    def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,
+                       want_probs=False):
+        """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
+        [B, n_memory] per hop).  Returns a namespace of device tensors."""
+        a = self.args
+        dev = self.device
+        if not item_indices.is_cuda:
+            raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
+        item32 = item_indices.to(torch.int32)
+        user32 = user_indices.to(torch.int32)
+        need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
+        ps = self._key_addressing(user32, item32, memories_h, memories_r, memories_t) if need_ps else None
+        importance = []
+        if a.PS_only:  # :142-144
+            user_o = ps
+            item_emb, scores, sig = ops.linear([self.entity_emb_matrix], None, self.dim, ids=[item32],
+                                               score_u=user_o)
+        else:
+            user_o = self._lookup(self.user_emb_matrix, user32) if a.HO_only else ps
+            if a.User_orient_kg_eh:
+                q = ps
+            else:
+                q = user_o if a.HO_only else self._lookup(self.user_emb_matrix, user32)
+            top = (self.n_mix_hop * self.h_hop) if a.wide_deep else self.h_hop
+            ents, rels = self.get_neighbors(item32, levels=top - 1)
+            item_emb, scores, sig, importance = self.agg_fun(ents, rels, q, user_o, want_probs)
+        del dev
+        return SimpleNamespace(scores=scores, scores_normalized=sig, user_o=user_o,
+                               item_embeddings=item_emb, importance_list=importance)
+
+    # ------------------------------------------------------------------ feed handling
+    def _to_device_ids(self, v, dtype, limit, what):
+        if isinstance(v, torch.Tensor):
+            t = v
+            if not t.is_cuda:
+                t = t.to(self.device)
+            return t.to(dtype).contiguous()
+        arr = np.asarray(v)
+        if arr.size and (arr.min() < 0 or arr.max() >= limit):
+            # the reference's CPU tf.gather raises InvalidArgument on out-of-range ids
+            raise IndexError(f"{what}: id out of range [0, {limit})")
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.device).to(dtype).contiguous()
+
+    def _feed(self, feed_dict):
+        n_lists = max(1, self.p_hop)
+        user = self._to_device_ids(feed_dict[self.user_indices], torch.int64, self.n_user, "user_indices")
+        item = self._to_device_ids(feed_dict[self.item_indices], torch.int64, self.n_entity, "item_indices")
+        mh = [self._to_device_ids(feed_dict[self.memories_h[i]], torch.int32, self.n_entity, "memories_h")
+              for i in range(n_lists)]
+        mr = [self._to_device_ids(feed_dict[self.memories_r[i]], torch.int32, self.n_relation, "memories_r")
+              for i in range(n_lists)]
+        mt = [self._to_device_ids(feed_dict[self.memories_t[i]], torch.int32, self.n_entity, "memories_t")
+              for i in range(n_lists)]
+        return user, item, mh, mr, mt
+
+    # ------------------------------------------------------------------ run wrappers
+    def train(self, sess, feed_dict):
+        """model.py:416-417.  Needs the backward path + Adam."""
+        raise NotImplementedError("MVIN.train: backward/Adam for the HIP path is not built yet "
+                                  "(scope row f-2); there is deliberately no autograd/CPU fallback")
+
+    def get_scores(self, sess, feed_dict):
+        """model.py:443-444."""
+        user, item, mh, mr, mt = self._feed(feed_dict)
+        out = self.forward_device(user, item, mh, mr, mt)
+        return item.cpu().numpy(), out.scores_normalized.cpu().numpy()
+
+    def eval(self, sess, feed_dict):
+        """model.py:419-426."""
+        from sklearn.metrics import f1_score, roc_auc_score
+        user, item, mh, mr, mt = self._feed(feed_dict)
+        labels = np.asarray(feed_dict[self.labels], dtype=np.float32)
+        scores = self.forward_device(user, item, mh, mr, mt).scores_normalized.cpu().numpy()
+        auc = roc_auc_score(y_true=labels, y_score=scores)
+        scores[scores >= 0.5] = 1
+        scores[scores < 0.5] = 0
+        f1 = f1_score(y_true=labels, y_pred=scores)
+        acc = np.mean(np.equal(scores, labels))
+        return auc, acc, f1
+
+    def eval_case_study(self, sess, feed_dict):
+        """model.py:428-441: ids of every level plus the attention weights of the i=0 pass."""
+        user, item, mh, mr, mt = self._feed(feed_dict)
+        out = self.forward_device(user, item, mh, mr, mt, want_probs=True)
+        L = self.n_mix_hop * self.h_hop
+        ents, rels = self.get_neighbors(item.to(torch.int32), levels=L)
+        imp = out.importance_list
+        imp0 = imp[0].cpu().numpy() if imp and imp[0] is not None else None
+        imp1 = imp[1].cpu().numpy() if len(imp) > 1 and imp[1] is not None else 0
+        return (user.cpu().numpy(), np.asarray(feed_dict[self.labels]), item.cpu().numpy(),
+                [e.cpu().numpy().astype(np.int64) for e in ents],
+                [r.cpu().numpy().astype(np.int64) for r in rels], imp0, imp1)

@@ -1,0 +1,182 @@
+"""Torch-tensor front end of the C ABI (include/mvin_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; all arithmetic of the
+path runs in libmvin_hip.so.  Every op requires CUDA(ROCm) tensors and raises otherwise --
+there is no CPU / eager fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+I32 = torch.int32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MvinHipError(f"{name}: expected a CUDA/ROCm tensor (mvin_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t, offset_elems=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + offset_elems * t.element_size())
+
+
+def ent_level_offsets(B, K, levels):
+    """Element offsets of entity levels 0..levels and relation levels 0..levels-1 in the
+    flat buffers written by mvin_expand_ids (see include/mvin_hip.h)."""
+    ent, rel, off_e, off_r, n = [], [], 0, 0, B
+    for e in range(levels + 1):
+        ent.append((off_e, n))
+        off_e += n
+        if e < levels:
+            n *= K
+            rel.append((off_r, n))
+            off_r += n
+    return ent, rel
+
+
+def expand_ids(adj_entity, adj_relation, items, K, levels, n_entity):
+    """MVIN.get_neighbors (model.py:243-256).  Returns (entities, relations): lists of int32
+    tensors [B, K^e] (e = 0..levels) and [B, K^(e+1)] (e = 0..levels-1), views of two flat
+    buffers."""
+    lib = _lib.load()
+    _chk(adj_entity, I32, "adj_entity")
+    _chk(adj_relation, I32, "adj_relation")
+    if items.dtype == torch.int64:
+        i64, i32 = _chk(items, torch.int64, "items"), None
+    else:
+        i64, i32 = None, _chk(items, I32, "items")
+    B = items.shape[0]
+    ent_flat = torch.empty(lib.mvin_ent_elems(B, K, levels), dtype=I32, device=items.device)
+    rel_flat = torch.empty(max(1, lib.mvin_rel_elems(B, K, levels)), dtype=I32, device=items.device)
+    _lib.check(lib.mvin_expand_ids(_p(adj_entity), _p(adj_relation), _p(i64), _p(i32), B, K, levels,
+                                   n_entity, _p(ent_flat), _p(rel_flat), _stream()), "mvin_expand_ids")
+    eo, ro = ent_level_offsets(B, K, levels)
+    ents = [ent_flat[o:o + n].view(B, -1) for o, n in eo]
+    rels = [rel_flat[o:o + n].view(B, -1) for o, n in ro]
+    return ents, rels
+
+
+def rel_score(relation_emb, urh_weights):
+    """t[r] = relation_emb[r] . urh_weights[D:2D]  (aggregators.py:130-133, k-dependent term)."""
+    lib = _lib.load()
+    _chk(relation_emb, F32, "relation_emb")
+    _chk(urh_weights, F32, "urh_weights")
+    nR, D = relation_emb.shape
+    t = torch.empty(nR, dtype=F32, device=relation_emb.device)
+    _lib.check(lib.mvin_rel_score(_p(relation_emb), _p(urh_weights), nR, D, _p(t), _stream()),
+               "mvin_rel_score")
+    return t
+
+
+def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1, relu=False,
+           rows=None, out=None, out_offset=0, ldo=None, nz=1, w_zstride=0, bias_zstride=0,
+           out_zstride=0, score_u=None):
+    """mvin_linear_fwd: out[z][r] = act(concat_s X_s[r] . W[z] + bias[z] + rowbias[r // rpg]).
+    ``srcs``: list of [*, Dsrc] fp32 tensors; ``ids``: matching list of int32 row-id tensors
+    or None.  Returns out, or (out, score, sigmoid) when ``score_u`` is given."""
+    lib = _lib.load()
+    a = _lib.LinearArgs()
+    nsrc = len(srcs)
+    ids = ids or [None] * nsrc
+    Dsrc = srcs[0].shape[-1]
+    for s in range(nsrc):
+        _chk(srcs[s], F32, f"src[{s}]")
+        if srcs[s].shape[-1] != Dsrc:
+            raise ValueError("all sources must share the row width")
+        a.src[s] = srcs[s].data_ptr()
+        if ids[s] is not None:
+            _chk(ids[s], I32, f"ids[{s}]")
+            a.ids[s] = ids[s].data_ptr()
+    if rows is None:
+        rows = ids[0].numel() if ids[0] is not None else srcs[0].numel() // Dsrc
+    dev = srcs[0].device
+    if out is None:
+        ldo = ldo or Dout
+        out = torch.empty((nz, rows, Dout) if nz > 1 else (rows, Dout), dtype=F32, device=dev)
+        if nz > 1 and out_zstride == 0:
+            out_zstride = rows * Dout
+    else:
+        _chk(out, F32, "out")
+        ldo = ldo or Dout
+    a.nsrc, a.Dsrc, a.Dout, a.rows = nsrc, Dsrc, Dout, rows
+    a.W = _chk(W, F32, "W").data_ptr() if W is not None else None
+    a.bias = _chk(bias, F32, "bias").data_ptr() if bias is not None else None
+    a.rowbias = _chk(rowbias, F32, "rowbias").data_ptr() if rowbias is not None else None
+    a.rows_per_group = rows_per_group
+    a.relu = 1 if relu else 0
+    a.out = out.data_ptr() + out_offset * 4
+    a.ldo = ldo
+    a.nz, a.w_zstride, a.bias_zstride, a.out_zstride = nz, w_zstride, bias_zstride, out_zstride
+    score = sig = None
+    if score_u is not None:
+        _chk(score_u, F32, "score_u")
+        score = torch.empty(rows, dtype=F32, device=dev)
+        sig = torch.empty(rows, dtype=F32, device=dev)
+        a.score_u, a.score_out, a.sigmoid_out = score_u.data_ptr(), score.data_ptr(), sig.data_ptr()
+    _lib.check(lib.mvin_linear_fwd(C.byref(a), _stream()), "mvin_linear_fwd")
+    return (out, score, sig) if score_u is not None else out
+
+
+def gather_attn(table, adj_entity, adj_relation, node_ids, rel_score_t, self_vec, Wc, c_child,
+                Wagg, bagg, B, N, K, D, want_probs=False):
+    """mvin_gather_attn_fwd: deepest hop, children gathered from ``table`` through the
+    adjacency of ``node_ids`` [B*N]; returns (out [B,N,D], probs [B,N,K] or None)."""
+    lib = _lib.load()
+    for t, dt, nm in ((table, F32, "table"), (adj_entity, I32, "adj_entity"),
+                      (adj_relation, I32, "adj_relation"), (node_ids, I32, "node_ids"),
+                      (rel_score_t, F32, "rel_score"), (self_vec, F32, "self_vec"), (Wc, F32, "Wc"),
+                      (c_child, F32, "c_child"), (Wagg, F32, "Wagg"), (bagg, F32, "bagg")):
+        _chk(t, dt, nm)
+    out = torch.empty((B, N, D), dtype=F32, device=table.device)
+    probs = torch.empty((B, N, K), dtype=F32, device=table.device) if want_probs else None
+    _lib.check(lib.mvin_gather_attn_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids),
+                                        _p(rel_score_t), _p(self_vec), _p(Wc), _p(c_child), _p(Wagg),
+                                        _p(bagg), B, N, K, D, table.shape[0], _p(out), _p(probs),
+                                        _stream()), "mvin_gather_attn_fwd")
+    return out, probs
+
+
+def agg(self_vec, neigh, rel_ids, rel_score_t, Wagg, bagg, B, N, K, D, want_probs=False):
+    """mvin_agg_fwd on materialised levels; ``rel_ids`` None with ``rel_score_t`` given means
+    ``rel_score_t`` already holds one logit per child ([B*N*K])."""
+    lib = _lib.load()
+    for t, dt, nm in ((self_vec, F32, "self_vec"), (neigh, F32, "neigh"), (rel_ids, I32, "rel_ids"),
+                      (rel_score_t, F32, "rel_score"), (Wagg, F32, "Wagg"), (bagg, F32, "bagg")):
+        _chk(t, dt, nm)
+    out = torch.empty((B, N, D), dtype=F32, device=self_vec.device)
+    probs = torch.empty((B, N, K), dtype=F32, device=self_vec.device) if want_probs else None
+    _lib.check(lib.mvin_agg_fwd(_p(self_vec), _p(neigh), _p(rel_ids), _p(rel_score_t), _p(Wagg),
+                                _p(bagg), B, N, K, D, _p(out), _p(probs), _stream()), "mvin_agg_fwd")
+    return out, probs
+
+
+def ripple_attn(entity_emb, score_ids, rel_ids, value_ids, V, w, mode, out, out_offset, ldo, nR):
+    """mvin_ripple_attn_fwd: one ripple-set attention read per pair, written into
+    ``out`` (a [B, ldo] buffer) at column offset ``out_offset``."""
+    lib = _lib.load()
+    for t, dt, nm in ((entity_emb, F32, "entity_emb"), (score_ids, I32, "score_ids"),
+                      (rel_ids, I32, "rel_ids"), (value_ids, I32, "value_ids"), (V, F32, "V"),
+                      (w, F32, "w"), (out, F32, "out")):
+        _chk(t, dt, nm)
+    B, Nm = score_ids.shape
+    D = entity_emb.shape[1]
+    _lib.check(lib.mvin_ripple_attn_fwd(_p(entity_emb), _p(score_ids), _p(rel_ids), _p(value_ids),
+                                        _p(V), _p(w), mode, B, Nm, D, nR, _p(out, out_offset), ldo,
+                                        _stream()), "mvin_ripple_attn_fwd")
+    return out

@@ -1,0 +1,39 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on seeded small cases."""
+import itertools
+
+import pytest
+
+from mvin_amd import synth
+from mvin_amd.config import ABLATIONS, make_args
+
+from parity import check_case
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # dim, K, H, M, P, Nm, B
+    dict(dim=8, neighbor_sample_size=3, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=4),
+    dict(dim=8, neighbor_sample_size=3, h_hop=2, n_mix_hop=2, p_hop=1, n_memory=4, batch_size=4),
+    dict(dim=16, neighbor_sample_size=8, h_hop=1, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=37),
+    dict(dim=16, neighbor_sample_size=8, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=33),
+    dict(dim=32, neighbor_sample_size=16, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=19),
+    dict(dim=64, neighbor_sample_size=32, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=9),
+    dict(dim=8, neighbor_sample_size=2, h_hop=3, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=5),
+    dict(dim=12, neighbor_sample_size=5, h_hop=1, n_mix_hop=2, p_hop=2, n_memory=7, batch_size=6),
+    dict(dim=128, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "D{dim}K{neighbor_sample_size}H{h_hop}M{n_mix_hop}".format(**s))
+def test_default_ablation(shape, hip_lib):
+    args = make_args(**shape)
+    case = synth.small_case(args, n_user=16, n_entity=200, n_relation=7, seed=11, zero_rows=5)
+    check_case(args, case, seed=3)
+
+
+@pytest.mark.parametrize("ablation", sorted(ABLATIONS))
+def test_every_ablation(ablation, hip_lib):
+    for shape in SHAPES[:2]:
+        args = make_args(ablation=ablation, **shape)
+        case = synth.small_case(args, seed=5)
+        check_case(args, case, seed=7)
