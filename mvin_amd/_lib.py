@@ -81,6 +81,14 @@ def load():
         raise MvinHipError(
             f"{path} is missing: build it with `python -m mvin_amd.build` (hipcc, gfx950). "
             "mvin_amd has no CPU fallback.")
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+    # It must be in the process BEFORE this library is opened so that our DT_NEEDED
+    # libamdhip64.so.7 resolves to the same runtime instance (streams and device pointers
+    # are shared with torch); otherwise /opt/rocm's copy is loaded as a second runtime.
+    import torch  # noqa: F401
+    hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip_rt):
+        C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
