@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the MVIN scoring hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the scoring path (MVIN.get_scores semantics: key addressing ->
+id expansion -> projection -> K-hop attention aggregation -> mix-hop combiner -> score)
+over one batch of synthetic (user, item, ripple-set) inputs already resident in HBM.
+Default workload = BASELINE.json's metric config C3: last-fm_50core-shaped tables,
+dim=64, hop=2 (n_mix_hop=1), fan-out=32, fp32.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field):
+  value     = pairs scored per second, whole job (all ranks), max-over-ranks time
+  roofline  = gather+attention kernel (mvin_gather_attn_fwd): algorithmic bytes per launch
+              (SURVEY.md 8(d) bytes(pair) x pairs per launch) / mean launch duration measured
+              with HIP events on the launch stream inside the timed steps
+  cpu_baseline = oracle/mirror_fp32.py (TF-graph-equivalent torch-CPU restatement) timed on
+              this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_pair(D, K, L, s=4):
+    """T*D*s + (T-K^L)*K*2*4 + D*s + 4, T = sum_{e<=L} K^e."""
+    T = sum(K ** e for e in range(L + 1))
+    return T * D * s + (T - K ** L) * K * 2 * 4 + D * s + 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dataset", default="last-fm_50core")
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--hop", type=int, default=2)
+    ap.add_argument("--mix", type=int, default=1)
+    ap.add_argument("--fanout", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=16384, help="pairs per GPU per step")
+    ap.add_argument("--adj", choices=["kg", "uniform"], default="kg")
+    ap.add_argument("--items", choices=["zipf", "uniform"], default="zipf")
+    ap.add_argument("--cpu-batch", type=int, default=128)
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, margs, case, params):
+    """Time the op-by-op torch-CPU mirror of the TF graph on a bounded sample."""
+    import torch
+    from oracle import mirror_fp32
+    from mvin_amd.config import make_args
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bc = min(args.cpu_batch, len(case.users))
+    cargs = make_args(**dict(vars(margs), batch_size=Bc))
+    pt = mirror_fp32.as_torch_params(params)
+    sl = slice(0, Bc)
+    feed = (case.users[sl], case.items[sl], [m[sl] for m in case.memories_h],
+            [m[sl] for m in case.memories_r], [m[sl] for m in case.memories_t])
+    mirror_fp32.forward(cargs, pt, case.adj_entity, case.adj_relation, *feed)  # warm-up
+    times = []
+    for _ in range(args.cpu_iters):
+        t0 = time.perf_counter()
+        ref = mirror_fp32.forward(cargs, pt, case.adj_entity, case.adj_relation, *feed)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": Bc / med, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_iters} timed passes (median) of {Bc} pairs of the same workload, "
+                      f"torch-CPU fp32 op-by-op mirror of the TF graph (oracle/mirror_fp32.py)"}, ref, Bc
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from mvin_amd import synth
+    from mvin_amd.config import make_args
+    from mvin_amd.model import MVIN
+    from mvin_amd.params import init_params
+
+    d = synth.DATASETS[a.dataset]
+    margs = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop,
+                      n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=a.batch)
+    # every rank scores its own batch of pairs (pairs are independent: no data-path collective);
+    # tables are replicated; seeds differ per rank so the ranks do not share a batch
+    case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch, seed=a.seed + 17 * rank,
+                              zipf=(a.items == "zipf"), uniform_adj=(a.adj == "uniform"))
+    if rank != 0:  # same KG / tables on every rank; only the pairs differ
+        base = synth.dataset_case(a.dataset, K=a.fanout, B=1, seed=a.seed, uniform_adj=(a.adj == "uniform"))
+        case.adj_entity, case.adj_relation = base.adj_entity, base.adj_relation
+    params = init_params(margs, case.n_user, case.n_entity, case.n_relation, seed=a.seed)
+    model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                 params=params, device=dev)
+    users = torch.from_numpy(case.users).to(dev)
+    items = torch.from_numpy(case.items).to(dev)
+    mh = [torch.from_numpy(m).to(dev) for m in case.memories_h]
+    mr = [torch.from_numpy(m).to(dev) for m in case.memories_r]
+    mt = [torch.from_numpy(m).to(dev) for m in case.memories_t]
+
+    def step():
+        return model.forward_device(users, items, mh, mr, mt)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    barrier()
+    model._profile = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = model._profile
+    model._profile = None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        L = a.hop * a.mix
+        bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L)
+        kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
+        kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
+        achieved = (bpp * a.batch / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
+        value = world * a.batch * a.steps / elapsed
+        rec = {
+            "metric": "(user,item) pairs scored/sec @ dim=%d hop=%d fan-out=%d; %% HBM roofline"
+                      % (a.dim, a.hop, a.fanout),
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.dataset}-shaped tables (nE={case.n_entity}, nU={case.n_user}, "
+                                   f"nR={case.n_relation}), dim={a.dim} hop={a.hop} n_mix_hop={a.mix} "
+                                   f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
+                                   f"full get_scores path",
+                       "pairs_per_gpu_per_step": a.batch, "adjacency": a.adj, "items": a.items,
+                       "parallelism": f"pairs-dp{world}-replicated-tables" if world > 1 else "single-gpu"},
+            "roofline": {"bound": "hbm", "kernel": "gather_attn_kernel (mvin_gather_attn_fwd)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "bytes_per_pair": bpp, "pairs_per_launch": a.batch,
+                         "avg_launch_ms": kern_avg_ms,
+                         "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cb, ref, Bc = cpu_baseline(a, margs, case, params)
+            rec["cpu_baseline"] = cb
+            got = out.scores[:Bc].cpu().numpy()
+            err = np.abs(got - ref.scores.numpy())
+            rec["parity_vs_cpu_sample"] = {"max_abs_err": float(err.max()),
+                                           "within_1e-5rel_1e-6abs": bool((err <= 1e-5 * np.abs(ref.scores.numpy()) + 1e-6).all())}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
