@@ -1,0 +1,72 @@
+"""CPU: libmvin_hip.so builds, loads and exports every symbol include/mvin_hip.h declares;
+argument validation returns error codes before anything touches a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mvin_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mvin_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    fns = header_functions()
+    for name in ("mvin_expand_ids", "mvin_gather_attn_fwd", "mvin_agg_fwd", "mvin_linear_fwd",
+                 "mvin_ripple_attn_fwd", "mvin_rel_score", "mvin_last_error", "mvin_abi_version"):
+        assert name in fns
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from mvin_amd import _lib
+    for name in header_functions():
+        assert hasattr(hip_lib, name), f"{name} declared in include/mvin_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in mvin_amd/_lib.py"
+    assert hip_lib.mvin_abi_version() == 1
+
+
+def test_single_hip_runtime_in_process(hip_lib):
+    with open("/proc/self/maps") as f:
+        rts = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
+    assert len(rts) == 1, rts
+
+
+def test_id_buffer_sizes(hip_lib):
+    # entities: B*(1+K+K^2), relations: B*(K+K^2)
+    assert hip_lib.mvin_ent_elems(3, 4, 2) == 3 * (1 + 4 + 16)
+    assert hip_lib.mvin_rel_elems(3, 4, 2) == 3 * (4 + 16)
+    assert hip_lib.mvin_rel_elems(3, 4, 0) == 0
+
+
+def test_argument_errors_are_reported_not_thrown(hip_lib):
+    from mvin_amd import _lib
+    rc = hip_lib.mvin_rel_score(None, None, 4, 8, None, None)
+    assert rc == -1 and b"null" in hip_lib.mvin_last_error()
+    rc = hip_lib.mvin_expand_ids(None, None, None, None, 4, 3, 1, 10, None, None, None)
+    assert rc < 0
+    a = _lib.LinearArgs()
+    a.nsrc, a.Dsrc, a.Dout = 1, 6, 8  # Dsrc not a multiple of 4
+    assert hip_lib.mvin_linear_fwd(C.byref(a), None) == -2
+    assert b"Dsrc" in hip_lib.mvin_last_error()
+    a.nsrc, a.Dsrc, a.Dout = 9, 8, 8
+    assert hip_lib.mvin_linear_fwd(C.byref(a), None) == -2
+    # D not a multiple of 4 / out of range
+    one = C.c_void_p(16)
+    rc = hip_lib.mvin_agg_fwd(one, one, None, None, one, None, 2, 2, 2, 6, one, None, None)
+    assert rc == -2 and b"D=6" in hip_lib.mvin_last_error()
+    rc = hip_lib.mvin_ripple_attn_fwd(one, one, None, one, None, None, 0, 1, 4, 8, 3, one, 8, None)
+    assert rc == -1  # mode 0 without V / rel_ids
+    with pytest.raises(_lib.MvinHipError):
+        _lib.check(rc, "mvin_ripple_attn_fwd")
+
+
+def test_ops_refuse_cpu_tensors(hip_lib):
+    import torch
+    from mvin_amd import _lib, ops
+    with pytest.raises(_lib.MvinHipError):
+        ops.rel_score(torch.zeros(3, 8), torch.zeros(24, 1))

@@ -1,0 +1,135 @@
+"""-m gpu: the reference's call surface (MVIN run wrappers, Aggregator.__call__) on the HIP path."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import synth
+from mvin_amd.config import make_args
+from mvin_amd.params import init_params
+from oracle import mirror_fp32
+
+from parity import assert_close, run_oracles
+
+pytestmark = pytest.mark.gpu
+
+
+def build(**kw):
+    from mvin_amd.model import MVIN
+    d = dict(dim=16, neighbor_sample_size=8, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=8, batch_size=24)
+    d.update(kw)
+    args = make_args(**d)
+    case = synth.small_case(args, n_user=20, n_entity=300, n_relation=6, seed=31, zero_rows=4)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=32, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                 params=params, device="cuda:0")
+    return args, case, params, model
+
+
+def feed_of(model, case, labels=None):
+    B = len(case.users)
+    feed = {model.user_indices: case.users, model.item_indices: case.items,
+            model.labels: labels if labels is not None else np.ones(B, np.float32)}
+    for i in range(len(case.memories_h)):
+        # train.py:117-120 feeds python lists of per-user numpy rows
+        feed[model.memories_h[i]] = [row for row in case.memories_h[i]]
+        feed[model.memories_r[i]] = [row for row in case.memories_r[i]]
+        feed[model.memories_t[i]] = [row for row in case.memories_t[i]]
+    return feed
+
+
+def test_get_scores_and_eval(hip_lib):
+    args, case, params, model = build()
+    m, _ = run_oracles(args, case, params)
+    labels = (np.arange(len(case.users)) % 2).astype(np.float32)
+    feed = feed_of(model, case, labels)
+    items, scores = model.get_scores(None, feed)
+    assert items.dtype == np.int64 and scores.dtype == np.float32
+    np.testing.assert_array_equal(items, case.items)
+    assert_close(scores, m.scores_normalized.numpy(), "get_scores")
+    auc, acc, f1 = model.eval(None, feed)
+    from sklearn.metrics import f1_score, roc_auc_score
+    ref = m.scores_normalized.numpy()
+    assert abs(auc - roc_auc_score(labels, ref)) < 1e-6
+    pred = (ref >= 0.5).astype(np.float32)
+    assert abs(acc - np.mean(pred == labels)) < 1e-6 and abs(f1 - f1_score(labels, pred)) < 1e-6
+
+
+def test_eval_case_study(hip_lib):
+    args, case, params, model = build()
+    m, _ = run_oracles(args, case, params)
+    u, lab, it, ents, rels, imp0, imp1 = model.eval_case_study(None, feed_of(model, case))
+    np.testing.assert_array_equal(u, case.users)
+    assert len(ents) == 3 and len(rels) == 2
+    for a, b in zip(ents, m.entities):
+        np.testing.assert_array_equal(a, b.numpy())
+    for a, b in zip(rels, m.relations):
+        np.testing.assert_array_equal(a, b.numpy())
+    K = args.neighbor_sample_size
+    assert imp0.shape == (len(u), 1, K) and imp1.shape == (len(u), K, K)
+    assert_close(imp0, m.importance_list[0].numpy(), "importance_list_0")
+    assert_close(imp1, m.importance_list[1].numpy(), "importance_list_1")
+
+
+def test_any_batch_length_and_train_not_built(hip_lib):
+    args, case, params, model = build()
+    sub = slice(0, 7)  # != args.batch_size: the reference's static reshapes would reject this
+    feed = {model.user_indices: case.users[sub], model.item_indices: case.items[sub], model.labels: np.ones(7)}
+    for i in range(len(case.memories_h)):
+        feed[model.memories_h[i]], feed[model.memories_r[i]], feed[model.memories_t[i]] = \
+            case.memories_h[i][sub], case.memories_r[i][sub], case.memories_t[i][sub]
+    _, s = model.get_scores(None, feed)
+    m, _ = run_oracles(args, case, params)
+    assert_close(s, m.scores_normalized.numpy()[sub], "ragged batch")
+    with pytest.raises(NotImplementedError):
+        model.train(None, feed)
+
+
+def test_out_of_range_ids_raise_like_tf_gather(hip_lib):
+    args, case, params, model = build()
+    feed = feed_of(model, case)
+    bad = case.items.copy()
+    bad[3] = case.n_entity
+    feed[model.item_indices] = bad
+    with pytest.raises(IndexError):
+        model.get_scores(None, feed)
+
+
+def test_stage_wise_tables_roundtrip(hip_lib, tmp_path):
+    from types import SimpleNamespace
+    args, case, params, model = build()
+    model.path = SimpleNamespace(emb=str(tmp_path) + "/")
+    model.save_pretrain_emb_fuc(None, None)
+    before = model.entity_emb_matrix.clone()
+    model.entity_emb_matrix.zero_()
+    model.restore_pretrain_emb()
+    assert torch.equal(before, model.entity_emb_matrix)
+
+
+@pytest.mark.parametrize("rela", [True, False])
+def test_aggregator_call_surface(rela, hip_lib):
+    from mvin_amd.aggregators import SumAggregator_urh_matrix
+    B, N, K, D, nR = 5, 7, 6, 16, 4
+    g = torch.Generator().manual_seed(3)
+    selfv, neigh = torch.randn(B, N, D, generator=g), torch.randn(B, N, K, D, generator=g)
+    rel_emb = torch.randn(nR, D, generator=g)
+    rel_ids = torch.randint(0, nR, (B, N, K), generator=g)
+    user = torch.randn(B, D, generator=g)
+    agg = SumAggregator_urh_matrix("m", B, D, name="0_0", User_orient_rela=rela, device="cuda:0", seed=5)
+    agg.bias.copy_(torch.randn(D, generator=g))
+    assert agg.name == "sumaggregator_urh_matrix_m_0_0"
+    ref_out, ref_p = mirror_fp32.aggregator_call(
+        {"weights": agg.weights.cpu(), "bias": agg.bias.cpu(), "urh_weights": agg.urh_weights.cpu(),
+         "User_orient_rela": rela}, selfv, neigh, rel_emb[rel_ids], user, B, D)
+    dev = "cuda:0"
+    # (a) the reference form: relation VECTORS
+    out, p = agg(selfv.to(dev), neigh.to(dev), rel_emb[rel_ids].to(dev), user.to(dev), None)
+    assert_close(out.cpu().numpy(), ref_out.numpy(), "aggregator out (vectors)")
+    # (b) relation IDS + bound table
+    agg.bind_relation_table(rel_emb.to(dev).contiguous())
+    out2, p2 = agg(selfv.to(dev), neigh.to(dev), rel_ids.to(dev), user.to(dev), None)
+    assert_close(out2.cpu().numpy(), ref_out.numpy(), "aggregator out (ids)")
+    if rela:
+        assert_close(p.cpu().numpy(), ref_p.numpy(), "probs (vectors)")
+        assert_close(p2.cpu().numpy(), ref_p.numpy(), "probs (ids)")
+    else:
+        assert p is None and p2 is None and ref_p is None

@@ -1,0 +1,99 @@
+"""CPU: host-side logic -- flags/ablations, parameter set, synthetic inputs, id layout."""
+import numpy as np
+import pytest
+
+from mvin_amd import synth
+from mvin_amd.config import ABLATIONS, make_args, tree_depth
+from mvin_amd.ops import ent_level_offsets
+from mvin_amd.params import aggregator_keys, init_params, xavier_uniform
+
+
+def test_parser_defaults_match_reference():
+    a = make_args()
+    # parser.py:8-57 defaults
+    assert (a.dim, a.neighbor_sample_size, a.h_hop, a.n_mix_hop, a.p_hop, a.n_memory, a.batch_size) == \
+        (8, 8, 3, 2, 1, 16, 512)
+    assert a.User_orient is True and a.wide_deep is True and a.PS_only is False
+    assert tree_depth(a) == 6
+
+
+def test_ablation_presets_match_reference_table():
+    # parameter_ablation.py:4-165 (SW, UO, UOR, UO_kg_eh, PS_O_ft, wide_deep, PS_only, HO_only)
+    assert ABLATIONS["all"] == (1, 1, 1, 1, 1, 1, 0, 0)
+    assert ABLATIONS["ho_only"] == (1, 1, 1, 0, 1, 1, 0, 1)
+    assert ABLATIONS["no_wd_ho_only"] == (1, 1, 1, 0, 1, 0, 0, 1)
+    assert ABLATIONS["no_uor_and_no_kg_eh_uo"] == (1, 1, 0, 0, 1, 1, 0, 0)
+    assert len(ABLATIONS) == 18
+    a = make_args(ablation="ps_only")
+    assert a.PS_only is True and a.HO_only is False
+    a = make_args(ablation="all", User_orient_rela=0)  # explicit switch wins
+    assert a.User_orient_rela is False
+
+
+def test_parameter_shapes_and_init():
+    a = make_args(dim=16, h_hop=2, n_mix_hop=2, p_hop=2)
+    p = init_params(a, 7, 50, 5, seed=0)
+    assert p["relation_emb_KGE_matrix"].shape == (5, 16, 16)
+    assert p["enti_transfer_matrix_1"].shape == (48, 16)
+    assert p["user_mlp_matrix"].shape == (48, 16)          # PS_O_ft: (P+1)*D rows (model.py:101)
+    assert "transfer_matrix_4" in p and "transfer_matrix_5" not in p
+    assert aggregator_keys(a) == [(0, 0), (1, 0), (0, 1), (1, 1)]
+    assert p["agg_1_1_urh_weights"].shape == (48, 1) and not p["agg_0_0_bias"].any()
+    a2 = make_args(dim=16, h_hop=2, n_mix_hop=2, p_hop=2, ablation="no_ps_o_ft")
+    assert init_params(a2, 7, 50, 5)["user_mlp_matrix"].shape == (32, 16)
+    assert aggregator_keys(make_args(ablation="no_wd", h_hop=3)) == [(0, 0), (1, 0), (2, 0)]
+    # xavier limit sqrt(6/(fan_in+fan_out)); 3-D fans as TF computes them
+    w = xavier_uniform(np.random.default_rng(0), (5, 16, 16))
+    assert np.abs(w).max() <= np.sqrt(6.0 / (16 * 5 + 16 * 5)) + 1e-7
+    with pytest.raises(ValueError):
+        init_params(make_args(p_hop=0, ablation="no_ps_o_ft"), 4, 10, 3)
+
+
+def test_level_offsets():
+    ent, rel = ent_level_offsets(B=3, K=4, levels=2)
+    assert ent == [(0, 3), (3, 12), (15, 48)]
+    assert rel == [(0, 12), (12, 48)]
+
+
+def test_sampler_rule_matches_reference():
+    # data_loader_user_set.py:375-388
+    kg = synth.synth_kg(500, 5, 6.0, seed=3)
+    indptr, dst, rel = synth.kg_to_csr(kg, 500)
+    K = 4
+    ae, ar = synth.sample_adjacency(indptr, dst, rel, K, seed=4)
+    deg = np.diff(indptr)
+    assert ae.shape == (500, K) and ae.dtype == np.int64
+    for x in range(500):
+        edges = list(zip(dst[indptr[x]:indptr[x + 1]], rel[indptr[x]:indptr[x + 1]]))
+        got = list(zip(ae[x], ar[x]))
+        if deg[x] == 0:
+            assert got == [(0, 0)] * K          # absent entity keeps the zero row
+        elif deg[x] >= K:
+            # without replacement: a sub-multiset of the edge list
+            pool = list(edges)
+            for g in got:
+                assert g in pool
+                pool.remove(g)
+        else:
+            assert set(got) <= set(edges)       # with replacement
+    # undirected: every triple appears under head and tail (construct_kg :324-343)
+    assert deg.sum() == 2 * len(kg)
+
+
+def test_dataset_case_shapes():
+    c = synth.dataset_case("amazon-book_20core", K=8, B=64, seed=1)
+    assert c.adj_entity.shape == (113487, 8) and c.n_relation == 39
+    assert len(c.memories_h) == 1 and c.memories_h[0].shape == (64, 16) and c.memories_h[0].dtype == np.int32
+    assert c.items.max() < 24915 and c.users.max() < 70585
+    mh, mr, mt = synth.memories_for(c.user_triplet_set, c.users[:5])
+    np.testing.assert_array_equal(mh[0], c.user_triplet_set[c.users[:5], 0, 0])
+    np.testing.assert_array_equal(mt[0], c.user_triplet_set[c.users[:5], 0, 2])
+
+
+def test_bench_algorithmic_bytes_match_survey():
+    import bench
+    assert bench.algorithmic_bytes_per_pair(16, 8, 1) == 708
+    assert bench.algorithmic_bytes_per_pair(32, 16, 2) == 37252
+    assert bench.algorithmic_bytes_per_pair(64, 32, 2) == 279300
+    assert bench.algorithmic_bytes_per_pair(64, 64, 2) == 1098756
+    assert bench.algorithmic_bytes_per_pair(128, 128, 3, s=2) == 558007812
