@@ -68,6 +68,9 @@ int mvin_rel_score(const float* relation_emb, const float* urh_weights, int nR, 
  * (NULL = identity copy; needs nsrc==1, Dsrc==Dout).  nz batches share the sources and
  * step W/bias/out by the given element strides.  Optional fused scoring epilogue
  * (model.py:158-159): score[r] = sum_j out[r,j]*score_u[r,j]; sigmoid[r] = 1/(1+exp(-score)).
+ * sum_sources = 1 feeds (X_0 + X_1 + ...) . W instead: the aggregator epilogue
+ * relu((self + neighbors_agg) . weights + bias) of aggregators.py:108-116 when neighbors_agg
+ * was produced by mvin_gather_attn_l2_fwd.
  * Covers: user-oriented projection (model.py:270-283), mix-hop combiner (:310-315),
  * user MLP (:232-236), the per-relation item projection of _key_addressing (:211-220). */
 typedef struct {
@@ -82,6 +85,7 @@ typedef struct {
     const float* rowbias;      /* [ceil(rows/rows_per_group), Dout] or NULL */
     int rows_per_group;
     int relu;
+    int sum_sources;           /* 1: X = sum_s X_s (Din = Dsrc) instead of the concatenation */
     float* out;
     int64_t ldo;                 /* out row stride in elements (>= Dout) */
     int nz;
@@ -108,6 +112,28 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
                          const float* Wagg, const float* bagg,
                          int B, int N, int K, int D, int n_entity,
                          float* out, float* probs, void* stream);
+
+/* Two deepest levels in one pass (hot kernel; MFMA dense phases).  For every PARENT node
+ * (level L-2; P = B * parents_per_pair of them, entity ids in parent_ids) with children
+ * x1[n] = adj_entity[parent, n] and grandchildren y[n,k] = adj_entity[x1[n], k]:
+ *     p[n,:]  = softmax_k(t0[adj_relation[x1[n], k]])                       (or uniform, t0 NULL)
+ *     self1[n] = table[x1[n]] . W1 + c1[b]                                  (or table[x1[n]], W1 NULL)
+ *     Z[n]    = self1[n] + ((sum_k p[n,k] table[y[n,k]]) . W2 + (sum_k p[n,k]) c2[b]) / K
+ *     out1[n] = relu(Z[n] . A0 + a0)            = aggregator (0,.) at hop L-1  (aggregators.py:98-146)
+ *     p0 = softmax_n(t0[adj_relation[parent, n]]), p1 = softmax_n(t1[adj_relation[parent, n]])
+ *     nagg0[parent] = (1/K) sum_n p0[n] self1[n]   -> neighbors_agg of aggregator (0,.) at hop L-2
+ *     nagg1[parent] = (1/K) sum_n p1[n] out1[n]    -> neighbors_agg of aggregator (1,.) at hop L-2
+ * (model.py:295-305 with i = 0 and i = 1).  probs_parent [P,K] = p0 and probs_child [P*K,K] = p are
+ * optional (model.py:294,304).  Returns -3 when (D, K) is outside the fused kernel's range
+ * (D in {16,32,64,128}, K a power of two in [4,256]); callers then use the per-level entry points. */
+int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                            const int32_t* parent_ids, const float* t0, const float* t1,
+                            const float* W1, const float* W2, const float* c1, const float* c2,
+                            const float* A0, const float* a0,
+                            int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                            float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
+                            void* stream);
+int mvin_gather_attn_l2_supported(int D, int K);
 
 /* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
  * other than the deepest hop; aggregators.py:98-152, model.py:295-305):

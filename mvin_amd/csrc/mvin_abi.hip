@@ -82,12 +82,12 @@ int mvin_linear_fwd(const mvin_linear_args* a, void* stream) {
     if (!a->out) return fail(-1, "mvin_linear_fwd: null out");
     for (int s = 0; s < a->nsrc; ++s)
         if (!a->src[s]) return fail(-1, "mvin_linear_fwd: null src[%d]", s);
-    if (!a->W && (a->nsrc != 1 || a->Dsrc != a->Dout))
+    if (!a->W && ((a->nsrc != 1 && !a->sum_sources) || a->Dsrc != a->Dout))
         return fail(-2, "mvin_linear_fwd: identity (W=NULL) needs nsrc==1 and Dsrc==Dout");
     if (a->ldo < a->Dout) return fail(-2, "mvin_linear_fwd: ldo < Dout");
     if (a->rowbias && a->rows_per_group < 1) return fail(-2, "mvin_linear_fwd: rows_per_group < 1");
-    if (a->score_u && a->Dout > a->nsrc * a->Dsrc + 4)
-        return fail(-2, "mvin_linear_fwd: fused score needs Dout <= nsrc*Dsrc + 4");
+    if (a->score_u && a->Dout > (a->sum_sources ? 1 : a->nsrc) * a->Dsrc + 4)
+        return fail(-2, "mvin_linear_fwd: fused score needs Dout <= Din + 4");
     if (a->rows == 0) return 0;
     return hip_result(mvin::launch_linear(*a, (hipStream_t)stream), "mvin_linear_fwd");
 }
@@ -129,6 +129,53 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
     if (probs && !rel_score) return fail(-2, "mvin_gather_attn_fwd: probs requested without rel_score");
     if (int rc = agg_common(g, B, N, K, D, "mvin_gather_attn_fwd")) return rc;
     return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_gather_attn_fwd");
+}
+
+int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supported(D, K) ? 1 : 0; }
+
+int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                            const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
+                            const float* W2, const float* c1, const float* c2, const float* A0,
+                            const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                            float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
+                            void* stream) {
+    const char* who = "mvin_gather_attn_l2_fwd";
+    if (!mvin::fused_l2_supported(D, K))
+        return fail(-3, "%s: unsupported shape D=%d K=%d (D in {16,32,64,128}, K power of two in [4,256])",
+                    who, D, K);
+    if (!table || !adj_entity || !parent_ids || !A0 || !nagg0 || !nagg1) return fail(-1, "%s: null pointer", who);
+    if ((t0 || t1) && !adj_relation) return fail(-1, "%s: attention needs adj_relation", who);
+    if ((W1 == nullptr) != (W2 == nullptr)) return fail(-1, "%s: W1 and W2 must be given together", who);
+    if (W1 && (!c1 || !c2)) return fail(-1, "%s: projection needs c1 and c2", who);
+    if ((probs_parent || probs_child) && !t0) return fail(-2, "%s: probs requested without t0", who);
+    if (B <= 0 || parents_per_pair <= 0 || n_entity <= 0 || nR <= 0 || nR > 4096)
+        return fail(-2, "%s: bad sizes B=%d parents_per_pair=%d n_entity=%d nR=%d", who, B, parents_per_pair,
+                    n_entity, nR);
+    mvin::FusedL2Args f{};
+    f.table = table;
+    f.adj_e = adj_entity;
+    f.adj_r = adj_relation;
+    f.parent_ids = parent_ids;
+    f.t0 = t0;
+    f.t1 = t1;
+    f.W1 = W1;
+    f.W2 = W2;
+    f.c1 = c1;
+    f.c2 = c2;
+    f.A0 = A0;
+    f.a0 = a0;
+    f.nagg0 = nagg0;
+    f.nagg1 = nagg1;
+    f.probs_parent = probs_parent;
+    f.probs_child = probs_child;
+    f.P = (int64_t)B * parents_per_pair;
+    f.parents_per_pair = parents_per_pair;
+    f.K = K;
+    f.nR = nR;
+    int l = 0;
+    while ((4 << l) < K) ++l;
+    f.lpn_log2 = l;
+    return hip_result(mvin::launch_gather_attn_l2(f, D, (hipStream_t)stream), who);
 }
 
 int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,

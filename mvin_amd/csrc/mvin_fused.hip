@@ -1,0 +1,359 @@
+// Fused two-level gather + attention kernel for gfx950 (MI355X) -- the hot kernel.
+//
+// Replaces, for the two deepest levels of the tree at once, the reference's
+//   tf.gather(adj_*) (model.py:251-252) -> embedding_lookup (:267-268) -> user-oriented
+//   projection (:270-283) -> SumAggregator_urh_matrix at hop L-1 (aggregators.py:98-146)
+// and the neighbor mixes of the two aggregator applications that consume those levels at hop
+// L-2 (i = 0: neighbors = projected level-(L-1) rows; i = 1: neighbors = hop-(L-1) outputs).
+//
+// One workgroup owns one PARENT node (a level-(L-2) node; for L = 2 the pair's item itself):
+//   prologue  : parent's adjacency row -> child ids x1[n], attention weights p0 (aggregator
+//               (0,.)) and p1 (aggregator (1,.)) over its K children           (wave 0)
+//   per tile of 32 children:
+//     phase A : each wave gathers the K grandchild rows of its children: adjacency rows as
+//               int4 (K/4 lanes per child), softmax over K by xor-shuffles inside the lane
+//               group, rows as 16-byte loads (D/4 lanes per row, 8 loads in flight per lane),
+//               S' = (1/K) sum_k p_k E[y_k] and the raw child row E[x1] -> LDS tile
+//     phase B : MFMA (v_mfma_f32_16x16x4_f32, weights resident in VGPRs as B fragments):
+//               self1 = E[x1].W1 + c1 ; Z = self1 + S'.W2 + (psum/K) c2 ; Z -> LDS ;
+//               nagg0 += sum_n p0[n] self1[n]   (from the accumulator registers)
+//     phase C : out1 = relu(Z.A0 + a0) (MFMA) ; nagg1 += sum_n p1[n] out1[n]
+//   epilogue  : nagg0/K, nagg1/K -> HBM (2 x D floats per parent).
+// Nothing of size K^L or K^(L-1) is ever written to memory.
+//
+// Supported: D in {16, 32, 64, 128}; K a power of two in [4, 256]; fp32.
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D, int NW>
+struct FusedGeom {
+    static constexpr int NT = D / 16;                   // 16-column MFMA tiles
+    static constexpr int MTW = (NW == NT) ? 2 : 1;      // 16-row MFMA tiles per wave
+    static constexpr int NPW = kTM / NW;                // children per wave per tile
+    static constexpr int LPR = D / 4;                   // lanes per table row (float4 each)
+    static constexpr int RPW = kWave / LPR;             // rows per wave-instruction
+    static constexpr int LDA = 2 * D + 2;               // LDS row stride: conflict-free A-fragment reads
+    static constexpr int LDZ = D + 2;
+    static constexpr int KS = D / 4;                    // MFMA k-steps per DxD matrix
+};
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) {
+    using G = FusedGeom<D, NW>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = a.K;
+    const int ntile = (K + kTM - 1) / kTM;
+    const int Kpad = ntile * kTM;
+    float* sA = smem;                                   // [32][LDA]  {E[x1] raw | S'}
+    float* sZ = sA + kTM * G::LDA;                      // [32][LDZ]
+    float* sP0 = sZ + kTM * G::LDZ;                     // [Kpad]
+    float* sP1 = sP0 + Kpad;                            // [Kpad]
+    float* sN0 = sP1 + Kpad;                            // [D]
+    float* sN1 = sN0 + D;                               // [D]
+    float* sT0 = sN1 + D;                               // [nR]
+    float* sT1 = sT0 + a.nR;                            // [nR]
+    int* sX1 = reinterpret_cast<int*>(sT1 + a.nR);      // [Kpad]
+    int2* sYP = reinterpret_cast<int2*>(sX1 + Kpad + ((Kpad + 2 * a.nR) & 1));  // [NW][NPW][K], 8-B aligned
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int g = lane / G::LPR, c = lane % G::LPR;
+    const int q16 = lane >> 4, l16 = lane & 15;
+    // dense-phase tile ownership
+    const int nt = (NW == G::NT) ? wave : (wave % G::NT);
+    const int mt0 = (NW == G::NT) ? 0 : (wave / G::NT);
+    const bool dense = mt0 < 2;
+    const int col = 16 * nt + l16;
+    const bool has_proj = a.W1 != nullptr;
+    const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
+    const float invK = 1.f / (float)K;
+    const float c2scale = has_att0 ? invK : 1.f;        // (sum_k p_k)/K
+
+    // ---- weights -> B fragments, resident for the whole (persistent) workgroup ----
+    float bW1[G::KS], bW2[G::KS], bA0[G::KS];
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+        const int kk = 4 * s + q16;
+        bW1[s] = (dense && has_proj) ? a.W1[kk * D + col] : 0.f;
+        bW2[s] = (dense && has_proj) ? a.W2[kk * D + col] : 0.f;
+        bA0[s] = dense ? a.A0[kk * D + col] : 0.f;
+    }
+    const float a0v = (dense && a.a0) ? a.a0[col] : 0.f;
+    for (int i = tid; i < a.nR; i += NW * 64) {
+        sT0[i] = has_att0 ? a.t0[i] : 0.f;
+        sT1[i] = has_att1 ? a.t1[i] : 0.f;
+    }
+
+    const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
+    const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
+
+    for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
+        const int64_t b = p / a.parents_per_pair;
+        __syncthreads();  // previous parent fully consumed (sP*, sN*, sX1)
+        // ---------------- prologue: the parent's children and their attention weights ----
+        if (wave == 0) {
+            const int64_t x0 = a.parent_ids[p];
+            float s0[4], s1[4];
+            int xs[4];
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = lane + 64 * i;
+                xs[i] = 0;
+                s0[i] = s1[i] = -INFINITY;
+                if (n < K) {
+                    xs[i] = a.adj_e[x0 * K + n];
+                    int r = 0;
+                    if (has_att0 || has_att1) r = a.adj_r[x0 * K + n];
+                    s0[i] = has_att0 ? sT0[r] : 0.f;
+                    s1[i] = has_att1 ? sT1[r] : 0.f;
+                    m0 = fmaxf(m0, s0[i]);
+                    m1 = fmaxf(m1, s1[i]);
+                }
+            }
+            m0 = wave_max(m0);
+            m1 = wave_max(m1);
+            float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = lane + 64 * i;
+                if (n < K) {
+                    s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
+                    s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
+                    z0 += s0[i];
+                    z1 += s1[i];
+                }
+            }
+            z0 = wave_sum(z0);
+            z1 = wave_sum(z1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = lane + 64 * i;
+                if (n < Kpad) {
+                    const bool in = n < K;
+                    const float p0 = in ? (has_att0 ? s0[i] / z0 : 1.f) : 0.f;
+                    const float p1 = in ? (has_att1 ? s1[i] / z1 : 1.f) : 0.f;
+                    sX1[n] = xs[i];
+                    sP0[n] = p0;
+                    sP1[n] = p1;
+                    if (in && a.probs_parent && has_att0) a.probs_parent[p * K + n] = p0;
+                }
+            }
+        }
+        if (tid < D) {
+            sN0[tid] = 0.f;
+            sN1[tid] = 0.f;
+        }
+        __syncthreads();
+
+        float nacc0 = 0.f, nacc1 = 0.f;
+        const float c1v = (dense && has_proj) ? a.c1[b * D + col] : 0.f;
+        const float c2v = (dense && has_proj) ? a.c2[b * D + col] * c2scale : 0.f;
+
+        for (int tile = 0; tile < ntile; ++tile) {
+            // ---------------- phase A: ids, softmax, row gather ----------------
+            const int node0 = tile * kTM + wave * G::NPW;
+            int2* ypw = sYP + (size_t)wave * G::NPW * K;
+            for (int it = 0; it * npi < G::NPW; ++it) {
+                const int nl = it * npi + (lane >> a.lpn_log2);
+                const int ch = lane & (lpn - 1);
+                const int n = node0 + nl;
+                const bool valid = nl < G::NPW && n < K;
+                int4 ye = make_int4(0, 0, 0, 0), re = make_int4(0, 0, 0, 0);
+                if (valid) {
+                    const int64_t xb = (int64_t)sX1[n] * K + 4 * ch;
+                    ye = *reinterpret_cast<const int4*>(a.adj_e + xb);
+                    if (has_att0) re = *reinterpret_cast<const int4*>(a.adj_r + xb);
+                }
+                float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f, sc3 = 0.f;
+                if (has_att0 && valid) {
+                    sc0 = sT0[re.x];
+                    sc1 = sT0[re.y];
+                    sc2 = sT0[re.z];
+                    sc3 = sT0[re.w];
+                }
+                float m = fmaxf(fmaxf(sc0, sc1), fmaxf(sc2, sc3));
+                for (int o = 1; o < lpn; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+                float e0 = 1.f, e1 = 1.f, e2 = 1.f, e3 = 1.f;
+                if (has_att0) {
+                    e0 = expf(sc0 - m);
+                    e1 = expf(sc1 - m);
+                    e2 = expf(sc2 - m);
+                    e3 = expf(sc3 - m);
+                }
+                float z = (e0 + e1) + (e2 + e3);
+                for (int o = 1; o < lpn; o <<= 1) z += __shfl_xor(z, o, kWave);
+                if (valid) {
+                    if (has_att0) {
+                        e0 /= z;
+                        e1 /= z;
+                        e2 /= z;
+                        e3 /= z;
+                        if (a.probs_child)
+                            *reinterpret_cast<float4*>(a.probs_child + ((p * K + n) * K + 4 * ch)) =
+                                make_float4(e0, e1, e2, e3);
+                    }
+                    int2* dst = ypw + nl * K + 4 * ch;
+                    dst[0] = make_int2(ye.x, __float_as_int(e0 * invK));
+                    dst[1] = make_int2(ye.y, __float_as_int(e1 * invK));
+                    dst[2] = make_int2(ye.z, __float_as_int(e2 * invK));
+                    dst[3] = make_int2(ye.w, __float_as_int(e3 * invK));
+                }
+            }
+            for (int nl = 0; nl < G::NPW; ++nl) {
+                const int n = node0 + nl;
+                const int row = wave * G::NPW + nl;
+                float* arow = sA + row * G::LDA;
+                if (n >= K) {  // padding child: finite zeros (its p0/p1 are 0)
+                    if (g == 0) {
+                        *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(0.f, 0.f);
+                        *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(0.f, 0.f);
+                    }
+                    continue;
+                }
+                const int2* yp = ypw + nl * K;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                for (int k = g; k < K; k += G::RPW) {
+                    const int2 e = yp[k];
+                    const float4 v = reinterpret_cast<const float4*>(a.table + (int64_t)e.x * D)[c];
+                    acc = f4_fma(__int_as_float(e.y), v, acc);
+                }
+                float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g == 0) sv = reinterpret_cast<const float4*>(a.table + (int64_t)sX1[n] * D)[c];
+                acc = group_xor_sum(acc, G::LPR);
+                if (g == 0) {
+                    *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
+                    *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
+                    *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
+                    *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
+                }
+            }
+            __syncthreads();
+            // ---------------- phase B: projections (MFMA), Z -> LDS, nagg0 ----------------
+            if (dense) {
+                f32x4 accE[G::MTW], accS[G::MTW];
+#pragma unroll
+                for (int m = 0; m < G::MTW; ++m) {
+                    accE[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    accS[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (has_proj) {
+#pragma unroll
+                    for (int s = 0; s < G::KS; ++s) {
+#pragma unroll
+                        for (int m = 0; m < G::MTW; ++m) {
+                            const float* ar = sA + (16 * (mt0 + m) + l16) * G::LDA + 4 * s + q16;
+                            accE[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], bW1[s], accE[m], 0, 0, 0);
+                            accS[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[D], bW2[s], accS[m], 0, 0, 0);
+                        }
+                    }
+                }
+                float part = 0.f;
+#pragma unroll
+                for (int m = 0; m < G::MTW; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * (mt0 + m) + 4 * q16 + r;
+                        float s1v, zv;
+                        if (has_proj) {
+                            s1v = accE[m][r] + c1v;
+                            zv = s1v + (accS[m][r] + c2v);
+                        } else {
+                            s1v = sA[row * G::LDA + col];
+                            zv = s1v + sA[row * G::LDA + D + col];
+                        }
+                        part = fmaf(sP0[tile * kTM + row], s1v, part);
+                        sZ[row * G::LDZ + col] = zv;
+                    }
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                nacc0 += part;
+            }
+            __syncthreads();
+            // ---------------- phase C: aggregator dense + relu (MFMA), nagg1 ----------------
+            if (dense) {
+                f32x4 acc2[G::MTW];
+#pragma unroll
+                for (int m = 0; m < G::MTW; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < G::KS; ++s) {
+#pragma unroll
+                    for (int m = 0; m < G::MTW; ++m) {
+                        const float az = sZ[(16 * (mt0 + m) + l16) * G::LDZ + 4 * s + q16];
+                        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bA0[s], acc2[m], 0, 0, 0);
+                    }
+                }
+                float part = 0.f;
+#pragma unroll
+                for (int m = 0; m < G::MTW; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * (mt0 + m) + 4 * q16 + r;
+                        const float o = fmaxf(acc2[m][r] + a0v, 0.f);
+                        part = fmaf(sP1[tile * kTM + row], o, part);
+                    }
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                nacc1 += part;
+            }
+            // the next tile's phase A touches sA / sYP only; sZ is rewritten after its barrier
+        }
+        // ---------------- epilogue ----------------
+        if (dense && q16 == 0) {
+            atomicAdd(&sN0[col], nacc0);
+            atomicAdd(&sN1[col], nacc1);
+        }
+        __syncthreads();
+        if (tid < D) {
+            a.nagg0[p * D + tid] = sN0[tid] * invK;
+            a.nagg1[p * D + tid] = sN1[tid] * invK;
+        }
+    }
+}
+
+size_t fused_l2_lds_bytes(int D, int NW, int K, int nR) {
+    const int ntile = (K + kTM - 1) / kTM, Kpad = ntile * kTM;
+    size_t words = (size_t)kTM * (2 * D + 2) + (size_t)kTM * (D + 2) + 2 * Kpad + 2 * D + 2 * nR + Kpad;
+    words += (Kpad + 2 * nR) & 1;  // keep sYP 8-byte aligned
+    return words * 4 + (size_t)NW * (kTM / NW) * K * sizeof(int2);
+}
+
+template <int D, int NW>
+static hipError_t launch_l2(const FusedL2Args& a, hipStream_t st) {
+    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t cap = 256 * 4;  // persistent: 256 CUs x up to 4 resident workgroups
+    const int grid = (int)(a.P < cap ? a.P : cap);
+    gather_attn_l2_kernel<D, NW><<<grid, NW * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+bool fused_l2_supported(int D, int K) {
+    const bool dok = D == 16 || D == 32 || D == 64 || D == 128;
+    const bool kok = K >= 4 && K <= 256 && (K & (K - 1)) == 0;
+    return dok && kok;
+}
+
+hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st) {
+    switch (D) {
+        case 16: return launch_l2<16, 4>(a, st);
+        case 32: return launch_l2<32, 4>(a, st);
+        case 64: return launch_l2<64, 4>(a, st);
+        case 128: return launch_l2<128, 8>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin

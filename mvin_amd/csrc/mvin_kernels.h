@@ -41,6 +41,27 @@ struct RippleArgs {
     int mode, Nm, D, nR, lpr_log2;
 };
 
+struct FusedL2Args {
+    const float* table;          // [nE, D]
+    const int32_t* adj_e;        // [nE, K]
+    const int32_t* adj_r;        // [nE, K]
+    const int32_t* parent_ids;   // [P] entity id of every level-(L-2) node
+    const float* t0;             // [nR] relation logits of aggregator (0,.) or NULL (uniform)
+    const float* t1;             // [nR] relation logits of aggregator (1,.) or NULL
+    const float* W1;             // [D, D] projection of level L-1 or NULL (User_orient off)
+    const float* W2;             // [D, D] projection of level L
+    const float* c1;             // [B, D] q.W1 + b1
+    const float* c2;             // [B, D] q.W2 + b2
+    const float* A0;             // [D, D] aggregator (0,.) weights
+    const float* a0;             // [D] bias or NULL
+    float* nagg0;                // [P, D] (1/K) sum_n p0[n] self1[n]
+    float* nagg1;                // [P, D] (1/K) sum_n p1[n] out1[n]
+    float* probs_parent;         // [P, K] or NULL
+    float* probs_child;          // [P*K, K] or NULL
+    int64_t P;
+    int parents_per_pair, K, nR, lpn_log2;
+};
+
 inline int lpr_log2_for(int D) {
     int l = 0;
     while ((4 << l) < D) ++l;
@@ -55,5 +76,7 @@ hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D,
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st);
 hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st);
 hipError_t launch_ripple(const RippleArgs& a, hipStream_t st);
+bool fused_l2_supported(int D, int K);
+hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st);
 
 }  // namespace mvin

@@ -62,7 +62,7 @@ template <int NR>
 __global__ __launch_bounds__(kBlock) void linear_kernel(mvin_linear_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RP = kTM / NR;
-    const int Din = a.nsrc * a.Dsrc;
+    const int Din = a.sum_sources ? a.Dsrc : a.nsrc * a.Dsrc;
     const int ldx = Din + 4;
     float* sX = smem;
     const int tid = threadIdx.x;
@@ -89,7 +89,12 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(mvin_linear_args a) {
                     const int64_t srow = ids ? (int64_t)ids[r] : r;
                     v = reinterpret_cast<const float4*>(src + srow * a.Dsrc)[c];
                 }
-                *reinterpret_cast<float4*>(sX + row * ldx + s * a.Dsrc + c * 4) = v;
+                float4* dst = reinterpret_cast<float4*>(sX + row * ldx + (a.sum_sources ? 0 : s * a.Dsrc) + c * 4);
+                if (a.sum_sources && s > 0) {  // same thread wrote this slot for s-1
+                    const float4 o = *dst;
+                    v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                }
+                *dst = v;
             }
         }
         __syncthreads();
@@ -399,7 +404,7 @@ hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D,
 
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st) {
     const int nr = nr_for(a.Dout);
-    const size_t lds = (size_t)kTM * (a.nsrc * a.Dsrc + 4) * sizeof(float);
+    const size_t lds = (size_t)kTM * ((a.sum_sources ? 1 : a.nsrc) * a.Dsrc + 4) * sizeof(float);
     const int64_t ntiles = (a.rows + kTM - 1) / kTM;
     dim3 grid(grid_for(ntiles), a.nz > 0 ? a.nz : 1);
 #define CALL(NRV)                                                         \

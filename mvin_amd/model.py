@@ -26,6 +26,7 @@ How the forward is arranged (see DESIGN.md for the data layout and the kernel ro
   * key addressing (model.py:161-240) uses (R h).v == h.(v R): V[b,r,:] = E[item_b].R_KGE[r]
     is computed once per pair, then each memory needs one D-long dot product.
 """
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -48,8 +49,11 @@ class Placeholder(object):
 
 class MVIN(object):
     def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
-                 params=None, device=None, seed=0):
+                 params=None, device=None, seed=0, fused=None):
         self.device = torch.device(device or "cuda")
+        # fused=False (or MVIN_FUSED=0) forces the per-level kernels (used by the tests to
+        # check both HIP paths against the oracle)
+        self.fused = (os.environ.get("MVIN_FUSED", "1") != "0") if fused is None else bool(fused)
         self._parse_args(args, adj_entity, adj_relation)
         self._build_inputs()
         self._build_model(n_user, n_entity, n_relation, params, seed)
@@ -267,11 +271,38 @@ class MVIN(object):
         return ops.agg(ev[hop].view(B * N, D), ev[hop + 1].view(B * N * K, D), rels[hop].view(-1), t,
                        agg.weights, agg.bias, B, N, K, D, want_probs=wp)
 
-    def aggregate_delta_whole(self, ents, rels, q, user_o, want_probs=False):
-        """model.py:259-324 -> (item_embeddings [B,D], scores, sigmoid, importance_list)."""
+    def aggregate_delta_whole(self, item32, q, user_o, want_probs=False):
+        """model.py:259-324 -> (item_embeddings [B,D], scores, sigmoid, importance_list).
+
+        Fast path (h_hop >= 2, dim in {16,32,64,128}, fan-out a power of two): the two deepest
+        levels run in ONE kernel (mvin_gather_attn_l2_fwd) that returns, per level-(L-2) node,
+        the neighbor aggregates consumed by aggregator (0,0) and (1,0) at hop L-2; levels L-1
+        and L are never materialised.  Otherwise the per-level kernels are used."""
         D, K, H, M = self.dim, self.n_neighbor, self.h_hop, self.n_mix_hop
         L = M * H
-        ev, c = self._project_levels(ents, q, L)
+        B = item32.shape[0]
+        use_l2 = self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K)
+        top = L - 1 if use_l2 else L          # levels 0..top-1 are materialised
+        ents, rels = self.get_neighbors(item32, levels=top - 1)
+        ev, c = self._project_levels(ents, q, top)
+        nagg = pp = pc = None
+        if use_l2:
+            a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
+            uo = self.args.User_orient
+            if self._profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            n0, n1, pp, pc = ops.gather_attn_l2(
+                self.entity_emb_matrix, self.adj_entity, self.adj_relation, ents[L - 2].view(-1),
+                a0.relation_scores() if a0.User_orient_rela else None,
+                a1.relation_scores() if a1.User_orient_rela else None,
+                self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
+                c[L - 1] if uo else None, c[L] if uo else None, a0.weights, a0.bias,
+                B, K ** (L - 2), K, D, self.n_relation, want_probs=want_probs and a0.User_orient_rela)
+            if self._profile is not None:
+                e1.record()
+                self._profile.append((e0, e1))
+            nagg = (n0, n1)
         importance = []
         out = None
         for n in range(M):
@@ -280,7 +311,18 @@ class MVIN(object):
                 agg = self._agg[(i, n)]
                 nxt, probs = [], []
                 for hop in range(L - (H * n + i)):
-                    fused = L if (n == 0 and i == 0 and hop == L - 1) else None
+                    if use_l2 and n == 0 and i == 0 and hop == L - 1:
+                        nxt.append(None)  # consumed inside the fused kernel (as nagg[1])
+                        probs.append(pc.view(B, K ** (L - 1), K) if pc is not None else None)
+                        continue
+                    if use_l2 and n == 0 and i <= 1 and hop == L - 2:
+                        # aggregators.py:108-116 with neighbors_agg from the fused kernel
+                        o = ops.linear([ev[hop].view(-1, D), nagg[i]], agg.weights, D, bias=agg.bias,
+                                       relu=True, sum_sources=True).view(B, -1, D)
+                        nxt.append(o)
+                        probs.append(pp.view(B, K ** (L - 2), K) if (i == 0 and pp is not None) else None)
+                        continue
+                    fused = L if (not use_l2 and n == 0 and i == 0 and hop == L - 1) else None
                     o, p = self._apply(agg, ev, ents, rels, hop, c, fused, want_probs and i == 0)
                     nxt.append(o)
                     probs.append(p)
@@ -297,16 +339,17 @@ class MVIN(object):
                 if last:
                     out = res
                 else:
-                    new.append(res.view(ev[0].shape[0], -1, D))
+                    new.append(res.view(B, -1, D))
             ev = new
         item_emb, scores, sig = out
         return item_emb, scores, sig, importance
 
-    def aggregate(self, ents, rels, q, user_o, want_probs=False):
+    def aggregate(self, item32, q, user_o, want_probs=False):
         """model.py:327-376 (wide_deep=False).  The reference revision cannot run this path
         (it treats the aggregator's tuple as a tensor, :366-374); the evident intent --
         element [0] -- is implemented.  Untested by the reference."""
         D, H = self.dim, self.h_hop
+        ents, rels = self.get_neighbors(item32, levels=H - 1)
         ev, c = self._project_levels(ents, q, H)
         for i in range(H):
             agg = self._agg[(i, 0)]
@@ -325,7 +368,6 @@ class MVIN(object):
         """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
         [B, n_memory] per hop).  Returns a namespace of device tensors."""
         a = self.args
-        dev = self.device
         if not item_indices.is_cuda:
             raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
         item32 = item_indices.to(torch.int32)
@@ -343,10 +385,7 @@ class MVIN(object):
                 q = ps
             else:
                 q = user_o if a.HO_only else self._lookup(self.user_emb_matrix, user32)
-            top = (self.n_mix_hop * self.h_hop) if a.wide_deep else self.h_hop
-            ents, rels = self.get_neighbors(item32, levels=top - 1)
-            item_emb, scores, sig, importance = self.agg_fun(ents, rels, q, user_o, want_probs)
-        del dev
+            item_emb, scores, sig, importance = self.agg_fun(item32, q, user_o, want_probs)
         return SimpleNamespace(scores=scores, scores_normalized=sig, user_o=user_o,
                                item_embeddings=item_emb, importance_list=importance)
 

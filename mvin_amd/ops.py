@@ -86,7 +86,7 @@ def rel_score(relation_emb, urh_weights):
 
 def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1, relu=False,
            rows=None, out=None, out_offset=0, ldo=None, nz=1, w_zstride=0, bias_zstride=0,
-           out_zstride=0, score_u=None):
+           out_zstride=0, score_u=None, sum_sources=False):
     """mvin_linear_fwd: out[z][r] = act(concat_s X_s[r] . W[z] + bias[z] + rowbias[r // rpg]).
     ``srcs``: list of [*, Dsrc] fp32 tensors; ``ids``: matching list of int32 row-id tensors
     or None.  Returns out, or (out, score, sigmoid) when ``score_u`` is given."""
@@ -120,6 +120,7 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a.rowbias = _chk(rowbias, F32, "rowbias").data_ptr() if rowbias is not None else None
     a.rows_per_group = rows_per_group
     a.relu = 1 if relu else 0
+    a.sum_sources = 1 if sum_sources else 0
     a.out = out.data_ptr() + out_offset * 4
     a.ldo = ldo
     a.nz, a.w_zstride, a.bias_zstride, a.out_zstride = nz, w_zstride, bias_zstride, out_zstride
@@ -180,3 +181,29 @@ def ripple_attn(entity_emb, score_ids, rel_ids, value_ids, V, w, mode, out, out_
                                         _p(V), _p(w), mode, B, Nm, D, nR, _p(out, out_offset), ldo,
                                         _stream()), "mvin_ripple_attn_fwd")
     return out
+
+
+def gather_attn_l2_supported(D, K):
+    return bool(_lib.load().mvin_gather_attn_l2_supported(D, K))
+
+
+def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, c1, c2, A0, a0,
+                   B, parents_per_pair, K, D, nR, want_probs=False):
+    """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  Returns
+    (nagg0 [P,D], nagg1 [P,D], probs_parent [P,K] | None, probs_child [P*K,K] | None)."""
+    lib = _lib.load()
+    for t, dt, nm in ((table, F32, "table"), (adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
+                      (parent_ids, I32, "parent_ids"), (t0, F32, "t0"), (t1, F32, "t1"), (W1, F32, "W1"),
+                      (W2, F32, "W2"), (c1, F32, "c1"), (c2, F32, "c2"), (A0, F32, "A0"), (a0, F32, "a0")):
+        _chk(t, dt, nm)
+    P = B * parents_per_pair
+    dev = table.device
+    nagg0 = torch.empty((P, D), dtype=F32, device=dev)
+    nagg1 = torch.empty((P, D), dtype=F32, device=dev)
+    pp = torch.empty((P, K), dtype=F32, device=dev) if want_probs else None
+    pc = torch.empty((P * K, K), dtype=F32, device=dev) if want_probs else None
+    _lib.check(lib.mvin_gather_attn_l2_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(parent_ids), _p(t0),
+                                           _p(t1), _p(W1), _p(W2), _p(c1), _p(c2), _p(A0), _p(a0), B,
+                                           parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
+                                           _p(pp), _p(pc), _stream()), "mvin_gather_attn_l2_fwd")
+    return nagg0, nagg1, pp, pc

@@ -21,19 +21,28 @@ SHAPES = [
     dict(dim=8, neighbor_sample_size=2, h_hop=3, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=5),
     dict(dim=12, neighbor_sample_size=5, h_hop=1, n_mix_hop=2, p_hop=2, n_memory=7, batch_size=6),
     dict(dim=128, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=3),
+    # shapes the fused two-level kernel (mvin_gather_attn_l2_fwd) takes
+    dict(dim=64, neighbor_sample_size=64, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=5),
+    dict(dim=32, neighbor_sample_size=8, h_hop=3, n_mix_hop=1, p_hop=1, n_memory=8, batch_size=4),
+    dict(dim=16, neighbor_sample_size=4, h_hop=2, n_mix_hop=2, p_hop=2, n_memory=8, batch_size=7),
+    dict(dim=128, neighbor_sample_size=16, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=8, batch_size=3),
+    dict(dim=64, neighbor_sample_size=128, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=8, batch_size=2),
 ]
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlevel"])
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "D{dim}K{neighbor_sample_size}H{h_hop}M{n_mix_hop}".format(**s))
-def test_default_ablation(shape, hip_lib):
+def test_default_ablation(shape, fused, hip_lib):
     args = make_args(**shape)
     case = synth.small_case(args, n_user=16, n_entity=200, n_relation=7, seed=11, zero_rows=5)
-    check_case(args, case, seed=3)
+    check_case(args, case, seed=3, fused=fused)
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlevel"])
 @pytest.mark.parametrize("ablation", sorted(ABLATIONS))
-def test_every_ablation(ablation, hip_lib):
-    for shape in SHAPES[:2]:
+def test_every_ablation(ablation, fused, hip_lib):
+    # SHAPES[0:2] only reach the per-level kernels (dim=8, K=3); SHAPES[3] and [11] the fused one
+    for shape in (SHAPES[0], SHAPES[1], SHAPES[3], SHAPES[11]):
         args = make_args(ablation=ablation, **shape)
         case = synth.small_case(args, seed=5)
-        check_case(args, case, seed=7)
+        check_case(args, case, seed=7, fused=fused)
