@@ -155,6 +155,20 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
                          const int32_t* value_ids, const float* V, const float* w, int mode,
                          int B, int Nm, int D, int nR, float* out, int64_t ldo, void* stream);
 
+/* All attention reads of MVIN._key_addressing for a batch in one pass (model.py:161-240):
+ * out[b, :] = [ o_hset (if w != NULL) | o_hop0 | ... | o_hop{P-1} ], each D wide, row stride ldo.
+ *   o_hset = sum_m softmax_m(E[mem_h[0][b,m]] . w[0:D])_m * E[mem_h[0][b,m]]                 (:162-197)
+ *   o_hop  = sum_m softmax_m(E[mem_h[hop][b,m]] . V[b, mem_r[hop][b,m], :])_m * E[mem_t[hop][b,m]]  (:210-230)
+ * mem_h/mem_r/mem_t are HOST arrays of max(1,P) device pointers ([B, Nm] int32 each).  Every table
+ * row is read once (head rows stay in registers between the logit and the weighted-sum pass).
+ * Returns -3 when Nm/D exceed the register-resident kernel (ceil(Nm / (64/ceil_pow2(D/4))) > 16);
+ * callers then use mvin_ripple_attn_fwd per read. */
+int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float* w,
+                            const int32_t* const* mem_h, const int32_t* const* mem_r,
+                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR,
+                            float* out, int64_t ldo, void* stream);
+int mvin_key_addressing_supported(int Nm, int D);
+
 #ifdef __cplusplus
 }
 #endif

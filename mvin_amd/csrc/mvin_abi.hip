@@ -225,4 +225,48 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
     return hip_result(mvin::launch_ripple(r, (hipStream_t)stream), "mvin_ripple_attn_fwd");
 }
 
+int mvin_key_addressing_supported(int Nm, int D) {
+    return (!bad_dim(D) && Nm > 0 && mvin::key_addr_nj(Nm, D) <= 16) ? 1 : 0;
+}
+
+int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float* w,
+                            const int32_t* const* mem_h, const int32_t* const* mem_r,
+                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, float* out,
+                            int64_t ldo, void* stream) {
+    const char* who = "mvin_key_addressing_fwd";
+    if (!entity_emb || !mem_h || !out) return fail(-1, "%s: null pointer", who);
+    if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
+    if (P == 0 && !w) return fail(-2, "%s: nothing to do (P == 0 and w == NULL)", who);
+    if (P > 0 && (!V || !mem_r || !mem_t || nR <= 0)) return fail(-1, "%s: hops need V, mem_r, mem_t, nR", who);
+    if (B <= 0 || Nm <= 0) return fail(-2, "%s: bad sizes B=%d Nm=%d", who, B, Nm);
+    if (bad_dim(D)) return fail(-2, "%s: D=%d (need %%4==0, 4..%d)", who, D, MVIN_MAX_DIM);
+    const int n_o = P + (w ? 1 : 0);
+    if (ldo < (int64_t)n_o * D || (ldo & 3)) return fail(-2, "%s: ldo=%lld", who, (long long)ldo);
+    if (mvin::key_addr_nj(Nm, D) > 16)
+        return fail(-3, "%s: unsupported shape Nm=%d D=%d for the register-resident kernel", who, Nm, D);
+    mvin::KeyAddrArgs k{};
+    k.E = entity_emb;
+    k.V = V;
+    k.w = w;
+    const int nh = P > 0 ? P : 1;
+    for (int i = 0; i < nh; ++i) {
+        if (!mem_h[i]) return fail(-1, "%s: null mem_h[%d]", who, i);
+        k.mem_h[i] = mem_h[i];
+        if (i < P) {
+            if (!mem_r[i] || !mem_t[i]) return fail(-1, "%s: null mem_r/mem_t[%d]", who, i);
+            k.mem_r[i] = mem_r[i];
+            k.mem_t[i] = mem_t[i];
+        }
+    }
+    k.out = out;
+    k.ldo = ldo;
+    k.B = B;
+    k.P = P;
+    k.Nm = Nm;
+    k.D = D;
+    k.nR = nR;
+    k.lpr_log2 = mvin::lpr_log2_for(D);
+    return hip_result(mvin::launch_key_addr(k, (hipStream_t)stream), who);
+}
+
 }  // extern "C"

@@ -41,6 +41,19 @@ struct RippleArgs {
     int mode, Nm, D, nR, lpr_log2;
 };
 
+struct KeyAddrArgs {
+    const float* E;            // [nE, D]
+    const float* V;            // [B, nR, D] or NULL (p_hop == 0)
+    const float* w;            // [D] h-set logit weights or NULL (PS_O_ft off)
+    const int32_t* mem_h[8];   // per hop [B, Nm]
+    const int32_t* mem_r[8];
+    const int32_t* mem_t[8];
+    float* out;                // [B, ldo]: [o_hset | o_hop0 | ...]
+    int64_t ldo;
+    int64_t B;
+    int P, Nm, D, nR, lpr_log2;
+};
+
 struct FusedL2Args {
     const float* table;          // [nE, D]
     const int32_t* adj_e;        // [nE, K]
@@ -76,6 +89,8 @@ hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D,
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st);
 hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st);
 hipError_t launch_ripple(const RippleArgs& a, hipStream_t st);
+int key_addr_nj(int Nm, int D);
+hipError_t launch_key_addr(const KeyAddrArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st);
 

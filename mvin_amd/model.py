@@ -215,17 +215,21 @@ class MVIN(object):
         nR = self.n_relation
         n_o = P + 1 if a.PS_O_ft else P
         o_cat = torch.empty((B, n_o * D), dtype=torch.float32, device=self.device)
-        slot = 0
-        if a.PS_O_ft:  # :162-197, :204-206
-            w_h = self.h_emb_item_mlp_matrix.view(-1)  # first D entries multiply h (concat order [h, user], :171)
-            ops.ripple_attn(self.entity_emb_matrix, mem_h[0], None, mem_h[0], None, w_h, 1,
-                            o_cat, 0, n_o * D, nR)
-            slot = 1
+        w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None  # first D entries multiply h ([h, user], :171)
+        V = None
         if P > 0:
             # V[b,r,:] = E[item_b] . R_KGE[r]   ((R h).v == h.(v R), :214-220)
             V = torch.empty((B, nR, D), dtype=torch.float32, device=self.device)
             ops.linear([self.entity_emb_matrix], self.relation_emb_KGE_matrix, D, ids=[item32], rows=B,
                        out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
+        if self.fused and ops.key_addressing_supported(self.n_memory, D):
+            ops.key_addressing(self.entity_emb_matrix, V, w_h, mem_h, mem_r, mem_t, P, o_cat, n_o * D, nR)
+        else:
+            slot = 0
+            if a.PS_O_ft:  # :162-197, :204-206
+                ops.ripple_attn(self.entity_emb_matrix, mem_h[0], None, mem_h[0], None, w_h, 1,
+                                o_cat, 0, n_o * D, nR)
+                slot = 1
             for hop in range(P):  # :210-230
                 ops.ripple_attn(self.entity_emb_matrix, mem_h[hop], mem_r[hop], mem_t[hop], V, None, 0,
                                 o_cat, (slot + hop) * D, n_o * D, nR)

@@ -207,3 +207,27 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
                                            parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
                                            _p(pp), _p(pc), _stream()), "mvin_gather_attn_l2_fwd")
     return nagg0, nagg1, pp, pc
+
+
+def key_addressing_supported(Nm, D):
+    return bool(_lib.load().mvin_key_addressing_supported(Nm, D))
+
+
+def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
+    """mvin_key_addressing_fwd: every preference-hop attention read of a batch in one launch;
+    fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...]."""
+    lib = _lib.load()
+    _chk(entity_emb, F32, "entity_emb"), _chk(V, F32, "V"), _chk(w, F32, "w"), _chk(out, F32, "out")
+    nh = max(1, P)
+    arr_t = C.c_void_p * nh
+    for lst, nm in ((mem_h[:nh], "mem_h"), (mem_r[:P], "mem_r"), (mem_t[:P], "mem_t")):
+        for t in lst:
+            _chk(t, I32, nm)
+    ph = arr_t(*[t.data_ptr() for t in mem_h[:nh]])
+    pr = arr_t(*([t.data_ptr() for t in mem_r[:P]] + [None] * (nh - P)))
+    pt = arr_t(*([t.data_ptr() for t in mem_t[:P]] + [None] * (nh - P)))
+    B, Nm = mem_h[0].shape
+    D = entity_emb.shape[1]
+    _lib.check(lib.mvin_key_addressing_fwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(out),
+                                           ldo, _stream()), "mvin_key_addressing_fwd")
+    return out
