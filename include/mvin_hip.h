@@ -85,6 +85,7 @@ typedef struct {
     const float* rowbias;      /* [ceil(rows/rows_per_group), Dout] or NULL */
     int rows_per_group;
     int relu;
+    int ids64;                 /* 1: ids[] point to int64 row ids (the reference's placeholder dtype) */
     int sum_sources;           /* 1: X = sum_s X_s (Din = Dsrc) instead of the concatenation */
     float* out;
     int64_t ldo;                 /* out row stride in elements (>= Dout) */
@@ -117,8 +118,9 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
  * (level L-2; P = B * parents_per_pair of them, entity ids in parent_ids) with children
  * x1[n] = adj_entity[parent, n] and grandchildren y[n,k] = adj_entity[x1[n], k]:
  *     p[n,:]  = softmax_k(t0[adj_relation[x1[n], k]])                       (or uniform, t0 NULL)
- *     self1[n] = table[x1[n]] . W1 + c1[b]                                  (or table[x1[n]], W1 NULL)
- *     Z[n]    = self1[n] + ((sum_k p[n,k] table[y[n,k]]) . W2 + (sum_k p[n,k]) c2[b]) / K
+ *     c1 = q[b] . W1 + b1, c2 = q[b] . W2 + b2        (the broadcast query of model.py:277-279)
+ *     self1[n] = table[x1[n]] . W1 + c1                                     (or table[x1[n]], W1 NULL)
+ *     Z[n]    = self1[n] + ((sum_k p[n,k] table[y[n,k]]) . W2 + (sum_k p[n,k]) c2) / K
  *     out1[n] = relu(Z[n] . A0 + a0)            = aggregator (0,.) at hop L-1  (aggregators.py:98-146)
  *     p0 = softmax_n(t0[adj_relation[parent, n]]), p1 = softmax_n(t1[adj_relation[parent, n]])
  *     nagg0[parent] = (1/K) sum_n p0[n] self1[n]   -> neighbors_agg of aggregator (0,.) at hop L-2
@@ -128,8 +130,8 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
  * (D in {16,32,64,128}, K a power of two in [4,256]); callers then use the per-level entry points. */
 int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1,
-                            const float* W1, const float* W2, const float* c1, const float* c2,
-                            const float* A0, const float* a0,
+                            const float* W1, const float* W2, const float* b1, const float* b2,
+                            const float* q, const float* A0, const float* a0,
                             int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                             void* stream);

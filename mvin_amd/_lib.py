@@ -28,6 +28,7 @@ class LinearArgs(C.Structure):
         ("rowbias", C.c_void_p),
         ("rows_per_group", C.c_int),
         ("relu", C.c_int),
+        ("ids64", C.c_int),
         ("sum_sources", C.c_int),
         ("out", C.c_void_p),
         ("ldo", C.c_int64),
@@ -55,7 +56,7 @@ SIGNATURES = {
                                        _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_gather_attn_l2_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
-                                          _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
+                                          _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
                                           _c_f32p, C.c_void_p]),
     "mvin_gather_attn_l2_supported": (C.c_int, [C.c_int, C.c_int]),

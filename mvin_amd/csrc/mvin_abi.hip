@@ -135,8 +135,8 @@ int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supporte
 
 int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
-                            const float* W2, const float* c1, const float* c2, const float* A0,
-                            const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                            const float* W2, const float* b1, const float* b2, const float* q,
+                            const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                             void* stream) {
     const char* who = "mvin_gather_attn_l2_fwd";
@@ -146,7 +146,7 @@ int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const
     if (!table || !adj_entity || !parent_ids || !A0 || !nagg0 || !nagg1) return fail(-1, "%s: null pointer", who);
     if ((t0 || t1) && !adj_relation) return fail(-1, "%s: attention needs adj_relation", who);
     if ((W1 == nullptr) != (W2 == nullptr)) return fail(-1, "%s: W1 and W2 must be given together", who);
-    if (W1 && (!c1 || !c2)) return fail(-1, "%s: projection needs c1 and c2", who);
+    if (W1 && !q) return fail(-1, "%s: projection needs the query vectors q", who);
     if ((probs_parent || probs_child) && !t0) return fail(-2, "%s: probs requested without t0", who);
     if (B <= 0 || parents_per_pair <= 0 || n_entity <= 0 || nR <= 0 || nR > 4096)
         return fail(-2, "%s: bad sizes B=%d parents_per_pair=%d n_entity=%d nR=%d", who, B, parents_per_pair,
@@ -160,8 +160,9 @@ int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const
     f.t1 = t1;
     f.W1 = W1;
     f.W2 = W2;
-    f.c1 = c1;
-    f.c2 = c2;
+    f.b1 = b1;
+    f.b2 = b2;
+    f.q = q;
     f.A0 = A0;
     f.a0 = a0;
     f.nagg0 = nagg0;

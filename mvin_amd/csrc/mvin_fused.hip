@@ -16,6 +16,7 @@
 //               S' = (1/K) sum_k p_k E[y_k] and the raw child row E[x1] -> LDS tile
 //     phase B : MFMA (v_mfma_f32_16x16x4_f32, weights resident in VGPRs as B fragments):
 //               self1 = E[x1].W1 + c1 ; Z = self1 + S'.W2 + (psum/K) c2 ; Z -> LDS ;
+//               (c_e = q_b.W_e + b_e is formed per pair from the same B fragments)
 //               nagg0 += sum_n p0[n] self1[n]   (from the accumulator registers)
 //     phase C : out1 = relu(Z.A0 + a0) (MFMA) ; nagg1 += sum_n p1[n] out1[n]
 //   epilogue  : nagg0/K, nagg1/K -> HBM (2 x D floats per parent).
@@ -82,6 +83,8 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
         bA0[s] = dense ? a.A0[kk * D + col] : 0.f;
     }
     const float a0v = (dense && a.a0) ? a.a0[col] : 0.f;
+    const float b1v = (dense && has_proj && a.b1) ? a.b1[col] : 0.f;
+    const float b2v = (dense && has_proj && a.b2) ? a.b2[col] : 0.f;
     for (int i = tid; i < a.nR; i += NW * 64) {
         sT0[i] = has_att0 ? a.t0[i] : 0.f;
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
@@ -150,8 +153,24 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
         __syncthreads();
 
         float nacc0 = 0.f, nacc1 = 0.f;
-        const float c1v = (dense && has_proj) ? a.c1[b * D + col] : 0.f;
-        const float c2v = (dense && has_proj) ? a.c2[b * D + col] * c2scale : 0.f;
+        // c_e[col] = q_b . W_e[:, col] + b_e[col] (model.py:277-279 applied to the broadcast query):
+        // the W columns are already in registers as B fragments, so this is KS FMAs + 2 shuffles
+        float c1v = 0.f, c2v = 0.f;
+        if (dense && has_proj) {
+            const float* qb = a.q + b * D;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                const float qv = qb[4 * s + q16];
+                c1v = fmaf(qv, bW1[s], c1v);
+                c2v = fmaf(qv, bW2[s], c2v);
+            }
+            c1v += __shfl_xor(c1v, 16, kWave);
+            c1v += __shfl_xor(c1v, 32, kWave);
+            c2v += __shfl_xor(c2v, 16, kWave);
+            c2v += __shfl_xor(c2v, 32, kWave);
+            c1v += b1v;
+            c2v = (c2v + b2v) * c2scale;
+        }
 
         for (int tile = 0; tile < ntile; ++tile) {
             // ---------------- phase A: ids, softmax, row gather ----------------

@@ -63,8 +63,9 @@ struct FusedL2Args {
     const float* t1;             // [nR] relation logits of aggregator (1,.) or NULL
     const float* W1;             // [D, D] projection of level L-1 or NULL (User_orient off)
     const float* W2;             // [D, D] projection of level L
-    const float* c1;             // [B, D] q.W1 + b1
-    const float* c2;             // [B, D] q.W2 + b2
+    const float* q;              // [B, D] query vector of every pair (transfer_o[0])
+    const float* b1;             // [D] projection biases (or NULL)
+    const float* b2;
     const float* A0;             // [D, D] aggregator (0,.) weights
     const float* a0;             // [D] bias or NULL
     float* nagg0;                // [P, D] (1/K) sum_n p0[n] self1[n]

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(mvin_linear_args a) {
                 const int64_t r = r0 + row;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < a.rows) {
-                    const int64_t srow = ids ? (int64_t)ids[r] : r;
+                    const int64_t srow = !ids ? r : (a.ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r]);
                     v = reinterpret_cast<const float4*>(src + srow * a.Dsrc)[c];
                 }
                 float4* dst = reinterpret_cast<float4*>(sX + row * ldx + (a.sum_sources ? 0 : s * a.Dsrc) + c * 4);

@@ -236,21 +236,29 @@ class MVIN(object):
         # :232-236
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
-    def _project_levels(self, ents, q, top):
-        """model.py:267-283 for levels 0..top-1 (level ``top`` is fused into the deepest hop).
-        Returns (ev list, c) with c[e] = q.W_e + b_e for every level ([L+1, B, D]) or None."""
+    def _project_levels(self, ents, q, top, need_c=()):
+        """model.py:267-283 for levels 0..top-1 (deeper levels are fused into the gather
+        kernels).  Returns (ev list, c) where c[e] = q.W_e + b_e ([B, D]) for the levels in
+        ``need_c`` and for 1..top-1 (level 0 adds q before the matmul instead)."""
         a, D, K = self.args, self.dim, self.n_neighbor
         B = ents[0].shape[0]
         E = self.entity_emb_matrix
-        if a.User_orient:
-            nlev = self._transfer_W.shape[0]
-            c = ops.linear([q], self._transfer_W, D, bias=self._transfer_b, nz=nlev, w_zstride=D * D,
-                           bias_zstride=D)
-            ev = [ops.linear([E], self.transfer_matrix_list[e], D, ids=[ents[e].view(-1)], rowbias=c[e],
-                             rows_per_group=K ** e).view(B, -1, D) for e in range(top)]
-            return ev, c
-        ev = [ops.linear([E], None, D, ids=[ents[e].view(-1)]).view(B, -1, D) for e in range(top)]
-        return ev, None
+        if not a.User_orient:
+            return [ops.linear([E], None, D, ids=[ents[e].view(-1)]).view(B, -1, D) for e in range(top)], {}
+        levels = sorted(set(range(1, top)) | set(need_c))
+        c = {}
+        if levels:
+            lo, hi = levels[0], levels[-1] + 1
+            cs = ops.linear([q], self._transfer_W[lo:hi], D, bias=self._transfer_b[lo:hi], nz=hi - lo,
+                            w_zstride=D * D, bias_zstride=D, out_zstride=B * D)
+            cs = cs.view(hi - lo, B, D)
+            c = {e: cs[e - lo] for e in range(lo, hi)}
+        # level 0: (E[item] + q) . W_0 + b_0 in one launch
+        ev = [ops.linear([E, q], self.transfer_matrix_list[0], D, ids=[ents[0].view(-1), None],
+                         bias=self.transfer_matrix_bias[0], sum_sources=True).view(B, 1, D)]
+        ev += [ops.linear([E], self.transfer_matrix_list[e], D, ids=[ents[e].view(-1)], rowbias=c[e],
+                          rows_per_group=K ** e).view(B, -1, D) for e in range(1, top)]
+        return ev, c
 
     def _apply(self, agg, ev, ents, rels, hop, c, fused_level, want_probs):
         """One aggregator application at one hop (model.py:296-305)."""
@@ -288,7 +296,7 @@ class MVIN(object):
         use_l2 = self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K)
         top = L - 1 if use_l2 else L          # levels 0..top-1 are materialised
         ents, rels = self.get_neighbors(item32, levels=top - 1)
-        ev, c = self._project_levels(ents, q, top)
+        ev, c = self._project_levels(ents, q, top, need_c=() if use_l2 else (L,))
         nagg = pp = pc = None
         if use_l2:
             a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
@@ -301,7 +309,8 @@ class MVIN(object):
                 a0.relation_scores() if a0.User_orient_rela else None,
                 a1.relation_scores() if a1.User_orient_rela else None,
                 self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
-                c[L - 1] if uo else None, c[L] if uo else None, a0.weights, a0.bias,
+                self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
+                q if uo else None, a0.weights, a0.bias,
                 B, K ** (L - 2), K, D, self.n_relation, want_probs=want_probs and a0.User_orient_rela)
             if self._profile is not None:
                 e1.record()
@@ -354,7 +363,7 @@ class MVIN(object):
         element [0] -- is implemented.  Untested by the reference."""
         D, H = self.dim, self.h_hop
         ents, rels = self.get_neighbors(item32, levels=H - 1)
-        ev, c = self._project_levels(ents, q, H)
+        ev, c = self._project_levels(ents, q, H, need_c=(H,))
         for i in range(H):
             agg = self._agg[(i, 0)]
             nxt = []
@@ -374,8 +383,8 @@ class MVIN(object):
         a = self.args
         if not item_indices.is_cuda:
             raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
-        item32 = item_indices.to(torch.int32)
-        user32 = user_indices.to(torch.int32)
+        item32 = item_indices.contiguous()   # int64 (reference dtype) or int32: kernels take both
+        user32 = user_indices.contiguous()
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
         ps = self._key_addressing(user32, item32, memories_h, memories_r, memories_t) if need_ps else None
         importance = []

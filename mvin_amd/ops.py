@@ -94,6 +94,7 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a = _lib.LinearArgs()
     nsrc = len(srcs)
     ids = ids or [None] * nsrc
+    ids64 = None
     Dsrc = srcs[0].shape[-1]
     for s in range(nsrc):
         _chk(srcs[s], F32, f"src[{s}]")
@@ -101,10 +102,13 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
             raise ValueError("all sources must share the row width")
         a.src[s] = srcs[s].data_ptr()
         if ids[s] is not None:
-            _chk(ids[s], I32, f"ids[{s}]")
+            if ids64 is None:
+                ids64 = ids[s].dtype == torch.int64
+            _chk(ids[s], torch.int64 if ids64 else I32, f"ids[{s}]")
             a.ids[s] = ids[s].data_ptr()
     if rows is None:
-        rows = ids[0].numel() if ids[0] is not None else srcs[0].numel() // Dsrc
+        first = next((i for i in ids if i is not None), None)
+        rows = first.numel() if first is not None else srcs[0].numel() // Dsrc
     dev = srcs[0].device
     if out is None:
         ldo = ldo or Dout
@@ -120,6 +124,7 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a.rowbias = _chk(rowbias, F32, "rowbias").data_ptr() if rowbias is not None else None
     a.rows_per_group = rows_per_group
     a.relu = 1 if relu else 0
+    a.ids64 = 1 if ids64 else 0
     a.sum_sources = 1 if sum_sources else 0
     a.out = out.data_ptr() + out_offset * 4
     a.ldo = ldo
@@ -187,14 +192,15 @@ def gather_attn_l2_supported(D, K):
     return bool(_lib.load().mvin_gather_attn_l2_supported(D, K))
 
 
-def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, c1, c2, A0, a0,
+def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0,
                    B, parents_per_pair, K, D, nR, want_probs=False):
     """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  Returns
     (nagg0 [P,D], nagg1 [P,D], probs_parent [P,K] | None, probs_child [P*K,K] | None)."""
     lib = _lib.load()
     for t, dt, nm in ((table, F32, "table"), (adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
                       (parent_ids, I32, "parent_ids"), (t0, F32, "t0"), (t1, F32, "t1"), (W1, F32, "W1"),
-                      (W2, F32, "W2"), (c1, F32, "c1"), (c2, F32, "c2"), (A0, F32, "A0"), (a0, F32, "a0")):
+                      (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"), (A0, F32, "A0"),
+                      (a0, F32, "a0")):
         _chk(t, dt, nm)
     P = B * parents_per_pair
     dev = table.device
@@ -203,7 +209,7 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     pp = torch.empty((P, K), dtype=F32, device=dev) if want_probs else None
     pc = torch.empty((P * K, K), dtype=F32, device=dev) if want_probs else None
     _lib.check(lib.mvin_gather_attn_l2_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(parent_ids), _p(t0),
-                                           _p(t1), _p(W1), _p(W2), _p(c1), _p(c2), _p(A0), _p(a0), B,
+                                           _p(t1), _p(W1), _p(W2), _p(b1), _p(b2), _p(q), _p(A0), _p(a0), B,
                                            parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
                                            _p(pp), _p(pc), _stream()), "mvin_gather_attn_l2_fwd")
     return nagg0, nagg1, pp, pc
