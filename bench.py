@@ -49,7 +49,16 @@ def parse():
     ap.add_argument("--hop", type=int, default=2)
     ap.add_argument("--mix", type=int, default=1)
     ap.add_argument("--fanout", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=16384, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=131072,
+                    help="TOTAL pairs per step over all ranks (strong scaling: each rank scores batch/N)")
+    ap.add_argument("--shard", choices=["auto", "rowshard", "replicate"], default="auto",
+                    help="entity table placement: row-sharded over the ranks with all-to-all row fetch "
+                         "(auto: when N>1) or replicated")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="row-sharded mode: serialise the row exchange and the scoring (default: the exchange "
+                         "for step i+1 runs on a side stream while step i is scored)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="with --shard rowshard on one GPU: still run the RCCL all-to-alls (world size 1)")
     ap.add_argument("--adj", choices=["kg", "uniform"], default="kg")
     ap.add_argument("--items", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--cpu-batch", type=int, default=128)
@@ -92,9 +101,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or a.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -104,29 +115,54 @@ def main():
     from mvin_amd.params import init_params
 
     d = synth.DATASETS[a.dataset]
+    if a.batch % world:
+        raise SystemExit("--batch must be divisible by the number of ranks")
+    Bl = a.batch // world                       # pairs this rank scores per step
     margs = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop,
-                      n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=a.batch)
-    # every rank scores its own batch of pairs (pairs are independent: no data-path collective);
-    # tables are replicated; seeds differ per rank so the ranks do not share a batch
-    case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch, seed=a.seed + 17 * rank,
+                      n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=Bl)
+    # one global synthetic batch (same seed everywhere); rank r scores pairs [r*Bl, (r+1)*Bl).
+    # Pairs are independent: no data-path reduction across ranks.
+    case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch, seed=a.seed,
                               zipf=(a.items == "zipf"), uniform_adj=(a.adj == "uniform"))
-    if rank != 0:  # same KG / tables on every rank; only the pairs differ
-        base = synth.dataset_case(a.dataset, K=a.fanout, B=1, seed=a.seed, uniform_adj=(a.adj == "uniform"))
-        case.adj_entity, case.adj_relation = base.adj_entity, base.adj_relation
+    sl = slice(rank * Bl, (rank + 1) * Bl)
     params = init_params(margs, case.n_user, case.n_entity, case.n_relation, seed=a.seed)
+    rowshard = a.shard == "rowshard" or (a.shard == "auto" and world > 1)
+    mparams = params
+    if rowshard:  # the model's entity table becomes the sharded table's working copy
+        mparams = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
     model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=params, device=dev)
-    users = torch.from_numpy(case.users).to(dev)
-    items = torch.from_numpy(case.items).to(dev)
-    mh = [torch.from_numpy(m).to(dev) for m in case.memories_h]
-    mr = [torch.from_numpy(m).to(dev) for m in case.memories_r]
-    mt = [torch.from_numpy(m).to(dev) for m in case.memories_t]
+                 params=mparams, device=dev)
+    runner = model
+    if rowshard:
+        from mvin_amd.dist import ShardedMVIN, shard_rows
+        shard = shard_rows(torch.from_numpy(params["entity_emb_matrix"]), rank, world)
+        runner = ShardedMVIN(model, shard, rank, world, is_shard=True, always_collective=a.force_collectives)
+    users = torch.from_numpy(case.users[sl]).to(dev)
+    items = torch.from_numpy(case.items[sl]).to(dev)
+    mh = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_h]
+    mr = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r]
+    mt = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t]
+
+    overlap = rowshard and not a.no_overlap
+    if overlap:
+        runner.enable_pipeline()
+    state = {"i": 0}
 
     def step():
-        return model.forward_device(users, items, mh, mr, mt)
+        if not overlap:
+            return runner.forward_device(users, items, mh, mr, mt)
+        # every step scores one batch AND performs one row exchange (for the following batch),
+        # on two streams; the same synthetic batch is re-used, the exchange is not skipped
+        i = state["i"]
+        if i == 0:
+            runner.prefetch(0, items, mh, mt)
+        out = runner.forward_prefetched(i % 2, users, items, mh, mr, mt)
+        runner.prefetch((i + 1) % 2, items, mh, mt)
+        state["i"] = i + 1
+        return out
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,36 +187,42 @@ def main():
         bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L)
         kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
         kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
-        achieved = (bpp * a.batch / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
-        value = world * a.batch * a.steps / elapsed
+        achieved = (bpp * Bl / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
+        value = a.batch * a.steps / elapsed
         rec = {
             "metric": "(user,item) pairs scored/sec @ dim=%d hop=%d fan-out=%d; %% HBM roofline"
                       % (a.dim, a.hop, a.fanout),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.dataset}-shaped tables (nE={case.n_entity}, nU={case.n_user}, "
                                    f"nR={case.n_relation}), dim={a.dim} hop={a.hop} n_mix_hop={a.mix} "
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
                                    f"full get_scores path",
-                       "pairs_per_gpu_per_step": a.batch, "adjacency": a.adj, "items": a.items,
-                       "parallelism": f"pairs-dp{world}-replicated-tables" if world > 1 else "single-gpu"},
-            "roofline": {"bound": "hbm", "kernel": "gather_attn_kernel (mvin_gather_attn_fwd)",
+                       "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
+                       "adjacency": a.adj, "items": a.items,
+                       "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
+                                       f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
+                                       f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"
+                                       if rowshard else
+                                       (f"pairs split over {world} ranks; tables replicated" if world > 1
+                                        else "single-gpu"))},
+            "roofline": {"bound": "hbm", "kernel": "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if model.fused else "gather_attn_kernel (mvin_gather_attn_fwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
-                         "bytes_per_pair": bpp, "pairs_per_launch": a.batch,
+                         "bytes_per_pair": bpp, "pairs_per_launch": Bl,
                          "avg_launch_ms": kern_avg_ms,
                          "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS},
         }
         if world == 1 and not a.no_cpu_baseline:
             cb, ref, Bc = cpu_baseline(a, margs, case, params)
             rec["cpu_baseline"] = cb
-            got = out.scores[:Bc].cpu().numpy()
+            got = out.scores[:Bc].cpu().numpy()  # rank 0 owns the first pairs of the global batch
             err = np.abs(got - ref.scores.numpy())
             rec["parity_vs_cpu_sample"] = {"max_abs_err": float(err.max()),
                                            "within_1e-5rel_1e-6abs": bool((err <= 1e-5 * np.abs(ref.scores.numpy()) + 1e-6).all())}
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

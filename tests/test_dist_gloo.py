@@ -1,0 +1,120 @@
+"""CPU, world_size=2 over gloo: the row-sharded entity table and its all-to-all row fetch
+(mvin_amd/dist.py).  The owner-side gather is injected (torch indexing here; the HIP gather
+kernel in production), everything else is the production code path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mvin_amd import synth
+from mvin_amd.config import make_args
+from mvin_amd.dist import ShardedEntityTable, mark_needed, shard_rows
+from mvin_amd.params import init_params
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _torch_gather(table, idx):
+    return table[idx.long()]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import mirror_fp32
+        args = make_args(dim=8, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=6)
+        case = synth.small_case(args, n_user=10, n_entity=97, n_relation=5, seed=40)   # same on every rank
+        params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=41)
+        full = torch.from_numpy(params["entity_emb_matrix"])
+        sl = slice(rank * 3, rank * 3 + 3)                                             # my pairs
+        items = torch.from_numpy(case.items[sl])
+        mh = [torch.from_numpy(m[sl]) for m in case.memories_h]
+        mt = [torch.from_numpy(m[sl]) for m in case.memories_t]
+        adj_e = torch.from_numpy(case.adj_entity.astype(np.int32))
+        need = mark_needed(case.n_entity, adj_e, items, 2, extra_ids=mh + mt)
+        table = ShardedEntityTable(shard_rows(full, rank, world), case.n_entity, rank, world, _torch_gather)
+        assert table.local.shape[0] == -(-case.n_entity // world)          # padded block
+        # ---- sparse regime: only the touched rows move ----
+        work = table.fetch(need)
+        idx = need.nonzero(as_tuple=True)[0]
+        assert torch.equal(work[idx], full[idx]), "fetched rows differ from the owners' rows"
+        assert table.last_stats["requested"] == idx.numel() and table.last_stats["remote"] > 0
+        rest = torch.ones(work.shape[0], dtype=torch.bool)
+        rest[idx] = False
+        assert not work[rest].any()                                        # untouched rows never written
+        # the marked set covers everything the scoring path reads: scores from the working
+        # table == scores from the full table
+        sargs = make_args(**dict(vars(args), batch_size=3))
+        feed = (case.users[sl], case.items[sl], [m[sl] for m in case.memories_h],
+                [m[sl] for m in case.memories_r], [m[sl] for m in case.memories_t])
+        ref = mirror_fp32.forward(sargs, params, case.adj_entity, case.adj_relation, *feed)
+        got = mirror_fp32.forward(sargs, dict(params, entity_emb_matrix=work[:case.n_entity].numpy()), case.adj_entity,
+                                  case.adj_relation, *feed)
+        assert torch.equal(ref.scores, got.scores)
+        # a second fetch with a different need set reuses the working table
+        need2 = torch.zeros_like(need)
+        need2[[1, 2, 50 + rank]] = True
+        work = table.fetch(need2)
+        assert torch.equal(work[:case.n_entity][need2], full[need2])
+        # ---- dense regime: one all-to-all brings every shard ----
+        w2 = table.fetch_all(table.new_work_table())
+        assert torch.equal(w2[:case.n_entity], full) and not w2[case.n_entity:].any()
+        assert table.last_stats["mode"] == "dense"
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        ret[rank] = f"FAIL {type(e).__name__}: {e}"
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_table_all_to_all_fetch_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_single_rank_fetch_and_block_partition():
+    full = torch.arange(11 * 4, dtype=torch.float32).view(11, 4) + 1
+    for world in (1, 2, 3, 8):
+        shards = [shard_rows(full, r, world) for r in range(world)]
+        n_local = -(-11 // world)
+        assert all(s.shape == (n_local, 4) for s in shards)
+        assert torch.equal(torch.cat(shards)[:11], full) and not torch.cat(shards)[11:].any()
+    t = ShardedEntityTable(full.clone(), 11, 0, 1, _torch_gather)
+    need = torch.zeros(11, dtype=torch.bool)
+    need[[0, 3, 10]] = True
+    w = t.fetch(need)
+    assert torch.equal(w[need], full[need]) and not w[~need].any()
+    assert torch.equal(t.fetch_all(), full)
+
+
+def test_mark_needed_matches_bruteforce_tree():
+    rng = np.random.default_rng(0)
+    nE, K = 60, 3
+    adj = rng.integers(0, nE, (nE, K))
+    items = np.array([5, 17, 5])
+    want = set(items.tolist())
+    level = items
+    for _ in range(3):
+        level = adj[level].reshape(-1)
+        want |= set(level.tolist())
+    extra = np.array([[58, 59]])
+    want |= {58, 59}
+    got = mark_needed(nE, torch.from_numpy(adj.astype(np.int32)), torch.from_numpy(items), 3,
+                      [torch.from_numpy(extra)])
+    assert set(got.nonzero(as_tuple=True)[0].tolist()) == want
