@@ -183,6 +183,19 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
+        # HBM/fabric traffic of the dominant kernel comes from separate rocprofv3 --pmc passes
+        # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) archived under profiles/; it is
+        # attached only when that profile was taken on exactly this workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+                pmc = json.load(f)
+            same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
+                                              "fanout": a.fanout, "adj": a.adj, "items": a.items})
+            if same and model.fused and world == 1:
+                traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
+        except (OSError, KeyError, ValueError):
+            traffic = None
         L = a.hop * a.mix
         bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L)
         kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
@@ -209,7 +222,10 @@ def main():
                                         else "single-gpu"))},
             "roofline": {"bound": "hbm", "kernel": "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if model.fused else "gather_attn_kernel (mvin_gather_attn_fwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "traffic_note": "bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE+WRITE_SIZE, "
+                                         "profiles/pmc_latest.json); far below the algorithmic bytes because the 27 MB "
+                                         "table is L2/Infinity-Cache resident" if traffic else None,
                          "bytes_per_pair": bpp, "pairs_per_launch": Bl,
                          "avg_launch_ms": kern_avg_ms,
                          "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS},
