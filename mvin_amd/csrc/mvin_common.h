@@ -21,6 +21,37 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ---- DPP cross-lane reductions (no LDS traffic) --------------------------------------------
+// A DPP "row" is 16 lanes.  quad_perm [1,0,3,2] (0xB1) = lane^1, quad_perm [2,3,0,1] (0x4E) =
+// lane^2, row_half_mirror (0x141) pairs lane i with 7-i inside each 8, row_mirror (0x140) pairs
+// i with 15-i: applied in that order with a commutative op every lane of an aligned 2/4/8/16
+// lane group ends up with the group's reduction.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+// sum over aligned groups of 2^l2 lanes (l2 wave-uniform, 0..6); every lane gets the result
+__device__ __forceinline__ float group_sum(float v, int l2) {
+    if (l2 >= 1) v += dpp_mov<0xB1>(v);
+    if (l2 >= 2) v += dpp_mov<0x4E>(v);
+    if (l2 >= 3) v += dpp_mov<0x141>(v);
+    if (l2 >= 4) v += dpp_mov<0x140>(v);
+    if (l2 >= 5) v += __shfl_xor(v, 16, kWave);
+    if (l2 >= 6) v += __shfl_xor(v, 32, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float group_max(float v, int l2) {
+    if (l2 >= 1) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if (l2 >= 2) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if (l2 >= 3) v = fmaxf(v, dpp_mov<0x141>(v));
+    if (l2 >= 4) v = fmaxf(v, dpp_mov<0x140>(v));
+    if (l2 >= 5) v = fmaxf(v, __shfl_xor(v, 16, kWave));
+    if (l2 >= 6) v = fmaxf(v, __shfl_xor(v, 32, kWave));
+    return v;
+}
+
 __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
     a.x = fmaf(s, v.x, a.x);
     a.y = fmaf(s, v.y, a.y);

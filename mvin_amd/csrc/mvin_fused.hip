@@ -194,8 +194,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     sc2 = sT0[re.z];
                     sc3 = sT0[re.w];
                 }
-                float m = fmaxf(fmaxf(sc0, sc1), fmaxf(sc2, sc3));
-                for (int o = 1; o < lpn; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+                float m = group_max(fmaxf(fmaxf(sc0, sc1), fmaxf(sc2, sc3)), a.lpn_log2);
                 float e0 = 1.f, e1 = 1.f, e2 = 1.f, e3 = 1.f;
                 if (has_att0) {
                     e0 = expf(sc0 - m);
@@ -203,8 +202,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     e2 = expf(sc2 - m);
                     e3 = expf(sc3 - m);
                 }
-                float z = (e0 + e1) + (e2 + e3);
-                for (int o = 1; o < lpn; o <<= 1) z += __shfl_xor(z, o, kWave);
+                const float z = group_sum((e0 + e1) + (e2 + e3), a.lpn_log2);
                 if (valid) {
                     if (has_att0) {
                         e0 /= z;

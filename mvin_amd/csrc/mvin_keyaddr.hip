@@ -13,7 +13,7 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-template <int NJ>
+template <int NJ, bool OWN>
 __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D, Nm = a.Nm;
@@ -31,14 +31,26 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
             const int32_t* mh = a.mem_h[hop] + b * Nm;
             const int32_t* mr = do_hop ? a.mem_r[hop] + b * Nm : nullptr;
             const int32_t* mt = do_hop ? a.mem_t[hop] + b * Nm : nullptr;
+            // ids: one coalesced load per list, then distributed to the row groups by bpermute
+            const int lm = lane < Nm ? lane : Nm - 1;
+            const int idh = mh[lm];
+            const int idt = do_hop ? mt[lm] : 0;
+            const int idr = do_hop ? mr[lm] : 0;
             int hid[NJ], tix[NJ], rid[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int m = j * rpw + g;
-                const bool v = m < Nm;
-                hid[j] = v ? mh[m] : 0;
-                tix[j] = (v && do_hop) ? mt[m] : 0;
-                rid[j] = (v && do_hop) ? mr[m] : 0;
+                int m = j * rpw + g;
+                if (Nm <= kWave) {
+                    m = m < Nm ? m : Nm - 1;
+                    hid[j] = __shfl(idh, m, kWave);
+                    tix[j] = __shfl(idt, m, kWave);
+                    rid[j] = __shfl(idr, m, kWave);
+                } else {  // more memories than lanes: per-row loads
+                    const bool v = m < Nm;
+                    hid[j] = v ? mh[m] : 0;
+                    tix[j] = (v && do_hop) ? mt[m] : 0;
+                    rid[j] = (v && do_hop) ? mr[m] : 0;
+                }
             }
             float4 hrow[NJ], trow[NJ];
 #pragma unroll
@@ -52,64 +64,94 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
                 if (do_hop && cact && j * rpw + g < Nm)
                     trow[j] = reinterpret_cast<const float4*>(a.E + (int64_t)tix[j] * D)[c];
             }
-            // ---- logits ----
-            float sh[NJ], ss[NJ];
             const float4 wv = (do_set && cact) ? reinterpret_cast<const float4*>(a.w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_h = make_float4(0.f, 0.f, 0.f, 0.f);
+            float zh = 1.f, zs = 1.f;
+            if constexpr (OWN) {
+                // ---- logits; lane c of a row group keeps the logit of row j == c ----
+                float oh = -INFINITY, os = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                float ph = 0.f, ps = 0.f;
-                if (do_hop && cact) {
-                    const float4 v = reinterpret_cast<const float4*>(a.V + (b * a.nR + rid[j]) * (int64_t)D)[c];
-                    ph = dot4(hrow[j], v);
+                for (int j = 0; j < NJ; ++j) {
+                    float ph = 0.f, ps = 0.f;
+                    if (do_hop && cact) {
+                        const float4 v = reinterpret_cast<const float4*>(a.V + (b * a.nR + rid[j]) * (int64_t)D)[c];
+                        ph = dot4(hrow[j], v);
+                    }
+                    if (do_set) ps = dot4(hrow[j], wv);
+                    if (do_hop) ph = group_sum(ph, a.lpr_log2);   // DPP: no LDS round trips
+                    if (do_set) ps = group_sum(ps, a.lpr_log2);
+                    const bool mine = (c == j) && (j * rpw + g < Nm);
+                    oh = mine ? ph : oh;
+                    os = mine ? ps : os;
                 }
-                if (do_set) ps = dot4(hrow[j], wv);
-                for (int o = 1; o < lpr; o <<= 1) {
-                    ph += __shfl_xor(ph, o, kWave);
-                    ps += __shfl_xor(ps, o, kWave);
+                // ---- softmax over the Nm memories (tf.nn.softmax, model.py:189 / :223): ONE exp
+                // per lane; the un-normalised weights return to the group's lanes by bpermute and
+                // 1/sum is applied once to the accumulated row sum ----
+                const float mxh = wave_max(oh), mxs = wave_max(os);
+                const bool own = oh != -INFINITY || os != -INFINITY;
+                const float xh = (own && do_hop) ? expf(oh - mxh) : 0.f;
+                const float xs = (own && do_set) ? expf(os - mxs) : 0.f;
+                zh = wave_sum(xh);
+                zs = wave_sum(xs);
+                const int gbase = lane & ~(lpr - 1);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {   // weighted sums (model.py:195 / :229)
+                    if (do_hop) acc_h = f4_fma(__shfl(xh, gbase | j, kWave), trow[j], acc_h);
+                    if (do_set) acc_s = f4_fma(__shfl(xs, gbase | j, kWave), hrow[j], acc_s);
                 }
-                const bool v = j * rpw + g < Nm;
-                sh[j] = v ? ph : -INFINITY;
-                ss[j] = v ? ps : -INFINITY;
-            }
-            // ---- softmax over the Nm memories: in-lane over j, across row groups by xor ----
-            float mxh = -INFINITY, mxs = -INFINITY;
+            } else {
+                // more rows per lane than lanes per row (Nm > 64): every lane exponentiates its rows
+                float sh[NJ], ss[NJ];
+                float mxh = -INFINITY, mxs = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                mxh = fmaxf(mxh, sh[j]);
-                mxs = fmaxf(mxs, ss[j]);
-            }
-            for (int o = lpr; o < kWave; o <<= 1) {
-                mxh = fmaxf(mxh, __shfl_xor(mxh, o, kWave));
-                mxs = fmaxf(mxs, __shfl_xor(mxs, o, kWave));
-            }
-            float zh = 0.f, zs = 0.f;
+                for (int j = 0; j < NJ; ++j) {
+                    float ph = 0.f, ps = 0.f;
+                    if (do_hop && cact) {
+                        const float4 v = reinterpret_cast<const float4*>(a.V + (b * a.nR + rid[j]) * (int64_t)D)[c];
+                        ph = dot4(hrow[j], v);
+                    }
+                    if (do_set) ps = dot4(hrow[j], wv);
+                    ph = group_sum(ph, a.lpr_log2);
+                    ps = group_sum(ps, a.lpr_log2);
+                    const bool v = j * rpw + g < Nm;
+                    sh[j] = v ? ph : -INFINITY;
+                    ss[j] = v ? ps : -INFINITY;
+                    mxh = fmaxf(mxh, sh[j]);
+                    mxs = fmaxf(mxs, ss[j]);
+                }
+                for (int o = lpr; o < kWave; o <<= 1) {
+                    mxh = fmaxf(mxh, __shfl_xor(mxh, o, kWave));
+                    mxs = fmaxf(mxs, __shfl_xor(mxs, o, kWave));
+                }
+                zh = zs = 0.f;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const bool v = j * rpw + g < Nm;
-                sh[j] = (v && do_hop) ? expf(sh[j] - mxh) : 0.f;
-                ss[j] = (v && do_set) ? expf(ss[j] - mxs) : 0.f;
-                zh += sh[j];
-                zs += ss[j];
+                for (int j = 0; j < NJ; ++j) {
+                    const bool v = j * rpw + g < Nm;
+                    const float eh = (v && do_hop) ? expf(sh[j] - mxh) : 0.f;
+                    const float es = (v && do_set) ? expf(ss[j] - mxs) : 0.f;
+                    zh += eh;
+                    zs += es;
+                    acc_h = f4_fma(eh, trow[j], acc_h);
+                    acc_s = f4_fma(es, hrow[j], acc_s);
+                }
+                for (int o = lpr; o < kWave; o <<= 1) {
+                    zh += __shfl_xor(zh, o, kWave);
+                    zs += __shfl_xor(zs, o, kWave);
+                }
             }
-            for (int o = lpr; o < kWave; o <<= 1) {
-                zh += __shfl_xor(zh, o, kWave);
-                zs += __shfl_xor(zs, o, kWave);
-            }
-            // ---- weighted sums (model.py:195 / :229) ----
             if (do_set) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc = f4_fma(ss[j] / zs, hrow[j], acc);
-                acc = group_xor_sum(acc, lpr);
-                if (cact && g == 0) *reinterpret_cast<float4*>(a.out + b * a.ldo + (c << 2)) = acc;
+                acc_s = group_xor_sum(acc_s, lpr);
+                const float inv = 1.f / zs;
+                if (cact && g == 0)
+                    *reinterpret_cast<float4*>(a.out + b * a.ldo + (c << 2)) =
+                        make_float4(acc_s.x * inv, acc_s.y * inv, acc_s.z * inv, acc_s.w * inv);
             }
             if (do_hop) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc = f4_fma(sh[j] / zh, trow[j], acc);
-                acc = group_xor_sum(acc, lpr);
+                acc_h = group_xor_sum(acc_h, lpr);
+                const float inv = 1.f / zh;
                 if (cact && g == 0)
-                    *reinterpret_cast<float4*>(a.out + b * a.ldo + (int64_t)(slot0 + hop) * D + (c << 2)) = acc;
+                    *reinterpret_cast<float4*>(a.out + b * a.ldo + (int64_t)(slot0 + hop) * D + (c << 2)) =
+                        make_float4(acc_h.x * inv, acc_h.y * inv, acc_h.z * inv, acc_h.w * inv);
             }
         }
     }
@@ -128,14 +170,20 @@ hipError_t launch_key_addr(const KeyAddrArgs& a, hipStream_t st) {
     const int64_t nblk = (a.B + 3) / 4;
     const int64_t cap = 256 * 8;
     const int grid = (int)(nblk < cap ? nblk : cap);
+    const bool own = nj <= (1 << a.lpr_log2);   // rows per lane <= lanes per row: one exp per lane
+#define MVIN_KA(NJV)                                                                   \
+    if (own) key_addr_kernel<NJV, true><<<grid, kBlock, 0, st>>>(a);                   \
+    else key_addr_kernel<NJV, false><<<grid, kBlock, 0, st>>>(a);                      \
+    break;
     switch (nj) {
-        case 1: key_addr_kernel<1><<<grid, kBlock, 0, st>>>(a); break;
-        case 2: key_addr_kernel<2><<<grid, kBlock, 0, st>>>(a); break;
-        case 4: key_addr_kernel<4><<<grid, kBlock, 0, st>>>(a); break;
-        case 8: key_addr_kernel<8><<<grid, kBlock, 0, st>>>(a); break;
-        case 16: key_addr_kernel<16><<<grid, kBlock, 0, st>>>(a); break;
+        case 1: MVIN_KA(1)
+        case 2: MVIN_KA(2)
+        case 4: MVIN_KA(4)
+        case 8: MVIN_KA(8)
+        case 16: MVIN_KA(16)
         default: return hipErrorInvalidValue;
     }
+#undef MVIN_KA
     return hipGetLastError();
 }
 
