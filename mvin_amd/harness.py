@@ -1,0 +1,264 @@
+"""Harness counterpart: the callers of the scoring path in the reference
+(src/model/MVIN/train.py:112-146, util.py:14-242), restated for the mvin_amd.MVIN model.
+
+Scope row f-3 / f-4 of SURVEY.md section 8: feed assembly, CTR evaluation, top-K evaluation
+and the attention case-study dump.  The epoch loop, early stopping and log book-keeping
+(train.py:16-109, train_util.py) are not rebuilt.  Behaviours kept on purpose:
+
+  * CTR eval walks FULL batches only and drops the ragged tail (util.py:49); metrics are
+    means of per-batch AUC / ACC / F1 (util.py:56);
+  * top-K eval scores every (user, item not in the user's train record) pair in batches of
+    ``batch_size``, padding the last batch with its last item (util.py:166-177);
+  * the NDCG hit list is built with the LAST k of ``k_list`` (the stale loop variable of
+    util.py:187-199), i.e. over the top-100 items, then cut at each k inside ndcg_at_k.
+
+``DeviceFeeder`` is the MI355X-first variant of the feed assembly: the ripple sets of all
+users live on the GPU once ([n_user, P, 3, Nm] int32) and a batch's memories are gathered there,
+so the per-step host work of train.py:117-120 (3*P python lists of B numpy rows) disappears.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------- feed assembly
+def get_feed_dict(args, model, data, user_triplet_set, start, end):
+    """train.py:112-122 / util.py:208-218."""
+    feed = {model.user_indices: data[start:end, 0],
+            model.item_indices: data[start:end, 1],
+            model.labels: data[start:end, 2]}
+    for i in range(max(1, args.p_hop)):
+        feed[model.memories_h[i]] = [user_triplet_set[u][i][0] for u in data[start:end, 0]]
+        feed[model.memories_r[i]] = [user_triplet_set[u][i][1] for u in data[start:end, 0]]
+        feed[model.memories_t[i]] = [user_triplet_set[u][i][2] for u in data[start:end, 0]]
+    return feed
+
+
+def get_feed_dict_top_k(args, model, user_list, item, label, user_triplet_set):
+    """train.py:124-134 / util.py:220-230."""
+    feed = {model.user_indices: user_list, model.item_indices: item, model.labels: label}
+    for i in range(max(1, args.p_hop)):
+        feed[model.memories_h[i]] = [user_triplet_set[u][i][0] for u in user_list]
+        feed[model.memories_r[i]] = [user_triplet_set[u][i][1] for u in user_list]
+        feed[model.memories_t[i]] = [user_triplet_set[u][i][2] for u in user_list]
+    return feed
+
+
+def get_user_record(data, is_train=True):
+    """train.py:136-146: user -> set of items with label 1."""
+    rec = {}
+    for u, i, lab in zip(data[:, 0], data[:, 1], data[:, 2]):
+        if lab == 1:
+            rec.setdefault(u, set()).add(i)
+    return rec
+
+
+class DeviceFeeder(object):
+    """Ripple sets resident on the GPU; batches assembled by device-side row selection."""
+
+    def __init__(self, model, user_triplet_set):
+        import torch
+        arr = np.asarray(user_triplet_set) if not isinstance(user_triplet_set, dict) else None
+        if arr is None:  # dict user -> [P,3,Nm] (the reference's defaultdict)
+            n_user = model.n_user
+            some = next(iter(user_triplet_set.values()))
+            arr = np.zeros((n_user,) + np.asarray(some).shape, dtype=np.int32)
+            for u, v in user_triplet_set.items():
+                arr[u] = v
+        self.model = model
+        self.uts = torch.from_numpy(np.ascontiguousarray(arr.astype(np.int32))).to(model.device)
+        self.P = self.uts.shape[1]
+
+    def memories(self, users_dev):
+        sel = self.uts[users_dev.long()]
+        return ([sel[:, i, 0].contiguous() for i in range(self.P)],
+                [sel[:, i, 1].contiguous() for i in range(self.P)],
+                [sel[:, i, 2].contiguous() for i in range(self.P)])
+
+    def scores(self, users, items):
+        """sigmoid scores of (users[i], items[i]) as a device tensor; inputs numpy or tensors."""
+        import torch
+        dev = self.model.device
+        u = torch.as_tensor(np.asarray(users) if not torch.is_tensor(users) else users).to(dev).long()
+        it = torch.as_tensor(np.asarray(items) if not torch.is_tensor(items) else items).to(dev).long()
+        mh, mr, mt = self.memories(u)
+        return self.model.forward_device(u, it, mh, mr, mt).scores_normalized
+
+
+# --------------------------------------------------------------------------- ranking metrics
+def precision_at_k(ranked, answers, k):
+    """metrics.py:33-48: |top-k intersect answers| / k."""
+    return len(set(ranked[:k]) & set(answers)) / k
+
+
+def recall_at_k(ranked, answers, k):
+    """metrics.py:96-111: |top-k intersect answers| / |answers|."""
+    return len(set(ranked[:k]) & set(answers)) / len(answers)
+
+
+def dcg_at_k(r, k):
+    """metrics.py:3-18 with method=1: sum_i r_i / log2(i + 2)."""
+    r = np.asarray(r, dtype=np.float64)[:k]
+    return float(np.sum(r / np.log2(np.arange(2, r.size + 2)))) if r.size else 0.0
+
+
+def ndcg_at_k(r, k):
+    """metrics.py:21-31."""
+    best = dcg_at_k(sorted(r, reverse=True), k)
+    return dcg_at_k(r, k) / best if best else 0.0
+
+
+# --------------------------------------------------------------------------- evaluations
+def ctr_eval(args, model, data, user_triplet_set, batch_size, sess=None):
+    """util.py:44-56 through the reference-shaped ``model.eval(sess, feed_dict)``."""
+    aucs, accs, f1s = [], [], []
+    start = 0
+    while start + batch_size <= data.shape[0]:
+        auc, acc, f1 = model.eval(sess, get_feed_dict(args, model, data, user_triplet_set, start, start + batch_size))
+        aucs.append(auc)
+        accs.append(acc)
+        f1s.append(f1)
+        start += batch_size
+    return aucs, accs, f1s, float(np.mean(aucs)), float(np.mean(accs)), float(np.mean(f1s))
+
+
+def ctr_eval_device(feeder, data, batch_size):
+    """Same numbers as ctr_eval, feeds assembled on the device."""
+    from sklearn.metrics import f1_score, roc_auc_score
+    aucs, accs, f1s = [], [], []
+    start = 0
+    while start + batch_size <= data.shape[0]:
+        blk = data[start:start + batch_size]
+        s = feeder.scores(blk[:, 0], blk[:, 1]).cpu().numpy()
+        labels = blk[:, 2].astype(np.float32)
+        aucs.append(roc_auc_score(y_true=labels, y_score=s))
+        pred = (s >= 0.5).astype(np.float32)
+        f1s.append(f1_score(y_true=labels, y_pred=pred))
+        accs.append(float(np.mean(pred == labels)))
+        start += batch_size
+    return aucs, accs, f1s, float(np.mean(aucs)), float(np.mean(accs)), float(np.mean(f1s))
+
+
+def topk_settings(train_data, eval_data, test_data, n_item, user_num=250, k_list=(1, 2, 5, 10, 25, 50, 100)):
+    """util.py:14-41 without the pickle round trip: the ``user_num`` users with the most
+    positive train interactions among those present in all three splits."""
+    train_record = get_user_record(train_data, True)
+    test_record = get_user_record(test_data, False)
+    eval_record = get_user_record(eval_data, False)
+    users = list(set(train_record) & set(test_record) & set(eval_record))
+    users = sorted(users, key=lambda u: len(train_record[u]), reverse=True)[:user_num]
+    return users, train_record, eval_record, test_record, set(range(n_item)), list(k_list)
+
+
+def _rank_metrics(item_sorted, truth, k_list, precision_list, recall_list, ndcg_list):
+    for k in k_list:
+        precision_list[k].append(precision_at_k(item_sorted, truth, k))
+        recall_list[k].append(recall_at_k(item_sorted, truth, k))
+    k_stale = k_list[-1]  # util.py:193 uses the loop variable left over from the loop above
+    r_hit = [1 if i in truth else 0 for i in item_sorted[:k_stale]]
+    for k in k_list:
+        ndcg_list[k].append(ndcg_at_k(r_hit, k))
+
+
+def topk_eval(args, user_triplet_set, model, user_list, train_record, eval_record, test_record, item_set,
+              k_list, batch_size, mode="test", sess=None):
+    """util.py:137-205 through ``model.get_scores(sess, feed_dict)``."""
+    precision_list = {k: [] for k in k_list}
+    recall_list = {k: [] for k in k_list}
+    ndcg_list = {k: [] for k in k_list}
+    ref = eval_record if mode == "eval" else test_record
+    for user in user_list:
+        if user not in ref:
+            continue
+        test_items = list(item_set - train_record[user])
+        score_of = {}
+        start = 0
+        while start + batch_size <= len(test_items):
+            items, scores = model.get_scores(sess, get_feed_dict_top_k(
+                args, model, [user] * batch_size, test_items[start:start + batch_size], [1] * batch_size,
+                user_triplet_set))
+            score_of.update(zip(items, scores))
+            start += batch_size
+        if start < len(test_items):  # pad the ragged tail with its last item (util.py:166-177)
+            pad = test_items[start:] + [test_items[-1]] * (batch_size - len(test_items) + start)
+            items, scores = model.get_scores(sess, get_feed_dict_top_k(
+                args, model, [user] * batch_size, pad, [1] * batch_size, user_triplet_set))
+            score_of.update(zip(items, scores))
+        item_sorted = [i for i, _ in sorted(score_of.items(), key=lambda x: x[1], reverse=True)]
+        _rank_metrics(item_sorted, ref[user], k_list, precision_list, recall_list, ndcg_list)
+    return ([float(np.mean(precision_list[k])) for k in k_list], [float(np.mean(recall_list[k])) for k in k_list],
+            [float(np.mean(ndcg_list[k])) for k in k_list], None, None)
+
+
+def topk_eval_device(feeder, user_list, train_record, eval_record, test_record, item_set, k_list,
+                     batch_size, mode="test"):
+    """top-K evaluation with device-side feeds.  Every (user, candidate item) pair is scored
+    exactly once (no padded duplicates: the scoring path takes any batch length); ranking
+    ties are broken like the reference's ``sorted`` (stable, by insertion order)."""
+    precision_list = {k: [] for k in k_list}
+    recall_list = {k: [] for k in k_list}
+    ndcg_list = {k: [] for k in k_list}
+    ref = eval_record if mode == "eval" else test_record
+    for user in user_list:
+        if user not in ref:
+            continue
+        test_items = np.fromiter(item_set - train_record[user], dtype=np.int64)
+        scores = np.empty(len(test_items), dtype=np.float32)
+        for start in range(0, len(test_items), batch_size):
+            blk = test_items[start:start + batch_size]
+            scores[start:start + len(blk)] = feeder.scores(np.full(len(blk), user, dtype=np.int64), blk).cpu().numpy()
+        order = np.argsort(-scores, kind="stable")
+        _rank_metrics(test_items[order].tolist(), ref[user], k_list, precision_list, recall_list, ndcg_list)
+    return ([float(np.mean(precision_list[k])) for k in k_list], [float(np.mean(recall_list[k])) for k in k_list],
+            [float(np.mean(ndcg_list[k])) for k in k_list], None, None)
+
+
+# --------------------------------------------------------------------------- case study (f-4)
+def _names(ids, table):
+    return [table[str(i)] if str(i) in table else str(i) for i in ids]
+
+
+def ctr_eval_case_study(args, model, data, user_triplet_set, user_history_dict, entity_index_2_name,
+                        rela_index_2_name, user_list, item_set_most_pop, batch_size, path, sess=None):
+    """util.py:59-127: dump sampled neighbors, relations and attention weights per selected
+    (user, item) pair in the reference's text layout.  Written to ``path`` (the reference derives
+    the file name from args.path.case_st / log_name / epoch / SW_stage)."""
+    nb = args.neighbor_sample_size
+    star20, star50 = "*" * 20, "*" * 50
+    with open(path, "w") as f:
+        f.write(f"{star50}\n case_study \n")
+        start = 0
+        while start + batch_size <= data.shape[0]:
+            users, labels, items, ents, rels, imp0, imp1 = model.eval_case_study(
+                sess, get_feed_dict(args, model, data, user_triplet_set, start, start + batch_size))
+            for b in range(batch_size):
+                if users[b] not in user_list or items[b] not in item_set_most_pop:
+                    continue
+                f.write(f"{star50}\n")
+                f.write(f"user_indices = {users[b]}, item_indices = {items[b]}, labels = {labels[b]}\n")
+                f.write(f"{star20} first_layer  {star20}\n")
+                f.write(f"et_index 0 = {','.join(str(x) for x in ents[0][b, :].tolist())}\n")
+                f.write(f"rela_index 0 = {','.join(str(x) for x in rels[0][b, :].tolist())}\n")
+                f.write(f"et_index 1 = {','.join(str(x) for x in ents[1][b, :].tolist())}\n")
+                f.write(f"{star20} second_layer  {star20}\n")
+                for k in range(nb):
+                    f.write(f"entities 0 = {k}\n")
+                    f.write(f"et_index 0 = {ents[1][b, k].tolist()}\n")
+                    f.write(f"rela_index 0 = {','.join(str(x) for x in rels[1][b, nb * k: nb * (k + 1)].tolist())}\n")
+                    f.write(f"et_index 1 = {','.join(str(x) for x in ents[2][b, nb * k: nb * (k + 1)].tolist())}\n")
+                f.write(f"{star20} entity_relation_name  {star20}\n")
+                hist = _names(user_history_dict.get(users[b], []), entity_index_2_name)
+                f.write(f"item_name = {_names([items[b]], entity_index_2_name)[0]}\n")
+                f.write(f"user_interact_items = {','.join(hist)}\n")
+                ename = [_names(e[b, :], entity_index_2_name) for e in ents]
+                rname = [_names(r[b, :], rela_index_2_name) for r in rels]
+                f.write(f"{star20} first_layer  {star20}\n")
+                f.write(f"et_index 0 = {','.join(ename[0])}\n")
+                pairs = ["rela = %s, enti = %s, att = %s" % p for p in zip(rname[0], ename[1], imp0[b, :][0])]
+                f.write("er rela pair 0 = " + "\n".join(pairs) + "\n")
+                f.write(f"{star20} second_layer  {star20}\n")
+                for k in range(nb):
+                    f.write(f"entities 0 = {k}\n")
+                    f.write(f"et_index 0 = {ename[1][k]}\n")
+                    pairs = ["rela = %s, enti = %s, att = %s" % p for p in
+                             zip(rname[1][nb * k: nb * (k + 1)], ename[2][nb * k: nb * (k + 1)], imp1[b, k])]
+                    f.write("er rela pair 1 = " + "\n".join(pairs) + "\n")
+            start += batch_size
