@@ -171,6 +171,25 @@ int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float
                             float* out, int64_t ldo, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 
+/* ---- inputs of the path, built on the GPU (data_loader_user_set.py) ------------------------
+ * Both take the undirected KG as CSR: indptr [nE+1] int64, dst/rel [nnz] int32, every triple
+ * listed under its head and under its tail in file order (construct_kg, :324-343).  Draws are a
+ * pure function of `seed` (the reference uses unseeded global generators: its RULES are
+ * reproduced, its draws cannot be).
+ *
+ * mvin_sample_adjacency: contruct_random_adj (:375-388).  adj_entity/adj_relation [nE, K] int32:
+ * K distinct edges when deg >= K, K draws with replacement when 0 < deg < K, zero row when deg == 0. */
+int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
+                          uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream);
+
+/* mvin_build_ripple_sets: get_user_triplet_set / _get_user_triplet_set (:392-441).
+ * hist_ptr [nU+1] int64 / hist_items int32: each user's positive train items in interaction order.
+ * out [nU, P, 3, Nm] int32 = (heads, relations, tails) per hop; n_neighbor (16 in the reference, <= 32)
+ * edges per seed entity enter the candidate list. */
+int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int32_t* rel,
+                           const int64_t* hist_ptr, const int32_t* hist_items, int n_user, int P, int Nm,
+                           int n_neighbor, uint64_t seed, int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

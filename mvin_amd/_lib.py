@@ -66,6 +66,10 @@ SIGNATURES = {
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_sample_adjacency": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_int, C.c_int, C.c_uint64, _c_i32p,
+                                        _c_i32p, C.c_void_p]),
+    "mvin_build_ripple_sets": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_void_p, _c_i32p, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_uint64, _c_i32p, C.c_void_p]),
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),

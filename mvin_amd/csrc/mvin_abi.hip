@@ -270,4 +270,33 @@ int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float
     return hip_result(mvin::launch_key_addr(k, (hipStream_t)stream), who);
 }
 
+int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
+                          uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream) {
+    if (!indptr || !dst || !rel || !adj_entity || !adj_relation) return fail(-1, "mvin_sample_adjacency: null pointer");
+    if (n_entity <= 0 || K <= 0) return fail(-2, "mvin_sample_adjacency: bad sizes n_entity=%d K=%d", n_entity, K);
+    return hip_result(mvin::launch_sample_adjacency(indptr, dst, rel, n_entity, K, seed, adj_entity, adj_relation,
+                                                    (hipStream_t)stream), "mvin_sample_adjacency");
+}
+
+int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int32_t* rel, const int64_t* hist_ptr,
+                           const int32_t* hist_items, int n_user, int P, int Nm, int n_neighbor, uint64_t seed,
+                           int32_t* out, void* stream) {
+    if (!indptr || !dst || !rel || !hist_ptr || !hist_items || !out) return fail(-1, "mvin_build_ripple_sets: null pointer");
+    if (n_user <= 0 || P <= 0 || Nm <= 0 || Nm > 4096 || n_neighbor <= 0 || n_neighbor > 32)
+        return fail(-2, "mvin_build_ripple_sets: bad sizes n_user=%d P=%d Nm=%d n_neighbor=%d", n_user, P, Nm, n_neighbor);
+    mvin::RippleBuildArgs r{};
+    r.indptr = indptr;
+    r.dst = dst;
+    r.rel = rel;
+    r.hist_ptr = hist_ptr;
+    r.hist_items = hist_items;
+    r.out = out;
+    r.n_user = n_user;
+    r.seed = seed;
+    r.P = P;
+    r.Nm = Nm;
+    r.n_neighbor = n_neighbor;
+    return hip_result(mvin::launch_ripple_build(r, (hipStream_t)stream), "mvin_build_ripple_sets");
+}
+
 }  // extern "C"

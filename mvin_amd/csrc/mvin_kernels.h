@@ -41,6 +41,18 @@ struct RippleArgs {
     int mode, Nm, D, nR, lpr_log2;
 };
 
+struct RippleBuildArgs {
+    const int64_t* indptr;      // [nE+1] CSR of the undirected KG
+    const int32_t* dst;         // [nnz] neighbor entity
+    const int32_t* rel;         // [nnz] relation
+    const int64_t* hist_ptr;    // [nU+1] CSR of the users' positive train items
+    const int32_t* hist_items;  // [.]
+    int32_t* out;               // [nU, P, 3, Nm]
+    int64_t n_user;
+    uint64_t seed;
+    int P, Nm, n_neighbor;
+};
+
 struct KeyAddrArgs {
     const float* E;            // [nE, D]
     const float* V;            // [B, nR, D] or NULL (p_hop == 0)
@@ -90,6 +102,9 @@ hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D,
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st);
 hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st);
 hipError_t launch_ripple(const RippleArgs& a, hipStream_t st);
+hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity,
+                                   int K, uint64_t seed, int32_t* adj_e, int32_t* adj_r, hipStream_t st);
+hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
 hipError_t launch_key_addr(const KeyAddrArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);

@@ -85,14 +85,19 @@ class MVIN(object):
         self.agg_fun = self.aggregate_delta_whole if args.wide_deep else self.aggregate
         if self.dim % 4 != 0 or not (4 <= self.dim <= 256):
             raise ValueError("dim must be a multiple of 4 in [4, 256] (16-byte row loads)")
-        adj_entity = np.asarray(adj_entity)
-        adj_relation = np.asarray(adj_relation)
-        if adj_entity.shape != adj_relation.shape or adj_entity.shape[1] != self.n_neighbor:
+        if tuple(adj_entity.shape) != tuple(adj_relation.shape) or adj_entity.shape[1] != self.n_neighbor:
             raise ValueError("adj_entity/adj_relation must both be [n_entity, neighbor_sample_size]")
-        # ids are int64 in the reference (data_loader_user_set.py:377-378); int32 on device
-        # halves the id traffic (n_entity < 2^31).
-        self.adj_entity = torch.from_numpy(adj_entity.astype(np.int32)).to(self.device).contiguous()
-        self.adj_relation = torch.from_numpy(adj_relation.astype(np.int32)).to(self.device).contiguous()
+        self.set_adjacency(adj_entity, adj_relation)
+
+    def set_adjacency(self, adj_entity, adj_relation):
+        """Install a (re-)sampled adjacency: numpy int64 arrays as the reference builds them
+        (data_loader_user_set.py:377-378) or device tensors from mvin_amd.data_prep.construct_adj.
+        Kept as int32 on the device: halves the id traffic (n_entity < 2^31)."""
+        def conv(a):
+            if isinstance(a, torch.Tensor):
+                return a.to(self.device).to(torch.int32).contiguous()
+            return torch.from_numpy(np.asarray(a).astype(np.int32)).to(self.device).contiguous()
+        self.adj_entity, self.adj_relation = conv(adj_entity), conv(adj_relation)
 
     def _build_inputs(self):
         """model.py:49-64."""

@@ -1,0 +1,86 @@
+"""CPU: the sampling rules of the data-preparation oracle (oracle/prep_ref.py) against the
+reference's rules (data_loader_user_set.py:375-388, :407-441)."""
+import numpy as np
+
+from mvin_amd import synth
+from oracle import prep_ref
+
+
+def small_kg(n_entity=80, seed=0):
+    kg = synth.synth_kg(n_entity, 4, 7.0, seed=seed)
+    return kg, prep_ref.build_csr(kg, n_entity)
+
+
+def test_csr_keeps_reference_insertion_order():
+    kg = np.array([[0, 1, 2], [2, 0, 0], [3, 2, 3], [0, 3, 1]])
+    indptr, dst, rel = prep_ref.build_csr(kg, 5)
+    # entity 0: (2,1) from triple 0 as head, (2,0) from triple 1 as tail, (1,3) from triple 3
+    assert list(zip(dst[indptr[0]:indptr[1]], rel[indptr[0]:indptr[1]])) == [(2, 1), (2, 0), (1, 3)]
+    # self loop 3-3 is listed twice (:336, :339)
+    assert list(zip(dst[indptr[3]:indptr[4]], rel[indptr[3]:indptr[4]])) == [(3, 2), (3, 2)]
+    assert indptr[5] == 8 and indptr[4] == indptr[5]     # entity 4 absent
+
+
+def test_adjacency_rule():
+    kg, (indptr, dst, rel) = small_kg()
+    K = 5
+    ae, ar = prep_ref.sample_adjacency(indptr, dst, rel, 80, K, seed=11)
+    deg = np.diff(indptr)
+    assert (deg >= K).any() and ((deg > 0) & (deg < K)).any()
+    for x in range(80):
+        edges = list(zip(dst[indptr[x]:indptr[x + 1]].tolist(), rel[indptr[x]:indptr[x + 1]].tolist()))
+        got = list(zip(ae[x].tolist(), ar[x].tolist()))
+        if deg[x] == 0:
+            assert got == [(0, 0)] * K
+        elif deg[x] >= K:
+            pool = list(edges)
+            for g in got:                # distinct edge positions: a sub-multiset of the edge list
+                assert g in pool
+                pool.remove(g)
+        else:
+            assert set(got) <= set(edges)
+    # a different seed gives a different sample, the same seed the same one
+    ae2, _ = prep_ref.sample_adjacency(indptr, dst, rel, 80, K, seed=12)
+    ae3, _ = prep_ref.sample_adjacency(indptr, dst, rel, 80, K, seed=11)
+    assert (ae != ae2).any() and (ae == ae3).all()
+
+
+def test_floyd_is_uniform_over_subsets():
+    counts = {}
+    for trial in range(6000):
+        s = tuple(sorted(prep_ref.floyd(5, 2, lambda i, b: prep_ref.rnd_below(b, 99, 7, trial, i, 0))))
+        counts[s] = counts.get(s, 0) + 1
+    assert len(counts) == 10 and min(counts.values()) > 480 and max(counts.values()) < 720
+
+
+def test_ripple_set_rule():
+    kg, (indptr, dst, rel) = small_kg(seed=3)
+    rng = np.random.default_rng(1)
+    n_user, Nm, P = 9, 8, 2
+    hist = [rng.choice(30, size=rng.integers(0, 5), replace=False) for _ in range(n_user)]
+    hist_ptr = np.concatenate([[0], np.cumsum([len(h) for h in hist])]).astype(np.int64)
+    hist_items = np.concatenate(hist + [np.zeros(0, int)]).astype(np.int32)
+    out = prep_ref.ripple_sets(indptr, dst, rel, hist_ptr, hist_items, n_user, P, Nm, 16, seed=5)
+    deg = np.diff(indptr)
+    for u in range(n_user):
+        seeds0 = set(hist[u].tolist())
+        if sum(min(deg[e], 16) for e in seeds0) == 0:
+            assert not out[u].any()
+            continue
+        for h in range(P):
+            heads, rels, tails = out[u, h]
+            seeds = seeds0 if h == 0 else set(out[u, h - 1, 2].tolist())
+            for e, r, t in zip(heads, rels, tails):
+                assert e in seeds                                   # heads are seeds (:422)
+                edges = set(zip(dst[indptr[e]:indptr[e + 1]].tolist(), rel[indptr[e]:indptr[e + 1]].tolist()))
+                assert (t, r) in edges                              # (tail, relation) is an edge of the head
+        # without replacement when enough candidates (:433)
+        C0 = sum(min(deg[e], 16) for e in hist[u])
+        if C0 >= Nm and all(deg[e] <= 16 for e in hist[u]):
+            trip = list(zip(*out[u, 0].tolist()))
+            edge_mult = {}
+            for e in hist[u]:
+                for t, r in zip(dst[indptr[e]:indptr[e + 1]].tolist(), rel[indptr[e]:indptr[e + 1]].tolist()):
+                    edge_mult[(e, r, t)] = edge_mult.get((e, r, t), 0) + 1
+            for k in set(trip):
+                assert trip.count(k) <= edge_mult[k]
