@@ -23,6 +23,8 @@
 // Nothing of size K^L or K^(L-1) is ever written to memory.
 //
 // Supported: D in {16, 32, 64, 128}; K a power of two in [4, 256]; fp32.
+#include <cstdlib>
+
 #include "mvin_kernels.h"
 
 namespace mvin {
@@ -41,23 +43,34 @@ struct FusedGeom {
     static constexpr int KS = D / 4;                    // MFMA k-steps per DxD matrix
 };
 
-template <int D, int NW>
+// KIT > 0: software-pipelined variant.  The three dependent id fetches that precede a parent's
+// row gathers (parent id -> parent adjacency row -> its children's adjacency rows) are issued
+// one parent AHEAD and land while the current parent is being gathered / multiplied:
+//   top of iteration p        : wave 0 issues the adjacency-row loads of parent p+G (registers)
+//   end of wave 0's phase A   : ... turns them into x1/p0/p1 of p+G in the OTHER LDS buffer
+//   after the post-A barrier  : every wave issues the int4 adjacency chunks of its children of
+//                               p+G (KIT x 2 int4 registers), consumed at the top of the next
+//                               iteration without waiting
+// KIT = number of int4 chunk iterations per wave per tile (= NPW*K/256 <= 2); KIT = 0 keeps the
+// unpipelined flow (any K <= 256).
+template <int D, int NW, int KIT>
 __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) {
     using G = FusedGeom<D, NW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NBUF = KIT > 0 ? 2 : 1;
     const int K = a.K;
     const int ntile = (K + kTM - 1) / kTM;
     const int Kpad = ntile * kTM;
     float* sA = smem;                                   // [32][LDA]  {E[x1] raw | S'}
     float* sZ = sA + kTM * G::LDA;                      // [32][LDZ]
-    float* sP0 = sZ + kTM * G::LDZ;                     // [Kpad]
-    float* sP1 = sP0 + Kpad;                            // [Kpad]
-    float* sN0 = sP1 + Kpad;                            // [D]
+    float* sP0b = sZ + kTM * G::LDZ;                    // [NBUF][Kpad]
+    float* sP1b = sP0b + NBUF * Kpad;                   // [NBUF][Kpad]
+    float* sN0 = sP1b + NBUF * Kpad;                    // [D]
     float* sN1 = sN0 + D;                               // [D]
     float* sT0 = sN1 + D;                               // [nR]
     float* sT1 = sT0 + a.nR;                            // [nR]
-    int* sX1 = reinterpret_cast<int*>(sT1 + a.nR);      // [Kpad]
-    int2* sYP = reinterpret_cast<int2*>(sX1 + Kpad + ((Kpad + 2 * a.nR) & 1));  // [NW][NPW][K], 8-B aligned
+    int* sX1b = reinterpret_cast<int*>(sT1 + a.nR);     // [NBUF][Kpad]
+    int2* sYP = reinterpret_cast<int2*>(sX1b + NBUF * Kpad);  // [NW][NPW][K]; offset is even: 8-B aligned
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -93,64 +106,120 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
     const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
 
+    // parent adjacency row -> registers (lane n handles children n, n+64, ...; K <= 256)
+    auto parent_load = [&](int64_t x0, int (&xs)[4], int (&rr)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            xs[i] = 0;
+            rr[i] = 0;
+            if (n < K) {
+                xs[i] = a.adj_e[x0 * K + n];
+                if (has_att0 || has_att1) rr[i] = a.adj_r[x0 * K + n];
+            }
+        }
+    };
+    // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
+    auto parent_store = [&](int64_t pp, const int (&xs)[4], const int (&rr)[4], int* sX1w, float* sP0w, float* sP1w) {
+        float s0[4], s1[4];
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            s0[i] = s1[i] = -INFINITY;
+            if (n < K) {
+                s0[i] = has_att0 ? sT0[rr[i]] : 0.f;
+                s1[i] = has_att1 ? sT1[rr[i]] : 0.f;
+                m0 = fmaxf(m0, s0[i]);
+                m1 = fmaxf(m1, s1[i]);
+            }
+        }
+        m0 = wave_max(m0);
+        m1 = wave_max(m1);
+        float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            if (n < K) {
+                s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
+                s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
+                z0 += s0[i];
+                z1 += s1[i];
+            }
+        }
+        z0 = wave_sum(z0);
+        z1 = wave_sum(z1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = lane + 64 * i;
+            if (n < Kpad) {
+                const bool in = n < K;
+                const float p0 = in ? (has_att0 ? s0[i] / z0 : 1.f) : 0.f;
+                const float p1 = in ? (has_att1 ? s1[i] / z1 : 1.f) : 0.f;
+                sX1w[n] = xs[i];
+                sP0w[n] = p0;
+                sP1w[n] = p1;
+                if (in && a.probs_parent && has_att0) a.probs_parent[pp * K + n] = p0;
+            }
+        }
+    };
+    // int4 chunk `it` of the adjacency rows of this wave's children in `tile`
+    auto chunk_load = [&](const int* sX1r, int tile, int it, int4& ye, int4& re) {
+        const int nl = it * npi + (lane >> a.lpn_log2);
+        const int n = tile * kTM + wave * G::NPW + nl;
+        ye = make_int4(0, 0, 0, 0);
+        re = make_int4(0, 0, 0, 0);
+        if (nl < G::NPW && n < K) {
+            const int64_t xb = (int64_t)sX1r[n] * K + 4 * (lane & (lpn - 1));
+            ye = *reinterpret_cast<const int4*>(a.adj_e + xb);
+            if (has_att0) re = *reinterpret_cast<const int4*>(a.adj_r + xb);
+        }
+    };
+
+    constexpr int KITR = KIT > 0 ? KIT : 1;
+    int4 pye[KITR], pre[KITR];          // prefetched chunks of (next parent, tile 0)
+    int64_t x0_next = 0;                // entity id of the parent after the current one
+    int buf = 0;
+    if (KIT > 0) {                      // pipeline fill for this workgroup's first parent
+        const int64_t p0i = blockIdx.x;
+        __syncthreads();                // sT0/sT1 visible
+        if (wave == 0 && p0i < a.P) {
+            int xs[4], rr[4];
+            parent_load(a.parent_ids[p0i], xs, rr);
+            parent_store(p0i, xs, rr, sX1b, sP0b, sP1b);
+            if (p0i + gridDim.x < a.P) x0_next = a.parent_ids[p0i + gridDim.x];
+        }
+        __syncthreads();
+        if (p0i < a.P) {
+#pragma unroll
+            for (int it = 0; it < KITR; ++it) chunk_load(sX1b, 0, it, pye[it], pre[it]);
+        }
+    }
+
     for (int64_t p = blockIdx.x; p < a.P; p += gridDim.x) {
         const int64_t b = p / a.parents_per_pair;
-        __syncthreads();  // previous parent fully consumed (sP*, sN*, sX1)
-        // ---------------- prologue: the parent's children and their attention weights ----
-        if (wave == 0) {
-            const int64_t x0 = a.parent_ids[p];
-            float s0[4], s1[4];
-            int xs[4];
-            float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = lane + 64 * i;
-                xs[i] = 0;
-                s0[i] = s1[i] = -INFINITY;
-                if (n < K) {
-                    xs[i] = a.adj_e[x0 * K + n];
-                    int r = 0;
-                    if (has_att0 || has_att1) r = a.adj_r[x0 * K + n];
-                    s0[i] = has_att0 ? sT0[r] : 0.f;
-                    s1[i] = has_att1 ? sT1[r] : 0.f;
-                    m0 = fmaxf(m0, s0[i]);
-                    m1 = fmaxf(m1, s1[i]);
-                }
+        const int64_t pn = p + gridDim.x;
+        const bool has_next = KIT > 0 && pn < a.P;
+        int* sX1 = sX1b + buf * Kpad;
+        float* sP0 = sP0b + buf * Kpad;
+        float* sP1 = sP1b + buf * Kpad;
+        int nxs[4], nrr[4];             // next parent's adjacency row (wave 0, pipelined variant)
+        if (KIT == 0) {
+            __syncthreads();  // previous parent fully consumed (sP*, sN*, sX1)
+            if (wave == 0) {
+                int xs[4], rr[4];
+                parent_load(a.parent_ids[p], xs, rr);
+                parent_store(p, xs, rr, sX1, sP0, sP1);
             }
-            m0 = wave_max(m0);
-            m1 = wave_max(m1);
-            float z0 = 0.f, z1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = lane + 64 * i;
-                if (n < K) {
-                    s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
-                    s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
-                    z0 += s0[i];
-                    z1 += s1[i];
-                }
-            }
-            z0 = wave_sum(z0);
-            z1 = wave_sum(z1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = lane + 64 * i;
-                if (n < Kpad) {
-                    const bool in = n < K;
-                    const float p0 = in ? (has_att0 ? s0[i] / z0 : 1.f) : 0.f;
-                    const float p1 = in ? (has_att1 ? s1[i] / z1 : 1.f) : 0.f;
-                    sX1[n] = xs[i];
-                    sP0[n] = p0;
-                    sP1[n] = p1;
-                    if (in && a.probs_parent && has_att0) a.probs_parent[p * K + n] = p0;
-                }
-            }
+        } else if (wave == 0 && has_next) {
+            parent_load(x0_next, nxs, nrr);                       // lands during this parent's phase A
+            x0_next = pn + gridDim.x < a.P ? a.parent_ids[pn + gridDim.x] : 0;
         }
         if (tid < D) {
             sN0[tid] = 0.f;
             sN1[tid] = 0.f;
         }
-        __syncthreads();
+        if (KIT == 0) __syncthreads();
 
         float nacc0 = 0.f, nacc1 = 0.f;
         // c_e[col] = q_b . W_e[:, col] + b_e[col] (model.py:277-279 applied to the broadcast query):
@@ -176,16 +245,19 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
             // ---------------- phase A: ids, softmax, row gather ----------------
             const int node0 = tile * kTM + wave * G::NPW;
             int2* ypw = sYP + (size_t)wave * G::NPW * K;
-            for (int it = 0; it * npi < G::NPW; ++it) {
+#pragma unroll
+            for (int it = 0; it < (KIT > 0 ? KITR : 8); ++it) {
+                if (it * npi >= G::NPW) break;
                 const int nl = it * npi + (lane >> a.lpn_log2);
                 const int ch = lane & (lpn - 1);
                 const int n = node0 + nl;
                 const bool valid = nl < G::NPW && n < K;
-                int4 ye = make_int4(0, 0, 0, 0), re = make_int4(0, 0, 0, 0);
-                if (valid) {
-                    const int64_t xb = (int64_t)sX1[n] * K + 4 * ch;
-                    ye = *reinterpret_cast<const int4*>(a.adj_e + xb);
-                    if (has_att0) re = *reinterpret_cast<const int4*>(a.adj_r + xb);
+                int4 ye, re;
+                if (KIT > 0 && tile == 0 && it < KITR) {
+                    ye = pye[it < KITR ? it : 0];
+                    re = pre[it < KITR ? it : 0];
+                } else {
+                    chunk_load(sX1, tile, it, ye, re);
                 }
                 float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f, sc3 = 0.f;
                 if (has_att0 && valid) {
@@ -251,7 +323,13 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
                 }
             }
+            if (KIT > 0 && tile == 0 && wave == 0 && has_next)
+                parent_store(pn, nxs, nrr, sX1b + (buf ^ 1) * Kpad, sP0b + (buf ^ 1) * Kpad, sP1b + (buf ^ 1) * Kpad);
             __syncthreads();
+            if (KIT > 0 && tile == ntile - 1 && has_next) {
+#pragma unroll
+                for (int it = 0; it < KITR; ++it) chunk_load(sX1b + (buf ^ 1) * Kpad, 0, it, pye[it], pre[it]);
+            }
             // ---------------- phase B: projections (MFMA), Z -> LDS, nagg0 ----------------
             if (dense) {
                 f32x4 accE[G::MTW], accS[G::MTW];
@@ -333,28 +411,40 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
             a.nagg0[p * D + tid] = sN0[tid] * invK;
             a.nagg1[p * D + tid] = sN1[tid] * invK;
         }
+        if (KIT > 0) buf ^= 1;
     }
 }
 
-size_t fused_l2_lds_bytes(int D, int NW, int K, int nR) {
+size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf) {
     const int ntile = (K + kTM - 1) / kTM, Kpad = ntile * kTM;
-    size_t words = (size_t)kTM * (2 * D + 2) + (size_t)kTM * (D + 2) + 2 * Kpad + 2 * D + 2 * nR + Kpad;
-    words += (Kpad + 2 * nR) & 1;  // keep sYP 8-byte aligned
+    const size_t words = (size_t)kTM * (2 * D + 2) + (size_t)kTM * (D + 2) + 3 * (size_t)nbuf * Kpad + 2 * D + 2 * nR;
     return words * 4 + (size_t)NW * (kTM / NW) * K * sizeof(int2);
 }
 
-template <int D, int NW>
+template <int D, int NW, int KIT>
 static hipError_t launch_l2(const FusedL2Args& a, hipStream_t st) {
-    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR);
+    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int64_t cap = 256 * 4;  // persistent: 256 CUs x up to 4 resident workgroups
     const int grid = (int)(a.P < cap ? a.P : cap);
-    gather_attn_l2_kernel<D, NW><<<grid, NW * 64, lds, st>>>(a);
+    gather_attn_l2_kernel<D, NW, KIT><<<grid, NW * 64, lds, st>>>(a);
     return hipGetLastError();
+}
+
+// chunk iterations per wave per tile: NPW children x K/4 lanes each over 64 lanes
+template <int D, int NW>
+static hipError_t launch_l2_pick(const FusedL2Args& a, hipStream_t st) {
+    static const bool nopipe = getenv("MVIN_L2_NOPIPE") != nullptr;
+    const int kit = ((kTM / NW) * (a.K / 4) + 63) / 64;
+    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1>(a, st);
+    if constexpr (D <= 32) {   // at D >= 64 the second chunk pair costs a wave of occupancy
+        if (!nopipe && kit == 2) return launch_l2<D, NW, 2>(a, st);
+    }
+    return launch_l2<D, NW, 0>(a, st);
 }
 
 bool fused_l2_supported(int D, int K) {
@@ -365,10 +455,10 @@ bool fused_l2_supported(int D, int K) {
 
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st) {
     switch (D) {
-        case 16: return launch_l2<16, 4>(a, st);
-        case 32: return launch_l2<32, 4>(a, st);
-        case 64: return launch_l2<64, 4>(a, st);
-        case 128: return launch_l2<128, 8>(a, st);
+        case 16: return launch_l2_pick<16, 4>(a, st);
+        case 32: return launch_l2_pick<32, 4>(a, st);
+        case 64: return launch_l2_pick<64, 4>(a, st);
+        case 128: return launch_l2_pick<128, 8>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
