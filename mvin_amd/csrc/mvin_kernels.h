@@ -100,6 +100,8 @@ hipError_t launch_expand(const int32_t* adj_e, const int32_t* adj_r, const int64
 hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D, float* t,
                             hipStream_t st);
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st);
+bool linear_mfma_supported(const mvin_linear_args& a);
+hipError_t launch_linear_mfma(const mvin_linear_args& a, hipStream_t st);
 hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st);
 hipError_t launch_ripple(const RippleArgs& a, hipStream_t st);
 hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity,

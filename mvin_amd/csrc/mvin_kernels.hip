@@ -6,6 +6,8 @@
 // node; a wave64 gathers the K child rows of a task with 16-byte loads (D/4 lanes per row,
 // 64/(D/4) rows per wave-instruction), the softmax over K is a wave-level reduction, and the
 // small dense epilogues run on tiles of kTM = 32 tasks staged in LDS.
+#include <cstdlib>
+
 #include "mvin_kernels.h"
 
 namespace mvin {
@@ -403,6 +405,8 @@ hipError_t launch_rel_score(const float* rel, const float* urh_w, int nR, int D,
 }
 
 hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st) {
+    static const bool no_mfma = getenv("MVIN_LINEAR_VALU") != nullptr;
+    if (!no_mfma && linear_mfma_supported(a)) return launch_linear_mfma(a, st);
     const int nr = nr_for(a.Dout);
     const size_t lds = (size_t)kTM * ((a.sum_sources ? 1 : a.nsrc) * a.Dsrc + 4) * sizeof(float);
     const int64_t ntiles = (a.rows + kTM - 1) / kTM;
