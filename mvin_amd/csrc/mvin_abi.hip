@@ -170,6 +170,7 @@ int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const
     f.probs_parent = probs_parent;
     f.probs_child = probs_child;
     f.P = (int64_t)B * parents_per_pair;
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * sizeof(float);
     f.parents_per_pair = parents_per_pair;
     f.K = K;
     f.nR = nR;

@@ -30,6 +30,8 @@
 namespace mvin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int D, int NW>
 struct FusedGeom {
@@ -103,6 +105,11 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
 
+    // entity table through a buffer descriptor when it is < 4 GiB (32-bit byte offsets)
+    const bool buf32 = a.table_bytes < (1ull << 32);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
+    const unsigned c16 = (unsigned)c * 16u;
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
     const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
 
@@ -307,14 +314,39 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                 }
                 const int2* yp = ypw + nl * K;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-                for (int k = g; k < K; k += G::RPW) {
-                    const int2 e = yp[k];
-                    const float4 v = reinterpret_cast<const float4*>(a.table + (int64_t)e.x * D)[c];
-                    acc = f4_fma(__int_as_float(e.y), v, acc);
-                }
                 float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g == 0) sv = reinterpret_cast<const float4*>(a.table + (int64_t)sX1[n] * D)[c];
+                if (buf32) {
+                    // 32-bit row offsets through a buffer descriptor: one VALU per row address
+                    // instead of a 64-bit shift+add chain; packed FMAs (2 f32 per issue)
+                    f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 8
+                    for (int k = g; k < K; k += G::RPW) {
+                        const int2 e = yp[k];
+                        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                            rsrc, ((unsigned)e.x * (unsigned)(D * 4)) + c16, 0, 0);
+                        const float w = __int_as_float(e.y);
+                        const f32x2 ww = {w, w};
+                        const f32x2 v01 = {__uint_as_float(raw[0]), __uint_as_float(raw[1])};
+                        const f32x2 v23 = {__uint_as_float(raw[2]), __uint_as_float(raw[3])};
+                        a01 = __builtin_elementwise_fma(ww, v01, a01);
+                        a23 = __builtin_elementwise_fma(ww, v23, a23);
+                    }
+                    acc = make_float4(a01[0], a01[1], a23[0], a23[1]);
+                    if (g == 0) {
+                        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                            rsrc, ((unsigned)sX1[n] * (unsigned)(D * 4)) + c16, 0, 0);
+                        sv = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                                         __uint_as_float(raw[3]));
+                    }
+                } else {   // tables >= 4 GiB: 64-bit global addressing
+#pragma unroll 8
+                    for (int k = g; k < K; k += G::RPW) {
+                        const int2 e = yp[k];
+                        const float4 v = reinterpret_cast<const float4*>(a.table + (int64_t)e.x * D)[c];
+                        acc = f4_fma(__int_as_float(e.y), v, acc);
+                    }
+                    if (g == 0) sv = reinterpret_cast<const float4*>(a.table + (int64_t)sX1[n] * D)[c];
+                }
                 acc = group_xor_sum(acc, G::LPR);
                 if (g == 0) {
                     *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);

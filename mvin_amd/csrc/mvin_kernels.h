@@ -85,6 +85,7 @@ struct FusedL2Args {
     float* probs_parent;         // [P, K] or NULL
     float* probs_child;          // [P*K, K] or NULL
     int64_t P;
+    uint64_t table_bytes;        // nE * D * 4 (buffer descriptor range)
     int parents_per_pair, K, nR, lpn_log2;
 };
 
