@@ -191,7 +191,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
             same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
-                                              "fanout": a.fanout, "adj": a.adj, "items": a.items})
+                                              "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch})
             if same and model.fused and world == 1:
                 traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
         except (OSError, KeyError, ValueError):
