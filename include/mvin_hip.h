@@ -171,6 +171,55 @@ int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float
                             float* out, int64_t ldo, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 
+/* ---- training (model.py:378-417): forward variants that keep what the backward needs, and the
+ * backward / optimizer kernels.  Gradients are ACCUMULATED into caller-zeroed buffers. ------------ */
+
+/* mvin_gather_attn_fwd / mvin_agg_fwd with two extra optional outputs:
+ * s_out [T,D] = (1/K) sum_k p_k child_k (before the projection), z_out [T,D] = self + neighbors_agg. */
+int mvin_gather_attn_fwd_ex(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                            const int32_t* node_ids, const float* rel_score, const float* self_vec,
+                            const float* Wc, const float* c_child, const float* Wagg, const float* bagg,
+                            int B, int N, int K, int D, int n_entity, float* out, float* probs,
+                            float* s_out, float* z_out, void* stream);
+int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
+                    const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
+                    float* s_out, float* z_out, void* stream);
+
+/* element-wise helpers: mode 0 y = alpha x + beta y | 1 sigmoid cross entropy (model.py:379): y = (sigmoid(x) -
+ * z) alpha, *accum += beta * ce(x, z) | 2 relu backward y = z > 0 ? x : 0 | 3 *accum += alpha sum x^2 |
+ * 4 Adam step (x param, y grad, z m, w v, alpha = lr_t) | 5 y[r,:] = beta y[r,:] + alpha z[r] x[r,:] (n = rows*D) |
+ * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D). */
+int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha,
+                 float beta, float beta1, float beta2, float eps, int D, int N, void* stream);
+
+/* dtable[ids[r], :] += alpha * x[r, :]  -- backward of tf.nn.embedding_lookup (ids int32 or int64). */
+int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D,
+                          float alpha, void* stream);
+
+/* dW[z] += X^T . (dY[z] masked by mask > 0), db[z] += column sums; X staged as in mvin_linear_fwd
+ * (args->src/ids/nsrc/Dsrc/Dout/rows/nz/sum_sources/ids64 are read, the rest ignored). */
+int mvin_linear_wgrad(const mvin_linear_args* args, const float* dY, int64_t ldy, int64_t dy_zstride,
+                      const float* mask, int64_t ldm, int64_t mask_zstride, float* dW, int64_t dw_zstride,
+                      float* db, int64_t db_zstride, void* stream);
+
+/* backward of the neighbor mix agg[t] = (1/K) sum_k p[t,k] c[t,k], p = softmax_k(t[rel]) (aggregators.py:118-152)
+ * given dvec = dL/d agg: children from the table through the adjacency (table/adj/node_ids given: dc_k is added
+ * atomically to dtable) or dense (child/rel_ids given: dchild written).  dT [nR] accumulates the logit gradients. */
+int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
+                 const float* child, const int32_t* rel_ids, const float* probs, const float* dvec,
+                 int64_t T, int K, int D, int nR, float* dtable, float* dchild, float* dT, void* stream);
+
+/* backward of mvin_rel_score: drel[r,:] += dT[r] urh_w[D:2D]; durh[D:2D] += sum_r dT[r] rel[r,:]. */
+int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, const float* dT, int nR, int D,
+                       float* drel, float* durh, void* stream);
+
+/* backward of mvin_key_addressing_fwd (+ the 2*l2*(h,t) regulariser rows of model.py:383-385): dout is the
+ * gradient of out; dE [nE,D], dV [B,nR,D], dw [D] are accumulated. */
+int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float* w,
+                            const int32_t* const* mem_h, const int32_t* const* mem_r, const int32_t* const* mem_t,
+                            int P, int B, int Nm, int D, int nR, const float* dout, int64_t ldo, float l2,
+                            float* dE, float* dV, float* dw, void* stream);
+
 /* ---- inputs of the path, built on the GPU (data_loader_user_set.py) ------------------------
  * Both take the undirected KG as CSR: indptr [nE+1] int64, dst/rel [nnz] int32, every triple
  * listed under its head and under its tail in file order (construct_kg, :324-343).  Draws are a

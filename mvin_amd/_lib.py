@@ -70,6 +70,23 @@ SIGNATURES = {
                                         _c_i32p, C.c_void_p]),
     "mvin_build_ripple_sets": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_void_p, _c_i32p, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_uint64, _c_i32p, C.c_void_p]),
+    "mvin_gather_attn_fwd_ex": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
+                                          _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_agg_fwd_ex": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_eltwise": (C.c_int, [C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_float,
+                               C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "mvin_scatter_add_rows": (C.c_int, [_c_f32p, C.c_void_p, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_float,
+                                        C.c_void_p]),
+    "mvin_linear_wgrad": (C.c_int, [C.POINTER(LinearArgs), _c_f32p, C.c_int64, C.c_int64, _c_f32p, C.c_int64,
+                                    C.c_int64, _c_f32p, C.c_int64, _c_f32p, C.c_int64, C.c_void_p]),
+    "mvin_agg_bwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64,
+                               C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_rel_score_bwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_key_addressing_bwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),

@@ -109,7 +109,18 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
                          const int32_t* node_ids, const float* rel_score, const float* self_vec,
                          const float* Wc, const float* c_child, const float* Wagg, const float* bagg, int B,
                          int N, int K, int D, int n_entity, float* out, float* probs, void* stream) {
+    return mvin_gather_attn_fwd_ex(table, adj_entity, adj_relation, node_ids, rel_score, self_vec, Wc, c_child,
+                                   Wagg, bagg, B, N, K, D, n_entity, out, probs, nullptr, nullptr, stream);
+}
+
+int mvin_gather_attn_fwd_ex(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                            const int32_t* node_ids, const float* rel_score, const float* self_vec,
+                            const float* Wc, const float* c_child, const float* Wagg, const float* bagg, int B,
+                            int N, int K, int D, int n_entity, float* out, float* probs, float* s_out,
+                            float* z_out, void* stream) {
     mvin::GatherAttnArgs g{};
+    g.s_out = s_out;
+    g.z_out = z_out;
     g.gather = 1;
     g.table = table;
     g.adj_e = adj_entity;
@@ -128,7 +139,7 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
     if (n_entity <= 0) return fail(-2, "mvin_gather_attn_fwd: n_entity=%d", n_entity);
     if (probs && !rel_score) return fail(-2, "mvin_gather_attn_fwd: probs requested without rel_score");
     if (int rc = agg_common(g, B, N, K, D, "mvin_gather_attn_fwd")) return rc;
-    return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_gather_attn_fwd");
+    return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_gather_attn_fwd_ex");
 }
 
 int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supported(D, K) ? 1 : 0; }
@@ -183,7 +194,16 @@ int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const
 int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
                  const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
                  void* stream) {
+    return mvin_agg_fwd_ex(self_vec, neigh, rel_ids, rel_score, Wagg, bagg, B, N, K, D, out, probs, nullptr,
+                           nullptr, stream);
+}
+
+int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
+                    const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
+                    float* s_out, float* z_out, void* stream) {
     mvin::GatherAttnArgs g{};
+    g.s_out = s_out;
+    g.z_out = z_out;
     g.gather = 0;
     g.neigh = neigh;
     g.rel_ids = rel_ids;
@@ -298,6 +318,153 @@ int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int3
     r.Nm = Nm;
     r.n_neighbor = n_neighbor;
     return hip_result(mvin::launch_ripple_build(r, (hipStream_t)stream), "mvin_build_ripple_sets");
+}
+
+// ---------------------------------------------------------------------------- training
+int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha, float beta,
+                 float beta1, float beta2, float eps, int D, int N, void* stream) {
+    if (mode < 0 || mode > 6) return fail(-2, "mvin_eltwise: mode=%d", mode);
+    if (mode == 6 && (!y || D <= 0 || N <= 0)) return fail(-2, "mvin_eltwise: mode 6 needs y, D, N");
+    if (n < 0) return fail(-2, "mvin_eltwise: n < 0");
+    if (n == 0) return 0;
+    if (!x) return fail(-1, "mvin_eltwise: null x");
+    if ((mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5) && !y) return fail(-1, "mvin_eltwise: null y");
+    if ((mode == 1 || mode == 2 || mode == 4 || mode == 5) && !z) return fail(-1, "mvin_eltwise: null z");
+    if (mode == 4 && !w) return fail(-1, "mvin_eltwise: null w");
+    if (mode == 3 && !accum) return fail(-1, "mvin_eltwise: null accum");
+    if (mode == 5 && D <= 0) return fail(-2, "mvin_eltwise: D <= 0");
+    mvin::EltArgs e{};
+    e.mode = mode;
+    e.n = n;
+    e.x = x;
+    e.y = y;
+    e.z = z;
+    e.w = w;
+    e.accum = accum;
+    e.alpha = alpha;
+    e.beta = beta;
+    e.beta1 = beta1;
+    e.beta2 = beta2;
+    e.eps = eps;
+    e.D = D > 0 ? D : 1;
+    e.N = N > 0 ? N : 1;
+    return hip_result(mvin::launch_eltwise(e, (hipStream_t)stream), "mvin_eltwise");
+}
+
+int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D, float alpha,
+                          void* stream) {
+    if (!dtable || !ids || !x) return fail(-1, "mvin_scatter_add_rows: null pointer");
+    if (rows < 0 || D < 4 || (D & 3)) return fail(-2, "mvin_scatter_add_rows: bad sizes rows=%lld D=%d", (long long)rows, D);
+    if (rows == 0) return 0;
+    return hip_result(mvin::launch_scatter_add_rows(dtable, (const int32_t*)ids, ids64, x, rows, D, alpha,
+                                                    (hipStream_t)stream), "mvin_scatter_add_rows");
+}
+
+int mvin_linear_wgrad(const mvin_linear_args* a, const float* dY, int64_t ldy, int64_t dy_zstride, const float* mask,
+                      int64_t ldm, int64_t mask_zstride, float* dW, int64_t dw_zstride, float* db, int64_t db_zstride,
+                      void* stream) {
+    if (!a || !dY || !dW) return fail(-1, "mvin_linear_wgrad: null pointer");
+    if (a->nsrc < 1 || a->nsrc > MVIN_MAX_SRC) return fail(-2, "mvin_linear_wgrad: nsrc=%d", a->nsrc);
+    if (a->Dsrc < 4 || (a->Dsrc & 3) || a->Dout < 1 || a->Dout > MVIN_MAX_DIM)
+        return fail(-2, "mvin_linear_wgrad: Dsrc=%d Dout=%d", a->Dsrc, a->Dout);
+    if ((size_t)a->nsrc * a->Dsrc > 4096) return fail(-2, "mvin_linear_wgrad: nsrc*Dsrc > 4096");
+    for (int s = 0; s < a->nsrc; ++s)
+        if (!a->src[s]) return fail(-1, "mvin_linear_wgrad: null src[%d]", s);
+    if (ldy < a->Dout || (mask && ldm < a->Dout)) return fail(-2, "mvin_linear_wgrad: ldy/ldm < Dout");
+    if (a->rows <= 0) return a->rows == 0 ? 0 : fail(-2, "mvin_linear_wgrad: rows < 0");
+    mvin::WgradArgs w{};
+    w.lin = *a;
+    w.dY = dY;
+    w.ldy = ldy;
+    w.dy_zstride = dy_zstride;
+    w.mask = mask;
+    w.ldm = ldm;
+    w.mask_zstride = mask_zstride;
+    w.dW = dW;
+    w.dw_zstride = dw_zstride;
+    w.db = db;
+    w.db_zstride = db_zstride;
+    return hip_result(mvin::launch_linear_wgrad(w, (hipStream_t)stream), "mvin_linear_wgrad");
+}
+
+int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
+                 const float* child, const int32_t* rel_ids, const float* probs, const float* dvec, int64_t T, int K,
+                 int D, int nR, float* dtable, float* dchild, float* dT, void* stream) {
+    const bool gather = table != nullptr;
+    if (!dvec) return fail(-1, "mvin_agg_bwd: null dvec");
+    if (gather && (!adj_entity || !node_ids || !dtable)) return fail(-1, "mvin_agg_bwd: gather form needs adjacency, node_ids, dtable");
+    if (!gather && (!child || !dchild)) return fail(-1, "mvin_agg_bwd: dense form needs child and dchild");
+    if (probs && (!dT || nR <= 0 || (gather ? !adj_relation : !rel_ids)))
+        return fail(-1, "mvin_agg_bwd: attention needs dT, nR and relation ids");
+    if (T <= 0 || K <= 0 || K > 4096) return fail(-2, "mvin_agg_bwd: bad sizes T=%lld K=%d", (long long)T, K);
+    if (bad_dim(D)) return fail(-2, "mvin_agg_bwd: D=%d", D);
+    mvin::AggBwdArgs g{};
+    g.gather = gather ? 1 : 0;
+    g.table = table;
+    g.adj_e = adj_entity;
+    g.adj_r = adj_relation;
+    g.node_ids = node_ids;
+    g.child = child;
+    g.rel_ids = rel_ids;
+    g.probs = probs;
+    g.dvec = dvec;
+    g.dtable = dtable;
+    g.dchild = dchild;
+    g.dT = probs ? dT : nullptr;
+    g.T = T;
+    g.K = K;
+    g.D = D;
+    g.nR = nR > 0 ? nR : 1;
+    g.lpr_log2 = mvin::lpr_log2_for(D);
+    return hip_result(mvin::launch_agg_bwd(g, (hipStream_t)stream), "mvin_agg_bwd");
+}
+
+int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, const float* dT, int nR, int D, float* drel,
+                       float* durh, void* stream) {
+    if (!relation_emb || !urh_weights || !dT || !drel || !durh) return fail(-1, "mvin_rel_score_bwd: null pointer");
+    if (nR <= 0 || D <= 0) return fail(-2, "mvin_rel_score_bwd: bad sizes");
+    return hip_result(mvin::launch_rel_score_bwd(relation_emb, urh_weights, dT, nR, D, drel, durh, (hipStream_t)stream),
+                      "mvin_rel_score_bwd");
+}
+
+int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float* w, const int32_t* const* mem_h,
+                            const int32_t* const* mem_r, const int32_t* const* mem_t, int P, int B, int Nm, int D,
+                            int nR, const float* dout, int64_t ldo, float l2, float* dE, float* dV, float* dw,
+                            void* stream) {
+    const char* who = "mvin_key_addressing_bwd";
+    if (!entity_emb || !mem_h || !dout || !dE) return fail(-1, "%s: null pointer", who);
+    if (P < 0 || P > 8 || (P == 0 && !w)) return fail(-2, "%s: P=%d", who, P);
+    if (P > 0 && (!V || !mem_r || !mem_t || !dV || nR <= 0)) return fail(-1, "%s: hops need V, mem_r, mem_t, dV, nR", who);
+    if (w && !dw) return fail(-1, "%s: w given without dw", who);
+    if (B <= 0 || Nm <= 0 || Nm > 8192) return fail(-2, "%s: bad sizes B=%d Nm=%d", who, B, Nm);
+    if (bad_dim(D)) return fail(-2, "%s: D=%d", who, D);
+    mvin::KeyAddrBwdArgs k{};
+    k.f.E = entity_emb;
+    k.f.V = V;
+    k.f.w = w;
+    const int nh = P > 0 ? P : 1;
+    for (int i = 0; i < nh; ++i) {
+        if (!mem_h[i]) return fail(-1, "%s: null mem_h[%d]", who, i);
+        k.f.mem_h[i] = mem_h[i];
+        if (i < P) {
+            if (!mem_r[i] || !mem_t[i]) return fail(-1, "%s: null mem_r/mem_t[%d]", who, i);
+            k.f.mem_r[i] = mem_r[i];
+            k.f.mem_t[i] = mem_t[i];
+        }
+    }
+    k.f.ldo = ldo;
+    k.f.B = B;
+    k.f.P = P;
+    k.f.Nm = Nm;
+    k.f.D = D;
+    k.f.nR = nR;
+    k.f.lpr_log2 = mvin::lpr_log2_for(D);
+    k.dout = dout;
+    k.dE = dE;
+    k.dV = dV;
+    k.dw = dw;
+    k.l2 = l2;
+    return hip_result(mvin::launch_key_addr_bwd(k, (hipStream_t)stream), who);
 }
 
 }  // extern "C"

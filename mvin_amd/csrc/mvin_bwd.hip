@@ -1,0 +1,434 @@
+// Backward kernels of the MVIN path (scope row f-2): gradients of the loss of
+// src/model/MVIN/model.py:378-412 with respect to every table and weight, so that MVIN.train
+// (model.py:416-417: forward + backward + Adam in one sess.run) runs on the GPU.
+// They mirror the forward kernels: what the forward gathers, the backward scatter-adds
+// (atomic float adds on table rows); softmax backward is a wave-level reduction; weight
+// gradients are row-reductions of outer products.  Correctness-first versions.
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+// ------------------------------------------------------------------------------------------
+// element-wise family
+// ------------------------------------------------------------------------------------------
+__global__ void eltwise_kernel(EltArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float local = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        switch (a.mode) {
+            case 0:  // y = alpha * x + beta * y
+                a.y[i] = a.alpha * a.x[i] + (a.beta != 0.f ? a.beta * a.y[i] : 0.f);
+                break;
+            case 1: {  // sigmoid cross entropy (tf.nn.sigmoid_cross_entropy_with_logits, model.py:379):
+                       // y = (sigmoid(s) - label) * alpha ; loss += max(s,0) - s*label + log1p(exp(-|s|))
+                const float s = a.x[i], lab = a.z[i];
+                a.y[i] = (1.f / (1.f + expf(-s)) - lab) * a.alpha;
+                local += (fmaxf(s, 0.f) - s * lab + log1pf(expf(-fabsf(s)))) * a.beta;
+                break;
+            }
+            case 2:  // relu backward: y = z > 0 ? x : 0   (z = forward output)
+                a.y[i] = a.z[i] > 0.f ? a.x[i] : 0.f;
+                break;
+            case 3:  // sum of squares: accum += alpha * x^2
+                local += a.alpha * a.x[i] * a.x[i];
+                break;
+            case 4: {  // Adam (tf.train.AdamOptimizer, model.py:414): x = param, y = grad, z = m, w = v
+                const float g = a.y[i];
+                const float m = a.beta1 * a.z[i] + (1.f - a.beta1) * g;
+                const float v = a.beta2 * a.w[i] + (1.f - a.beta2) * g * g;
+                a.z[i] = m;
+                a.w[i] = v;
+                a.x[i] -= a.alpha * m / (sqrtf(v) + a.eps);
+                break;
+            }
+            case 5: {  // row scale: y[r, :] = beta * y[r, :] + alpha * z[r] * x[r, :]   (n = rows * D)
+                const int64_t r = i / a.D;
+                a.y[i] = (a.beta != 0.f ? a.beta * a.y[i] : 0.f) + a.alpha * a.z[r] * a.x[i];
+                break;
+            }
+            case 6: {  // group row sum: y[g, j] = alpha * sum_{n < N} x[(g*N + n), j]   (n = groups * D)
+                const int64_t gidx = i / a.D;
+                const int j = (int)(i - gidx * a.D);
+                float sgm = 0.f;
+                for (int q = 0; q < a.N; ++q) sgm += a.x[(gidx * a.N + q) * a.D + j];
+                a.y[i] = a.alpha * sgm;
+                break;
+            }
+        }
+    }
+    if (a.accum) {
+        local = wave_sum(local);
+        if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(a.accum, local);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dTable[ids[r], :] += alpha * X[r, :]      (backward of tf.nn.embedding_lookup)
+// ------------------------------------------------------------------------------------------
+__global__ void scatter_add_rows_kernel(float* __restrict__ dtable, const int32_t* __restrict__ ids, int ids64,
+                                        const float* __restrict__ x, int64_t rows, int D, float alpha) {
+    const int c4 = D >> 2;
+    const int64_t n = rows * c4, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / c4;
+        const int c = (int)(i - r * c4);
+        const int64_t row = ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r];
+        const float4 v = reinterpret_cast<const float4*>(x + r * D)[c];
+        float* d = dtable + row * D + 4 * c;
+        atomicAdd(d + 0, alpha * v.x);
+        atomicAdd(d + 1, alpha * v.y);
+        atomicAdd(d + 2, alpha * v.z);
+        atomicAdd(d + 3, alpha * v.w);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of the rows x dense operator:  dW[z] += X^T . dY[z],  db[z] += sum_r dY[z][r]
+// X = concat / sum of sources exactly as mvin_linear_fwd stages them; dY optionally masked by the
+// forward output (relu).  grid = (row blocks, Din blocks, nz); each thread owns up to 16 entries
+// of the [IB x Dout] slab of dW and walks the block's row tiles.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Din = a.lin.sum_sources ? a.lin.Dsrc : a.lin.nsrc * a.lin.Dsrc;
+    const int Dout = a.lin.Dout;
+    const int ldx = Din + 4, ldy = Dout + 1;
+    float* sX = smem;                 // [32][ldx]
+    float* sY = sX + kTM * ldx;       // [32][ldy]
+    const int tid = threadIdx.x;
+    const int z = blockIdx.z;
+    const int IB = a.IB;
+    const int i0 = blockIdx.y * IB;
+    const int nib = (Din - i0) < IB ? (Din - i0) : IB;
+    const int nent = nib * Dout;      // entries of this block's dW slab
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float accb = 0.f;
+    const float* dY = a.dY + (size_t)z * a.dy_zstride;
+    const int c4 = a.lin.Dsrc >> 2;
+    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * kTM;
+        for (int s = 0; s < a.lin.nsrc; ++s) {
+            const float* src = a.lin.src[s];
+            const int32_t* ids = a.lin.ids[s];
+            for (int idx = tid; idx < kTM * c4; idx += kBlock) {
+                const int row = idx / c4, c = idx - row * c4;
+                const int64_t r = r0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < a.lin.rows) {
+                    const int64_t srow = !ids ? r : (a.lin.ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r]);
+                    v = reinterpret_cast<const float4*>(src + srow * a.lin.Dsrc)[c];
+                }
+                float4* dst = reinterpret_cast<float4*>(sX + row * ldx + (a.lin.sum_sources ? 0 : s * a.lin.Dsrc) + c * 4);
+                if (a.lin.sum_sources && s > 0) {
+                    const float4 o = *dst;
+                    v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                }
+                *dst = v;
+            }
+        }
+        for (int idx = tid; idx < kTM * Dout; idx += kBlock) {
+            const int row = idx / Dout, j = idx - row * Dout;
+            const int64_t r = r0 + row;
+            float v = 0.f;
+            if (r < a.lin.rows) {
+                v = dY[r * a.ldy + j];
+                if (a.mask) v = a.mask[(size_t)z * a.mask_zstride + r * a.ldm + j] > 0.f ? v : 0.f;
+            }
+            sY[row * ldy + j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int e = tid + kBlock * q;
+            if (e < nent) {
+                const int i = i0 + e / Dout, j = e % Dout;
+                float s = acc[q];
+                for (int row = 0; row < kTM; ++row) s = fmaf(sX[row * ldx + i], sY[row * ldy + j], s);
+                acc[q] = s;
+            }
+        }
+        if (a.db && blockIdx.y == 0 && tid < Dout)
+            for (int row = 0; row < kTM; ++row) accb += sY[row * ldy + tid];
+        __syncthreads();
+    }
+    float* dW = a.dW + (size_t)z * a.dw_zstride;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = tid + kBlock * q;
+        if (e < nent && acc[q] != 0.f) atomicAdd(dW + (size_t)(i0 + e / Dout) * Dout + e % Dout, acc[q]);
+    }
+    if (a.db && blockIdx.y == 0 && tid < Dout && accb != 0.f) atomicAdd(a.db + (size_t)z * a.db_zstride + tid, accb);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of the neighbor mix (aggregators.py:118-152): agg[t] = (1/K) sum_k p[t,k] c[t,k],
+// p = softmax_k(logit[rel[t,k]]).  Given dvec[t] = dL/d agg[t]:
+//     g_k = dvec . c_k ;  dc_k = (p_k / K) dvec ;  dlogit_k = (p_k / K) (g_k - sum_j p_j g_j)
+// children c_k: dense rows (child[t*K+k]) -> dchild written; or table rows through the adjacency
+// (deepest hop) -> dc_k atomically added to dtable[y_k].  dT[rel] accumulates the logit gradients
+// (block-level LDS table, flushed with one atomic per relation).  One wave per task.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void agg_bwd_kernel(AggBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sT = smem;                          // [nR]
+    float* sG = sT + a.nR;                     // [4 waves][K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = a.D, K = a.K;
+    const int lpr = 1 << a.lpr_log2, rpw = kWave >> a.lpr_log2;
+    const int g = lane >> a.lpr_log2, c = lane & (lpr - 1);
+    const bool cact = (c << 2) < D;
+    float* gk = sG + wave * K;
+    for (int i = tid; i < a.nR; i += kBlock) sT[i] = 0.f;
+    __syncthreads();
+    const float invK = 1.f / (float)K;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.T; t += (int64_t)gridDim.x * 4) {
+        const int64_t xbase = a.gather ? (int64_t)a.node_ids[t] * K : 0;
+        const float4 dv = cact ? reinterpret_cast<const float4*>(a.dvec + t * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // pass 1: g_k = dvec . c_k
+        for (int k0 = 0; k0 < K; k0 += rpw) {
+            const int k = k0 + g;
+            float part = 0.f;
+            if (k < K && cact) {
+                const float* row = a.gather ? a.table + (int64_t)a.adj_e[xbase + k] * D : a.child + (t * K + k) * (int64_t)D;
+                const float4 v = reinterpret_cast<const float4*>(row)[c];
+                part = fmaf(dv.x, v.x, fmaf(dv.y, v.y, fmaf(dv.z, v.z, dv.w * v.w)));
+            }
+            part = group_sum(part, a.lpr_log2);
+            if (k < K && c == 0) gk[k] = part;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float pg = 0.f;  // sum_j p_j g_j
+        for (int k = lane; k < K; k += kWave) pg += (a.probs ? a.probs[t * K + k] : 1.f) * gk[k];
+        pg = wave_sum(pg);
+        // logit gradients -> relation table
+        if (a.probs) {
+            for (int k = lane; k < K; k += kWave) {
+                const float p = a.probs[t * K + k];
+                const float dl = p * invK * (gk[k] - pg);
+                const int r = a.gather ? a.adj_r[xbase + k] : a.rel_ids[t * K + k];
+                atomicAdd(&sT[r], dl);
+            }
+        }
+        // pass 2: child gradients
+        for (int k0 = 0; k0 < K; k0 += rpw) {
+            const int k = k0 + g;
+            if (k < K && cact) {
+                const float w = (a.probs ? a.probs[t * K + k] : 1.f) * invK;
+                const float4 o = make_float4(w * dv.x, w * dv.y, w * dv.z, w * dv.w);
+                if (a.gather) {
+                    float* d = a.dtable + (int64_t)a.adj_e[xbase + k] * D + 4 * c;
+                    atomicAdd(d + 0, o.x);
+                    atomicAdd(d + 1, o.y);
+                    atomicAdd(d + 2, o.z);
+                    atomicAdd(d + 3, o.w);
+                } else {
+                    reinterpret_cast<float4*>(a.dchild + (t * K + k) * (int64_t)D)[c] = o;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (a.dT)
+        for (int i = tid; i < a.nR; i += kBlock)
+            if (sT[i] != 0.f) atomicAdd(a.dT + i, sT[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of mvin_rel_score: t[r] = Rel[r] . w[D:2D]
+// ------------------------------------------------------------------------------------------
+__global__ void rel_score_bwd_kernel(const float* __restrict__ rel, const float* __restrict__ urh_w,
+                                     const float* __restrict__ dT, int nR, int D, float* __restrict__ drel,
+                                     float* __restrict__ durh) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    float dw = 0.f;
+    const float w = urh_w[D + d];
+    for (int r = 0; r < nR; ++r) {
+        const float g = dT[r];
+        atomicAdd(drel + (size_t)r * D + d, g * w);
+        dw = fmaf(g, rel[(size_t)r * D + d], dw);
+    }
+    atomicAdd(durh + D + d, dw);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward of the key-addressing reads (model.py:161-240), one wave per pair.  Recomputes the
+// logits and softmaxes of the forward, then for every memory m of every hop:
+//   hop : do = dL/d o_hop ;  g_m = do . t_m ;  dl_m = p_m (g_m - sum p g)
+//         dE[t_m] += p_m do (+ 2 l2 t_m) ; dE[h_m] += dl_m V[b,r_m] (+ 2 l2 h_m) ; dV[b,r_m] += dl_m h_m
+//   set : ds = dL/d o_hset ; g'_m = ds . h0_m ; dl'_m = p'_m (g'_m - sum p' g')
+//         dE[h0_m] += p'_m ds + dl'_m w_h ;  dw_h += dl'_m h0_m
+// (the 2 l2 terms are the sum(h_emb^2) + sum(t_emb^2) regularisers of model.py:383-385).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int D = a.f.D, Nm = a.f.Nm;
+    const int lpr = 1 << a.f.lpr_log2, rpw = kWave >> a.f.lpr_log2;
+    const int g = lane >> a.f.lpr_log2, c = lane & (lpr - 1);
+    const bool cact = (c << 2) < D;
+    float* sL = smem + wave * 2 * Nm;    // logits -> probabilities
+    float* sGm = sL + Nm;                // g_m
+    const int slot0 = a.f.w ? 1 : 0;
+    const int nhop = a.f.P > 0 ? a.f.P : 1;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < a.f.B; b += (int64_t)gridDim.x * 4) {
+        for (int hop = 0; hop < nhop; ++hop) {
+            const int32_t* mh = a.f.mem_h[hop] + b * Nm;
+            for (int pass = 0; pass < 2; ++pass) {   // pass 0: hop read, pass 1: h-set read (hop 0 only)
+                const bool is_set = pass == 1;
+                if (is_set ? !(hop == 0 && a.f.w) : !(hop < a.f.P)) continue;
+                const int32_t* mr = is_set ? nullptr : a.f.mem_r[hop] + b * Nm;
+                const int32_t* mv = is_set ? mh : a.f.mem_t[hop] + b * Nm;   // value rows
+                const float4 dvo = cact ? reinterpret_cast<const float4*>(
+                                              a.dout + b * a.f.ldo + (int64_t)(is_set ? 0 : slot0 + hop) * D)[c] : z4;
+                // logits and g_m
+                for (int m0 = 0; m0 < Nm; m0 += rpw) {
+                    const int m = m0 + g;
+                    float pl = 0.f, pg = 0.f;
+                    if (m < Nm && cact) {
+                        const float4 h = reinterpret_cast<const float4*>(a.f.E + (int64_t)mh[m] * D)[c];
+                        const float4 sv = is_set ? reinterpret_cast<const float4*>(a.f.w)[c]
+                                                 : reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + mr[m]) * (int64_t)D)[c];
+                        pl = fmaf(h.x, sv.x, fmaf(h.y, sv.y, fmaf(h.z, sv.z, h.w * sv.w)));
+                        const float4 val = reinterpret_cast<const float4*>(a.f.E + (int64_t)mv[m] * D)[c];
+                        pg = fmaf(dvo.x, val.x, fmaf(dvo.y, val.y, fmaf(dvo.z, val.z, dvo.w * val.w)));
+                    }
+                    pl = group_sum(pl, a.f.lpr_log2);
+                    pg = group_sum(pg, a.f.lpr_log2);
+                    if (m < Nm && c == 0) {
+                        sL[m] = pl;
+                        sGm[m] = pg;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                float mx = -INFINITY;
+                for (int m = lane; m < Nm; m += kWave) mx = fmaxf(mx, sL[m]);
+                mx = wave_max(mx);
+                float zs = 0.f;
+                for (int m = lane; m < Nm; m += kWave) {
+                    const float e = expf(sL[m] - mx);
+                    sL[m] = e;
+                    zs += e;
+                }
+                zs = wave_sum(zs);
+                float pgs = 0.f;
+                for (int m = lane; m < Nm; m += kWave) {
+                    const float p = sL[m] / zs;
+                    sL[m] = p;
+                    pgs += p * sGm[m];
+                }
+                pgs = wave_sum(pgs);
+                __builtin_amdgcn_wave_barrier();
+                // scatter
+                for (int m0 = 0; m0 < Nm; m0 += rpw) {
+                    const int m = m0 + g;
+                    if (m < Nm && cact) {
+                        const float p = sL[m];
+                        const float dl = p * (sGm[m] - pgs);
+                        const int64_t hrow = mh[m], vrow = mv[m];
+                        const float4 h = reinterpret_cast<const float4*>(a.f.E + hrow * D)[c];
+                        float4 dh, dval;
+                        if (is_set) {
+                            const float4 w4 = reinterpret_cast<const float4*>(a.f.w)[c];
+                            // value row == head row
+                            dh = make_float4(p * dvo.x + dl * w4.x, p * dvo.y + dl * w4.y, p * dvo.z + dl * w4.z,
+                                             p * dvo.w + dl * w4.w);
+                            dval = z4;
+                            float* dw = a.dw + 4 * c;
+                            atomicAdd(dw + 0, dl * h.x);
+                            atomicAdd(dw + 1, dl * h.y);
+                            atomicAdd(dw + 2, dl * h.z);
+                            atomicAdd(dw + 3, dl * h.w);
+                        } else {
+                            const int r = mr[m];
+                            const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
+                            const float4 val = reinterpret_cast<const float4*>(a.f.E + vrow * D)[c];
+                            const float l2 = 2.f * a.l2;
+                            dh = make_float4(dl * v4.x + l2 * h.x, dl * v4.y + l2 * h.y, dl * v4.z + l2 * h.z,
+                                             dl * v4.w + l2 * h.w);
+                            dval = make_float4(p * dvo.x + l2 * val.x, p * dvo.y + l2 * val.y, p * dvo.z + l2 * val.z,
+                                               p * dvo.w + l2 * val.w);
+                            float* dV = a.dV + (b * a.f.nR + r) * (int64_t)D + 4 * c;
+                            atomicAdd(dV + 0, dl * h.x);
+                            atomicAdd(dV + 1, dl * h.y);
+                            atomicAdd(dV + 2, dl * h.z);
+                            atomicAdd(dV + 3, dl * h.w);
+                            float* dt = a.dE + vrow * D + 4 * c;
+                            atomicAdd(dt + 0, dval.x);
+                            atomicAdd(dt + 1, dval.y);
+                            atomicAdd(dt + 2, dval.z);
+                            atomicAdd(dt + 3, dval.w);
+                        }
+                        float* de = a.dE + hrow * D + 4 * c;
+                        atomicAdd(de + 0, dh.x);
+                        atomicAdd(de + 1, dh.y);
+                        atomicAdd(de + 2, dh.z);
+                        atomicAdd(de + 3, dh.w);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static int blocks_for(int64_t n, int per) {
+    int64_t b = (n + per - 1) / per;
+    return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+hipError_t launch_eltwise(const EltArgs& a, hipStream_t st) {
+    eltwise_kernel<<<blocks_for(a.n, 1024), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64, const float* x, int64_t rows, int D,
+                                   float alpha, hipStream_t st) {
+    scatter_add_rows_kernel<<<blocks_for(rows * (D / 4), 1024), 256, 0, st>>>(dtable, ids, ids64, x, rows, D, alpha);
+    return hipGetLastError();
+}
+
+hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st) {
+    const int Din = a.lin.sum_sources ? a.lin.Dsrc : a.lin.nsrc * a.lin.Dsrc;
+    a.IB = 4096 / a.lin.Dout;
+    if (a.IB < 1) a.IB = 1;
+    if (a.IB > Din) a.IB = Din;
+    const int ny = (Din + a.IB - 1) / a.IB;
+    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
+    int gx = (int)(ntiles < 64 ? (ntiles < 1 ? 1 : ntiles) : 64);
+    const size_t lds = ((size_t)kTM * (Din + 4) + (size_t)kTM * (a.lin.Dout + 1)) * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    linear_wgrad_kernel<<<dim3(gx, ny, a.lin.nz > 0 ? a.lin.nz : 1), kBlock, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_agg_bwd(const AggBwdArgs& a, hipStream_t st) {
+    const size_t lds = ((size_t)a.nR + 4 * (size_t)a.K) * sizeof(float);
+    agg_bwd_kernel<<<blocks_for(a.T, 4), kBlock, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const float* dT, int nR, int D, float* drel,
+                                float* durh, hipStream_t st) {
+    rel_score_bwd_kernel<<<(D + 63) / 64, 64, 0, st>>>(rel, urh_w, dT, nR, D, drel, durh);
+    return hipGetLastError();
+}
+
+hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)4 * 2 * a.f.Nm * sizeof(float);
+    key_addr_bwd_kernel<<<blocks_for(a.f.B, 4), kBlock, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace mvin

@@ -24,6 +24,8 @@ struct GatherAttnArgs {
     const float* bagg;        // [D] or NULL
     float* out;               // [T, D]
     float* probs;             // [T, K] or NULL
+    float* s_out;             // [T, D] or NULL: (1/K) sum_k p_k child_k before the projection (training)
+    float* z_out;             // [T, D] or NULL: self + neighbors_agg, the input of the dense layer (training)
     int64_t T;
     int N, K, D, lpr_log2;
 };
@@ -88,6 +90,67 @@ struct FusedL2Args {
     uint64_t table_bytes;        // nE * D * 4 (buffer descriptor range)
     int parents_per_pair, K, nR, lpn_log2;
 };
+
+// ---- backward (mvin_bwd.hip) ----
+struct EltArgs {
+    int mode;
+    int64_t n;
+    float* x;
+    float* y;
+    float* z;
+    float* w;
+    float* accum;
+    float alpha, beta, beta1, beta2, eps;
+    int D, N;
+};
+
+struct WgradArgs {
+    mvin_linear_args lin;     // sources / rows / Dsrc / Dout / nz as in the forward
+    const float* dY;          // [rows, ldy] (+ z * dy_zstride)
+    int64_t ldy, dy_zstride;
+    const float* mask;        // forward output for relu masking or NULL
+    int64_t ldm, mask_zstride;
+    float* dW;                // [Din, Dout] (+ z * dw_zstride), accumulated
+    int64_t dw_zstride;
+    float* db;                // [Dout] (+ z * db_zstride) or NULL, accumulated
+    int64_t db_zstride;
+    int IB;
+};
+
+struct AggBwdArgs {
+    int gather;
+    const float* table;       // gather: [nE, D]
+    const int32_t* adj_e;
+    const int32_t* adj_r;
+    const int32_t* node_ids;  // [T]
+    const float* child;       // dense: [T*K, D]
+    const int32_t* rel_ids;   // dense: [T*K]
+    const float* probs;       // [T, K] or NULL (uniform)
+    const float* dvec;        // [T, D]
+    float* dtable;            // gather: [nE, D] accumulated atomically
+    float* dchild;            // dense: [T*K, D] written
+    float* dT;                // [nR] accumulated or NULL
+    int64_t T;
+    int K, D, nR, lpr_log2;
+};
+
+struct KeyAddrBwdArgs {
+    KeyAddrArgs f;            // forward arguments (out unused)
+    const float* dout;        // [B, ldo] gradient of [o_hset | o_hop0 | ...]
+    float* dE;                // [nE, D] accumulated
+    float* dV;                // [B, nR, D] accumulated (zero-initialised by the caller)
+    float* dw;                // [D] accumulated (h-set logit weights) or NULL
+    float l2;                 // l2_weight of the sum(h^2)+sum(t^2) regulariser
+};
+
+hipError_t launch_eltwise(const EltArgs& a, hipStream_t st);
+hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64, const float* x, int64_t rows, int D,
+                                   float alpha, hipStream_t st);
+hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st);
+hipError_t launch_agg_bwd(const AggBwdArgs& a, hipStream_t st);
+hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const float* dT, int nR, int D, float* drel,
+                                float* durh, hipStream_t st);
+hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a, hipStream_t st);
 
 inline int lpr_log2_for(int D) {
     int l = 0;

@@ -245,7 +245,14 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                 }
             }
             acc = group_xor_sum(acc, lpr);
-            if (cact && g == 0) *reinterpret_cast<float4*>(sS + trow * ldx + (c << 2)) = acc;
+            if (cact && g == 0) {
+                *reinterpret_cast<float4*>(sS + trow * ldx + (c << 2)) = acc;
+                if (a.s_out) {
+                    const float ik = 1.f / (float)K;
+                    *reinterpret_cast<float4*>(a.s_out + t * D + (c << 2)) =
+                        make_float4(acc.x * ik, acc.y * ik, acc.z * ik, acc.w * ik);
+                }
+            }
         }
         __syncthreads();
         // ---------------- phase B ----------------
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                     float v = acc[i];
                     if (a.Wc && a.c_child) v = fmaf(psum, a.c_child[(t / a.N) * D + j], v);
                     zv = a.self_vec[t * D + j] + v / invK_den;
+                    if (a.z_out) a.z_out[t * D + j] = zv;
                 }
                 sZ[row * ldx + j] = zv;
             }

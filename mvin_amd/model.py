@@ -6,7 +6,7 @@ op of the scoring path is a hand-written gfx950 kernel reached through the C ABI
     model.get_scores(sess, feed_dict) -> (item_indices, sigmoid_scores)     model.py:443-444
     model.eval(sess, feed_dict)       -> (auc, acc, f1)                      model.py:419-426
     model.eval_case_study(sess, feed) -> 7-tuple                             model.py:428-441
-    model.train(sess, feed_dict)      -> NotImplementedError (backward + Adam is a later row)
+    model.train(sess, feed_dict)      -> (None, loss)                        model.py:416-417
 
 ``sess`` is accepted and ignored (there is no TF session); feed keys are the placeholder
 sentinels ``model.user_indices / item_indices / labels / memories_{h,r,t}[i]``
@@ -164,6 +164,7 @@ class MVIN(object):
         """model.py:378-414 (loss + Adam): the backward path is a later row of the scope
         table; nothing is built here yet."""
         self.optimizer = None
+        self.trainer = None   # created on the first train() call (mvin_amd.training.Trainer)
 
     def parameters_dict(self):
         """All parameters as numpy arrays under the names of mvin_amd/params.py."""
@@ -434,9 +435,14 @@ class MVIN(object):
 
     # ------------------------------------------------------------------ run wrappers
     def train(self, sess, feed_dict):
-        """model.py:416-417.  Needs the backward path + Adam."""
-        raise NotImplementedError("MVIN.train: backward/Adam for the HIP path is not built yet "
-                                  "(scope row f-2); there is deliberately no autograd/CPU fallback")
+        """model.py:416-417: one optimisation step (forward, loss of :378-412, backward, Adam of :414)
+        on the GPU -> (None, loss).  The optimizer state lives in ``self.trainer``."""
+        if self.trainer is None:
+            from .training import Trainer
+            self.trainer = Trainer(self)
+        user, item, mh, mr, mt = self._feed(feed_dict)
+        labels = torch.as_tensor(np.asarray(feed_dict[self.labels], dtype=np.float32)).to(self.device)
+        return None, self.trainer.step(user, item, labels, mh, mr, mt)
 
     def get_scores(self, sess, feed_dict):
         """model.py:443-444."""

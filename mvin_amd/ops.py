@@ -237,3 +237,119 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     _lib.check(lib.mvin_key_addressing_fwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(out),
                                            ldo, _stream()), "mvin_key_addressing_fwd")
     return out
+
+
+# ------------------------------------------------------------------------------- training ops
+def _fill_linear_args(a, srcs, ids, Dout, rows, nz, sum_sources):
+    nsrc = len(srcs)
+    ids = ids or [None] * nsrc
+    ids64 = None
+    Dsrc = srcs[0].shape[-1]
+    for s in range(nsrc):
+        _chk(srcs[s], F32, f"src[{s}]")
+        a.src[s] = srcs[s].data_ptr()
+        if ids[s] is not None:
+            if ids64 is None:
+                ids64 = ids[s].dtype == torch.int64
+            _chk(ids[s], torch.int64 if ids64 else I32, f"ids[{s}]")
+            a.ids[s] = ids[s].data_ptr()
+    if rows is None:
+        first = next((i for i in ids if i is not None), None)
+        rows = first.numel() if first is not None else srcs[0].numel() // Dsrc
+    a.nsrc, a.Dsrc, a.Dout, a.rows, a.nz = nsrc, Dsrc, Dout, rows, nz
+    a.ids64 = 1 if ids64 else 0
+    a.sum_sources = 1 if sum_sources else 0
+    return rows
+
+
+def gather_attn_ex(table, adj_entity, adj_relation, node_ids, rel_score_t, self_vec, Wc, c_child, Wagg, bagg,
+                   B, N, K, D):
+    """mvin_gather_attn_fwd_ex -> (out, probs | None, s_out, z_out)."""
+    lib = _lib.load()
+    dev = table.device
+    out = torch.empty((B, N, D), dtype=F32, device=dev)
+    probs = torch.empty((B, N, K), dtype=F32, device=dev) if rel_score_t is not None else None
+    s_out = torch.empty((B * N, D), dtype=F32, device=dev)
+    z_out = torch.empty((B * N, D), dtype=F32, device=dev)
+    _lib.check(lib.mvin_gather_attn_fwd_ex(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids), _p(rel_score_t),
+                                           _p(self_vec), _p(Wc), _p(c_child), _p(Wagg), _p(bagg), B, N, K, D,
+                                           table.shape[0], _p(out), _p(probs), _p(s_out), _p(z_out), _stream()),
+               "mvin_gather_attn_fwd_ex")
+    return out, probs, s_out, z_out
+
+
+def agg_ex(self_vec, neigh, rel_ids, rel_score_t, Wagg, bagg, B, N, K, D):
+    """mvin_agg_fwd_ex -> (out, probs | None, z_out)."""
+    lib = _lib.load()
+    dev = self_vec.device
+    out = torch.empty((B, N, D), dtype=F32, device=dev)
+    probs = torch.empty((B, N, K), dtype=F32, device=dev) if rel_score_t is not None else None
+    z_out = torch.empty((B * N, D), dtype=F32, device=dev)
+    _lib.check(lib.mvin_agg_fwd_ex(_p(self_vec), _p(neigh), _p(rel_ids), _p(rel_score_t), _p(Wagg), _p(bagg), B, N, K,
+                                   D, _p(out), _p(probs), None, _p(z_out), _stream()), "mvin_agg_fwd_ex")
+    return out, probs, z_out
+
+
+def eltwise(mode, n, x, y=None, z=None, w=None, accum=None, alpha=1.0, beta=0.0, beta1=0.0, beta2=0.0, eps=0.0,
+            D=1, N=1):
+    lib = _lib.load()
+    _lib.check(lib.mvin_eltwise(mode, n, _p(x), _p(y), _p(z), _p(w), _p(accum), alpha, beta, beta1, beta2, eps, D, N,
+                                _stream()), "mvin_eltwise")
+
+
+def axpby(alpha, x, beta, y):
+    """y = alpha*x + beta*y (in place on y)."""
+    eltwise(0, x.numel(), x, y, alpha=alpha, beta=beta)
+    return y
+
+
+def scatter_add_rows(dtable, ids, x, alpha=1.0):
+    lib = _lib.load()
+    _chk(dtable, F32, "dtable"), _chk(x, F32, "x")
+    D = dtable.shape[-1]
+    _lib.check(lib.mvin_scatter_add_rows(_p(dtable), _p(ids), 1 if ids.dtype == torch.int64 else 0, _p(x),
+                                         ids.numel(), D, alpha, _stream()), "mvin_scatter_add_rows")
+
+
+def linear_wgrad(srcs, dY, dW, *, ids=None, db=None, mask=None, sum_sources=False, rows=None, nz=1, ldy=None,
+                 dy_zstride=0, ldm=None, mask_zstride=0, dw_zstride=0, db_zstride=0):
+    """dW[z] += X^T . dY[z] (X staged like ops.linear), db[z] += column sums."""
+    lib = _lib.load()
+    a = _lib.LinearArgs()
+    Dout = dW.shape[-1]
+    _fill_linear_args(a, srcs, ids, Dout, rows, nz, sum_sources)
+    ldy = ldy or Dout
+    ldm = ldm or Dout
+    _lib.check(lib.mvin_linear_wgrad(C.byref(a), _p(dY), ldy, dy_zstride, _p(mask), ldm, mask_zstride, _p(dW),
+                                     dw_zstride, _p(db), db_zstride, _stream()), "mvin_linear_wgrad")
+
+
+def agg_bwd(dvec, probs, T, K, D, nR, *, table=None, adj_entity=None, adj_relation=None, node_ids=None, child=None,
+            rel_ids=None, dtable=None, dT=None):
+    """mvin_agg_bwd; returns dchild (dense form) or None (gather form: dtable updated in place)."""
+    lib = _lib.load()
+    dchild = torch.empty((T * K, D), dtype=F32, device=dvec.device) if table is None else None
+    _lib.check(lib.mvin_agg_bwd(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids), _p(child), _p(rel_ids),
+                                _p(probs), _p(dvec), T, K, D, nR, _p(dtable), _p(dchild), _p(dT), _stream()),
+               "mvin_agg_bwd")
+    return dchild
+
+
+def rel_score_bwd(relation_emb, urh_weights, dT, drel, durh):
+    lib = _lib.load()
+    nR, D = relation_emb.shape
+    _lib.check(lib.mvin_rel_score_bwd(_p(relation_emb), _p(urh_weights), _p(dT), nR, D, _p(drel), _p(durh), _stream()),
+               "mvin_rel_score_bwd")
+
+
+def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, l2, dE, dV, dw):
+    lib = _lib.load()
+    nh = max(1, P)
+    arr_t = C.c_void_p * nh
+    ph = arr_t(*[t.data_ptr() for t in mem_h[:nh]])
+    pr = arr_t(*([t.data_ptr() for t in mem_r[:P]] + [None] * (nh - P)))
+    pt = arr_t(*([t.data_ptr() for t in mem_t[:P]] + [None] * (nh - P)))
+    B, Nm = mem_h[0].shape
+    D = entity_emb.shape[1]
+    _lib.check(lib.mvin_key_addressing_bwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(dout), ldo,
+                                           l2, _p(dE), _p(dV), _p(dw), _stream()), "mvin_key_addressing_bwd")

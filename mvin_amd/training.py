@@ -1,0 +1,409 @@
+"""Training step of the MVIN path on the GPU (scope row f-2): the reference's
+``sess.run([optimizer, loss])`` of model.py:416-417 -- forward, loss of model.py:378-412,
+backward, tf.train.AdamOptimizer(lr) update (model.py:414) -- with every arithmetic step in
+libmvin_hip.so (mvin_bwd.hip + the forward kernels in their ``_ex`` form that keeps what the
+backward needs).  PyTorch only allocates buffers; there is no autograd and no CPU fallback.
+
+The forward used for training is the per-level path (the deepest hop still gathers the K^L
+rows without materialising them); each step records a closure that turns the gradient of its
+output into gradients of its inputs and parameters, and the closures run in reverse.
+
+Gradient identities used (see DESIGN.md 3.1 for the forward algebra they mirror):
+  * attention logits are t[r] = Rel[r].w_r, so dRel / d urh_weights[D:2D] come from the nR-entry
+    dT table; the user and self slices of urh_weights only receive their L2 term (exactly what
+    autograd gives: the softmax is shift invariant);
+  * deepest hop: agg = S'.W_L + (psum/K) c_L with S' = (1/K) sum_k p_k E[y_k], so
+    dS' = dZ.W_L^T feeds one gather-form mvin_agg_bwd that scatter-adds (p_k/K) dS' into dE[y_k];
+  * key addressing: s_m = h_m . V[b, r_m], V = E[item].R_KGE[r]  =>  dR_KGE[r] = E[item]^T dV[:, r].
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .params import aggregator_keys
+
+F32 = torch.float32
+
+
+class _Grads(object):
+    """Gradient accumulators keyed by tensor identity."""
+
+    def __init__(self):
+        self.g = {}
+        self.keep = []   # keep keyed tensors alive so ids stay unique
+
+    def add(self, t, g):
+        k = id(t)
+        if k in self.g:
+            ops.axpby(1.0, g.view(-1), 1.0, self.g[k].view(-1))
+        else:
+            self.g[k] = g
+            self.keep.append(t)
+
+    def get(self, t):
+        return self.g.get(id(t))
+
+
+class Trainer(object):
+    """Owns the Adam state of an mvin_amd.model.MVIN and runs training steps on it."""
+
+    def __init__(self, model, lr=None, beta1=0.9, beta2=0.999, eps=1e-8):
+        a = model.args
+        if not a.wide_deep:
+            raise NotImplementedError("training the legacy aggregate path (wide_deep=False) is not built; the "
+                                      "reference cannot run it either (model.py:366-374)")
+        self.m = model
+        self.lr = model.lr if lr is None else lr
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.t = 0
+        self.params = self._named_params()
+        self.adam_m = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.adam_v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.last_grads = None
+
+    # ------------------------------------------------------------------ parameters
+    def _named_params(self):
+        m = self.m
+        p = {"user_emb_matrix": m.user_emb_matrix, "entity_emb_matrix": m.entity_emb_matrix,
+             "relation_emb_matrix": m.relation_emb_matrix, "relation_emb_KGE_matrix": m.relation_emb_KGE_matrix,
+             "user_mlp_matrix": m.user_mlp_matrix, "user_mlp_bias": m.user_mlp_bias,
+             "transfer_W": m._transfer_W, "transfer_b": m._transfer_b,
+             "h_emb_item_mlp_matrix": m.h_emb_item_mlp_matrix, "h_emb_item_mlp_bias": m.h_emb_item_mlp_bias}
+        for n in range(m.n_mix_hop):
+            p[f"enti_transfer_matrix_{n}"] = m.enti_transfer_matrix_list[n]
+            p[f"enti_transfer_bias_{n}"] = m.enti_transfer_bias_list[n]
+        for (i, n), agg in m._agg.items():
+            p[f"agg_{i}_{n}_weights"], p[f"agg_{i}_{n}_bias"] = agg.weights, agg.bias
+            p[f"agg_{i}_{n}_urh_weights"] = agg.urh_weights
+        return p
+
+    def grads_by_reference_name(self):
+        """Last step's gradients under the names of mvin_amd/params.py (numpy), for tests."""
+        out = {}
+        for k, g in self.last_grads.items():
+            if k == "transfer_W":
+                for e in range(g.shape[0]):
+                    out[f"transfer_matrix_{e}"] = g[e].cpu().numpy()
+            elif k == "transfer_b":
+                for e in range(g.shape[0]):
+                    out[f"transfer_bias_{e}"] = g[e].cpu().numpy()
+            else:
+                out[k] = g.cpu().numpy()
+        return out
+
+    # ------------------------------------------------------------------ small helpers
+    @staticmethod
+    def _T(w):
+        return w.t().contiguous()
+
+    def _lookup(self, table, ids):
+        return ops.linear([table], None, table.shape[-1], ids=[ids])
+
+    # ------------------------------------------------------------------ one step
+    def step(self, user_indices, item_indices, labels, memories_h, memories_r, memories_t, apply=True):
+        """One training step on device-resident inputs.  Returns the loss (python float)."""
+        m, a = self.m, self.m.args
+        dev = m.device
+        D, K, H, M, P, nR = m.dim, m.n_neighbor, m.h_hop, m.n_mix_hop, m.p_hop, m.n_relation
+        L = M * H
+        B = item_indices.shape[0]
+        E, U, R = m.entity_emb_matrix, m.user_emb_matrix, m.relation_emb_KGE_matrix
+        user = user_indices.contiguous()
+        item = item_indices.contiguous()
+        labels = labels.to(F32).contiguous()
+        G = _Grads()
+        dP = {k: torch.zeros_like(v) for k, v in self.params.items()}   # parameter gradients
+        loss_acc = torch.zeros(1, dtype=F32, device=dev)
+        tape = []
+
+        def zeros(*shape):
+            return torch.zeros(shape, dtype=F32, device=dev)
+
+        # ================================================================ forward
+        need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
+        n_o = P + 1 if a.PS_O_ft else P
+        ps = None
+        if need_ps:
+            w_h = m.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
+            V = None
+            if P > 0:
+                V = torch.empty((B, nR, D), dtype=F32, device=dev)
+                ops.linear([E], R, D, ids=[item], rows=B, out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
+            o_cat = torch.empty((B, n_o * D), dtype=F32, device=dev)
+            if ops.key_addressing_supported(m.n_memory, D):
+                ops.key_addressing(E, V, w_h, memories_h, memories_r, memories_t, P, o_cat, n_o * D, nR)
+            else:
+                slot = 0
+                if a.PS_O_ft:
+                    ops.ripple_attn(E, memories_h[0], None, memories_h[0], None, w_h, 1, o_cat, 0, n_o * D, nR)
+                    slot = 1
+                for hop in range(P):
+                    ops.ripple_attn(E, memories_h[hop], memories_r[hop], memories_t[hop], V, None, 0, o_cat,
+                                    (slot + hop) * D, n_o * D, nR)
+            ps = ops.linear([o_cat], m.user_mlp_matrix, D, bias=m.user_mlp_bias)
+
+            def bwd_ps():
+                d = G.get(ps)
+                if d is None:
+                    return
+                ops.linear_wgrad([o_cat], d, dP["user_mlp_matrix"], db=dP["user_mlp_bias"])
+                do_cat = torch.empty_like(o_cat)
+                for s in range(n_o):  # d o_s = d . Wu[sD:(s+1)D]^T
+                    ops.linear([d], self._T(m.user_mlp_matrix[s * D:(s + 1) * D]), D, out=do_cat, out_offset=s * D,
+                               ldo=n_o * D)
+                dV = zeros(B, nR, D) if P > 0 else None
+                dw = zeros(D) if a.PS_O_ft else None
+                ops.key_addressing_bwd(E, V, w_h, memories_h, memories_r, memories_t, P, do_cat, n_o * D, nR,
+                                       float(a.l2_weight), dP["entity_emb_matrix"], dV, dw)
+                if a.PS_O_ft:
+                    ops.axpby(1.0, dw, 1.0, dP["h_emb_item_mlp_matrix"].view(-1)[:D])
+                if P > 0:
+                    # V[b,r,:] = E[item_b] . R[r]  =>  dR[r] += E[item]^T dV[:,r] ; dE[item] += sum_r dV[:,r] R[r]^T
+                    ops.linear_wgrad([E], dV, dP["relation_emb_KGE_matrix"], ids=[item], rows=B, nz=nR, ldy=nR * D,
+                                     dy_zstride=D, dw_zstride=D * D)
+                    ditem = zeros(B, D)
+                    for r in range(nR):
+                        tmp = ops.linear([dV[:, r, :].contiguous()], self._T(R[r]), D)
+                        ops.axpby(1.0, tmp.view(-1), 1.0, ditem.view(-1))
+                    ops.scatter_add_rows(dP["entity_emb_matrix"], item, ditem)
+            tape.append(bwd_ps)
+
+        u_emb = None
+        if a.HO_only or not a.User_orient_kg_eh:
+            u_emb = self._lookup(U, user)
+
+            def bwd_u():
+                d = G.get(u_emb)
+                if d is not None:
+                    ops.scatter_add_rows(dP["user_emb_matrix"], user, d)
+            tape.append(bwd_u)
+        user_o = u_emb if a.HO_only else ps
+        q = ps if a.User_orient_kg_eh else u_emb
+
+        dT = {}
+        if a.PS_only:
+            item_emb = self._lookup(E, item)
+
+            def bwd_item():
+                d = G.get(item_emb)
+                if d is not None:
+                    ops.scatter_add_rows(dP["entity_emb_matrix"], item, d)
+            tape.append(bwd_item)
+        else:
+            ents, rels = m.get_neighbors(item, levels=L - 1)
+            Wt, bt = m.transfer_matrix_list, m.transfer_matrix_bias
+            ev = []
+            c = None
+            if a.User_orient:
+                # c[e] = q . W_e + b_e for e = 1..L
+                c_all = ops.linear([q], m._transfer_W[1:], D, bias=m._transfer_b[1:], nz=L, w_zstride=D * D,
+                                   bias_zstride=D, out_zstride=B * D).view(L, B, D)
+                c = [c_all[e] for e in range(L)]      # stable tensor objects: gradients are keyed by identity
+
+                def bwd_c():
+                    for e in range(1, L + 1):
+                        d = G.get(c[e - 1])
+                        if d is None:
+                            continue
+                        ops.linear_wgrad([q], d, dP["transfer_W"][e], db=dP["transfer_b"][e])
+                        G.add(q, ops.linear([d], self._T(Wt[e]), D))
+                tape.append(bwd_c)
+                ev0 = ops.linear([E, q], Wt[0], D, ids=[ents[0].view(-1), None], bias=bt[0], sum_sources=True).view(B, 1, D)
+
+                def bwd_ev0():
+                    d = G.get(ev0)
+                    if d is None:
+                        return
+                    d2 = d.view(B, D)
+                    ops.linear_wgrad([E, q], d2, dP["transfer_W"][0], ids=[ents[0].view(-1), None], db=dP["transfer_b"][0],
+                                     sum_sources=True)
+                    dx = ops.linear([d2], self._T(Wt[0]), D)
+                    ops.scatter_add_rows(dP["entity_emb_matrix"], ents[0].view(-1), dx)
+                    G.add(q, dx.clone())
+                tape.append(bwd_ev0)
+                ev.append(ev0)
+                for e in range(1, L):
+                    ids_e = ents[e].view(-1)
+                    t_e = ops.linear([E], Wt[e], D, ids=[ids_e], rowbias=c[e - 1], rows_per_group=K ** e).view(B, -1, D)
+
+                    def bwd_ev(e=e, ids_e=ids_e, t_e=t_e):
+                        d = G.get(t_e)
+                        if d is None:
+                            return
+                        d2 = d.view(-1, D)
+                        ops.linear_wgrad([E], d2, dP["transfer_W"][e], ids=[ids_e])
+                        ops.scatter_add_rows(dP["entity_emb_matrix"], ids_e, ops.linear([d2], self._T(Wt[e]), D))
+                        dc = torch.empty((B, D), dtype=F32, device=dev)
+                        ops.eltwise(6, B * D, d2, dc, alpha=1.0, D=D, N=K ** e)
+                        G.add(c[e - 1], dc)
+                    tape.append(bwd_ev)
+                    ev.append(t_e)
+            else:
+                for e in range(L):
+                    ids_e = ents[e].view(-1)
+                    t_e = self._lookup(E, ids_e).view(B, -1, D)
+
+                    def bwd_raw(ids_e=ids_e, t_e=t_e):
+                        d = G.get(t_e)
+                        if d is not None:
+                            ops.scatter_add_rows(dP["entity_emb_matrix"], ids_e, d.view(-1, D))
+                    tape.append(bwd_raw)
+                    ev.append(t_e)
+
+            def apply_agg(key, cur, hop, fused):
+                agg = m._agg[key]
+                N = K ** hop
+                T = B * N
+                t_tab = agg.relation_scores() if agg.User_orient_rela else None
+                if agg.User_orient_rela and key not in dT:
+                    dT[key] = zeros(nR)
+                self_t = cur[hop]
+                if fused:
+                    Wc = Wt[L] if a.User_orient else None
+                    cc = c[L - 1] if a.User_orient else None
+                    node_ids = ents[hop].view(-1)
+                    out, probs, S, Z = ops.gather_attn_ex(E, m.adj_entity, m.adj_relation, node_ids, t_tab,
+                                                          self_t.view(T, D), Wc, cc, agg.weights, agg.bias, B, N, K, D)
+                else:
+                    child_t = cur[hop + 1]
+                    rel_ids = rels[hop].view(-1)
+                    out, probs, Z = ops.agg_ex(self_t.view(T, D), child_t.view(T * K, D), rel_ids, t_tab, agg.weights,
+                                               agg.bias, B, N, K, D)
+
+                def bwd():
+                    d = G.get(out)
+                    if d is None:
+                        return
+                    dm = torch.empty((T, D), dtype=F32, device=dev)
+                    ops.eltwise(2, T * D, d.view(-1), dm.view(-1), z=out.view(-1))       # relu'
+                    i, n = key
+                    ops.linear_wgrad([Z], dm, dP[f"agg_{i}_{n}_weights"], db=dP[f"agg_{i}_{n}_bias"])
+                    dZ = ops.linear([dm], self._T(agg.weights), D)                       # d(self + neighbors_agg)
+                    G.add(self_t, dZ.view_as(self_t).clone())
+                    dTk = dT.get(key)
+                    pr = probs.view(T, K) if probs is not None else None
+                    if fused:
+                        if a.User_orient:
+                            psum_over_k = (1.0 / K) if agg.User_orient_rela else 1.0
+                            ops.linear_wgrad([S], dZ, dP["transfer_W"][L])               # dW_L += S'^T dZ
+                            dS = ops.linear([dZ], self._T(Wt[L]), D)
+                            dc = torch.empty((B, D), dtype=F32, device=dev)
+                            ops.eltwise(6, B * D, dZ, dc, alpha=psum_over_k, D=D, N=N)
+                            G.add(c[L - 1], dc)
+                        else:
+                            dS = dZ
+                        ops.agg_bwd(dS, pr, T, K, D, nR, table=E, adj_entity=m.adj_entity, adj_relation=m.adj_relation,
+                                    node_ids=node_ids, dtable=dP["entity_emb_matrix"], dT=dTk)
+                    else:
+                        dchild = ops.agg_bwd(dZ, pr, T, K, D, nR, child=child_t.view(T * K, D), rel_ids=rel_ids, dT=dTk)
+                        G.add(child_t, dchild.view_as(child_t))
+                tape.append(bwd)
+                return out
+
+            item_emb = None
+            for n in range(M):
+                stages = [ev]
+                for i in range(H):
+                    nxt = [apply_agg((i, n), ev, hop, fused=(n == 0 and i == 0 and hop == L - 1))
+                           for hop in range(L - (H * n + i))]
+                    ev = nxt
+                    stages.append(ev)
+                keep = (M - n - 1) * H + 1
+                Wm, bm = m.enti_transfer_matrix_list[n], m.enti_transfer_bias_list[n]
+                new = []
+                for e in range(keep):
+                    srcs = [st[e] for st in stages]
+                    res = ops.linear([s_.view(-1, D) for s_ in srcs], Wm, D, bias=bm).view(B, -1, D)
+
+                    def bwd_comb(srcs=srcs, res=res, n=n, Wm=Wm):
+                        d = G.get(res)
+                        if d is None:
+                            return
+                        d2 = d.view(-1, D)
+                        ops.linear_wgrad([s_.view(-1, D) for s_ in srcs], d2, dP[f"enti_transfer_matrix_{n}"],
+                                         db=dP[f"enti_transfer_bias_{n}"])
+                        for si, s_ in enumerate(srcs):
+                            G.add(s_, ops.linear([d2], self._T(Wm[si * D:(si + 1) * D]), D).view_as(s_))
+                    tape.append(bwd_comb)
+                    if n == M - 1:
+                        item_emb = res
+                    else:
+                        new.append(res)
+                ev = new
+
+        # scores = sum_d user_o * item_emb (model.py:158) ; loss (model.py:379-380)
+        _, scores, _ = ops.linear([item_emb.view(B, D)], None, D, score_u=user_o)
+        dscore = torch.empty(B, dtype=F32, device=dev)
+        ops.eltwise(1, B, scores, dscore, z=labels, accum=loss_acc, alpha=1.0 / B, beta=1.0 / B)
+        du = torch.empty((B, D), dtype=F32, device=dev)
+        di = torch.empty((B, D), dtype=F32, device=dev)
+        ops.eltwise(5, B * D, item_emb.view(B, D), du, z=dscore, alpha=1.0, beta=0.0, D=D)
+        ops.eltwise(5, B * D, user_o, di, z=dscore, alpha=1.0, beta=0.0, D=D)
+        G.add(user_o, du)
+        G.add(item_emb, di.view_as(item_emb))
+
+        # ================================================================ backward
+        for fn in reversed(tape):
+            fn()
+        for (i, n), g in dT.items():   # relation-logit tables -> relation_emb and urh_weights[D:2D]
+            ops.rel_score_bwd(m.relation_emb_matrix, m._agg[(i, n)].urh_weights, g, dP["relation_emb_matrix"],
+                              dP[f"agg_{i}_{n}_urh_weights"].view(-1))
+
+        # ================================================================ L2 terms (model.py:382-412)
+        l2w, l2a = float(a.l2_weight), float(a.l2_agg_weight)
+
+        def l2_term(name, coef, sl=None):
+            if coef == 0.0:
+                return
+            x = self.params[name] if sl is None else self.params[name][sl]
+            g = dP[name] if sl is None else dP[name][sl]
+            ops.axpby(coef, x.reshape(-1), 1.0, g.reshape(-1))            # d(coef * sum(x^2)/2) = coef * x
+            ops.eltwise(3, x.numel(), x.reshape(-1), accum=loss_acc, alpha=coef * 0.5)
+
+        l2_term("relation_emb_matrix", l2w)
+        if P > 0:
+            l2_term("user_mlp_matrix", l2w)
+            l2_term("user_mlp_bias", l2w)
+            for e in range(L + 1):
+                cnt = (1 if e <= H else 0) + (1 if e == L else 0)        # :407-408 plus the LAST matrix (:405)
+                l2_term("transfer_W", l2w * cnt, e)
+                l2_term("transfer_b", l2w * cnt, e)
+        l2_term("h_emb_item_mlp_matrix", l2w)
+        l2_term("h_emb_item_mlp_bias", l2w)
+        l2_term("user_emb_matrix", l2a)
+        if not a.PS_only:
+            for (i, n) in aggregator_keys(a):
+                l2_term(f"agg_{i}_{n}_weights", l2a)
+                l2_term(f"agg_{i}_{n}_urh_weights", l2a)
+        for n in range(M):
+            l2_term(f"enti_transfer_matrix_{n}", l2a)
+            l2_term(f"enti_transfer_bias_{n}", l2a)
+        # gathered-row regulariser (model.py:383-386): sum(h^2) + sum(t^2) + sum(r_emb^2) per hop
+        for hop in range(P):
+            for ids in (memories_h[hop], memories_t[hop]):
+                rows = self._lookup(E, ids.reshape(-1))
+                ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
+                if not need_ps:   # otherwise mvin_key_addressing_bwd already added 2*l2*rows
+                    ops.scatter_add_rows(dP["entity_emb_matrix"], ids.reshape(-1), rows, alpha=2.0 * l2w)
+            cnt = torch.bincount(memories_r[hop].reshape(-1).long(), minlength=nR).to(F32)
+            ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
+                        beta=1.0, D=D * D)
+            for r, k in enumerate(cnt.tolist()):
+                if k:
+                    ops.eltwise(3, D * D, R[r].reshape(-1), accum=loss_acc, alpha=l2w * k)
+
+        self.last_grads = dP
+        loss = float(loss_acc.item())
+        if apply:
+            self.apply_adam(dP)
+        return loss
+
+    def apply_adam(self, grads):
+        """tf.train.AdamOptimizer step on every parameter (dense; see oracle/train_ref.AdamRef)."""
+        self.t += 1
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        for k, p in self.params.items():
+            ops.eltwise(4, p.numel(), p.view(-1), grads[k].view(-1), self.adam_m[k].view(-1), self.adam_v[k].view(-1),
+                        alpha=float(lr_t), beta1=self.b1, beta2=self.b2, eps=self.eps)
+        for agg in self.m.aggregators:
+            agg.invalidate()
