@@ -83,6 +83,40 @@ class DeviceFeeder(object):
         return self.model.forward_device(u, it, mh, mr, mt).scores_normalized
 
 
+# --------------------------------------------------------------------------- training loop
+def train_epoch(args, model, train_data, user_triplet_set, sess=None, rng=None):
+    """One epoch of train.py:56-64 through ``model.train(sess, feed_dict)``: shuffle, then full
+    minibatches only (the ragged tail is skipped, train.py:60-62).  Returns the list of losses."""
+    (rng or np.random).shuffle(train_data)
+    losses, start = [], 0
+    while start + args.batch_size <= train_data.shape[0]:
+        _, loss = model.train(sess, get_feed_dict(args, model, train_data, user_triplet_set, start,
+                                                  start + args.batch_size))
+        losses.append(loss)
+        start += args.batch_size
+    return losses
+
+
+def train_epoch_device(feeder, train_data, batch_size, rng=None):
+    """Same epoch with device-side feeds (ripple sets gathered on the GPU)."""
+    import torch
+    from .training import Trainer
+    model = feeder.model
+    if model.trainer is None:
+        model.trainer = Trainer(model)
+    (rng or np.random).shuffle(train_data)
+    dev = model.device
+    data = torch.from_numpy(np.ascontiguousarray(train_data)).to(dev)
+    losses, start = [], 0
+    while start + batch_size <= data.shape[0]:
+        blk = data[start:start + batch_size]
+        users, items, labels = blk[:, 0].contiguous(), blk[:, 1].contiguous(), blk[:, 2].to(torch.float32)
+        mh, mr, mt = feeder.memories(users)
+        losses.append(model.trainer.step(users, items, labels, mh, mr, mt))
+        start += batch_size
+    return losses
+
+
 # --------------------------------------------------------------------------- ranking metrics
 def precision_at_k(ranked, answers, k):
     """metrics.py:33-48: |top-k intersect answers| / k."""
