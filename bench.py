@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--shard", choices=["auto", "rowshard", "replicate"], default="auto",
                     help="entity table placement: row-sharded over the ranks with all-to-all row fetch "
                          "(auto: when N>1) or replicated")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the scoring pass as one hipGraph (for launch-bound batch sizes; single GPU)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="row-sharded mode: serialise the row exchange and the scoring (default: the exchange "
                          "for step i+1 runs on a side stream while step i is scored)")
@@ -143,12 +145,19 @@ def main():
     mr = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r]
     mt = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t]
 
+    scorer = None
+    if a.graph and not rowshard:
+        from mvin_amd.graph import GraphedScorer
+        scorer = GraphedScorer(model, Bl)
+        scorer.load(users, items, mh, mr, mt)
     overlap = rowshard and not a.no_overlap
     if overlap:
         runner.enable_pipeline()
     state = {"i": 0}
 
     def step():
+        if scorer is not None:
+            return scorer.replay()
         if not overlap:
             return runner.forward_device(users, items, mh, mr, mt)
         # every step scores one batch AND performs one row exchange (for the following batch),
@@ -213,7 +222,7 @@ def main():
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
-                       "adjacency": a.adj, "items": a.items,
+                       "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
                        "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
                                        f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"

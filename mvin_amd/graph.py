@@ -1,0 +1,48 @@
+"""hipGraph replay of the scoring path for launch-bound batch sizes.
+
+At the reference's own batch sizes (512 / 1024, src/bash/mvin_*.sh) one scoring pass is ~10 short
+kernels: launch latency, not the GPU, sets the step time.  ``GraphedScorer`` captures
+``MVIN.forward_device`` once on static input buffers (torch.cuda.CUDAGraph = hipGraph on ROCm; the
+ctypes launches into libmvin_hip.so are recorded like any other kernel on the capture stream) and
+replays it per batch: one graph launch instead of ~10 kernel launches plus Python glue.
+"""
+import torch
+
+
+class GraphedScorer(object):
+    def __init__(self, model, batch_size, warmup=2):
+        self.model = model
+        dev = model.device
+        B, Nm, P = batch_size, model.n_memory, max(1, model.p_hop)
+        self.users = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.items = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.mh = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        self.mr = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        self.mt = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up outside capture (fills the relation-logit caches)
+            for _ in range(warmup):
+                model.forward_device(self.users, self.items, self.mh, self.mr, self.mt)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = model.forward_device(self.users, self.items, self.mh, self.mr, self.mt)
+
+    def load(self, users, items, mem_h, mem_r, mem_t):
+        """Copy a batch (device tensors) into the graph's static input buffers."""
+        self.users.copy_(users)
+        self.items.copy_(items)
+        for i in range(len(self.mh)):
+            self.mh[i].copy_(mem_h[i])
+            self.mr[i].copy_(mem_r[i])
+            self.mt[i].copy_(mem_t[i])
+
+    def replay(self):
+        """Score whatever is in the static buffers; returns the (static) output namespace."""
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, users, items, mem_h, mem_r, mem_t):
+        self.load(users, items, mem_h, mem_r, mem_t)
+        return self.replay()
