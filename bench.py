@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--shard", choices=["auto", "rowshard", "replicate"], default="auto",
                     help="entity table placement: row-sharded over the ranks with all-to-all row fetch "
                          "(auto: when N>1) or replicated")
+    ap.add_argument("--table-dtype", choices=["f32", "bf16"], default="f32",
+                    help="storage type of the entity table (arithmetic is fp32 either way; bf16 = BASELINE config C5)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the scoring pass as one hipGraph (for launch-bound batch sizes; single GPU)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -133,11 +135,13 @@ def main():
     if rowshard:  # the model's entity table becomes the sharded table's working copy
         mparams = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
     model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=mparams, device=dev)
+                 params=mparams, device=dev, table_dtype=a.table_dtype)
     runner = model
     if rowshard:
         from mvin_amd.dist import ShardedMVIN, shard_rows
         shard = shard_rows(torch.from_numpy(params["entity_emb_matrix"]), rank, world)
+        if a.table_dtype == "bf16":
+            shard = shard.to(torch.bfloat16)
         runner = ShardedMVIN(model, shard, rank, world, is_shard=True, always_collective=a.force_collectives)
     users = torch.from_numpy(case.users[sl]).to(dev)
     items = torch.from_numpy(case.items[sl]).to(dev)
@@ -200,13 +204,14 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
             same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
-                                              "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch})
+                                              "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch}
+                    and a.table_dtype == "f32")
             if same and model.fused and world == 1:
                 traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
         except (OSError, KeyError, ValueError):
             traffic = None
         L = a.hop * a.mix
-        bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L)
+        bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L, s=2 if a.table_dtype == "bf16" else 4)
         kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
         kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = (bpp * Bl / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
@@ -223,6 +228,7 @@ def main():
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
+                       "entity_table_dtype": a.table_dtype,
                        "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
                                        f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"

@@ -11,8 +11,9 @@
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (torch allocates; the library
  *    holds no state except a per-thread last-error string);
- *  - tensors are dense row-major; ids are int32 (the reference's int64 ids are accepted
- *    only at mvin_expand_ids, model.py:50-51); tables are fp32;
+ *  - tensors are dense row-major; ids are int32 (int64 also at mvin_expand_ids and in
+ *    mvin_linear_args, the reference's placeholder dtype, model.py:50-51); tables are fp32, the
+ *    entity table optionally bf16 (table_bf16 / src_bf16) with fp32 arithmetic;
  *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); launches
  *    are asynchronous on it; the library never synchronises;
  *  - return 0 on success, <0 for argument/shape errors, >0 = hipError_t of the launch.
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 1
+#define MVIN_ABI_VERSION 2
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -94,6 +95,7 @@ typedef struct {
     const float* score_u;      /* [rows, Dout] or NULL */
     float* score_out;          /* [rows] or NULL */
     float* sigmoid_out;        /* [rows] or NULL */
+    int src_bf16;              /* bit s set: src[s] is a bf16 table (read as bf16, widened to fp32) */
 } mvin_linear_args;
 int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
 
@@ -126,15 +128,16 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
  *     nagg0[parent] = (1/K) sum_n p0[n] self1[n]   -> neighbors_agg of aggregator (0,.) at hop L-2
  *     nagg1[parent] = (1/K) sum_n p1[n] out1[n]    -> neighbors_agg of aggregator (1,.) at hop L-2
  * (model.py:295-305 with i = 0 and i = 1).  probs_parent [P,K] = p0 and probs_child [P*K,K] = p are
- * optional (model.py:294,304).  Returns -3 when (D, K) is outside the fused kernel's range
+ * optional (model.py:294,304).  table_bf16 = 1: the entity table holds bf16 rows (BASELINE config C5);
+ * arithmetic stays fp32.  Returns -3 when (D, K) is outside the fused kernel's range
  * (D in {16,32,64,128}, K a power of two in [4,256]); callers then use the per-level entry points. */
-int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1,
                             const float* W1, const float* W2, const float* b1, const float* b2,
                             const float* q, const float* A0, const float* a0,
                             int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
-                            void* stream);
+                            int table_bf16, void* stream);
 int mvin_gather_attn_l2_supported(int D, int K);
 
 /* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
@@ -165,10 +168,10 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
  * row is read once (head rows stay in registers between the logit and the weighted-sum pass).
  * Returns -3 when Nm/D exceed the register-resident kernel (ceil(Nm / (64/ceil_pow2(D/4))) > 16);
  * callers then use mvin_ripple_attn_fwd per read. */
-int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float* w,
+int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR,
-                            float* out, int64_t ldo, void* stream);
+                            float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 
 /* ---- training (model.py:378-417): forward variants that keep what the backward needs, and the
@@ -176,11 +179,11 @@ int mvin_key_addressing_supported(int Nm, int D);
 
 /* mvin_gather_attn_fwd / mvin_agg_fwd with two extra optional outputs:
  * s_out [T,D] = (1/K) sum_k p_k child_k (before the projection), z_out [T,D] = self + neighbors_agg. */
-int mvin_gather_attn_fwd_ex(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* node_ids, const float* rel_score, const float* self_vec,
                             const float* Wc, const float* c_child, const float* Wagg, const float* bagg,
                             int B, int N, int K, int D, int n_entity, float* out, float* probs,
-                            float* s_out, float* z_out, void* stream);
+                            float* s_out, float* z_out, int table_bf16, void* stream);
 int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
                     const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
                     float* s_out, float* z_out, void* stream);

@@ -39,6 +39,7 @@ class LinearArgs(C.Structure):
         ("score_u", C.c_void_p),
         ("score_out", C.c_void_p),
         ("sigmoid_out", C.c_void_p),
+        ("src_bf16", C.c_int),
     ]
 
 
@@ -58,13 +59,13 @@ SIGNATURES = {
     "mvin_gather_attn_l2_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
                                           _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
-                                          _c_f32p, C.c_void_p]),
+                                          _c_f32p, C.c_int, C.c_void_p]),
     "mvin_gather_attn_l2_supported": (C.c_int, [C.c_int, C.c_int]),
     "mvin_agg_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_key_addressing_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int,
-                                          C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_void_p]),
+                                          C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
     "mvin_sample_adjacency": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_int, C.c_int, C.c_uint64, _c_i32p,
                                         _c_i32p, C.c_void_p]),
@@ -72,7 +73,7 @@ SIGNATURES = {
                                          C.c_int, C.c_int, C.c_uint64, _c_i32p, C.c_void_p]),
     "mvin_gather_attn_fwd_ex": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p,
                                           _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                          C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+                                          C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_void_p]),
     "mvin_agg_fwd_ex": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                   C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_eltwise": (C.c_int, [C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_float,
@@ -127,8 +128,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 1:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 1")
+    if ver != 2:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 2")
     _lib = lib
     return lib
 

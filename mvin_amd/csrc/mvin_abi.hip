@@ -110,15 +110,16 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
                          const float* Wc, const float* c_child, const float* Wagg, const float* bagg, int B,
                          int N, int K, int D, int n_entity, float* out, float* probs, void* stream) {
     return mvin_gather_attn_fwd_ex(table, adj_entity, adj_relation, node_ids, rel_score, self_vec, Wc, c_child,
-                                   Wagg, bagg, B, N, K, D, n_entity, out, probs, nullptr, nullptr, stream);
+                                   Wagg, bagg, B, N, K, D, n_entity, out, probs, nullptr, nullptr, 0, stream);
 }
 
-int mvin_gather_attn_fwd_ex(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* node_ids, const float* rel_score, const float* self_vec,
                             const float* Wc, const float* c_child, const float* Wagg, const float* bagg, int B,
                             int N, int K, int D, int n_entity, float* out, float* probs, float* s_out,
-                            float* z_out, void* stream) {
+                            float* z_out, int table_bf16, void* stream) {
     mvin::GatherAttnArgs g{};
+    g.table_bf16 = table_bf16 ? 1 : 0;
     g.s_out = s_out;
     g.z_out = z_out;
     g.gather = 1;
@@ -144,12 +145,12 @@ int mvin_gather_attn_fwd_ex(const float* table, const int32_t* adj_entity, const
 
 int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supported(D, K) ? 1 : 0; }
 
-int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
                             const float* W2, const float* b1, const float* b2, const float* q,
                             const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
-                            void* stream) {
+                            int table_bf16, void* stream) {
     const char* who = "mvin_gather_attn_l2_fwd";
     if (!mvin::fused_l2_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {16,32,64,128}, K power of two in [4,256])",
@@ -181,14 +182,14 @@ int mvin_gather_attn_l2_fwd(const float* table, const int32_t* adj_entity, const
     f.probs_parent = probs_parent;
     f.probs_child = probs_child;
     f.P = (int64_t)B * parents_per_pair;
-    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * sizeof(float);
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * (table_bf16 ? 2 : 4);
     f.parents_per_pair = parents_per_pair;
     f.K = K;
     f.nR = nR;
     int l = 0;
     while ((4 << l) < K) ++l;
     f.lpn_log2 = l;
-    return hip_result(mvin::launch_gather_attn_l2(f, D, (hipStream_t)stream), who);
+    return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
 }
 
 int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
@@ -251,10 +252,10 @@ int mvin_key_addressing_supported(int Nm, int D) {
     return (!bad_dim(D) && Nm > 0 && mvin::key_addr_nj(Nm, D) <= 16) ? 1 : 0;
 }
 
-int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float* w,
+int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, float* out,
-                            int64_t ldo, void* stream) {
+                            int64_t ldo, int table_bf16, void* stream) {
     const char* who = "mvin_key_addressing_fwd";
     if (!entity_emb || !mem_h || !out) return fail(-1, "%s: null pointer", who);
     if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
@@ -288,7 +289,7 @@ int mvin_key_addressing_fwd(const float* entity_emb, const float* V, const float
     k.D = D;
     k.nR = nR;
     k.lpr_log2 = mvin::lpr_log2_for(D);
-    return hip_result(mvin::launch_key_addr(k, (hipStream_t)stream), who);
+    return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 
 int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,

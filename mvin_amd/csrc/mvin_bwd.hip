@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
     const int slot0 = a.f.w ? 1 : 0;
     const int nhop = a.f.P > 0 ? a.f.P : 1;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Ef = reinterpret_cast<const float*>(a.f.E);   // training keeps the tables in fp32
 
     for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < a.f.B; b += (int64_t)gridDim.x * 4) {
         for (int hop = 0; hop < nhop; ++hop) {
@@ -292,11 +293,11 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                     const int m = m0 + g;
                     float pl = 0.f, pg = 0.f;
                     if (m < Nm && cact) {
-                        const float4 h = reinterpret_cast<const float4*>(a.f.E + (int64_t)mh[m] * D)[c];
+                        const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)mh[m] * D)[c];
                         const float4 sv = is_set ? reinterpret_cast<const float4*>(a.f.w)[c]
                                                  : reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + mr[m]) * (int64_t)D)[c];
                         pl = fmaf(h.x, sv.x, fmaf(h.y, sv.y, fmaf(h.z, sv.z, h.w * sv.w)));
-                        const float4 val = reinterpret_cast<const float4*>(a.f.E + (int64_t)mv[m] * D)[c];
+                        const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)mv[m] * D)[c];
                         pg = fmaf(dvo.x, val.x, fmaf(dvo.y, val.y, fmaf(dvo.z, val.z, dvo.w * val.w)));
                     }
                     pl = group_sum(pl, a.f.lpr_log2);
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                         const float p = sL[m];
                         const float dl = p * (sGm[m] - pgs);
                         const int64_t hrow = mh[m], vrow = mv[m];
-                        const float4 h = reinterpret_cast<const float4*>(a.f.E + hrow * D)[c];
+                        const float4 h = reinterpret_cast<const float4*>(Ef + hrow * D)[c];
                         float4 dh, dval;
                         if (is_set) {
                             const float4 w4 = reinterpret_cast<const float4*>(a.f.w)[c];
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                         } else {
                             const int r = mr[m];
                             const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
-                            const float4 val = reinterpret_cast<const float4*>(a.f.E + vrow * D)[c];
+                            const float4 val = reinterpret_cast<const float4*>(Ef + vrow * D)[c];
                             const float l2 = 2.f * a.l2;
                             dh = make_float4(dl * v4.x + l2 * h.x, dl * v4.y + l2 * h.y, dl * v4.z + l2 * h.z,
                                              dl * v4.w + l2 * h.w);

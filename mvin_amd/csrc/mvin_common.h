@@ -52,6 +52,19 @@ __device__ __forceinline__ float group_max(float v, int l2) {
     return v;
 }
 
+// ---- entity-table rows: fp32 (16-byte lane loads) or bf16 (8-byte lane loads, widened to fp32
+// exactly: bf16 -> f32 is a 16-bit shift) ------------------------------------------------------
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {
+    return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u),
+                       __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+}
+
+// chunk c (4 elements) of row `row` of a [*, D] table; bf16 is wave-uniform
+__device__ __forceinline__ float4 load_row4(const void* table, int bf16, int64_t row, int D, int c) {
+    if (bf16) return bf16x4_to_f32(reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(table) + row * D)[c]);
+    return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(table) + row * D)[c];
+}
+
 __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
     a.x = fmaf(s, v.x, a.x);
     a.y = fmaf(s, v.y, a.y);

@@ -55,7 +55,7 @@ struct FusedGeom {
 //                               iteration without waiting
 // KIT = number of int4 chunk iterations per wave per tile (= NPW*K/256 <= 2); KIT = 0 keeps the
 // unpipelined flow (any K <= 256).
-template <int D, int NW, int KIT>
+template <int D, int NW, int KIT, bool BF>
 __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) {
     using G = FusedGeom<D, NW>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     }
 
     // entity table through a buffer descriptor when it is < 4 GiB (32-bit byte offsets)
-    const bool buf32 = a.table_bytes < (1ull << 32);
+    const bool buf32 = !BF && a.table_bytes < (1ull << 32);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
+        const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
     const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
@@ -315,7 +315,17 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                 const int2* yp = ypw + nl * K;
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (buf32) {
+                if (BF) {
+                    // bf16 table: 8-byte lane loads (4 elements), widened to fp32 exactly
+                    const uint16_t* tb = reinterpret_cast<const uint16_t*>(a.table);
+#pragma unroll 8
+                    for (int k = g; k < K; k += G::RPW) {
+                        const int2 e = yp[k];
+                        const float4 v = bf16x4_to_f32(reinterpret_cast<const uint2*>(tb + (int64_t)e.x * D)[c]);
+                        acc = f4_fma(__int_as_float(e.y), v, acc);
+                    }
+                    if (g == 0) sv = bf16x4_to_f32(reinterpret_cast<const uint2*>(tb + (int64_t)sX1[n] * D)[c]);
+                } else if (buf32) {
                     // 32-bit row offsets through a buffer descriptor: one VALU per row address
                     // instead of a 64-bit shift+add chain; packed FMAs (2 f32 per issue)
                     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
@@ -339,13 +349,14 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                                          __uint_as_float(raw[3]));
                     }
                 } else {   // tables >= 4 GiB: 64-bit global addressing
+                    const float* tf = reinterpret_cast<const float*>(a.table);
 #pragma unroll 8
                     for (int k = g; k < K; k += G::RPW) {
                         const int2 e = yp[k];
-                        const float4 v = reinterpret_cast<const float4*>(a.table + (int64_t)e.x * D)[c];
+                        const float4 v = reinterpret_cast<const float4*>(tf + (int64_t)e.x * D)[c];
                         acc = f4_fma(__int_as_float(e.y), v, acc);
                     }
-                    if (g == 0) sv = reinterpret_cast<const float4*>(a.table + (int64_t)sX1[n] * D)[c];
+                    if (g == 0) sv = reinterpret_cast<const float4*>(tf + (int64_t)sX1[n] * D)[c];
                 }
                 acc = group_xor_sum(acc, G::LPR);
                 if (g == 0) {
@@ -453,30 +464,30 @@ size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf) {
     return words * 4 + (size_t)NW * (kTM / NW) * K * sizeof(int2);
 }
 
-template <int D, int NW, int KIT>
+template <int D, int NW, int KIT, bool BF>
 static hipError_t launch_l2(const FusedL2Args& a, hipStream_t st) {
     const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int64_t cap = 256 * 4;  // persistent: 256 CUs x up to 4 resident workgroups
     const int grid = (int)(a.P < cap ? a.P : cap);
-    gather_attn_l2_kernel<D, NW, KIT><<<grid, NW * 64, lds, st>>>(a);
+    gather_attn_l2_kernel<D, NW, KIT, BF><<<grid, NW * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
 // chunk iterations per wave per tile: NPW children x K/4 lanes each over 64 lanes
-template <int D, int NW>
+template <int D, int NW, bool BF>
 static hipError_t launch_l2_pick(const FusedL2Args& a, hipStream_t st) {
     static const bool nopipe = getenv("MVIN_L2_NOPIPE") != nullptr;
     const int kit = ((kTM / NW) * (a.K / 4) + 63) / 64;
-    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1>(a, st);
+    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1, BF>(a, st);
     if constexpr (D <= 32) {   // at D >= 64 the second chunk pair costs a wave of occupancy
-        if (!nopipe && kit == 2) return launch_l2<D, NW, 2>(a, st);
+        if (!nopipe && kit == 2) return launch_l2<D, NW, 2, BF>(a, st);
     }
-    return launch_l2<D, NW, 0>(a, st);
+    return launch_l2<D, NW, 0, BF>(a, st);
 }
 
 bool fused_l2_supported(int D, int K) {
@@ -485,12 +496,21 @@ bool fused_l2_supported(int D, int K) {
     return dok && kok;
 }
 
-hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st) {
+hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
+    if (table_bf16) {
+        switch (D) {
+            case 16: return launch_l2_pick<16, 4, true>(a, st);
+            case 32: return launch_l2_pick<32, 4, true>(a, st);
+            case 64: return launch_l2_pick<64, 4, true>(a, st);
+            case 128: return launch_l2_pick<128, 8, true>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (D) {
-        case 16: return launch_l2_pick<16, 4>(a, st);
-        case 32: return launch_l2_pick<32, 4>(a, st);
-        case 64: return launch_l2_pick<64, 4>(a, st);
-        case 128: return launch_l2_pick<128, 8>(a, st);
+        case 16: return launch_l2_pick<16, 4, false>(a, st);
+        case 32: return launch_l2_pick<32, 4, false>(a, st);
+        case 64: return launch_l2_pick<64, 4, false>(a, st);
+        case 128: return launch_l2_pick<128, 8, false>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -10,7 +10,8 @@ namespace mvin {
 
 struct GatherAttnArgs {
     int gather;               // 1: children through adjacency + table; 0: dense neigh rows
-    const float* table;       // [nE, D]
+    int table_bf16;           // the table holds bf16 rows
+    const void* table;        // [nE, D]
     const int32_t* adj_e;     // [nE, K]
     const int32_t* adj_r;     // [nE, K]
     const int32_t* node_ids;  // [T]
@@ -56,7 +57,7 @@ struct RippleBuildArgs {
 };
 
 struct KeyAddrArgs {
-    const float* E;            // [nE, D]
+    const void* E;             // [nE, D] fp32 (or bf16 when the kernel is instantiated with BF)
     const float* V;            // [B, nR, D] or NULL (p_hop == 0)
     const float* w;            // [D] h-set logit weights or NULL (PS_O_ft off)
     const int32_t* mem_h[8];   // per hop [B, Nm]
@@ -69,7 +70,7 @@ struct KeyAddrArgs {
 };
 
 struct FusedL2Args {
-    const float* table;          // [nE, D]
+    const void* table;           // [nE, D] fp32 (or bf16: BF instantiation)
     const int32_t* adj_e;        // [nE, K]
     const int32_t* adj_r;        // [nE, K]
     const int32_t* parent_ids;   // [P] entity id of every level-(L-2) node
@@ -172,8 +173,8 @@ hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, co
                                    int K, uint64_t seed, int32_t* adj_e, int32_t* adj_r, hipStream_t st);
 hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
-hipError_t launch_key_addr(const KeyAddrArgs& a, hipStream_t st);
+hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 bool fused_l2_supported(int D, int K);
-hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, hipStream_t st);
+hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 
 }  // namespace mvin

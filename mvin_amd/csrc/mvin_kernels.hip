@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(mvin_linear_args a) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < a.rows) {
                     const int64_t srow = !ids ? r : (a.ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r]);
-                    v = reinterpret_cast<const float4*>(src + srow * a.Dsrc)[c];
+                    v = load_row4(src, (a.src_bf16 >> s) & 1, srow, a.Dsrc, c);
                 }
                 float4* dst = reinterpret_cast<float4*>(sX + row * ldx + (a.sum_sources ? 0 : s * a.Dsrc) + c * 4);
                 if (a.sum_sources && s > 0) {  // same thread wrote this slot for s-1
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                 for (int k = g; k < K; k += rpw) {
                     const int2 e = yp[k];
                     if (cact) {
-                        const float4 v = reinterpret_cast<const float4*>(a.table + (int64_t)e.x * D)[c];
+                        const float4 v = load_row4(a.table, a.table_bf16, e.x, D, c);
                         acc = f4_fma(__int_as_float(e.y), v, acc);
                     }
                 }

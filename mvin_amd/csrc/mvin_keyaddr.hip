@@ -13,7 +13,7 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-template <int NJ, bool OWN>
+template <int NJ, bool OWN, bool BF>
 __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D, Nm = a.Nm;
@@ -56,13 +56,13 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 hrow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cact && j * rpw + g < Nm) hrow[j] = reinterpret_cast<const float4*>(a.E + (int64_t)hid[j] * D)[c];
+                if (cact && j * rpw + g < Nm) hrow[j] = load_row4(a.E, BF, hid[j], D, c);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 trow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (do_hop && cact && j * rpw + g < Nm)
-                    trow[j] = reinterpret_cast<const float4*>(a.E + (int64_t)tix[j] * D)[c];
+                    trow[j] = load_row4(a.E, BF, tix[j], D, c);
             }
             const float4 wv = (do_set && cact) ? reinterpret_cast<const float4*>(a.w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_h = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -165,15 +165,20 @@ int key_addr_nj(int Nm, int D) {
     return nj;  // > 16 means: not supported by the register-resident kernel
 }
 
-hipError_t launch_key_addr(const KeyAddrArgs& a, hipStream_t st) {
+hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st) {
     const int nj = key_addr_nj(a.Nm, a.D);
     const int64_t nblk = (a.B + 3) / 4;
     const int64_t cap = 256 * 8;
     const int grid = (int)(nblk < cap ? nblk : cap);
     const bool own = nj <= (1 << a.lpr_log2);   // rows per lane <= lanes per row: one exp per lane
-#define MVIN_KA(NJV)                                                                   \
-    if (own) key_addr_kernel<NJV, true><<<grid, kBlock, 0, st>>>(a);                   \
-    else key_addr_kernel<NJV, false><<<grid, kBlock, 0, st>>>(a);                      \
+#define MVIN_KA(NJV)                                                                       \
+    if (table_bf16) {                                                                      \
+        if (own) key_addr_kernel<NJV, true, true><<<grid, kBlock, 0, st>>>(a);             \
+        else key_addr_kernel<NJV, false, true><<<grid, kBlock, 0, st>>>(a);                \
+    } else {                                                                               \
+        if (own) key_addr_kernel<NJV, true, false><<<grid, kBlock, 0, st>>>(a);            \
+        else key_addr_kernel<NJV, false, false><<<grid, kBlock, 0, st>>>(a);               \
+    }                                                                                      \
     break;
     switch (nj) {
         case 1: MVIN_KA(1)

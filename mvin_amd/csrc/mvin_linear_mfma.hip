@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a)
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < a.rows) {
                     const int64_t srow = !ids ? r : (a.ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r]);
-                    v = reinterpret_cast<const float4*>(src + srow * a.Dsrc)[c];
+                    v = load_row4(src, (a.src_bf16 >> s) & 1, srow, a.Dsrc, c);
                 }
                 float* dst = sX + row * LDX + (a.sum_sources ? 0 : s * a.Dsrc) + c * 4;
                 if (a.sum_sources && s > 0) {  // same thread wrote this slot for s-1

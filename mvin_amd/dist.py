@@ -136,6 +136,8 @@ class ShardedEntityTable(object):
 def hip_row_gather(table, idx_int32):
     """Owner-side row gather on the GPU: mvin_linear_fwd in its identity/gather form."""
     from . import ops
+    if table.dtype != torch.float32:   # bf16 shard: rows move as bf16 (pure data movement)
+        return table.index_select(0, idx_int32.long())
     return ops.linear([table], None, table.shape[1], ids=[idx_int32.contiguous()])
 
 

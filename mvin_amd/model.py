@@ -49,8 +49,13 @@ class Placeholder(object):
 
 class MVIN(object):
     def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
-                 params=None, device=None, seed=0, fused=None):
+                 params=None, device=None, seed=0, fused=None, table_dtype="f32"):
+        """``table_dtype="bf16"`` keeps the entity embedding table in bf16 (BASELINE config C5):
+        rows are widened to fp32 inside the kernels, all arithmetic stays fp32; scoring only."""
         self.device = torch.device(device or "cuda")
+        if table_dtype not in ("f32", "bf16"):
+            raise ValueError("table_dtype must be 'f32' or 'bf16'")
+        self.table_dtype = table_dtype
         # fused=False (or MVIN_FUSED=0) forces the per-level kernels (used by the tests to
         # check both HIP paths against the oracle)
         self.fused = (os.environ.get("MVIN_FUSED", "1") != "0") if fused is None else bool(fused)
@@ -124,6 +129,8 @@ class MVIN(object):
 
         self.user_emb_matrix = dev(params["user_emb_matrix"])
         self.entity_emb_matrix = dev(params["entity_emb_matrix"])
+        if self.table_dtype == "bf16":
+            self.entity_emb_matrix = self.entity_emb_matrix.to(torch.bfloat16).contiguous()
         self.relation_emb_matrix = dev(params["relation_emb_matrix"])
         self.relation_emb_KGE_matrix = dev(params["relation_emb_KGE_matrix"])
         for t, shape in ((self.user_emb_matrix, (n_user, D)), (self.entity_emb_matrix, (n_entity, D)),
@@ -169,7 +176,7 @@ class MVIN(object):
     def parameters_dict(self):
         """All parameters as numpy arrays under the names of mvin_amd/params.py."""
         L = self.n_mix_hop * self.h_hop
-        p = {k: getattr(self, k).cpu().numpy() for k in
+        p = {k: getattr(self, k).float().cpu().numpy() for k in
              ("user_emb_matrix", "entity_emb_matrix", "relation_emb_matrix", "relation_emb_KGE_matrix",
               "user_mlp_matrix", "user_mlp_bias", "h_emb_item_mlp_matrix", "h_emb_item_mlp_bias")}
         for n in range(self.n_mix_hop):
@@ -194,13 +201,13 @@ class MVIN(object):
 
     def save_pretrain_emb_fuc(self, sess=None, saver=None):
         """model.py:66-67 / train.py:43-51: persist the four ``STWS`` embedding tables."""
-        np.savez(self._emb_path(), **{k: getattr(self, k).cpu().numpy() for k in self._STWS})
+        np.savez(self._emb_path(), **{k: getattr(self, k).float().cpu().numpy() for k in self._STWS})
 
     def restore_pretrain_emb(self):
         """train.py:53-54 counterpart."""
         with np.load(self._emb_path()) as z:
             for k in self._STWS:
-                getattr(self, k).copy_(torch.from_numpy(z[k]).to(self.device))
+                getattr(self, k).copy_(torch.from_numpy(z[k]).to(self.device))   # casts to the table dtype
         for agg in self.aggregators:
             agg.invalidate()
 
@@ -228,7 +235,10 @@ class MVIN(object):
             V = torch.empty((B, nR, D), dtype=torch.float32, device=self.device)
             ops.linear([self.entity_emb_matrix], self.relation_emb_KGE_matrix, D, ids=[item32], rows=B,
                        out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
-        if self.fused and ops.key_addressing_supported(self.n_memory, D):
+        bf16 = self.entity_emb_matrix.dtype == torch.bfloat16
+        if bf16 and not ops.key_addressing_supported(self.n_memory, D):
+            raise NotImplementedError("bf16 entity table: n_memory/dim outside mvin_key_addressing_fwd's range")
+        if (self.fused or bf16) and ops.key_addressing_supported(self.n_memory, D):
             ops.key_addressing(self.entity_emb_matrix, V, w_h, mem_h, mem_r, mem_t, P, o_cat, n_o * D, nR)
         else:
             slot = 0

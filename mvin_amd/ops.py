@@ -12,6 +12,15 @@ from . import _lib
 
 F32 = torch.float32
 I32 = torch.int32
+BF16 = torch.bfloat16
+
+
+def _chk_table(t, name):
+    """Entity-style table: fp32 or bf16 (bf16 rows are widened to fp32 inside the kernels)."""
+    if t is None:
+        return 0
+    _chk(t, BF16 if t.dtype == BF16 else F32, name)
+    return 1 if t.dtype == BF16 else 0
 
 
 def _stream():
@@ -96,8 +105,9 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     ids = ids or [None] * nsrc
     ids64 = None
     Dsrc = srcs[0].shape[-1]
+    src_bf16 = 0
     for s in range(nsrc):
-        _chk(srcs[s], F32, f"src[{s}]")
+        src_bf16 |= _chk_table(srcs[s], f"src[{s}]") << s
         if srcs[s].shape[-1] != Dsrc:
             raise ValueError("all sources must share the row width")
         a.src[s] = srcs[s].data_ptr()
@@ -125,6 +135,7 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a.rows_per_group = rows_per_group
     a.relu = 1 if relu else 0
     a.ids64 = 1 if ids64 else 0
+    a.src_bf16 = src_bf16
     a.sum_sources = 1 if sum_sources else 0
     a.out = out.data_ptr() + out_offset * 4
     a.ldo = ldo
@@ -141,20 +152,21 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
 
 def gather_attn(table, adj_entity, adj_relation, node_ids, rel_score_t, self_vec, Wc, c_child,
                 Wagg, bagg, B, N, K, D, want_probs=False):
-    """mvin_gather_attn_fwd: deepest hop, children gathered from ``table`` through the
-    adjacency of ``node_ids`` [B*N]; returns (out [B,N,D], probs [B,N,K] or None)."""
+    """mvin_gather_attn_fwd(_ex): deepest hop, children gathered from ``table`` (fp32 or bf16)
+    through the adjacency of ``node_ids`` [B*N]; returns (out [B,N,D], probs [B,N,K] or None)."""
     lib = _lib.load()
-    for t, dt, nm in ((table, F32, "table"), (adj_entity, I32, "adj_entity"),
+    bf = _chk_table(table, "table")
+    for t, dt, nm in ((adj_entity, I32, "adj_entity"),
                       (adj_relation, I32, "adj_relation"), (node_ids, I32, "node_ids"),
                       (rel_score_t, F32, "rel_score"), (self_vec, F32, "self_vec"), (Wc, F32, "Wc"),
                       (c_child, F32, "c_child"), (Wagg, F32, "Wagg"), (bagg, F32, "bagg")):
         _chk(t, dt, nm)
     out = torch.empty((B, N, D), dtype=F32, device=table.device)
     probs = torch.empty((B, N, K), dtype=F32, device=table.device) if want_probs else None
-    _lib.check(lib.mvin_gather_attn_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids),
-                                        _p(rel_score_t), _p(self_vec), _p(Wc), _p(c_child), _p(Wagg),
-                                        _p(bagg), B, N, K, D, table.shape[0], _p(out), _p(probs),
-                                        _stream()), "mvin_gather_attn_fwd")
+    _lib.check(lib.mvin_gather_attn_fwd_ex(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids),
+                                           _p(rel_score_t), _p(self_vec), _p(Wc), _p(c_child), _p(Wagg),
+                                           _p(bagg), B, N, K, D, table.shape[0], _p(out), _p(probs), None, None,
+                                           bf, _stream()), "mvin_gather_attn_fwd_ex")
     return out, probs
 
 
@@ -197,7 +209,8 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  Returns
     (nagg0 [P,D], nagg1 [P,D], probs_parent [P,K] | None, probs_child [P*K,K] | None)."""
     lib = _lib.load()
-    for t, dt, nm in ((table, F32, "table"), (adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
+    bf = _chk_table(table, "table")
+    for t, dt, nm in ((adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
                       (parent_ids, I32, "parent_ids"), (t0, F32, "t0"), (t1, F32, "t1"), (W1, F32, "W1"),
                       (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"), (A0, F32, "A0"),
                       (a0, F32, "a0")):
@@ -211,7 +224,7 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     _lib.check(lib.mvin_gather_attn_l2_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(parent_ids), _p(t0),
                                            _p(t1), _p(W1), _p(W2), _p(b1), _p(b2), _p(q), _p(A0), _p(a0), B,
                                            parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
-                                           _p(pp), _p(pc), _stream()), "mvin_gather_attn_l2_fwd")
+                                           _p(pp), _p(pc), bf, _stream()), "mvin_gather_attn_l2_fwd")
     return nagg0, nagg1, pp, pc
 
 
@@ -223,7 +236,8 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     """mvin_key_addressing_fwd: every preference-hop attention read of a batch in one launch;
     fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...]."""
     lib = _lib.load()
-    _chk(entity_emb, F32, "entity_emb"), _chk(V, F32, "V"), _chk(w, F32, "w"), _chk(out, F32, "out")
+    bf = _chk_table(entity_emb, "entity_emb")
+    _chk(V, F32, "V"), _chk(w, F32, "w"), _chk(out, F32, "out")
     nh = max(1, P)
     arr_t = C.c_void_p * nh
     for lst, nm in ((mem_h[:nh], "mem_h"), (mem_r[:P], "mem_r"), (mem_t[:P], "mem_t")):
@@ -235,7 +249,7 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     B, Nm = mem_h[0].shape
     D = entity_emb.shape[1]
     _lib.check(lib.mvin_key_addressing_fwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(out),
-                                           ldo, _stream()), "mvin_key_addressing_fwd")
+                                           ldo, bf, _stream()), "mvin_key_addressing_fwd")
     return out
 
 
@@ -246,7 +260,7 @@ def _fill_linear_args(a, srcs, ids, Dout, rows, nz, sum_sources):
     ids64 = None
     Dsrc = srcs[0].shape[-1]
     for s in range(nsrc):
-        _chk(srcs[s], F32, f"src[{s}]")
+        _chk(srcs[s], F32, f"src[{s}]")   # training keeps every table in fp32
         a.src[s] = srcs[s].data_ptr()
         if ids[s] is not None:
             if ids64 is None:
@@ -273,7 +287,7 @@ def gather_attn_ex(table, adj_entity, adj_relation, node_ids, rel_score_t, self_
     z_out = torch.empty((B * N, D), dtype=F32, device=dev)
     _lib.check(lib.mvin_gather_attn_fwd_ex(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids), _p(rel_score_t),
                                            _p(self_vec), _p(Wc), _p(c_child), _p(Wagg), _p(bagg), B, N, K, D,
-                                           table.shape[0], _p(out), _p(probs), _p(s_out), _p(z_out), _stream()),
+                                           table.shape[0], _p(out), _p(probs), _p(s_out), _p(z_out), 0, _stream()),
                "mvin_gather_attn_fwd_ex")
     return out, probs, s_out, z_out
 

@@ -52,6 +52,8 @@ class Trainer(object):
         if not a.wide_deep:
             raise NotImplementedError("training the legacy aggregate path (wide_deep=False) is not built; the "
                                       "reference cannot run it either (model.py:366-374)")
+        if model.entity_emb_matrix.dtype != torch.float32:
+            raise NotImplementedError("training needs fp32 tables (table_dtype='bf16' is a scoring-only layout)")
         self.m = model
         self.lr = model.lr if lr is None else lr
         self.b1, self.b2, self.eps = beta1, beta2, eps

@@ -1,0 +1,84 @@
+"""-m gpu: bf16 entity table (BASELINE config C5's dtype).  The kernels widen bf16 rows to fp32
+exactly and compute in fp32, so a bf16-table model must agree with an fp32-table model whose
+table was rounded to bf16 to fp32 round-off, and with the fp32 oracle on the unrounded table
+to bf16 precision (~1e-2)."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import synth
+from mvin_amd.config import make_args
+from mvin_amd.params import init_params
+from oracle import mirror_fp32
+
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    dict(dim=64, neighbor_sample_size=32, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=12),   # fused + key_addr<16>
+    dict(dim=128, neighbor_sample_size=16, h_hop=3, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=3),   # depth 3
+    dict(dim=8, neighbor_sample_size=3, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=5),       # per-level kernels
+    dict(dim=32, neighbor_sample_size=8, h_hop=1, n_mix_hop=2, p_hop=2, n_memory=8, batch_size=6),
+]
+
+
+def run(model, case):
+    dev = model.device
+    out = model.forward_device(torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+                               [torch.from_numpy(m).to(dev) for m in case.memories_h],
+                               [torch.from_numpy(m).to(dev) for m in case.memories_r],
+                               [torch.from_numpy(m).to(dev) for m in case.memories_t], want_probs=True)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlevel"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "D{dim}K{neighbor_sample_size}H{h_hop}M{n_mix_hop}".format(**s))
+def test_bf16_table(shape, fused, hip_lib):
+    from mvin_amd.model import MVIN
+    args = make_args(**shape)
+    case = synth.small_case(args, n_user=16, n_entity=400, n_relation=7, seed=81, zero_rows=4)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=82, random_agg_bias=True)
+    rounded = dict(params, entity_emb_matrix=torch.from_numpy(params["entity_emb_matrix"]).to(torch.bfloat16).float().numpy())
+    mk = lambda p, dt: MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                            params=p, device="cuda:0", fused=fused, table_dtype=dt)
+    m16 = mk(params, "bf16")
+    assert m16.entity_emb_matrix.dtype == torch.bfloat16
+    got = run(m16, case)
+    ref32 = run(mk(rounded, "f32"), case)
+    # same arithmetic on the same (bf16-representable) values
+    assert_close(got.scores.cpu().numpy(), ref32.scores.cpu().numpy(), "bf16 table vs fp32 table holding the rounded rows",
+                 rtol=2e-6, atol=2e-7)
+    for a, b in zip(got.importance_list, ref32.importance_list):
+        assert torch.equal(a, b)     # attention weights do not depend on the entity table
+    # against the fp32 oracle on the unrounded table: bf16 storage precision
+    ref = mirror_fp32.forward(args, params, case.adj_entity, case.adj_relation, case.users, case.items,
+                              case.memories_h, case.memories_r, case.memories_t)
+    assert_close(got.scores.cpu().numpy(), ref.scores.numpy(), "bf16 table vs fp32 oracle", rtol=1e-2, atol=2e-3)
+    # and against the oracle evaluated on the rounded table: the north-star tolerance
+    ref_r = mirror_fp32.forward(args, rounded, case.adj_entity, case.adj_relation, case.users, case.items,
+                                case.memories_h, case.memories_r, case.memories_t)
+    assert_close(got.scores.cpu().numpy(), ref_r.scores.numpy(), "bf16 table vs oracle on rounded table")
+
+
+def test_c5_shape_two_paths_agree(hip_lib):
+    """BASELINE config C5's shape (D=128, H=3, K=128, bf16 table; 2.1 M rows per pair): too large for the
+    CPU oracle, so the two independent HIP paths (fused two-level kernel vs per-level kernels) must agree,
+    and permuting every node's children must leave the scores unchanged."""
+    from mvin_amd.model import MVIN
+    d = synth.DATASETS["amazon-book_20core"]
+    args = make_args(dim=128, neighbor_sample_size=128, h_hop=3, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=2)
+    case = synth.dataset_case("amazon-book_20core", K=128, B=2, seed=4, uniform_adj=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=5, random_agg_bias=True)
+    mk = lambda ae, ar, fused: MVIN(args, case.n_user, case.n_entity, case.n_relation, ae, ar, params=params,
+                                    device="cuda:0", fused=fused, table_dtype="bf16")
+    a = run(mk(case.adj_entity, case.adj_relation, True), case).scores.cpu().numpy()
+    b = run(mk(case.adj_entity, case.adj_relation, False), case).scores.cpu().numpy()
+    assert_close(a, b, "fused vs per-level at C5 shape", rtol=1e-5, atol=1e-6)
+    rng = np.random.default_rng(6)
+    perm = np.argsort(rng.random((case.n_entity, 128)), axis=1)
+    ae, ar = np.take_along_axis(case.adj_entity, perm, 1), np.take_along_axis(case.adj_relation, perm, 1)
+    c = run(mk(ae, ar, True), case).scores.cpu().numpy()
+    assert_close(c, a, "child permutation at C5 shape", rtol=1e-5, atol=1e-6)
+    del d
