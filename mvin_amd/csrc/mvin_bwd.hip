@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                 pgs = wave_sum(pgs);
                 __builtin_amdgcn_wave_barrier();
                 // scatter
+                float4 dwacc = z4;   // h-set logit-weight gradient: per-lane partial, ONE atomic set per pair
                 for (int m0 = 0; m0 < Nm; m0 += rpw) {
                     const int m = m0 + g;
                     if (m < Nm && cact) {
@@ -341,11 +342,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                             dh = make_float4(p * dvo.x + dl * w4.x, p * dvo.y + dl * w4.y, p * dvo.z + dl * w4.z,
                                              p * dvo.w + dl * w4.w);
                             dval = z4;
-                            float* dw = a.dw + 4 * c;
-                            atomicAdd(dw + 0, dl * h.x);
-                            atomicAdd(dw + 1, dl * h.y);
-                            atomicAdd(dw + 2, dl * h.z);
-                            atomicAdd(dw + 3, dl * h.w);
+                            dwacc = f4_fma(dl, h, dwacc);
                         } else {
                             const int r = mr[m];
                             const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
@@ -371,6 +368,16 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                         atomicAdd(de + 1, dh.y);
                         atomicAdd(de + 2, dh.z);
                         atomicAdd(de + 3, dh.w);
+                    }
+                }
+                if (is_set) {
+                    dwacc = group_xor_sum(dwacc, lpr);
+                    if (cact && g == 0) {
+                        float* dw = a.dw + 4 * c;
+                        atomicAdd(dw + 0, dwacc.x);
+                        atomicAdd(dw + 1, dwacc.y);
+                        atomicAdd(dw + 2, dwacc.z);
+                        atomicAdd(dw + 3, dwacc.w);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
