@@ -130,7 +130,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("MVIN_DIST_BACKEND", "nccl")
+        if backend == "nccl":       # = RCCL; the production transport
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
+        else:                       # tests only: N ranks time-sharing the GPUs of a smaller box over gloo
+            local_rank %= torch.cuda.device_count()
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 

@@ -1,0 +1,64 @@
+"""Worker of tests/test_gpu_dist.py::test_two_ranks_one_gpu: one of WORLD ranks that time-share
+cuda:0 and talk over gloo (RCCL refuses two ranks on one device).  Everything but the transport
+is the production path: HIP kernels, ShardedMVIN in both regimes, the two-stream pipeline."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from mvin_amd import synth  # noqa: E402
+from mvin_amd.config import make_args  # noqa: E402
+from mvin_amd.dist import ShardedMVIN, shard_rows  # noqa: E402
+from mvin_amd.model import MVIN  # noqa: E402
+from mvin_amd.params import init_params  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    Bl = 48
+    args = make_args(dim=32, neighbor_sample_size=8, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=16, batch_size=Bl)
+    case = synth.small_case(make_args(**dict(vars(args), batch_size=Bl * world)),   # the global batch
+                            n_user=50, n_entity=5003, n_relation=7, seed=61)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=62, random_agg_bias=True)
+    mk = lambda p: MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                        params=p, device=dev)
+    ref_model = mk(params)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    feed = (torch.from_numpy(case.users[sl]).to(dev), torch.from_numpy(case.items[sl]).to(dev),
+            [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_h],
+            [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r],
+            [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t])
+    ref = ref_model.forward_device(*feed).scores
+    full = torch.from_numpy(params["entity_emb_matrix"])
+    zeroed = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
+    for regime in ("dense", "sparse"):
+        sh = ShardedMVIN(mk(zeroed), shard_rows(full, rank, world), rank, world, is_shard=True, regime=regime)
+        got = sh.forward_device(*feed).scores
+        assert torch.equal(got, ref), f"rank {rank} {regime}: sharded scores differ from replicated"
+        st = sh.table.last_stats
+        assert st["mode"] == regime and st["remote"] > 0, st
+        sh.enable_pipeline()
+        sh.prefetch(0, feed[1], feed[2], feed[4])
+        for i in range(3):
+            out = sh.forward_prefetched(i % 2, *feed)
+            sh.prefetch((i + 1) % 2, feed[1], feed[2], feed[4])
+            assert torch.equal(out.scores, ref), f"rank {rank} {regime}: pipelined step {i} differs"
+        torch.cuda.synchronize()
+    # ranks really scored different pairs: gather a checksum of every rank's slice
+    sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums, ref.double().sum().cpu().reshape(1))
+    assert len({float(x) for x in sums}) == world
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()
