@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--hop", type=int, default=2)
     ap.add_argument("--mix", type=int, default=1)
     ap.add_argument("--fanout", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=131072,
+    ap.add_argument("--batch", type=int, default=262144,
                     help="TOTAL pairs per step over all ranks (strong scaling: each rank scores batch/N)")
     ap.add_argument("--shard", choices=["auto", "rowshard", "replicate"], default="auto",
                     help="entity table placement: row-sharded over the ranks with all-to-all row fetch "
@@ -63,6 +63,11 @@ def parse():
                          "for step i+1 runs on a side stream while step i is scored)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="with --shard rowshard on one GPU: still run the RCCL all-to-alls (world size 1)")
+    ap.add_argument("--hoist", choices=["off", "cached", "step"], default="off",
+                    help="entity-table mode of the two deepest levels (MVIN.hoist_entity_tables; SURVEY 7.3-c route "
+                         "2b): 'cached' builds the per-entity tables once (weights frozen, e.g. top-K eval), 'step' "
+                         "rebuilds them inside every timed step.  A separate mode with its own bytes per pair -- "
+                         "never the headline number")
     ap.add_argument("--adj", choices=["kg", "uniform"], default="kg")
     ap.add_argument("--items", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--cpu-batch", type=int, default=512)
@@ -165,7 +170,8 @@ def main():
     if rowshard:  # the model's entity table becomes the sharded table's working copy
         mparams = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
     model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=mparams, device=dev, table_dtype=a.table_dtype)
+                 params=mparams, device=dev, table_dtype=a.table_dtype,
+                 hoist={"off": False, "cached": True, "step": "step"}[a.hoist])
     runner = model
     if rowshard:
         from mvin_amd.dist import ShardedMVIN, shard_rows
@@ -230,18 +236,27 @@ def main():
         # (FETCH_SIZE, WRITE_SIZE; gfx950 correction applied) archived under profiles/; it is
         # attached only when that profile was taken on exactly this workload
         traffic = None
+        hoisted = a.hoist != "off" and model.hoist_supported()
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
             same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
                                               "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch}
                     and a.table_dtype == "f32")
-            if same and model.fused and world == 1:
+            if same and model.fused and world == 1 and not hoisted:
                 traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
         except (OSError, KeyError, ValueError):
             traffic = None
         L = a.hop * a.mix
         bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L, s=2 if a.table_dtype == "bf16" else 4)
+        bpp_faithful = bpp
+        if hoisted:
+            # bytes this mode really needs per pair: K+1 fp32 rows of the hoisted tables + the adjacency row
+            # per level-(L-2) node, + (mode 'step') the table build amortised over the rank's pairs
+            K, D, s_ = a.fanout, a.dim, (2 if a.table_dtype == "bf16" else 4)
+            bpp = K ** (L - 2) * ((K + 1) * D * 4 + 2 * K * 4) + D * 4 + 4
+            if a.hoist == "step":
+                bpp += case.n_entity * (K * D * s_ + 2 * K * 4 + D * s_ + 4 * D * 4) / Bl
         kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
         kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = (bpp * Bl / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
@@ -258,14 +273,16 @@ def main():
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
-                       "entity_table_dtype": a.table_dtype,
+                       "entity_table_dtype": a.table_dtype, "entity_table_mode": a.hoist,
                        "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
                                        f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"
                                        if rowshard else
                                        (f"pairs split over {world} ranks; tables replicated" if world > 1
                                         else "single-gpu"))},
-            "roofline": {"bound": "hbm", "kernel": "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if model.fused else "gather_attn_kernel (mvin_gather_attn_fwd)",
+            "roofline": {"bound": "hbm", "kernel": ("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
+                                                    "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                         else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if model.fused else "gather_attn_kernel (mvin_gather_attn_fwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": "bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE+WRITE_SIZE, "
@@ -273,7 +290,8 @@ def main():
                                          "table is L2/Infinity-Cache resident" if traffic else None,
                          "bytes_per_pair": bpp, "pairs_per_launch": Bl,
                          "avg_launch_ms": kern_avg_ms,
-                         "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS},
+                         "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS,
+                         "faithful_bytes_per_pair": bpp_faithful},
         }
         if world == 1 and not a.no_cpu_baseline:
             cb, ref, Bc = cpu_baseline(a, margs, case, params)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 2
+#define MVIN_ABI_VERSION 3
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -173,6 +173,19 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR,
                             float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
+
+/* Entity-table ("hoisted") mode building block -- an inference-side re-association of
+ * model.py:295-305 / aggregators.py:118-146 at the two deepest levels (SURVEY.md 7.3-c route 2b):
+ *   out[i, :] = (1/K) sum_k w_k * f(table[adj_entity[x_i, k], :] + rowbias[i / nodes_per_group, :])
+ *   x_i = node_ids ? node_ids[i] : i;  w = softmax_k(rel_score[adj_relation[x_i, k]]) or 1 (rel_score NULL);
+ *   f = relu when relu != 0, identity otherwise.  table: [n_entity, D] fp32 or bf16; out [nodes, D] fp32.
+ * Used twice by mvin_amd/model.py: over ALL entities to build S[e] (the user-independent neighbor mix
+ * of aggregator (0,.)), and per level-(L-2) node over the hoisted table R1 with the pair's constant as
+ * rowbias.  Returns -3 for K > 256. */
+int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                        const int32_t* node_ids, const float* rel_score, const float* rowbias, int64_t nodes,
+                        int nodes_per_group, int K, int D, int n_entity, int nR, int relu, float* out,
+                        int table_bf16, void* stream);
 
 /* ---- training (model.py:378-417): forward variants that keep what the backward needs, and the
  * backward / optimizer kernels.  Gradients are ACCUMULATED into caller-zeroed buffers. ------------ */

@@ -67,6 +67,8 @@ SIGNATURES = {
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_gather_mix_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int, C.c_void_p]),
     "mvin_sample_adjacency": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_int, C.c_int, C.c_uint64, _c_i32p,
                                         _c_i32p, C.c_void_p]),
     "mvin_build_ripple_sets": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_void_p, _c_i32p, C.c_int, C.c_int,
@@ -128,8 +130,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 2:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 2")
+    if ver != 3:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 3")
     _lib = lib
     return lib
 

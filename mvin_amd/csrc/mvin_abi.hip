@@ -292,6 +292,38 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 
+int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                        const int32_t* node_ids, const float* rel_score, const float* rowbias, int64_t nodes,
+                        int nodes_per_group, int K, int D, int n_entity, int nR, int relu, float* out,
+                        int table_bf16, void* stream) {
+    const char* who = "mvin_gather_mix_fwd";
+    if (!table || !adj_entity || !out) return fail(-1, "%s: null pointer", who);
+    if (rel_score && (!adj_relation || nR <= 0)) return fail(-1, "%s: rel_score needs adj_relation and nR", who);
+    if (nodes <= 0 || K <= 0 || n_entity <= 0) return fail(-2, "%s: bad sizes nodes=%lld K=%d n_entity=%d", who,
+                                                          (long long)nodes, K, n_entity);
+    if (!node_ids && nodes > n_entity) return fail(-2, "%s: nodes=%lld > n_entity=%d without node_ids", who,
+                                                   (long long)nodes, n_entity);
+    if (rowbias && nodes_per_group <= 0) return fail(-2, "%s: nodes_per_group=%d", who, nodes_per_group);
+    if (bad_dim(D)) return fail(-2, "%s: D=%d (need %%4==0, 4..%d)", who, D, MVIN_MAX_DIM);
+    if (K > 256) return fail(-3, "%s: K=%d > 256 is outside this kernel", who, K);
+    mvin::GatherMixArgs g{};
+    g.table = table;
+    g.adj_e = adj_entity;
+    g.adj_r = adj_relation;
+    g.node_ids = node_ids;
+    g.rel_score = rel_score;
+    g.rowbias = rowbias;
+    g.out = out;
+    g.nodes = nodes;
+    g.npg = nodes_per_group > 0 ? nodes_per_group : 1;
+    g.K = K;
+    g.D = D;
+    g.lpr_log2 = mvin::lpr_log2_for(D);
+    g.relu = relu ? 1 : 0;
+    g.table_bf16 = table_bf16 ? 1 : 0;
+    return hip_result(mvin::launch_gather_mix(g, (hipStream_t)stream), who);
+}
+
 int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
                           uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream) {
     if (!indptr || !dst || !rel || !adj_entity || !adj_relation) return fail(-1, "mvin_sample_adjacency: null pointer");

@@ -69,6 +69,18 @@ struct KeyAddrArgs {
     int P, Nm, D, nR, lpr_log2;
 };
 
+struct GatherMixArgs {
+    const void* table;         // [nE, D] fp32 or bf16
+    const int32_t* adj_e;      // [nE, K]
+    const int32_t* adj_r;      // [nE, K]
+    const int32_t* node_ids;   // [nodes] or NULL (node i = entity i)
+    const float* rel_score;    // [nR] relation logits or NULL (plain mean)
+    const float* rowbias;      // [ceil(nodes / npg), D] added to every child row, or NULL
+    float* out;                // [nodes, D]
+    int64_t nodes;
+    int npg, K, D, lpr_log2, relu, table_bf16;
+};
+
 struct FusedL2Args {
     const void* table;           // [nE, D] fp32 (or bf16: BF instantiation)
     const int32_t* adj_e;        // [nE, K]
@@ -174,6 +186,7 @@ hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, co
 hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
+hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 

@@ -49,9 +49,12 @@ class Placeholder(object):
 
 class MVIN(object):
     def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
-                 params=None, device=None, seed=0, fused=None, table_dtype="f32"):
+                 params=None, device=None, seed=0, fused=None, table_dtype="f32", hoist=False):
         """``table_dtype="bf16"`` keeps the entity embedding table in bf16 (BASELINE config C5):
-        rows are widened to fp32 inside the kernels, all arithmetic stays fp32; scoring only."""
+        rows are widened to fp32 inside the kernels, all arithmetic stays fp32; scoring only.
+        ``hoist``: entity-table mode of the two deepest levels (see ``hoist_entity_tables``):
+        False = off (the faithful per-pair gather), True = per-entity tables cached until a
+        parameter / the adjacency changes, "step" = rebuilt inside every forward."""
         self.device = torch.device(device or "cuda")
         if table_dtype not in ("f32", "bf16"):
             raise ValueError("table_dtype must be 'f32' or 'bf16'")
@@ -59,6 +62,10 @@ class MVIN(object):
         # fused=False (or MVIN_FUSED=0) forces the per-level kernels (used by the tests to
         # check both HIP paths against the oracle)
         self.fused = (os.environ.get("MVIN_FUSED", "1") != "0") if fused is None else bool(fused)
+        if hoist not in (False, True, "step"):
+            raise ValueError("hoist must be False, True or 'step'")
+        self.hoist = hoist
+        self._hoisted = None
         self._parse_args(args, adj_entity, adj_relation)
         self._build_inputs()
         self._build_model(n_user, n_entity, n_relation, params, seed)
@@ -103,6 +110,7 @@ class MVIN(object):
                 return a.to(self.device).to(torch.int32).contiguous()
             return torch.from_numpy(np.asarray(a).astype(np.int32)).to(self.device).contiguous()
         self.adj_entity, self.adj_relation = conv(adj_entity), conv(adj_relation)
+        self._hoisted = None
 
     def _build_inputs(self):
         """model.py:49-64."""
@@ -208,8 +216,14 @@ class MVIN(object):
         with np.load(self._emb_path()) as z:
             for k in self._STWS:
                 getattr(self, k).copy_(torch.from_numpy(z[k]).to(self.device))   # casts to the table dtype
+        self.invalidate()
+
+    def invalidate(self):
+        """Call after changing parameters in place through raw pointers (the optimizer does):
+        drops every derived table (relation logits, hoisted entity tables)."""
         for agg in self.aggregators:
             agg.invalidate()
+        self._hoisted = None
 
     # ------------------------------------------------------------------ graph pieces
     def get_neighbors(self, seeds, levels=None):
@@ -299,6 +313,85 @@ class MVIN(object):
         return ops.agg(ev[hop].view(B * N, D), ev[hop + 1].view(B * N * K, D), rels[hop].view(-1), t,
                        agg.weights, agg.bias, B, N, K, D, want_probs=wp)
 
+    # ------------------------------------------------------------------ entity-table (hoisted) mode
+    def hoist_supported(self):
+        a = self.args
+        return bool(a.wide_deep and not a.PS_only and self.h_hop >= 2 and self.n_neighbor <= 256)
+
+    def _hoist_key(self):
+        a0 = self._agg[(0, 0)]
+        ts = (self.entity_emb_matrix, self._transfer_W, self._transfer_b, a0.weights, a0.bias, a0.urh_weights,
+              self.relation_emb_matrix, self.adj_entity, self.adj_relation)
+        return tuple((id(t), t._version) for t in ts)
+
+    def hoist_entity_tables(self):
+        """Entity-table mode of the two deepest levels (SURVEY.md 7.3-c route 2b; an exact
+        re-association of model.py:295-305 + aggregators.py:98-146, not a different model).
+
+        Aggregator (0,0)'s attention weights do not depend on the pair (7.3-a) and everything it
+        does below level L-2 before its ReLU is linear in entity rows, so with
+            S[e]  = (1/K) sum_k p_k(e) E[adj(e,k)]                 (one gather over ALL entities)
+            R1[e] = (E[e].W_{L-1} + S[e].W_L) . A0                  N0[e] = S[e].W_{L-1}
+        the per-pair work at a level-(L-2) node x shrinks from K + K^2 row gathers to K + 1:
+            neighbors_agg for aggregator (0,0) = N0[x] + c_{L-1}/K        (c/K -> c without the softmax)
+            neighbors_agg for aggregator (1,0) = (1/K) sum_k p'_k(x) relu(R1[adj(x,k)] + d)
+            d = (c_{L-1} + c_L/K).A0 + a0,  c_e = q.W_e + b_e       (per pair)
+        Building costs one pass over n_entity*K rows (~n_entity/K pairs' worth), so it pays as
+        soon as a batch holds more level-(L-1) nodes than there are entities; it changes the
+        algorithmic bytes per pair and is therefore always reported as its own mode."""
+        if not self.hoist_supported():
+            raise ValueError("entity-table mode needs wide_deep, h_hop >= 2 and fan-out <= 256")
+        D, K = self.dim, self.n_neighbor
+        L = self.n_mix_hop * self.h_hop
+        E = self.entity_emb_matrix
+        a0 = self._agg[(0, 0)]
+        h = SimpleNamespace(key=self._hoist_key())
+        t0 = a0.relation_scores() if a0.User_orient_rela else None
+        S = ops.gather_mix(E, self.adj_entity, self.adj_relation, None, t0, None, self.n_entity, 1, K,
+                           self.n_relation)
+        if self.args.User_orient:
+            W1, W2 = self.transfer_matrix_list[L - 1], self.transfer_matrix_list[L]
+            b1, b2 = self.transfer_matrix_bias[L - 1], self.transfer_matrix_bias[L]
+            X = ops.linear([E, S], torch.cat([W1, W2]).contiguous(), D)           # E.W1 + S.W2
+            h.R1 = ops.linear([X], a0.weights, D)
+            h.N0 = ops.linear([S], W1, D)
+            # q -> (c1 + c2/K, c1/K) in one launch
+            inv = 1.0 / K if a0.User_orient_rela else 1.0   # sum_k w_k / K: softmax weights sum to 1, plain-mean weights to K
+            h.Wq = torch.stack([W2, W1]).contiguous()
+            h.bq = torch.stack([b2, b1]).contiguous()
+            ops.axpby(1.0, W1, inv, h.Wq[0])
+            ops.axpby(1.0, b1, inv, h.bq[0])
+            ops.axpby(0.0, W1, inv, h.Wq[1])
+            ops.axpby(0.0, b1, inv, h.bq[1])
+        else:
+            h.R1 = ops.linear([E, S], a0.weights, D, sum_sources=True)
+            h.N0 = S
+        self._hoisted = h
+        return h
+
+    def _hoisted_naggs(self, parents, q, B):
+        """(neighbors_agg of aggregator (0,0), of aggregator (1,0)) at the level-(L-2) nodes."""
+        D, K = self.dim, self.n_neighbor
+        h = self._hoisted
+        if self.hoist == "step" or h is None or h.key != self._hoist_key():
+            h = self.hoist_entity_tables()
+        a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
+        P = parents.numel()
+        ppp = P // B
+        t1 = a1.relation_scores() if a1.User_orient_rela else None
+        if self.args.User_orient:
+            cs = ops.linear([q], h.Wq, D, bias=h.bq, nz=2, w_zstride=D * D, bias_zstride=D, out_zstride=B * D)
+            cs = cs.view(2, B, D)
+            d = ops.linear([cs[0]], a0.weights, D, bias=a0.bias)
+            n0 = ops.linear([h.N0], None, D, ids=[parents], rowbias=cs[1], rows_per_group=ppp)
+            n1 = ops.gather_mix(h.R1, self.adj_entity, self.adj_relation, parents, t1, d, P, ppp, K,
+                                self.n_relation, relu=True)
+        else:
+            n0 = ops.linear([h.N0], None, D, ids=[parents])
+            n1 = ops.gather_mix(h.R1, self.adj_entity, self.adj_relation, parents, t1, a0.bias.view(1, D), P, P, K,
+                                self.n_relation, relu=True)
+        return n0, n1
+
     def aggregate_delta_whole(self, item32, q, user_o, want_probs=False):
         """model.py:259-324 -> (item_embeddings [B,D], scores, sigmoid, importance_list).
 
@@ -309,12 +402,21 @@ class MVIN(object):
         D, K, H, M = self.dim, self.n_neighbor, self.h_hop, self.n_mix_hop
         L = M * H
         B = item32.shape[0]
-        use_l2 = self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K)
+        use_hoist = bool(self.hoist) and not want_probs and self.hoist_supported()
+        use_l2 = use_hoist or (self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K))
         top = L - 1 if use_l2 else L          # levels 0..top-1 are materialised
         ents, rels = self.get_neighbors(item32, levels=top - 1)
         ev, c = self._project_levels(ents, q, top, need_c=() if use_l2 else (L,))
         nagg = pp = pc = None
-        if use_l2:
+        if use_hoist:
+            if self._profile is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            nagg = self._hoisted_naggs(ents[L - 2].view(-1), q, B)
+            if self._profile is not None:
+                e1.record()
+                self._profile.append((e0, e1))
+        elif use_l2:
             a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
             uo = self.args.User_orient
             if self._profile is not None:

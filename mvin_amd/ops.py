@@ -228,6 +228,23 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     return nagg0, nagg1, pp, pc
 
 
+def gather_mix(table, adj_entity, adj_relation, node_ids, rel_score_t, rowbias, nodes, nodes_per_group, K, nR,
+               relu=False):
+    """mvin_gather_mix_fwd: out[i] = (1/K) sum_k w_k f(table[adj_entity[x_i,k]] + rowbias[i // npg]) ->
+    [nodes, D] fp32 (x_i = node_ids[i], or i when node_ids is None)."""
+    lib = _lib.load()
+    bf = _chk_table(table, "table")
+    for t, dt, nm in ((adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
+                      (node_ids, I32, "node_ids"), (rel_score_t, F32, "rel_score"), (rowbias, F32, "rowbias")):
+        _chk(t, dt, nm)
+    D = table.shape[1]
+    out = torch.empty((nodes, D), dtype=F32, device=table.device)
+    _lib.check(lib.mvin_gather_mix_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids), _p(rel_score_t),
+                                       _p(rowbias), nodes, nodes_per_group, K, D, table.shape[0], nR,
+                                       1 if relu else 0, _p(out), bf, _stream()), "mvin_gather_mix_fwd")
+    return out
+
+
 def key_addressing_supported(Nm, D):
     return bool(_lib.load().mvin_key_addressing_supported(Nm, D))
 

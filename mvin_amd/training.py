@@ -407,5 +407,4 @@ class Trainer(object):
         for k, p in self.params.items():
             ops.eltwise(4, p.numel(), p.view(-1), grads[k].view(-1), self.adam_m[k].view(-1), self.adam_v[k].view(-1),
                         alpha=float(lr_t), beta1=self.b1, beta2=self.b2, eps=self.eps)
-        for agg in self.m.aggregators:
-            agg.invalidate()
+        self.m.invalidate()

@@ -18,11 +18,11 @@ def run_oracles(args, case, params):
     return m, e
 
 
-def run_hip(args, case, params, want_probs=True, fused=None):
+def run_hip(args, case, params, want_probs=True, fused=None, hoist=False, table_dtype="f32"):
     import torch
     from mvin_amd.model import MVIN
     model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=params, device="cuda:0", fused=fused)
+                 params=params, device="cuda:0", fused=fused, hoist=hoist, table_dtype=table_dtype)
     dev = model.device
     out = model.forward_device(
         torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
@@ -44,14 +44,14 @@ def assert_close(got, ref, what, rtol=RTOL, atol=ATOL):
                            f"{err.max():.3e}, worst ratio {(err / bound).max():.2f}")
 
 
-def check_case(args, case, params=None, seed=0, fused=None):
+def check_case(args, case, params=None, seed=0, fused=None, hoist=False):
     """HIP path vs fp32 mirror (tolerance above) and vs fp64 (error no worse than 4x the
     mirror's own fp32 round-off, with a 1e-6 floor)."""
     if params is None:
         params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=seed,
                              random_agg_bias=True)
     m, e = run_oracles(args, case, params)
-    _, out = run_hip(args, case, params, fused=fused)
+    _, out = run_hip(args, case, params, fused=fused, hoist=hoist, want_probs=not hoist)
     got = out.scores.cpu().numpy()
     assert_close(got, m.scores.numpy(), "scores vs fp32 mirror")
     assert_close(out.scores_normalized.cpu().numpy(), m.scores_normalized.numpy(), "sigmoid scores")
@@ -60,6 +60,8 @@ def check_case(args, case, params=None, seed=0, fused=None):
     err_hip = np.abs(got - e.scores).max()
     err_mir = np.abs(m.scores.numpy() - e.scores).max()
     assert err_hip <= 4 * err_mir + 1e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}"
+    if hoist:   # attention outputs come from the faithful path only (requested with want_probs)
+        return out, m, e
     for h, (pg, pm) in enumerate(zip(out.importance_list, m.importance_list)):
         if pm is None:
             assert pg is None
