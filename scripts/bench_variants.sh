@@ -1,0 +1,41 @@
+#!/bin/bash
+# Run ON the GPU box: the bench.py variants quoted in DESIGN.md section 4, one JSON line each
+# (with the command that produced it) -> gpurun_out/bench_variants.jsonl
+root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$root"; mkdir -p gpurun_out; out=gpurun_out/bench_variants.jsonl; : > $out
+run() {
+  line=$(python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | grep '^{' | tail -1)
+  [ -n "$line" ] && python - "$line" "$*" >> $out <<'PY'
+import json, sys
+r = json.loads(sys.argv[1]); r["variant_args"] = sys.argv[2]; print(json.dumps(r))
+PY
+}
+C2="--dataset MovieLens-1M --dim 32 --fanout 16"
+C4="--dataset amazon-book_20core --dim 64 --fanout 64 --batch 32768"
+C5="--dataset amazon-book_20core --dim 128 --hop 3 --fanout 128 --table-dtype bf16"
+run                                             # C3 default
+run --adj uniform --items uniform               # worst-case locality
+run --batch 16384
+run --batch 512
+run --batch 512 --graph
+run --n-entity 16000000 --batch 32768           # 4 GB table: HBM-bound
+run $C2 --batch 524288
+run $C4
+run $C5 --batch 64 --steps 3 --warmup 1
+# entity-table mode (separate mode, own bytes per pair)
+run --hoist cached
+run --hoist step
+run --hoist cached --batch 512
+run --hoist cached --batch 512 --graph
+run --hoist cached --adj uniform --items uniform
+run --hoist cached --n-entity 16000000 --batch 32768
+run $C2 --batch 524288 --hoist cached
+run $C4 --hoist cached
+run $C5 --batch 4096 --steps 3 --warmup 1 --hoist cached
+run $C5 --batch 4096 --steps 3 --warmup 1 --hoist step
+python - <<'PY'
+import json
+for l in open("gpurun_out/bench_variants.jsonl"):
+    r = json.loads(l)
+    print(f'{r["variant_args"]:75s} {r["value"]:14.1f} pairs/s  {r["ms_per_step"]:9.3f} ms  kernel {r["roofline"]["avg_launch_ms"]} ms  {r["roofline"]["achieved"]} GB/s')
+PY
