@@ -33,11 +33,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int D, int NW>
+template <int D, int NW, int TMV>
 struct FusedGeom {
+    static constexpr int TM = TMV;                      // children (rows) per tile: 32, or 16 when K <= 16
+    static constexpr int RT = TM / 16;                  // 16-row MFMA tiles per tile
     static constexpr int NT = D / 16;                   // 16-column MFMA tiles
-    static constexpr int MTW = (NW == NT) ? 2 : 1;      // 16-row MFMA tiles per wave
-    static constexpr int NPW = kTM / NW;                // children per wave per tile
+    static constexpr int MTW = (NW == NT) ? RT : 1;     // 16-row MFMA tiles per wave
+    static constexpr int NPW = TM / NW;                 // children per wave per tile
     static constexpr int LPR = D / 4;                   // lanes per table row (float4 each)
     static constexpr int RPW = kWave / LPR;             // rows per wave-instruction
     static constexpr int LDA = 2 * D + 2;               // LDS row stride: conflict-free A-fragment reads
@@ -55,9 +57,10 @@ struct FusedGeom {
 //                               iteration without waiting
 // KIT = number of int4 chunk iterations per wave per tile (= NPW*K/256 <= 2); KIT = 0 keeps the
 // unpipelined flow (any K <= 256).
-template <int D, int NW, int KIT, bool BF>
+template <int D, int NW, int KIT, bool BF, int TMV>
 __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) {
-    using G = FusedGeom<D, NW>;
+    using G = FusedGeom<D, NW, TMV>;
+    constexpr int kTM = G::TM;                          // shadows the 32-row default of mvin_common.h
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NBUF = KIT > 0 ? 2 : 1;
     const int K = a.K;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     // dense-phase tile ownership
     const int nt = (NW == G::NT) ? wave : (wave % G::NT);
     const int mt0 = (NW == G::NT) ? 0 : (wave / G::NT);
-    const bool dense = mt0 < 2;
+    const bool dense = mt0 < G::RT;
     const int col = 16 * nt + l16;
     const bool has_proj = a.W1 != nullptr;
     const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
+    const int ypld = (TMV == 16) ? K + 1 : K;           // sYP row stride (odd in the 16-row variant: the lane
+                                                        // groups read different rows at once)
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
     const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
 
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
         for (int tile = 0; tile < ntile; ++tile) {
             // ---------------- phase A: ids, softmax, row gather ----------------
             const int node0 = tile * kTM + wave * G::NPW;
-            int2* ypw = sYP + (size_t)wave * G::NPW * K;
+            int2* ypw = sYP + (size_t)wave * G::NPW * ypld;
 #pragma unroll
             for (int it = 0; it < (KIT > 0 ? KITR : 8); ++it) {
                 if (it * npi >= G::NPW) break;
@@ -292,13 +297,48 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                             *reinterpret_cast<float4*>(a.probs_child + ((p * K + n) * K + 4 * ch)) =
                                 make_float4(e0, e1, e2, e3);
                     }
-                    int2* dst = ypw + nl * K + 4 * ch;
+                    int2* dst = ypw + nl * ypld + 4 * ch;
                     dst[0] = make_int2(ye.x, __float_as_int(e0 * invK));
                     dst[1] = make_int2(ye.y, __float_as_int(e1 * invK));
                     dst[2] = make_int2(ye.z, __float_as_int(e2 * invK));
                     dst[3] = make_int2(ye.w, __float_as_int(e3 * invK));
                 }
             }
+            if constexpr (TMV == 16) {
+                // 16-row variant: as many lane groups per wave as children per wave (256/D), so every
+                // lane group owns ONE child: its K rows are K independent loads in flight and the
+                // weighted sum never leaves the group (no cross-group reduction)
+                static_assert(G::RPW == G::NPW, "one lane group per child");
+                const int n = node0 + g;
+                float* arow = sA + (wave * G::NPW + g) * G::LDA;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < K) {
+                    const int2* yp = ypw + g * ypld;
+                    auto row4 = [&](int id) -> float4 {
+                        if (BF)
+                            return bf16x4_to_f32(reinterpret_cast<const uint2*>(
+                                reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
+                        if (buf32) {
+                            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                                rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+                            return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]),
+                                               __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+                        }
+                        return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
+                    };
+#pragma unroll 8
+                    for (int k = 0; k < K; ++k) {
+                        const int2 e = yp[k];
+                        acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                    }
+                    sv = row4(sX1[n]);
+                }
+                *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
+                *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
+                *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
+                *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
+            } else
             for (int nl = 0; nl < G::NPW; ++nl) {
                 const int n = node0 + nl;
                 const int row = wave * G::NPW + nl;
@@ -458,36 +498,43 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     }
 }
 
-size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf) {
+size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf, int kTM) {
     const int ntile = (K + kTM - 1) / kTM, Kpad = ntile * kTM;
     const size_t words = (size_t)kTM * (2 * D + 2) + (size_t)kTM * (D + 2) + 3 * (size_t)nbuf * Kpad + 2 * D + 2 * nR;
-    return words * 4 + (size_t)NW * (kTM / NW) * K * sizeof(int2);
+    return words * 4 + (size_t)NW * (kTM / NW) * (kTM == 16 ? K + 1 : K) * sizeof(int2);
 }
 
-template <int D, int NW, int KIT, bool BF>
+template <int D, int NW, int KIT, bool BF, int TMV>
 static hipError_t launch_l2(const FusedL2Args& a, hipStream_t st) {
-    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1);
+    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1, TMV);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT, BF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT, BF, TMV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int64_t cap = 256 * 4;  // persistent: 256 CUs x up to 4 resident workgroups
+    const int64_t cap = 256 * 4 * (32 / TMV);  // persistent: 256 CUs x up to 4 resident 32-row workgroups
     const int grid = (int)(a.P < cap ? a.P : cap);
-    gather_attn_l2_kernel<D, NW, KIT, BF><<<grid, NW * 64, lds, st>>>(a);
+    gather_attn_l2_kernel<D, NW, KIT, BF, TMV><<<grid, NW * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
 // chunk iterations per wave per tile: NPW children x K/4 lanes each over 64 lanes
-template <int D, int NW, bool BF>
+template <int D, int NW, bool BF, int TMV>
 static hipError_t launch_l2_pick(const FusedL2Args& a, hipStream_t st) {
     static const bool nopipe = getenv("MVIN_L2_NOPIPE") != nullptr;
-    const int kit = ((kTM / NW) * (a.K / 4) + 63) / 64;
-    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1, BF>(a, st);
+    const int kit = ((TMV / NW) * (a.K / 4) + 63) / 64;
+    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1, BF, TMV>(a, st);
     if constexpr (D <= 32) {   // at D >= 64 the second chunk pair costs a wave of occupancy
-        if (!nopipe && kit == 2) return launch_l2<D, NW, 2, BF>(a, st);
+        if (!nopipe && kit == 2) return launch_l2<D, NW, 2, BF, TMV>(a, st);
     }
-    return launch_l2<D, NW, 0, BF>(a, st);
+    return launch_l2<D, NW, 0, BF, TMV>(a, st);
+}
+
+// K <= 16: a 32-row tile would be at most half full (idle waves in the gather phase, padded MFMA
+// rows), so the parent's children go in ONE 16-row tile owned by a workgroup of D/16 waves.
+template <int D, bool BF>
+static hipError_t launch_l2_small(const FusedL2Args& a, hipStream_t st) {
+    return launch_l2_pick<D, D / 16, BF, 16>(a, st);
 }
 
 bool fused_l2_supported(int D, int K) {
@@ -497,20 +544,22 @@ bool fused_l2_supported(int D, int K) {
 }
 
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
+    static const bool no_small = getenv("MVIN_L2_NOSMALL") != nullptr;
+    const bool small = a.K <= 16 && !no_small;
     if (table_bf16) {
         switch (D) {
-            case 16: return launch_l2_pick<16, 4, true>(a, st);
-            case 32: return launch_l2_pick<32, 4, true>(a, st);
-            case 64: return launch_l2_pick<64, 4, true>(a, st);
-            case 128: return launch_l2_pick<128, 8, true>(a, st);
+            case 16: return small ? launch_l2_small<16, true>(a, st) : launch_l2_pick<16, 4, true, 32>(a, st);
+            case 32: return small ? launch_l2_small<32, true>(a, st) : launch_l2_pick<32, 4, true, 32>(a, st);
+            case 64: return small ? launch_l2_small<64, true>(a, st) : launch_l2_pick<64, 4, true, 32>(a, st);
+            case 128: return small ? launch_l2_small<128, true>(a, st) : launch_l2_pick<128, 8, true, 32>(a, st);
             default: return hipErrorInvalidValue;
         }
     }
     switch (D) {
-        case 16: return launch_l2_pick<16, 4, false>(a, st);
-        case 32: return launch_l2_pick<32, 4, false>(a, st);
-        case 64: return launch_l2_pick<64, 4, false>(a, st);
-        case 128: return launch_l2_pick<128, 8, false>(a, st);
+        case 16: return small ? launch_l2_small<16, false>(a, st) : launch_l2_pick<16, 4, false, 32>(a, st);
+        case 32: return small ? launch_l2_small<32, false>(a, st) : launch_l2_pick<32, 4, false, 32>(a, st);
+        case 64: return small ? launch_l2_small<64, false>(a, st) : launch_l2_pick<64, 4, false, 32>(a, st);
+        case 128: return small ? launch_l2_small<128, false>(a, st) : launch_l2_pick<128, 8, false, 32>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
