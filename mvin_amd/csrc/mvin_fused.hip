@@ -9,11 +9,14 @@
 // One workgroup owns one PARENT node (a level-(L-2) node; for L = 2 the pair's item itself):
 //   prologue  : parent's adjacency row -> child ids x1[n], attention weights p0 (aggregator
 //               (0,.)) and p1 (aggregator (1,.)) over its K children           (wave 0)
-//   per tile of 32 children:
+//   per tile of 32 children (16 when K <= 16, with D/16 waves per workgroup):
 //     phase A : each wave gathers the K grandchild rows of its children: adjacency rows as
 //               int4 (K/4 lanes per child), softmax over K by xor-shuffles inside the lane
 //               group, rows as 16-byte loads (D/4 lanes per row, 8 loads in flight per lane),
-//               S' = (1/K) sum_k p_k E[y_k] and the raw child row E[x1] -> LDS tile
+//               S' = (1/K) sum_k p_k E[y_k] and the raw child row E[x1] -> LDS tile.
+//               Two lane-group mappings: one group per child (GPC: the sum stays inside the
+//               group) or the groups of a wave striding over one child's k (xor-reduced);
+//               launch_l2_pick chooses per shape from measurements
 //     phase B : MFMA (v_mfma_f32_16x16x4_f32, weights resident in VGPRs as B fragments):
 //               self1 = E[x1].W1 + c1 ; Z = self1 + S'.W2 + (psum/K) c2 ; Z -> LDS ;
 //               (c_e = q_b.W_e + b_e is formed per pair from the same B fragments)
@@ -57,7 +60,7 @@ struct FusedGeom {
 //                               iteration without waiting
 // KIT = number of int4 chunk iterations per wave per tile (= NPW*K/256 <= 2); KIT = 0 keeps the
 // unpipelined flow (any K <= 256).
-template <int D, int NW, int KIT, bool BF, int TMV>
+template <int D, int NW, int KIT, bool BF, int TMV, bool GPC>
 __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) {
     using G = FusedGeom<D, NW, TMV>;
     constexpr int kTM = G::TM;                          // shadows the 32-row default of mvin_common.h
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
-    const int ypld = (TMV == 16) ? K + 1 : K;           // sYP row stride (odd in the 16-row variant: the lane
+    const int ypld = GPC ? K + 1 : K;           // sYP row stride (odd in the 16-row variant: the lane
                                                         // groups read different rows at once)
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
     const int npi = kWave >> a.lpn_log2;                // children per wave-instruction
@@ -304,40 +307,44 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     dst[3] = make_int2(ye.w, __float_as_int(e3 * invK));
                 }
             }
-            if constexpr (TMV == 16) {
-                // 16-row variant: as many lane groups per wave as children per wave (256/D), so every
-                // lane group owns ONE child: its K rows are K independent loads in flight and the
-                // weighted sum never leaves the group (no cross-group reduction)
-                static_assert(G::RPW == G::NPW, "one lane group per child");
-                const int n = node0 + g;
-                float* arow = sA + (wave * G::NPW + g) * G::LDA;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (n < K) {
-                    const int2* yp = ypw + g * ypld;
-                    auto row4 = [&](int id) -> float4 {
-                        if (BF)
-                            return bf16x4_to_f32(reinterpret_cast<const uint2*>(
-                                reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
-                        if (buf32) {
-                            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
-                                rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
-                            return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]),
-                                               __uint_as_float(raw[2]), __uint_as_float(raw[3]));
-                        }
-                        return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
-                    };
-#pragma unroll 8
-                    for (int k = 0; k < K; ++k) {
-                        const int2 e = yp[k];
-                        acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+            if constexpr (GPC) {
+                // one lane group per child: its K rows are K independent loads in flight and the
+                // weighted sum never leaves the group (no cross-group reduction).  In the 16-row
+                // variant there are exactly as many lane groups per wave as children per wave (256/D).
+                static_assert(G::NPW % G::RPW == 0, "children per wave must be a multiple of the lane groups");
+                auto row4 = [&](int id) -> float4 {
+                    if (BF)
+                        return bf16x4_to_f32(reinterpret_cast<const uint2*>(
+                            reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
+                    if (buf32) {
+                        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                            rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+                        return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]),
+                                           __uint_as_float(raw[2]), __uint_as_float(raw[3]));
                     }
-                    sv = row4(sX1[n]);
+                    return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
+                };
+#pragma unroll
+                for (int j = 0; j < G::NPW / G::RPW; ++j) {
+                    const int nl = j * G::RPW + g;
+                    const int n = node0 + nl;
+                    float* arow = sA + (wave * G::NPW + nl) * G::LDA;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (n < K) {
+                        const int2* yp = ypw + nl * ypld;
+#pragma unroll 8
+                        for (int k = 0; k < K; ++k) {
+                            const int2 e = yp[k];
+                            acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                        }
+                        sv = row4(sX1[n]);
+                    }
+                    *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
+                    *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
+                    *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
+                    *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
                 }
-                *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
-                *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
-                *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
-                *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
             } else
             for (int nl = 0; nl < G::NPW; ++nl) {
                 const int n = node0 + nl;
@@ -498,36 +505,42 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     }
 }
 
-size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf, int kTM) {
+size_t fused_l2_lds_bytes(int D, int NW, int K, int nR, int nbuf, int kTM, bool gpc) {
     const int ntile = (K + kTM - 1) / kTM, Kpad = ntile * kTM;
     const size_t words = (size_t)kTM * (2 * D + 2) + (size_t)kTM * (D + 2) + 3 * (size_t)nbuf * Kpad + 2 * D + 2 * nR;
-    return words * 4 + (size_t)NW * (kTM / NW) * (kTM == 16 ? K + 1 : K) * sizeof(int2);
+    return words * 4 + (size_t)NW * (kTM / NW) * (gpc ? K + 1 : K) * sizeof(int2);
 }
 
-template <int D, int NW, int KIT, bool BF, int TMV>
+template <int D, int NW, int KIT, bool BF, int TMV, bool GPC>
 static hipError_t launch_l2(const FusedL2Args& a, hipStream_t st) {
-    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1, TMV);
+    const size_t lds = fused_l2_lds_bytes(D, NW, a.K, a.nR, KIT > 0 ? 2 : 1, TMV, GPC);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT, BF, TMV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gather_attn_l2_kernel<D, NW, KIT, BF, TMV, GPC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     const int64_t cap = 256 * 4 * (32 / TMV);  // persistent: 256 CUs x up to 4 resident 32-row workgroups
     const int grid = (int)(a.P < cap ? a.P : cap);
-    gather_attn_l2_kernel<D, NW, KIT, BF, TMV><<<grid, NW * 64, lds, st>>>(a);
+    gather_attn_l2_kernel<D, NW, KIT, BF, TMV, GPC><<<grid, NW * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
 // chunk iterations per wave per tile: NPW children x K/4 lanes each over 64 lanes
+// The gather phase has two lane-group mappings.  GPC (one lane group per child, no cross-group
+// reduction) is the faster one wherever the id-pipelined variants (KIT > 0) apply and a wave has at
+// least as many children as lane groups (D >= 32): measured 1.08x (D=64,K=32) to 1.9x (D=32,K=32).
+// The unpipelined variant (KIT = 0: K >= 64 at D >= 64) keeps the groups-stride-over-k mapping,
+// which is the faster one there (K=64: 3.9 vs 6.2 ms).
 template <int D, int NW, bool BF, int TMV>
 static hipError_t launch_l2_pick(const FusedL2Args& a, hipStream_t st) {
     static const bool nopipe = getenv("MVIN_L2_NOPIPE") != nullptr;
+    constexpr bool GPC = (TMV == 16) || D >= 32;
     const int kit = ((TMV / NW) * (a.K / 4) + 63) / 64;
-    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1, BF, TMV>(a, st);
+    if (!nopipe && kit <= 1) return launch_l2<D, NW, 1, BF, TMV, GPC>(a, st);
     if constexpr (D <= 32) {   // at D >= 64 the second chunk pair costs a wave of occupancy
-        if (!nopipe && kit == 2) return launch_l2<D, NW, 2, BF, TMV>(a, st);
+        if (!nopipe && kit == 2) return launch_l2<D, NW, 2, BF, TMV, GPC>(a, st);
     }
-    return launch_l2<D, NW, 0, BF, TMV>(a, st);
+    return launch_l2<D, NW, 0, BF, TMV, TMV == 16>(a, st);
 }
 
 // K <= 16: a 32-row tile would be at most half full (idle waves in the gather phase, padded MFMA
