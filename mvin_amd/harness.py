@@ -56,6 +56,11 @@ class DeviceFeeder(object):
 
     def __init__(self, model, user_triplet_set):
         import torch
+        self.model = model
+        if torch.is_tensor(user_triplet_set):   # already [n_user, P, 3, n_memory] (data_prep.get_user_triplet_set)
+            self.uts = user_triplet_set.to(model.device).to(torch.int32).contiguous()
+            self.P = self.uts.shape[1]
+            return
         arr = np.asarray(user_triplet_set) if not isinstance(user_triplet_set, dict) else None
         if arr is None:  # dict user -> [P,3,Nm] (the reference's defaultdict)
             n_user = model.n_user

@@ -15,3 +15,49 @@ def test_train_and_eval_on_synthetic_signal(hip_lib, monkeypatch):
     out = run_synthetic.main()
     assert out["loss"][-1] < out["loss"][0] - 0.05          # it trains
     assert max(out["auc"]) > 0.54                           # and generalises to held-out pairs (chance = 0.5)
+
+
+def test_from_reference_file_formats(hip_lib, tmp_path):
+    """data/<dataset>/ in the reference's on-disk formats -> load_data (GPU samplers) -> MVIN ->
+    CTR / top-K evaluation through the harness."""
+    import numpy as np
+    import torch
+    from mvin_amd import data_io, harness
+    from mvin_amd.config import make_args
+    from mvin_amd.model import MVIN
+
+    rng = np.random.default_rng(0)
+    n_user, n_item, n_ent, n_rel = 30, 20, 80, 4
+    ratings = np.stack([rng.integers(0, n_user, 900), rng.integers(0, n_item, 900), rng.integers(0, 2, 900)], 1)
+    heads = np.concatenate([np.arange(n_ent), rng.integers(0, n_ent, 400)])       # every entity appears
+    kg = np.stack([heads, rng.integers(0, n_rel, heads.size), rng.integers(0, n_ent, heads.size)], 1)
+    np.savetxt(tmp_path / "ratings_final.txt", ratings, fmt="%d")
+    np.savetxt(tmp_path / "kg_final.txt", kg, fmt="%d")
+    parts = np.split(ratings[rng.permutation(900)], [540, 720])
+    for name, part in zip(("train", "eval", "test"), parts):
+        with open(tmp_path / f"{name}_pd.csv", "w") as f:
+            f.write(",item,like,user\n")
+            for i, (u, it, l) in enumerate(part):
+                f.write(f"{i},{it},{l},{u}\n")
+    K, P, Nm = 4, 2, 8
+    (nu, ni, ne, nr, train, ev, test, adj_e, adj_r, uts, pop, hist) = data_io.load_data(
+        str(tmp_path), K, P, Nm, device="cuda:0")
+    assert (nu, ni, ne, nr) == (ratings[:, 0].max() + 1, ratings[:, 1].max() + 1, n_ent, n_rel)
+    assert tuple(adj_e.shape) == (n_ent, K) and tuple(uts.shape) == (nu, P, 3, Nm)
+    # every sampled (neighbor, relation) is an edge of the undirected KG
+    edges = {(int(h), int(t), int(r)) for h, r, t in kg} | {(int(t), int(h), int(r)) for h, r, t in kg}
+    ae, ar = adj_e.cpu().numpy(), adj_r.cpu().numpy()
+    assert all((e, int(ae[e, k]), int(ar[e, k])) in edges for e in range(n_ent) for k in range(K))
+    # hop-0 heads of a user's ripple set are items of its history
+    u0 = next(iter(hist))
+    assert set(uts[u0, 0, 0].cpu().tolist()) <= set(hist[u0])
+    args = make_args(dim=16, neighbor_sample_size=K, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=64)
+    model = MVIN(args, nu, ne, nr, adj_e, adj_r, device="cuda:0", seed=1)
+    feeder = harness.DeviceFeeder(model, uts)
+    res = harness.ctr_eval_device(feeder, ev, 64)
+    assert len(res[0]) == ev.shape[0] // 64 and 0.0 <= res[3] <= 1.0
+    tr_rec, ev_rec, te_rec = (harness.get_user_record(d, flag) for d, flag in ((train, True), (ev, False), (test, False)))
+    users = [u for u in te_rec if u in tr_rec][:5]
+    p, r, n, _, _ = harness.topk_eval_device(feeder, users, tr_rec, ev_rec, te_rec, set(range(ni)), [1, 5], 64)
+    assert len(p) == 2 and all(0.0 <= x <= 1.0 for x in p + r + n)
+    torch.cuda.synchronize()
