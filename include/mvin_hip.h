@@ -170,7 +170,7 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
  * callers then use mvin_ripple_attn_fwd per read. */
 int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
-                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR,
+                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
                             float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 

@@ -65,7 +65,8 @@ SIGNATURES = {
                                C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_key_addressing_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int,
-                                          C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_void_p]),
+                                          C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int,
+                                          C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
     "mvin_gather_mix_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int, C.c_void_p]),

@@ -254,9 +254,10 @@ int mvin_key_addressing_supported(int Nm, int D) {
 
 int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
-                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, float* out,
-                            int64_t ldo, int table_bf16, void* stream) {
+                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
+                            float* out, int64_t ldo, int table_bf16, void* stream) {
     const char* who = "mvin_key_addressing_fwd";
+    if (n_entity <= 0) return fail(-2, "%s: n_entity=%d", who, n_entity);
     if (!entity_emb || !mem_h || !out) return fail(-1, "%s: null pointer", who);
     if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
     if (P == 0 && !w) return fail(-2, "%s: nothing to do (P == 0 and w == NULL)", who);
@@ -289,6 +290,7 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     k.D = D;
     k.nR = nR;
     k.lpr_log2 = mvin::lpr_log2_for(D);
+    k.table_bytes = (uint64_t)n_entity * D * (table_bf16 ? 2 : 4);
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 

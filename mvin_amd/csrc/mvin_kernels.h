@@ -67,6 +67,7 @@ struct KeyAddrArgs {
     int64_t ldo;
     int64_t B;
     int P, Nm, D, nR, lpr_log2;
+    uint64_t table_bytes;      // size of E in bytes (0: unknown -> 64-bit addressing)
 };
 
 struct GatherMixArgs {

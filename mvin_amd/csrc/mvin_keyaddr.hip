@@ -13,7 +13,11 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) {
     return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w)));
 }
 
-template <int NJ, bool OWN, bool BF>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// BUF: fp32 table below 4 GiB read through a buffer descriptor (32-bit byte offsets: one VALU per
+// row address instead of a 64-bit multiply-add chain, and half the address registers)
+template <int NJ, bool OWN, bool BF, bool BUF>
 __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int D = a.D, Nm = a.Nm;
@@ -22,12 +26,25 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     const bool cact = (c << 2) < D;
     const int slot0 = a.w ? 1 : 0;
     const int nhop = a.P > 0 ? a.P : 1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.E), 0, BUF ? (int)a.table_bytes : 0, 0x00020000);
+    const unsigned c16 = (unsigned)c * 16u;
+    auto row4 = [&](int id) -> float4 {
+        if constexpr (BUF) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)id * (unsigned)(D * 4) + c16, 0, 0);
+            return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                               __uint_as_float(raw[3]));
+        } else {
+            return load_row4(a.E, BF, id, D, c);
+        }
+    };
 
     for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < a.B; b += (int64_t)gridDim.x * 4) {
         for (int hop = 0; hop < nhop; ++hop) {
             const bool do_hop = hop < a.P;
             const bool do_set = hop == 0 && a.w != nullptr;
             if (!do_hop && !do_set) continue;
+            const char* vb = reinterpret_cast<const char*>(a.V + b * a.nR * (int64_t)D);   // wave-uniform base
             const int32_t* mh = a.mem_h[hop] + b * Nm;
             const int32_t* mr = do_hop ? a.mem_r[hop] + b * Nm : nullptr;
             const int32_t* mt = do_hop ? a.mem_t[hop] + b * Nm : nullptr;
@@ -56,13 +73,13 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 hrow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (cact && j * rpw + g < Nm) hrow[j] = load_row4(a.E, BF, hid[j], D, c);
+                if (cact && j * rpw + g < Nm) hrow[j] = row4(hid[j]);
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 trow[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (do_hop && cact && j * rpw + g < Nm)
-                    trow[j] = load_row4(a.E, BF, tix[j], D, c);
+                    trow[j] = row4(tix[j]);
             }
             const float4 wv = (do_set && cact) ? reinterpret_cast<const float4*>(a.w)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 acc_s = make_float4(0.f, 0.f, 0.f, 0.f), acc_h = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
                 for (int j = 0; j < NJ; ++j) {
                     float ph = 0.f, ps = 0.f;
                     if (do_hop && cact) {
-                        const float4 v = reinterpret_cast<const float4*>(a.V + (b * a.nR + rid[j]) * (int64_t)D)[c];
+                        const float4 v = *reinterpret_cast<const float4*>(vb + ((unsigned)rid[j] * (unsigned)(D * 4) + c16));
                         ph = dot4(hrow[j], v);
                     }
                     if (do_set) ps = dot4(hrow[j], wv);
@@ -107,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
                 for (int j = 0; j < NJ; ++j) {
                     float ph = 0.f, ps = 0.f;
                     if (do_hop && cact) {
-                        const float4 v = reinterpret_cast<const float4*>(a.V + (b * a.nR + rid[j]) * (int64_t)D)[c];
+                        const float4 v = *reinterpret_cast<const float4*>(vb + ((unsigned)rid[j] * (unsigned)(D * 4) + c16));
                         ph = dot4(hrow[j], v);
                     }
                     if (do_set) ps = dot4(hrow[j], wv);
@@ -171,14 +188,14 @@ hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st)
     const int64_t cap = 256 * 8;
     const int grid = (int)(nblk < cap ? nblk : cap);
     const bool own = nj <= (1 << a.lpr_log2);   // rows per lane <= lanes per row: one exp per lane
-#define MVIN_KA(NJV)                                                                       \
-    if (table_bf16) {                                                                      \
-        if (own) key_addr_kernel<NJV, true, true><<<grid, kBlock, 0, st>>>(a);             \
-        else key_addr_kernel<NJV, false, true><<<grid, kBlock, 0, st>>>(a);                \
-    } else {                                                                               \
-        if (own) key_addr_kernel<NJV, true, false><<<grid, kBlock, 0, st>>>(a);            \
-        else key_addr_kernel<NJV, false, false><<<grid, kBlock, 0, st>>>(a);               \
-    }                                                                                      \
+    const bool buf = !table_bf16 && a.table_bytes > 0 && a.table_bytes < (1ull << 32);
+#define MVIN_KA2(NJV, OWNV)                                                                        \
+    if (table_bf16) key_addr_kernel<NJV, OWNV, true, false><<<grid, kBlock, 0, st>>>(a);            \
+    else if (buf) key_addr_kernel<NJV, OWNV, false, true><<<grid, kBlock, 0, st>>>(a);              \
+    else key_addr_kernel<NJV, OWNV, false, false><<<grid, kBlock, 0, st>>>(a);
+#define MVIN_KA(NJV)                          \
+    if (own) { MVIN_KA2(NJV, true) }          \
+    else { MVIN_KA2(NJV, false) }             \
     break;
     switch (nj) {
         case 1: MVIN_KA(1)
@@ -189,6 +206,7 @@ hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st)
         default: return hipErrorInvalidValue;
     }
 #undef MVIN_KA
+#undef MVIN_KA2
     return hipGetLastError();
 }
 

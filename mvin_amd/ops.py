@@ -265,8 +265,9 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     pt = arr_t(*([t.data_ptr() for t in mem_t[:P]] + [None] * (nh - P)))
     B, Nm = mem_h[0].shape
     D = entity_emb.shape[1]
-    _lib.check(lib.mvin_key_addressing_fwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(out),
-                                           ldo, bf, _stream()), "mvin_key_addressing_fwd")
+    _lib.check(lib.mvin_key_addressing_fwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR,
+                                           entity_emb.shape[0], _p(out), ldo, bf, _stream()),
+               "mvin_key_addressing_fwd")
     return out
 
 
