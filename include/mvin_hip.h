@@ -204,9 +204,25 @@ int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* re
 /* element-wise helpers: mode 0 y = alpha x + beta y | 1 sigmoid cross entropy (model.py:379): y = (sigmoid(x) -
  * z) alpha, *accum += beta * ce(x, z) | 2 relu backward y = z > 0 ? x : 0 | 3 *accum += alpha sum x^2 |
  * 4 Adam step (x param, y grad, z m, w v, alpha = lr_t) | 5 y[r,:] = beta y[r,:] + alpha z[r] x[r,:] (n = rows*D) |
- * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D). */
+ * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D) | 7 *accum += alpha sum_r z[r] sum x[r,:]^2 (n = rows*D). */
 int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha,
                  float beta, float beta1, float beta2, float eps, int D, int N, void* stream);
+
+/* All parameters in one launch: the L2 terms of model.py:387-412 and (apply_adam != 0) the
+ * tf.train.AdamOptimizer update of model.py:414.  Gradients and Adam moments are flat buffers of
+ * `total` floats; segs_device[s] = {x: first element of the parameter (slice), off: its offset in the
+ * flat buffers (ascending, segs[0].off == 0, contiguous), n: elements, l2: coefficient c of the
+ * term (c/2) sum(x^2)}:  g += c x ; *loss_accum += (c/2) sum x^2 ; then m, v, x <- Adam(g, lr_t). */
+typedef struct {
+    float* x;
+    int64_t off;
+    int64_t n;
+    float l2;
+    int pad_;
+} mvin_param_seg;
+int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+                       float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
+                       float eps, void* stream);
 
 /* dtable[ids[r], :] += alpha * x[r, :]  -- backward of tf.nn.embedding_lookup (ids int32 or int64). */
 int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D,

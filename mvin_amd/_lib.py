@@ -79,6 +79,8 @@ SIGNATURES = {
                                           C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_void_p]),
     "mvin_agg_fwd_ex": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                   C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_l2_adam_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int,
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvin_eltwise": (C.c_int, [C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mvin_scatter_add_rows": (C.c_int, [_c_f32p, C.c_void_p, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_float,

@@ -358,16 +358,16 @@ int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int3
 // ---------------------------------------------------------------------------- training
 int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha, float beta,
                  float beta1, float beta2, float eps, int D, int N, void* stream) {
-    if (mode < 0 || mode > 6) return fail(-2, "mvin_eltwise: mode=%d", mode);
+    if (mode < 0 || mode > 7) return fail(-2, "mvin_eltwise: mode=%d", mode);
     if (mode == 6 && (!y || D <= 0 || N <= 0)) return fail(-2, "mvin_eltwise: mode 6 needs y, D, N");
     if (n < 0) return fail(-2, "mvin_eltwise: n < 0");
     if (n == 0) return 0;
     if (!x) return fail(-1, "mvin_eltwise: null x");
     if ((mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5) && !y) return fail(-1, "mvin_eltwise: null y");
-    if ((mode == 1 || mode == 2 || mode == 4 || mode == 5) && !z) return fail(-1, "mvin_eltwise: null z");
+    if ((mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 7) && !z) return fail(-1, "mvin_eltwise: null z");
     if (mode == 4 && !w) return fail(-1, "mvin_eltwise: null w");
-    if (mode == 3 && !accum) return fail(-1, "mvin_eltwise: null accum");
-    if (mode == 5 && D <= 0) return fail(-2, "mvin_eltwise: D <= 0");
+    if ((mode == 3 || mode == 7) && !accum) return fail(-1, "mvin_eltwise: null accum");
+    if ((mode == 5 || mode == 7) && D <= 0) return fail(-2, "mvin_eltwise: D <= 0");
     mvin::EltArgs e{};
     e.mode = mode;
     e.n = n;
@@ -384,6 +384,18 @@ int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, fl
     e.D = D > 0 ? D : 1;
     e.N = N > 0 ? N : 1;
     return hip_result(mvin::launch_eltwise(e, (hipStream_t)stream), "mvin_eltwise");
+}
+
+int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+                       float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
+                       float eps, void* stream) {
+    const char* who = "mvin_l2_adam_multi";
+    if (!segs_device || !g_flat) return fail(-1, "%s: null pointer", who);
+    if (nseg <= 0 || nseg > 256) return fail(-2, "%s: nseg=%d (1..256)", who, nseg);
+    if (total <= 0) return fail(-2, "%s: total=%lld", who, (long long)total);
+    if (apply_adam && (!m_flat || !v_flat)) return fail(-1, "%s: Adam step needs the moment buffers", who);
+    return hip_result(mvin::launch_l2_adam_multi(segs_device, nseg, total, g_flat, m_flat, v_flat, loss_accum,
+                                                 apply_adam, lr_t, beta1, beta2, eps, (hipStream_t)stream), who);
 }
 
 int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D, float alpha,

@@ -46,6 +46,11 @@ __global__ void eltwise_kernel(EltArgs a) {
                 a.y[i] = (a.beta != 0.f ? a.beta * a.y[i] : 0.f) + a.alpha * a.z[r] * a.x[i];
                 break;
             }
+            case 7: {  // row-weighted sum of squares: accum += alpha * z[r] * x[r, :]^2   (n = rows * D)
+                const float xv = a.x[i];
+                local += a.alpha * a.z[i / a.D] * xv * xv;
+                break;
+            }
             case 6: {  // group row sum: y[g, j] = alpha * sum_{n < N} x[(g*N + n), j]   (n = groups * D)
                 const int64_t gidx = i / a.D;
                 const int j = (int)(i - gidx * a.D);
@@ -390,6 +395,60 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
 static int blocks_for(int64_t n, int per) {
     int64_t b = (n + per - 1) / per;
     return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+// ------------------------------------------------------------------------------------------
+// every parameter of the model in ONE launch: L2 terms of model.py:387-412 (loss += l2/2 sum x^2,
+// g += l2 x) and, optionally, the tf.train.AdamOptimizer update (model.py:414).  Gradients and
+// the Adam moments live in flat buffers; a static segment table maps flat ranges to parameters.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg* __restrict__ segs, int nseg,
+                                                            int64_t total, float* __restrict__ g,
+                                                            float* __restrict__ mo, float* __restrict__ vo,
+                                                            float* accum, int apply_adam, float lr_t, float b1,
+                                                            float b2, float eps) {
+    __shared__ int64_t s_off[257];
+    for (int i = threadIdx.x; i < nseg; i += blockDim.x) s_off[i] = segs[i].off;
+    if (threadIdx.x == 0) s_off[nseg] = total;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float local = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int lo = 0, hi = nseg - 1;           // last segment with off <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const mvin_param_seg sg = segs[lo];
+        float* xp = sg.x + (i - sg.off);
+        const float x = *xp;
+        float gr = g[i];
+        if (sg.l2 != 0.f) {
+            gr = fmaf(sg.l2, x, gr);
+            local = fmaf(0.5f * sg.l2 * x, x, local);
+            g[i] = gr;
+        }
+        if (apply_adam) {
+            const float m = b1 * mo[i] + (1.f - b1) * gr;
+            const float v = b2 * vo[i] + (1.f - b2) * gr * gr;
+            mo[i] = m;
+            vo[i] = v;
+            *xp = x - lr_t * m / (sqrtf(v) + eps);
+        }
+    }
+    if (accum) {
+        local = wave_sum(local);
+        if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(accum, local);
+    }
+}
+
+hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
+                                float* accum, int apply_adam, float lr_t, float b1, float b2, float eps,
+                                hipStream_t st) {
+    l2_adam_multi_kernel<<<blocks_for(total, 2048), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
+                                                                  lr_t, b1, b2, eps);
+    return hipGetLastError();
 }
 
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t st) {

@@ -329,6 +329,16 @@ def eltwise(mode, n, x, y=None, z=None, w=None, accum=None, alpha=1.0, beta=0.0,
                                 _stream()), "mvin_eltwise")
 
 
+def l2_adam_multi(segs, nseg, total, g, m, v, loss_accum, apply_adam, lr_t, beta1, beta2, eps):
+    """mvin_l2_adam_multi over the flat gradient / Adam-moment buffers (see include/mvin_hip.h)."""
+    lib = _lib.load()
+    for t, nm in ((g, "g"), (m, "m"), (v, "v"), (loss_accum, "loss_accum")):
+        _chk(t, F32, nm)
+    _lib.check(lib.mvin_l2_adam_multi(_p(segs), nseg, total, _p(g), _p(m), _p(v), _p(loss_accum),
+                                      1 if apply_adam else 0, lr_t, beta1, beta2, eps, _stream()),
+               "mvin_l2_adam_multi")
+
+
 def axpby(alpha, x, beta, y):
     """y = alpha*x + beta*y (in place on y)."""
     eltwise(0, x.numel(), x, y, alpha=alpha, beta=beta)

@@ -59,9 +59,60 @@ class Trainer(object):
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
         self.params = self._named_params()
-        self.adam_m = {k: torch.zeros_like(v) for k, v in self.params.items()}
-        self.adam_v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self._build_flat_state()
         self.last_grads = None
+
+    def _l2_coefficients(self):
+        """Coefficient c of the (c/2) sum(x^2) term of every parameter (slice), model.py:387-412."""
+        m, a = self.m, self.m.args
+        H, M, P = m.h_hop, m.n_mix_hop, m.p_hop
+        L = M * H
+        l2w, l2a = float(a.l2_weight), float(a.l2_agg_weight)
+        c = {k: 0.0 for k in self.params}
+        c["relation_emb_matrix"] = l2w
+        lvl = [0.0] * (L + 1)
+        if P > 0:
+            c["user_mlp_matrix"] = c["user_mlp_bias"] = l2w
+            # :407-408 (the first H+1 projections) plus the LAST matrix once more (:405)
+            lvl = [l2w * ((1 if e <= H else 0) + (1 if e == L else 0)) for e in range(L + 1)]
+        c["transfer_W"] = c["transfer_b"] = lvl
+        c["h_emb_item_mlp_matrix"] = c["h_emb_item_mlp_bias"] = l2w
+        c["user_emb_matrix"] = l2a
+        if not a.PS_only:
+            for (i, n) in aggregator_keys(a):
+                c[f"agg_{i}_{n}_weights"] = c[f"agg_{i}_{n}_urh_weights"] = l2a
+        for n in range(M):
+            c[f"enti_transfer_matrix_{n}"] = c[f"enti_transfer_bias_{n}"] = l2a
+        return c
+
+    def _build_flat_state(self):
+        """Gradients and Adam moments of ALL parameters live in three flat buffers (one zero-fill and
+        one optimizer launch per step); a device table maps flat ranges to parameter storage."""
+        dev = self.m.device
+        coef = self._l2_coefficients()
+        segs, off = [], 0
+        self._slices = {}
+        for k, p in self.params.items():
+            self._slices[k] = (off, p.numel())
+            cs = coef[k]
+            if isinstance(cs, list):           # per-level coefficients of the stacked projections
+                per = p.numel() // len(cs)
+                for e, ce in enumerate(cs):
+                    segs.append((p.data_ptr() + 4 * e * per, off + e * per, per, ce))
+            else:
+                segs.append((p.data_ptr(), off, p.numel(), cs))
+            off += p.numel()
+        self._total = off
+        self._g = torch.zeros(off, dtype=F32, device=dev)
+        self._m = torch.zeros(off, dtype=F32, device=dev)
+        self._v = torch.zeros(off, dtype=F32, device=dev)
+        view = lambda buf: {k: buf[o:o + n].view_as(self.params[k]) for k, (o, n) in self._slices.items()}
+        self._grads, self.adam_m, self.adam_v = view(self._g), view(self._m), view(self._v)
+        table = np.zeros(len(segs), dtype=[("x", "<u8"), ("off", "<i8"), ("n", "<i8"), ("l2", "<f4"), ("pad", "<i4")])
+        for i, (ptr, o, n, c) in enumerate(segs):
+            table[i] = (ptr, o, n, c, 0)
+        self._nseg = len(segs)
+        self._segs = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
 
     # ------------------------------------------------------------------ parameters
     def _named_params(self):
@@ -114,7 +165,8 @@ class Trainer(object):
         item = item_indices.contiguous()
         labels = labels.to(F32).contiguous()
         G = _Grads()
-        dP = {k: torch.zeros_like(v) for k, v in self.params.items()}   # parameter gradients
+        self._g.zero_()
+        dP = self._grads                                                  # parameter gradients (views of _g)
         loss_acc = torch.zeros(1, dtype=F32, device=dev)
         tape = []
 
@@ -352,34 +404,7 @@ class Trainer(object):
                               dP[f"agg_{i}_{n}_urh_weights"].view(-1))
 
         # ================================================================ L2 terms (model.py:382-412)
-        l2w, l2a = float(a.l2_weight), float(a.l2_agg_weight)
-
-        def l2_term(name, coef, sl=None):
-            if coef == 0.0:
-                return
-            x = self.params[name] if sl is None else self.params[name][sl]
-            g = dP[name] if sl is None else dP[name][sl]
-            ops.axpby(coef, x.reshape(-1), 1.0, g.reshape(-1))            # d(coef * sum(x^2)/2) = coef * x
-            ops.eltwise(3, x.numel(), x.reshape(-1), accum=loss_acc, alpha=coef * 0.5)
-
-        l2_term("relation_emb_matrix", l2w)
-        if P > 0:
-            l2_term("user_mlp_matrix", l2w)
-            l2_term("user_mlp_bias", l2w)
-            for e in range(L + 1):
-                cnt = (1 if e <= H else 0) + (1 if e == L else 0)        # :407-408 plus the LAST matrix (:405)
-                l2_term("transfer_W", l2w * cnt, e)
-                l2_term("transfer_b", l2w * cnt, e)
-        l2_term("h_emb_item_mlp_matrix", l2w)
-        l2_term("h_emb_item_mlp_bias", l2w)
-        l2_term("user_emb_matrix", l2a)
-        if not a.PS_only:
-            for (i, n) in aggregator_keys(a):
-                l2_term(f"agg_{i}_{n}_weights", l2a)
-                l2_term(f"agg_{i}_{n}_urh_weights", l2a)
-        for n in range(M):
-            l2_term(f"enti_transfer_matrix_{n}", l2a)
-            l2_term(f"enti_transfer_bias_{n}", l2a)
+        l2w = float(a.l2_weight)   # the per-parameter terms are added by mvin_l2_adam_multi below
         # gathered-row regulariser (model.py:383-386): sum(h^2) + sum(t^2) + sum(r_emb^2) per hop
         for hop in range(P):
             for ids in (memories_h[hop], memories_t[hop]):
@@ -390,21 +415,17 @@ class Trainer(object):
             cnt = torch.bincount(memories_r[hop].reshape(-1).long(), minlength=nR).to(F32)
             ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
                         beta=1.0, D=D * D)
-            for r, k in enumerate(cnt.tolist()):
-                if k:
-                    ops.eltwise(3, D * D, R[r].reshape(-1), accum=loss_acc, alpha=l2w * k)
+            ops.eltwise(7, nR * D * D, R.view(-1), z=cnt, accum=loss_acc, alpha=l2w, D=D * D)   # no host sync
 
-        self.last_grads = dP
-        loss = float(loss_acc.item())
+        # per-parameter L2 terms and (apply) the tf.train.AdamOptimizer step (dense; oracle/train_ref.AdamRef):
+        # one launch over the flat gradient / moment buffers
+        lr_t = 0.0
         if apply:
-            self.apply_adam(dP)
-        return loss
-
-    def apply_adam(self, grads):
-        """tf.train.AdamOptimizer step on every parameter (dense; see oracle/train_ref.AdamRef)."""
-        self.t += 1
-        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        for k, p in self.params.items():
-            ops.eltwise(4, p.numel(), p.view(-1), grads[k].view(-1), self.adam_m[k].view(-1), self.adam_v[k].view(-1),
-                        alpha=float(lr_t), beta1=self.b1, beta2=self.b2, eps=self.eps)
-        self.m.invalidate()
+            self.t += 1
+            lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        ops.l2_adam_multi(self._segs, self._nseg, self._total, self._g, self._m, self._v, loss_acc, apply,
+                          float(lr_t), self.b1, self.b2, self.eps)
+        if apply:
+            self.m.invalidate()
+        self.last_grads = dP
+        return float(loss_acc.item())
