@@ -11,6 +11,21 @@ namespace mvin {
 // ------------------------------------------------------------------------------------------
 // element-wise family
 // ------------------------------------------------------------------------------------------
+// *accum += sum over the block of `local`: ONE atomic per workgroup (a per-wave atomic on a single
+// address serialises: 32 k atomics cost ~100 us)
+__device__ __forceinline__ void block_accumulate(float* accum, float local) {
+    __shared__ float s_part[16];
+    local = wave_sum(local);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_part[wave] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += s_part[i];
+        if (t != 0.f) atomicAdd(accum, t);
+    }
+}
+
 __global__ void eltwise_kernel(EltArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float local = 0.f;
@@ -61,10 +76,7 @@ __global__ void eltwise_kernel(EltArgs a) {
             }
         }
     }
-    if (a.accum) {
-        local = wave_sum(local);
-        if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(a.accum, local);
-    }
+    if (a.accum) block_accumulate(a.accum, local);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -437,10 +449,7 @@ __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg
             *xp = x - lr_t * m / (sqrtf(v) + eps);
         }
     }
-    if (accum) {
-        local = wave_sum(local);
-        if ((threadIdx.x & 63) == 0 && local != 0.f) atomicAdd(accum, local);
-    }
+    if (accum) block_accumulate(accum, local);
 }
 
 hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
