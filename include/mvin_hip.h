@@ -236,10 +236,15 @@ int mvin_linear_wgrad(const mvin_linear_args* args, const float* dY, int64_t ldy
 
 /* backward of the neighbor mix agg[t] = (1/K) sum_k p[t,k] c[t,k], p = softmax_k(t[rel]) (aggregators.py:118-152)
  * given dvec = dL/d agg: children from the table through the adjacency (table/adj/node_ids given: dc_k is added
- * atomically to dtable) or dense (child/rel_ids given: dchild written).  dT [nR] accumulates the logit gradients. */
+ * atomically to dtable) or dense (child/rel_ids given: dchild written).  dT [nR] accumulates the logit gradients.
+ * By-entity form (gather, node_ids == NULL, rel_score [nR] given instead of probs): task t is entity t and dvec
+ * [T = n_entity, D] holds dL/d agg summed over every tree node carrying that entity -- the backward is linear in
+ * dvec and depends on a node only through its entity, so the duplicates of a batch cost one pass; all-zero rows
+ * are skipped. */
 int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
-                 const float* child, const int32_t* rel_ids, const float* probs, const float* dvec,
-                 int64_t T, int K, int D, int nR, float* dtable, float* dchild, float* dT, void* stream);
+                 const float* child, const int32_t* rel_ids, const float* probs, const float* rel_score,
+                 const float* dvec, int64_t T, int K, int D, int nR, float* dtable, float* dchild, float* dT,
+                 void* stream);
 
 /* backward of mvin_rel_score: drel[r,:] += dT[r] urh_w[D:2D]; durh[D:2D] += sum_r dT[r] rel[r,:]. */
 int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, const float* dT, int nR, int D,

@@ -87,7 +87,7 @@ SIGNATURES = {
                                         C.c_void_p]),
     "mvin_linear_wgrad": (C.c_int, [C.POINTER(LinearArgs), _c_f32p, C.c_int64, C.c_int64, _c_f32p, C.c_int64,
                                     C.c_int64, _c_f32p, C.c_int64, _c_f32p, C.c_int64, C.c_void_p]),
-    "mvin_agg_bwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64,
+    "mvin_agg_bwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int64,
                                C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_rel_score_bwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_key_addressing_bwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),

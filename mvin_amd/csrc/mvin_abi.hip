@@ -435,13 +435,15 @@ int mvin_linear_wgrad(const mvin_linear_args* a, const float* dY, int64_t ldy, i
 }
 
 int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
-                 const float* child, const int32_t* rel_ids, const float* probs, const float* dvec, int64_t T, int K,
-                 int D, int nR, float* dtable, float* dchild, float* dT, void* stream) {
+                 const float* child, const int32_t* rel_ids, const float* probs, const float* rel_score,
+                 const float* dvec, int64_t T, int K, int D, int nR, float* dtable, float* dchild, float* dT,
+                 void* stream) {
     const bool gather = table != nullptr;
     if (!dvec) return fail(-1, "mvin_agg_bwd: null dvec");
-    if (gather && (!adj_entity || !node_ids || !dtable)) return fail(-1, "mvin_agg_bwd: gather form needs adjacency, node_ids, dtable");
+    if (gather && (!adj_entity || !dtable)) return fail(-1, "mvin_agg_bwd: gather form needs adjacency and dtable");
     if (!gather && (!child || !dchild)) return fail(-1, "mvin_agg_bwd: dense form needs child and dchild");
-    if (probs && (!dT || nR <= 0 || (gather ? !adj_relation : !rel_ids)))
+    if (rel_score && (!gather || probs)) return fail(-2, "mvin_agg_bwd: rel_score is for the gather form without probs");
+    if ((probs || rel_score) && (!dT || nR <= 0 || (gather ? !adj_relation : !rel_ids)))
         return fail(-1, "mvin_agg_bwd: attention needs dT, nR and relation ids");
     if (T <= 0 || K <= 0 || K > 4096) return fail(-2, "mvin_agg_bwd: bad sizes T=%lld K=%d", (long long)T, K);
     if (bad_dim(D)) return fail(-2, "mvin_agg_bwd: D=%d", D);
@@ -454,10 +456,12 @@ int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* a
     g.child = child;
     g.rel_ids = rel_ids;
     g.probs = probs;
+    g.rel_score = rel_score;
+    g.skip_zero = (gather && !node_ids) ? 1 : 0;
     g.dvec = dvec;
     g.dtable = dtable;
     g.dchild = dchild;
-    g.dT = probs ? dT : nullptr;
+    g.dT = (probs || rel_score) ? dT : nullptr;
     g.T = T;
     g.K = K;
     g.D = D;

@@ -188,22 +188,52 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(WgradArgs a) {
 // (deepest hop) -> dc_k atomically added to dtable[y_k].  dT[rel] accumulates the logit gradients
 // (block-level LDS table, flushed with one atomic per relation).  One wave per task.
 // ------------------------------------------------------------------------------------------
+// "By entity" form (gather form with node_ids == NULL and rel_score given): task t IS entity t, dvec
+// [nE, D] holds the gradient rows already summed over every tree node that carries that entity
+// (everything here is linear in dvec and depends on the node only through its entity), the attention
+// weights are recomputed from rel_score, and tasks whose row is all zero are skipped.
 __global__ __launch_bounds__(kBlock) void agg_bwd_kernel(AggBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sT = smem;                          // [nR]
     float* sG = sT + a.nR;                     // [4 waves][K]
+    float* sP = sG + 4 * a.K;                  // [4 waves][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D, K = a.K;
     const int lpr = 1 << a.lpr_log2, rpw = kWave >> a.lpr_log2;
     const int g = lane >> a.lpr_log2, c = lane & (lpr - 1);
     const bool cact = (c << 2) < D;
     float* gk = sG + wave * K;
+    float* pk = sP + wave * K;
+    const bool att = a.probs != nullptr || a.rel_score != nullptr;
     for (int i = tid; i < a.nR; i += kBlock) sT[i] = 0.f;
     __syncthreads();
     const float invK = 1.f / (float)K;
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.T; t += (int64_t)gridDim.x * 4) {
-        const int64_t xbase = a.gather ? (int64_t)a.node_ids[t] * K : 0;
+        const int64_t xbase = a.gather ? (a.node_ids ? (int64_t)a.node_ids[t] : t) * K : 0;
         const float4 dv = cact ? reinterpret_cast<const float4*>(a.dvec + t * D)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.skip_zero && !__any(dv.x != 0.f || dv.y != 0.f || dv.z != 0.f || dv.w != 0.f)) continue;
+        // attention weights of this task -> pk
+        if (a.probs) {
+            for (int k = lane; k < K; k += kWave) pk[k] = a.probs[t * K + k];
+        } else if (a.rel_score) {   // softmax_k(rel_score[adj_r[x, k]]), as the forward computes it
+            float mx = -INFINITY;
+            for (int k = lane; k < K; k += kWave) {
+                const float sc = a.rel_score[a.adj_r[xbase + k]];
+                pk[k] = sc;
+                mx = fmaxf(mx, sc);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int k = lane; k < K; k += kWave) {
+                const float e = expf(pk[k] - mx);
+                pk[k] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            for (int k = lane; k < K; k += kWave) pk[k] = pk[k] / sum;
+        } else {
+            for (int k = lane; k < K; k += kWave) pk[k] = 1.f;
+        }
         // pass 1: g_k = dvec . c_k
         for (int k0 = 0; k0 < K; k0 += rpw) {
             const int k = k0 + g;
@@ -218,13 +248,12 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_kernel(AggBwdArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
         float pg = 0.f;  // sum_j p_j g_j
-        for (int k = lane; k < K; k += kWave) pg += (a.probs ? a.probs[t * K + k] : 1.f) * gk[k];
+        for (int k = lane; k < K; k += kWave) pg += pk[k] * gk[k];
         pg = wave_sum(pg);
         // logit gradients -> relation table
-        if (a.probs) {
+        if (att) {
             for (int k = lane; k < K; k += kWave) {
-                const float p = a.probs[t * K + k];
-                const float dl = p * invK * (gk[k] - pg);
+                const float dl = pk[k] * invK * (gk[k] - pg);
                 const int r = a.gather ? a.adj_r[xbase + k] : a.rel_ids[t * K + k];
                 atomicAdd(&sT[r], dl);
             }
@@ -233,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_kernel(AggBwdArgs a) {
         for (int k0 = 0; k0 < K; k0 += rpw) {
             const int k = k0 + g;
             if (k < K && cact) {
-                const float w = (a.probs ? a.probs[t * K + k] : 1.f) * invK;
+                const float w = pk[k] * invK;
                 const float4 o = make_float4(w * dv.x, w * dv.y, w * dv.z, w * dv.w);
                 if (a.gather) {
                     float* d = a.dtable + (int64_t)a.adj_e[xbase + k] * D + 4 * c;
@@ -490,7 +519,7 @@ hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st) {
 }
 
 hipError_t launch_agg_bwd(const AggBwdArgs& a, hipStream_t st) {
-    const size_t lds = ((size_t)a.nR + 4 * (size_t)a.K) * sizeof(float);
+    const size_t lds = ((size_t)a.nR + 8 * (size_t)a.K) * sizeof(float);
     agg_bwd_kernel<<<blocks_for(a.T, 4), kBlock, lds, st>>>(a);
     return hipGetLastError();
 }

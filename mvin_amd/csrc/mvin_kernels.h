@@ -139,7 +139,9 @@ struct AggBwdArgs {
     const int32_t* node_ids;  // [T]
     const float* child;       // dense: [T*K, D]
     const int32_t* rel_ids;   // dense: [T*K]
-    const float* probs;       // [T, K] or NULL (uniform)
+    const float* probs;       // [T, K] or NULL (uniform, unless rel_score is given)
+    const float* rel_score;   // [nR]: recompute the softmax instead of reading probs (by-entity form)
+    int skip_zero;            // skip tasks whose dvec row is all zero
     const float* dvec;        // [T, D]
     float* dtable;            // gather: [nE, D] accumulated atomically
     float* dchild;            // dense: [T*K, D] written

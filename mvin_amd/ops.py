@@ -367,13 +367,14 @@ def linear_wgrad(srcs, dY, dW, *, ids=None, db=None, mask=None, sum_sources=Fals
 
 
 def agg_bwd(dvec, probs, T, K, D, nR, *, table=None, adj_entity=None, adj_relation=None, node_ids=None, child=None,
-            rel_ids=None, dtable=None, dT=None):
-    """mvin_agg_bwd; returns dchild (dense form) or None (gather form: dtable updated in place)."""
+            rel_ids=None, dtable=None, dT=None, rel_score=None):
+    """mvin_agg_bwd; returns dchild (dense form) or None (gather form: dtable updated in place).
+    Gather form with node_ids=None and rel_score given = the by-entity form (dvec is [n_entity, D])."""
     lib = _lib.load()
     dchild = torch.empty((T * K, D), dtype=F32, device=dvec.device) if table is None else None
     _lib.check(lib.mvin_agg_bwd(_p(table), _p(adj_entity), _p(adj_relation), _p(node_ids), _p(child), _p(rel_ids),
-                                _p(probs), _p(dvec), T, K, D, nR, _p(dtable), _p(dchild), _p(dT), _stream()),
-               "mvin_agg_bwd")
+                                _p(probs), _p(rel_score), _p(dvec), T, K, D, nR, _p(dtable), _p(dchild), _p(dT),
+                                _stream()), "mvin_agg_bwd")
     return dchild
 
 

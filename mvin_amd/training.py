@@ -16,6 +16,8 @@ Gradient identities used (see DESIGN.md 3.1 for the forward algebra they mirror)
     dS' = dZ.W_L^T feeds one gather-form mvin_agg_bwd that scatter-adds (p_k/K) dS' into dE[y_k];
   * key addressing: s_m = h_m . V[b, r_m], V = E[item].R_KGE[r]  =>  dR_KGE[r] = E[item]^T dV[:, r].
 """
+import os
+
 import numpy as np
 import torch
 
@@ -58,6 +60,7 @@ class Trainer(object):
         self.lr = model.lr if lr is None else lr
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
+        self.by_entity = os.environ.get("MVIN_TRAIN_BY_ENTITY", "1") != "0"   # de-duplicated deepest-hop backward
         self.params = self._named_params()
         self._build_flat_state()
         self.last_grads = None
@@ -346,8 +349,19 @@ class Trainer(object):
                             G.add(c[L - 1], dc)
                         else:
                             dS = dZ
-                        ops.agg_bwd(dS, pr, T, K, D, nR, table=E, adj_entity=m.adj_entity, adj_relation=m.adj_relation,
-                                    node_ids=node_ids, dtable=dP["entity_emb_matrix"], dT=dTk)
+                        if self.by_entity and (pr is not None or not agg.User_orient_rela):
+                            # the deepest hop's backward is linear in dS and depends on a node only through
+                            # its entity: sum dS per entity first (T row scatter-adds), then ONE pass per
+                            # touched entity instead of one per tree node (a batch repeats entities heavily)
+                            Gx = zeros(m.n_entity, D)
+                            ops.scatter_add_rows(Gx, node_ids, dS)
+                            ops.agg_bwd(Gx, None, m.n_entity, K, D, nR, table=E, adj_entity=m.adj_entity,
+                                        adj_relation=m.adj_relation, node_ids=None, rel_score=t_tab,
+                                        dtable=dP["entity_emb_matrix"], dT=dTk)
+                        else:
+                            ops.agg_bwd(dS, pr, T, K, D, nR, table=E, adj_entity=m.adj_entity,
+                                        adj_relation=m.adj_relation, node_ids=node_ids,
+                                        dtable=dP["entity_emb_matrix"], dT=dTk)
                     else:
                         dchild = ops.agg_bwd(dZ, pr, T, K, D, nR, child=child_t.view(T * K, D), rel_ids=rel_ids, dT=dTk)
                         G.add(child_t, dchild.view_as(child_t))
