@@ -174,6 +174,13 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
                             float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 
+/* out[r, :] = softmax(x[r, :]) over n columns (tf.nn.softmax, model.py:189 / :223).  Building block of the
+ * SHARED-USER form of MVIN._key_addressing (one user scored against many items, as util.py:145-181 does for
+ * top-K evaluation): with one ripple set for the whole batch the reads become dense products,
+ *   logits = E[items] . A^T,  A[m] = R_KGE[r_m] . E[h_m]   ->  row softmax  ->  o = P . E[t]   (mvin_linear_fwd),
+ * instead of 2*Nm row gathers per pair. */
+int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
+
 /* Entity-table ("hoisted") mode building block -- an inference-side re-association of
  * model.py:295-305 / aggregators.py:118-146 at the two deepest levels (SURVEY.md 7.3-c route 2b):
  *   out[i, :] = (1/K) sum_k w_k * f(table[adj_entity[x_i, k], :] + rowbias[i / nodes_per_group, :])

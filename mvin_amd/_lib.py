@@ -68,6 +68,7 @@ SIGNATURES = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int,
                                           C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_row_softmax_fwd": (C.c_int, [_c_f32p, C.c_int64, C.c_int, _c_f32p, C.c_void_p]),
     "mvin_gather_mix_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int, C.c_void_p]),
     "mvin_sample_adjacency": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, C.c_int, C.c_int, C.c_uint64, _c_i32p,

@@ -326,6 +326,12 @@ int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int3
     return hip_result(mvin::launch_gather_mix(g, (hipStream_t)stream), who);
 }
 
+int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream) {
+    if (!x || !out) return fail(-1, "mvin_row_softmax_fwd: null pointer");
+    if (rows <= 0 || n <= 0 || n > 4096) return fail(-2, "mvin_row_softmax_fwd: bad sizes rows=%lld n=%d", (long long)rows, n);
+    return hip_result(mvin::launch_row_softmax(x, rows, n, out, (hipStream_t)stream), "mvin_row_softmax_fwd");
+}
+
 int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
                           uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream) {
     if (!indptr || !dst || !rel || !adj_entity || !adj_relation) return fail(-1, "mvin_sample_adjacency: null pointer");

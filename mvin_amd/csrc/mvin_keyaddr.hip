@@ -174,6 +174,31 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     }
 }
 
+// Row softmax (tf.nn.softmax over the last axis, model.py:189 / :223) for the shared-user form of
+// key addressing (mvin_amd/model.py:_key_addressing_shared): out[r, :] = softmax(x[r, :]), one wave
+// per row, n <= 4096.
+__global__ __launch_bounds__(kBlock) void row_softmax_kernel(const float* __restrict__ x, int64_t rows, int n,
+                                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4) {
+        const float* xr = x + r * n;
+        float mx = -INFINITY;
+        for (int i = lane; i < n; i += kWave) mx = fmaxf(mx, xr[i]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int i = lane; i < n; i += kWave) sum += expf(xr[i] - mx);
+        sum = wave_sum(sum);
+        for (int i = lane; i < n; i += kWave) out[r * n + i] = expf(xr[i] - mx) / sum;
+    }
+}
+
+hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st) {
+    const int64_t nblk = (rows + 3) / 4;
+    const int64_t cap = 256 * 16;
+    row_softmax_kernel<<<(int)(nblk < cap ? nblk : cap), kBlock, 0, st>>>(x, rows, n, out);
+    return hipGetLastError();
+}
+
 int key_addr_nj(int Nm, int D) {
     const int rpw = kWave >> lpr_log2_for(D);
     const int need = (Nm + rpw - 1) / rpw;

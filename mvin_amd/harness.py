@@ -88,6 +88,19 @@ class DeviceFeeder(object):
         return self.model.forward_device(u, it, mh, mr, mt).scores_normalized
 
 
+    def scores_user(self, user, items):
+        """sigmoid scores of ONE user against ``items``: the shared-user form of the path (the
+        user's ripple sets are read once per call, not once per pair)."""
+        import torch
+        dev = self.model.device
+        it = torch.as_tensor(np.asarray(items) if not torch.is_tensor(items) else items).to(dev).long()
+        sel = self.uts[int(user)]                                   # [P, 3, Nm]
+        u = torch.full((1,), int(user), dtype=torch.int64, device=dev)
+        return self.model.forward_device(u, it, [sel[i, 0].contiguous() for i in range(self.P)],
+                                         [sel[i, 1].contiguous() for i in range(self.P)],
+                                         [sel[i, 2].contiguous() for i in range(self.P)]).scores_normalized
+
+
 # --------------------------------------------------------------------------- training loop
 def train_epoch(args, model, train_data, user_triplet_set, sess=None, rng=None):
     """One epoch of train.py:56-64 through ``model.train(sess, feed_dict)``: shuffle, then full
@@ -243,7 +256,7 @@ def topk_eval_device(feeder, user_list, train_record, eval_record, test_record, 
         scores = np.empty(len(test_items), dtype=np.float32)
         for start in range(0, len(test_items), batch_size):
             blk = test_items[start:start + batch_size]
-            scores[start:start + len(blk)] = feeder.scores(np.full(len(blk), user, dtype=np.int64), blk).cpu().numpy()
+            scores[start:start + len(blk)] = feeder.scores_user(user, blk).cpu().numpy()
         order = np.argsort(-scores, kind="stable")
         _rank_metrics(test_items[order].tolist(), ref[user], k_list, precision_list, recall_list, ndcg_list)
     return ([float(np.mean(precision_list[k])) for k in k_list], [float(np.mean(recall_list[k])) for k in k_list],

@@ -266,6 +266,42 @@ class MVIN(object):
         # :232-236
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
+    def _key_addressing_shared(self, item32, mem_h, mem_r, mem_t):
+        """model.py:161-240 when EVERY pair of the batch carries the same ripple sets (one user
+        scored against many items: the top-K evaluation of util.py:145-181).  ``mem_*``: per hop
+        ONE [n_memory] int32 id list.  With the memories fixed the reads turn into dense products
+            A[m] = R_KGE[r_m] . E[h_m]         ([Nm, D], once per call)
+            logits = E[items] . A^T  ->  softmax over Nm  ->  o = P . E[t]
+        on the MFMA linear kernel: ~2 KB of [B, Nm] traffic per pair instead of 2*Nm gathered rows,
+        and no [B, nR, D] item projection.  The h-set read (:162-197) does not depend on the item."""
+        a, D, P, Nm, nR = self.args, self.dim, self.p_hop, self.n_memory, self.n_relation
+        E = self.entity_emb_matrix
+        B = item32.shape[0]
+        n_o = P + 1 if a.PS_O_ft else P
+        o_cat = torch.empty((B, n_o * D), dtype=torch.float32, device=self.device)
+        slot0 = 0
+        if a.PS_O_ft:
+            o1 = torch.empty((1, D), dtype=torch.float32, device=self.device)
+            w_h = self.h_emb_item_mlp_matrix.view(-1)
+            if ops.key_addressing_supported(Nm, D):
+                ops.key_addressing(E, None, w_h, [mem_h[0].view(1, Nm)], [], [], 0, o1, D, nR)
+            else:
+                ops.ripple_attn(E, mem_h[0].view(1, Nm), None, mem_h[0].view(1, Nm), None, w_h, 1, o1, 0, D, nR)
+            o_cat.view(B, n_o, D)[:, 0, :] = o1           # broadcast (plumbing)
+            slot0 = 1
+        if P > 0:
+            Rt = self.relation_emb_KGE_matrix.transpose(1, 2).contiguous()   # W[z] = R[z]^T so that x.W = R.x
+            ar = torch.arange(Nm, dtype=torch.int64, device=self.device)
+        for hop in range(P):
+            Hall = ops.linear([E], Rt, D, ids=[mem_h[hop]], rows=Nm, nz=nR, w_zstride=D * D)     # [nR, Nm, D]
+            sel = (mem_r[hop].long() * Nm + ar).to(torch.int32)
+            A = ops.linear([Hall.view(nR * Nm, D)], None, D, ids=[sel])                           # [Nm, D]
+            logits = ops.linear([E], A.t().contiguous(), Nm, ids=[item32])                        # [B, Nm]
+            Pm = ops.row_softmax(logits)
+            T = ops.linear([E], None, D, ids=[mem_t[hop]])                                        # [Nm, D] fp32
+            ops.linear([Pm], T, D, out=o_cat, out_offset=(slot0 + hop) * D, ldo=n_o * D)
+        return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
+
     def _project_levels(self, ents, q, top, need_c=()):
         """model.py:267-283 for levels 0..top-1 (deeper levels are fused into the gather
         kernels).  Returns (ev list, c) where c[e] = q.W_e + b_e ([B, D]) for the levels in
@@ -497,14 +533,31 @@ class MVIN(object):
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,
                        want_probs=False):
         """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
-        [B, n_memory] per hop).  Returns a namespace of device tensors."""
+        [B, n_memory] per hop).  Returns a namespace of device tensors.
+        Shared-user form: ripple sets given as ONE [n_memory] list per hop (and ``user_indices`` a
+        single id or [B]) score one user against ``item_indices`` -- see ``_key_addressing_shared``."""
         a = self.args
         if not item_indices.is_cuda:
             raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
         item32 = item_indices.contiguous()   # int64 (reference dtype) or int32: kernels take both
         user32 = user_indices.contiguous()
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
-        ps = self._key_addressing(user32, item32, memories_h, memories_r, memories_t) if need_ps else None
+        shared = memories_h[0].dim() == 1      # one user's ripple sets for the whole batch
+        if shared and user32.numel() == 1:
+            user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
+        if shared and (self.n_memory % 4 != 0 or self.n_memory > 256):
+            # outside the dense form (the [B, Nm] logits go through mvin_linear_fwd): replicate the sets
+            rep = lambda lst: [m_.reshape(1, -1).expand(item32.shape[0], -1).contiguous() for m_ in lst]
+            memories_h, memories_r, memories_t = rep(memories_h), rep(memories_r), rep(memories_t)
+            shared = False
+        if not need_ps:
+            ps = None
+        elif shared:
+            ps = self._key_addressing_shared(item32, [m_.contiguous() for m_ in memories_h],
+                                             [m_.contiguous() for m_ in memories_r],
+                                             [m_.contiguous() for m_ in memories_t])
+        else:
+            ps = self._key_addressing(user32, item32, memories_h, memories_r, memories_t)
         importance = []
         if a.PS_only:  # :142-144
             user_o = ps

@@ -245,6 +245,15 @@ def gather_mix(table, adj_entity, adj_relation, node_ids, rel_score_t, rowbias, 
     return out
 
 
+def row_softmax(x):
+    """mvin_row_softmax_fwd: softmax over the last axis of a [rows, n] fp32 tensor."""
+    lib = _lib.load()
+    _chk(x, F32, "x")
+    out = torch.empty_like(x)
+    _lib.check(lib.mvin_row_softmax_fwd(_p(x), x.shape[0], x.shape[1], _p(out), _stream()), "mvin_row_softmax_fwd")
+    return out
+
+
 def key_addressing_supported(Nm, D):
     return bool(_lib.load().mvin_key_addressing_supported(Nm, D))
 
