@@ -237,13 +237,15 @@ def main():
         # attached only when that profile was taken on exactly this workload
         traffic = None
         hoisted = a.hoist != "off" and model.hoist_supported()
+        from mvin_amd import ops as _ops
+        used_l2 = bool(model.fused and a.hop >= 2 and _ops.gather_attn_l2_supported(a.dim, a.fanout))
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
                 pmc = json.load(f)
             same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
                                               "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch}
                     and a.table_dtype == "f32")
-            if same and model.fused and world == 1 and not hoisted:
+            if same and used_l2 and world == 1 and not hoisted:
                 traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
         except (OSError, KeyError, ValueError):
             traffic = None
@@ -282,7 +284,7 @@ def main():
                                         else "single-gpu"))},
             "roofline": {"bound": "hbm", "kernel": ("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                                                     "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
-                         else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if model.fused else "gather_attn_kernel (mvin_gather_attn_fwd)",
+                         else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if used_l2 else "gather_attn_kernel (mvin_gather_attn_fwd)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "traffic_note": "bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE+WRITE_SIZE, "
