@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--hop", type=int, default=2)
     ap.add_argument("--mix", type=int, default=1)
     ap.add_argument("--fanout", type=int, default=32)
-    ap.add_argument("--batch", type=int, default=262144,
+    ap.add_argument("--batch", type=int, default=524288,
                     help="TOTAL pairs per step over all ranks (strong scaling: each rank scores batch/N)")
     ap.add_argument("--shard", choices=["auto", "rowshard", "replicate"], default="auto",
                     help="entity table placement: row-sharded over the ranks with all-to-all row fetch "
