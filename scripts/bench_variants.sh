@@ -14,7 +14,8 @@ C2="--dataset MovieLens-1M --dim 32 --fanout 16"
 C4="--dataset amazon-book_20core --dim 64 --fanout 64 --batch 32768"
 C5="--dataset amazon-book_20core --dim 128 --hop 3 --fanout 128 --table-dtype bf16"
 run                                             # C3 default
-run --adj uniform --items uniform               # worst-case locality
+run --batch 262144
+run --batch 262144 --adj uniform --items uniform   # worst-case locality
 run --batch 16384
 run --batch 512
 run --batch 512 --graph
@@ -23,11 +24,11 @@ run $C2 --batch 524288
 run $C4
 run $C5 --batch 64 --steps 3 --warmup 1
 # entity-table mode (separate mode, own bytes per pair)
-run --hoist cached
-run --hoist step
+run --batch 262144 --hoist cached
+run --batch 262144 --hoist step
 run --hoist cached --batch 512
 run --hoist cached --batch 512 --graph
-run --hoist cached --adj uniform --items uniform
+run --batch 262144 --hoist cached --adj uniform --items uniform
 run --hoist cached --n-entity 16000000 --batch 32768
 run $C2 --batch 524288 --hoist cached
 run $C4 --hoist cached
