@@ -51,6 +51,20 @@ def main():
             sh.prefetch((i + 1) % 2, feed[1], feed[2], feed[4])
             assert torch.equal(out.scores, ref), f"rank {rank} {regime}: pipelined step {i} differs"
         torch.cuda.synchronize()
+    # entity-table mode on top of the sharded table: the per-entity tables must be rebuilt whenever an
+    # exchange refills the working table (tracked through the tensor version counter)
+    hm = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=zeroed,
+              device=dev, hoist=True)
+    sh = ShardedMVIN(hm, shard_rows(full, rank, world), rank, world, is_shard=True, regime="dense")
+    got = sh.forward_device(*feed).scores
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), f"rank {rank}: hoisted sharded scores differ"
+    sh.table.local.mul_(1.5)
+    sh.table.refresh()
+    scaled = dict(params, entity_emb_matrix=params["entity_emb_matrix"] * np.float32(1.5))
+    ref2 = mk(scaled).forward_device(*feed).scores
+    got2 = sh.forward_device(*feed).scores
+    assert not torch.allclose(ref2, ref)
+    assert torch.allclose(got2, ref2, rtol=1e-5, atol=1e-6), f"rank {rank}: stale entity tables after an exchange"
     # ranks really scored different pairs: gather a checksum of every rank's slice
     sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(sums, ref.double().sum().cpu().reshape(1))
