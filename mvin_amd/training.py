@@ -49,8 +49,14 @@ class _Grads(object):
 class Trainer(object):
     """Owns the Adam state of an mvin_amd.model.MVIN and runs training steps on it."""
 
-    def __init__(self, model, lr=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    def __init__(self, model, lr=None, beta1=0.9, beta2=0.999, eps=1e-8, group=None, world=1):
+        """``world`` > 1: data-parallel training, one process per GPU.  Every rank steps on its own
+        1/world of the batch; the data-dependent gradients (and loss terms) of all ranks are summed
+        with ONE all-reduce of the flat gradient buffer (RCCL: torch.distributed backend "nccl") before
+        the per-parameter L2 terms and the Adam update, which every rank then applies identically --
+        parameters stay bit-identical across ranks."""
         a = model.args
+        self.group, self.world = group, int(world)
         if not a.wide_deep:
             raise NotImplementedError("training the legacy aggregate path (wide_deep=False) is not built; the "
                                       "reference cannot run it either (model.py:366-374)")
@@ -402,7 +408,9 @@ class Trainer(object):
         # scores = sum_d user_o * item_emb (model.py:158) ; loss (model.py:379-380)
         _, scores, _ = ops.linear([item_emb.view(B, D)], None, D, score_u=user_o)
         dscore = torch.empty(B, dtype=F32, device=dev)
-        ops.eltwise(1, B, scores, dscore, z=labels, accum=loss_acc, alpha=1.0 / B, beta=1.0 / B)
+        # reduce_mean over the GLOBAL batch (model.py:379): with data parallelism the ranks' sums add up
+        inv_b = 1.0 / (B * self.world)
+        ops.eltwise(1, B, scores, dscore, z=labels, accum=loss_acc, alpha=inv_b, beta=inv_b)
         du = torch.empty((B, D), dtype=F32, device=dev)
         di = torch.empty((B, D), dtype=F32, device=dev)
         ops.eltwise(5, B * D, item_emb.view(B, D), du, z=dscore, alpha=1.0, beta=0.0, D=D)
@@ -433,6 +441,10 @@ class Trainer(object):
 
         # per-parameter L2 terms and (apply) the tf.train.AdamOptimizer step (dense; oracle/train_ref.AdamRef):
         # one launch over the flat gradient / moment buffers
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self._g, group=self.group)        # one bucket: every gradient of the model
+            dist.all_reduce(loss_acc, group=self.group)
         lr_t = 0.0
         if apply:
             self.t += 1

@@ -65,6 +65,31 @@ def main():
     got2 = sh.forward_device(*feed).scores
     assert not torch.allclose(ref2, ref)
     assert torch.allclose(got2, ref2, rtol=1e-5, atol=1e-6), f"rank {rank}: stale entity tables after an exchange"
+    # data-parallel training: each rank steps on its slice, one all-reduce of the flat gradient buffer;
+    # after 3 steps every rank holds the parameters of a single-process trainer fed the whole batch
+    from mvin_amd.training import Trainer
+    targs = make_args(**dict(vars(args), lr=5e-3, l2_weight=1e-4, l2_agg_weight=1e-5))
+    lab = (np.arange(Bl * world) % 3 == 0).astype(np.float32)
+    mkt = lambda: MVIN(targs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                       params=params, device=dev)
+    whole, part = mkt(), mkt()
+    t_whole, t_part = Trainer(whole), Trainer(part, world=world)
+    full_feed = (torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+                 torch.from_numpy(lab).to(dev),
+                 [torch.from_numpy(m_).to(dev) for m_ in case.memories_h],
+                 [torch.from_numpy(m_).to(dev) for m_ in case.memories_r],
+                 [torch.from_numpy(m_).to(dev) for m_ in case.memories_t])
+    my_feed = (feed[0], feed[1], torch.from_numpy(lab[sl]).to(dev), feed[2], feed[3], feed[4])
+    for step in range(3):
+        lw = t_whole.step(*full_feed)
+        lp = t_part.step(*my_feed)
+        assert abs(lw - lp) <= 1e-5 * abs(lw) + 1e-6, f"rank {rank} step {step}: loss {lp} vs {lw}"
+    for k, v in t_whole.params.items():
+        assert torch.allclose(t_part.params[k], v, rtol=1e-4, atol=1e-6), f"rank {rank}: parameter {k} diverged"
+    mine = torch.cat([v.reshape(-1) for v in t_part.params.values()]).double().sum().cpu().reshape(1)
+    sums2 = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sums2, mine)
+    assert len({float(x) for x in sums2}) == 1, "parameters differ between ranks"
     # ranks really scored different pairs: gather a checksum of every rank's slice
     sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
     dist.all_gather(sums, ref.double().sum().cpu().reshape(1))
