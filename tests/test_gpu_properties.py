@@ -120,3 +120,31 @@ def test_empty_like_edges(hip_lib):
     assert torch.equal(out.scores, out.scores[0].expand_as(out.scores))
     one = run(model, case, slice(0, 1))
     assert torch.equal(one.scores, out.scores[:1])
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C4"])
+def test_full_size_entity_table_and_shared_user_modes(name, hip_lib):
+    """Dataset-sized tables: the entity-table mode and the shared-user form give the faithful path's
+    scores (same tolerance as against the oracle), batch independence holds in both."""
+    from mvin_amd.model import MVIN
+    args, case, params, model = setup(name, B=2048)
+    hm = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+              device="cuda:0", hoist=True)
+    dev = model.device
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    feed = (d(case.users), d(case.items), [d(m) for m in case.memories_h], [d(m) for m in case.memories_r],
+            [d(m) for m in case.memories_t])
+    ref = model.forward_device(*feed).scores
+    got = hm.forward_device(*feed).scores
+    assert_close(got.cpu().numpy(), ref.cpu().numpy(), f"{name} entity-table mode vs faithful")
+    part = hm.forward_device(feed[0][5:105], feed[1][5:105], *[[m[5:105].contiguous() for m in lst] for lst in feed[2:]])
+    assert torch.equal(part.scores, got[5:105])
+    # one user's ripple sets for every pair: shared-user form == per-pair form fed the replicated sets
+    u = int(case.users[0])
+    one = lambda lst: [m[0].contiguous() for m in lst]
+    rep = lambda lst: [m[:1].expand(m.shape[0], -1).contiguous() for m in lst]
+    users = torch.full_like(feed[0], u)
+    a = model.forward_device(users, feed[1], rep(feed[2]), rep(feed[3]), rep(feed[4])).scores
+    for mdl in (model, hm):
+        b = mdl.forward_device(users[:1], feed[1], one(feed[2]), one(feed[3]), one(feed[4])).scores
+        assert_close(b.cpu().numpy(), a.cpu().numpy(), f"{name} shared-user form vs per-pair")
