@@ -82,7 +82,13 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int g = lane / G::LPR, c = lane % G::LPR;
+    // elements of a table row per lane: 4 (16-byte fp32 / 8-byte bf16 loads), or 8 bf16 (16-byte loads)
+    // at D = 128, where halving the load instructions pays (C5: +49 %); at D <= 64 the narrower rows
+    // would leave too few rows per lane group in flight (measured slower)
+    constexpr bool WIDE = BF && D == 128 && TMV == 32;
+    constexpr int EPL = WIDE ? 8 : 4;
+    constexpr int LPRX = D / EPL, RPWX = kWave / LPRX;
+    const int g = lane / LPRX, c = lane % LPRX;
     const int q16 = lane >> 4, l16 = lane & 15;
     // dense-phase tile ownership
     const int nt = (NW == G::NT) ? wave : (wave % G::NT);
@@ -116,6 +122,22 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
+    // bf16 row chunk of this lane: 8 elements, widened to fp32 exactly
+    auto load8 = [&](int id, float4& lo, float4& hi) {
+        const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
+        lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
+        hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
+    };
+    // this lane's EPL floats of an LDS tile row half (float2 stores: rows are 8-byte aligned)
+    auto put = [&](float* dst, float4 lo, float4 hi) {
+        float* q = dst + EPL * c;
+        *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
+        *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
+        if constexpr (WIDE) {
+            *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
+            *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
+        }
+    };
     const int ypld = GPC ? K + 1 : K;           // sYP row stride (odd in the 16-row variant: the lane
                                                         // groups read different rows at once)
     const int lpn = 1 << a.lpn_log2;                    // lanes per child adjacency row (K/4)
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                 // one lane group per child: its K rows are K independent loads in flight and the
                 // weighted sum never leaves the group (no cross-group reduction).  In the 16-row
                 // variant there are exactly as many lane groups per wave as children per wave (256/D).
-                static_assert(G::NPW % G::RPW == 0, "children per wave must be a multiple of the lane groups");
+                static_assert(G::NPW % RPWX == 0, "children per wave must be a multiple of the lane groups");
                 auto row4 = [&](int id) -> float4 {
                     if (BF)
                         return bf16x4_to_f32(reinterpret_cast<const uint2*>(
@@ -325,25 +347,35 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
                 };
 #pragma unroll
-                for (int j = 0; j < G::NPW / G::RPW; ++j) {
-                    const int nl = j * G::RPW + g;
+                for (int j = 0; j < G::NPW / RPWX; ++j) {
+                    const int nl = j * RPWX + g;
                     const int n = node0 + nl;
                     float* arow = sA + (wave * G::NPW + nl) * G::LDA;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                    float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
+                    float4 sv = acc, sv1 = acc;
                     if (n < K) {
                         const int2* yp = ypw + nl * ypld;
+                        if constexpr (WIDE) {
 #pragma unroll 8
-                        for (int k = 0; k < K; ++k) {
-                            const int2 e = yp[k];
-                            acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                            for (int k = 0; k < K; ++k) {
+                                const int2 e = yp[k];
+                                float4 lo, hi;
+                                load8(e.x, lo, hi);
+                                acc = f4_fma(__int_as_float(e.y), lo, acc);
+                                acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
+                            }
+                            load8(sX1[n], sv, sv1);
+                        } else {
+#pragma unroll 8
+                            for (int k = 0; k < K; ++k) {
+                                const int2 e = yp[k];
+                                acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                            }
+                            sv = row4(sX1[n]);
                         }
-                        sv = row4(sX1[n]);
                     }
-                    *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
-                    *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
-                    *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
-                    *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
+                    put(arow, sv, sv1);
+                    put(arow + D, acc, acc1);
                 }
             } else
             for (int nl = 0; nl < G::NPW; ++nl) {
@@ -352,21 +384,32 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                 float* arow = sA + row * G::LDA;
                 if (n >= K) {  // padding child: finite zeros (its p0/p1 are 0)
                     if (g == 0) {
-                        *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(0.f, 0.f);
-                        *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(0.f, 0.f);
-                        *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(0.f, 0.f);
-                        *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(0.f, 0.f);
+                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                        put(arow, z, z);
+                        put(arow + D, z, z);
                     }
                     continue;
                 }
                 const int2* yp = ypw + nl * K;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (BF) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
+                float4 sv = acc, sv1 = acc;
+                if constexpr (WIDE) {
+                    // bf16 table, D = 128: 16-byte lane loads (8 elements), widened to fp32 exactly
+#pragma unroll 8
+                    for (int k = g; k < K; k += RPWX) {
+                        const int2 e = yp[k];
+                        float4 lo, hi;
+                        load8(e.x, lo, hi);
+                        acc = f4_fma(__int_as_float(e.y), lo, acc);
+                        acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
+                    }
+                    if (g == 0) load8(sX1[n], sv, sv1);
+                    acc1 = group_xor_sum(acc1, LPRX);
+                } else if (BF) {
                     // bf16 table: 8-byte lane loads (4 elements), widened to fp32 exactly
                     const uint16_t* tb = reinterpret_cast<const uint16_t*>(a.table);
 #pragma unroll 8
-                    for (int k = g; k < K; k += G::RPW) {
+                    for (int k = g; k < K; k += RPWX) {
                         const int2 e = yp[k];
                         const float4 v = bf16x4_to_f32(reinterpret_cast<const uint2*>(tb + (int64_t)e.x * D)[c]);
                         acc = f4_fma(__int_as_float(e.y), v, acc);
@@ -377,7 +420,7 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                     // instead of a 64-bit shift+add chain; packed FMAs (2 f32 per issue)
                     f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll 8
-                    for (int k = g; k < K; k += G::RPW) {
+                    for (int k = g; k < K; k += RPWX) {
                         const int2 e = yp[k];
                         const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
                             rsrc, ((unsigned)e.x * (unsigned)(D * 4)) + c16, 0, 0);
@@ -398,19 +441,17 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
                 } else {   // tables >= 4 GiB: 64-bit global addressing
                     const float* tf = reinterpret_cast<const float*>(a.table);
 #pragma unroll 8
-                    for (int k = g; k < K; k += G::RPW) {
+                    for (int k = g; k < K; k += RPWX) {
                         const int2 e = yp[k];
                         const float4 v = reinterpret_cast<const float4*>(tf + (int64_t)e.x * D)[c];
                         acc = f4_fma(__int_as_float(e.y), v, acc);
                     }
                     if (g == 0) sv = reinterpret_cast<const float4*>(tf + (int64_t)sX1[n] * D)[c];
                 }
-                acc = group_xor_sum(acc, G::LPR);
+                acc = group_xor_sum(acc, LPRX);
                 if (g == 0) {
-                    *reinterpret_cast<float2*>(arow + 4 * c) = make_float2(sv.x, sv.y);
-                    *reinterpret_cast<float2*>(arow + 4 * c + 2) = make_float2(sv.z, sv.w);
-                    *reinterpret_cast<float2*>(arow + D + 4 * c) = make_float2(acc.x, acc.y);
-                    *reinterpret_cast<float2*>(arow + D + 4 * c + 2) = make_float2(acc.z, acc.w);
+                    put(arow, sv, sv1);
+                    put(arow + D, acc, acc1);
                 }
             }
             if (KIT > 0 && tile == 0 && wave == 0 && has_next)
