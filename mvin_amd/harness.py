@@ -263,6 +263,77 @@ def topk_eval_device(feeder, user_list, train_record, eval_record, test_record, 
             [float(np.mean(ndcg_list[k])) for k in k_list], None, None)
 
 
+# --------------------------------------------------------------------------- the train.py loop
+class EarlyStop(object):
+    """train_util.py:20-61 (Early_stop_info): keep the best evaluation score, save the stage-wise
+    tables whenever it improves (``save_final_model``), stop after ``early_stop`` epochs without
+    improvement once ``tolerance`` epochs have passed."""
+
+    def __init__(self, tolerance=2, early_stop=3, save_final_model=True):
+        self.best, self.best_saved = -float("inf"), -float("inf")
+        self.counter, self.tolerance, self.early_stop = 0, tolerance, early_stop
+        self.save_final_model = save_final_model
+
+    def update(self, epoch, score, model):
+        if score > self.best_saved:
+            self.best_saved = score
+            if self.save_final_model and model.path is not None and getattr(model.path, "emb", None):
+                model.save_pretrain_emb_fuc(None, None)
+        if epoch + 1 > self.tolerance:
+            if score > self.best:
+                self.best, self.counter = score, 0
+            else:
+                self.counter += 1
+            if self.counter >= self.early_stop:
+                return True
+        return False
+
+
+def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=None, topk_batch=65536):
+    """train.py:16-109 on the GPU path.  ``data`` = the tuple of mvin_amd.data_io.load_data (or the
+    reference's own ``load_data`` prefix): (n_user, n_item, n_entity, n_relation, train, eval, test,
+    adj_entity, adj_relation, user_triplet_set, ...).  Per epoch: shuffle, full minibatches only
+    (:56-64), then CTR evaluation on train/eval/test with early stopping on the eval AUC (:87-103) or,
+    with ``show_topk``, top-K evaluation with early stopping on eval recall@k_list[2] (:67-86).
+    Returns (model, history): one dict per epoch."""
+    from .model import MVIN
+    n_user, n_item, n_entity, n_relation = data[0], data[1], data[2], data[3]
+    train_data, eval_data, test_data = (np.asarray(d) for d in data[4:7])
+    adj_entity, adj_relation, uts = data[7], data[8], data[9]
+    if model is None:
+        model = MVIN(args, n_user, n_entity, n_relation, adj_entity, adj_relation, device=device)
+        if getattr(args, "load_pretrain_emb", False):
+            model.restore_pretrain_emb()                                       # train.py:53-54
+    feeder = DeviceFeeder(model, uts)
+    stop = EarlyStop(getattr(args, "tolerance", 2), getattr(args, "early_stop", 3),
+                     getattr(args, "save_final_model", True))
+    if show_topk:
+        user_list, train_rec, eval_rec, test_rec, item_set, k_list = topk_settings(train_data, eval_data, test_data,
+                                                                                   n_item)
+    history = []
+    train_data = train_data.copy()
+    for epoch in range(getattr(args, "n_epochs", 20)):
+        losses = train_epoch_device(feeder, train_data, args.batch_size, rng=rng)
+        rec = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else float("nan")}
+        if show_topk:
+            for mode in ("eval", "test"):
+                p, r, n, _, _ = topk_eval_device(feeder, user_list, train_rec, eval_rec, test_rec, item_set, k_list,
+                                                 topk_batch, mode=mode)
+                rec[mode] = {"precision": p, "recall": r, "ndcg": n}
+            score = rec["eval"]["recall"][2]
+        else:
+            for name, d in (("train", train_data), ("eval", eval_data), ("test", test_data)):
+                _, _, _, auc, acc, f1 = ctr_eval_device(feeder, d, args.batch_size)
+                rec[name] = {"auc": auc, "acc": acc, "f1": f1}
+            score = rec["eval"]["auc"]                                          # Eval_score_info.eval_st_score
+        history.append(rec)
+        if log:
+            log(rec)
+        if stop.update(epoch, score, model):
+            break
+    return model, history
+
+
 # --------------------------------------------------------------------------- case study (f-4)
 def _names(ids, table):
     return [table[str(i)] if str(i) in table else str(i) for i in ids]

@@ -61,3 +61,35 @@ def test_from_reference_file_formats(hip_lib, tmp_path):
     p, r, n, _, _ = harness.topk_eval_device(feeder, users, tr_rec, ev_rec, te_rec, set(range(ni)), [1, 5], 64)
     assert len(p) == 2 and all(0.0 <= x <= 1.0 for x in p + r + n)
     torch.cuda.synchronize()
+
+
+def test_train_loop_counterpart(hip_lib, tmp_path):
+    """harness.train = train.py:16-109: epochs with CTR evaluation and early stopping, then the same
+    with top-K evaluation, on the synthetic-signal data of scripts/run_synthetic.py."""
+    import types
+    import numpy as np
+    from mvin_amd import data_prep, harness, synth
+    from mvin_amd.config import make_args
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import run_synthetic
+    rng = np.random.default_rng(0)
+    n_user, n_item, n_ent, n_rel, K, P, Nm = 300, 200, 1500, 6, 8, 2, 16
+    kg = np.stack([rng.integers(0, n_ent, 8000), rng.integers(0, n_rel, 8000), rng.integers(0, n_ent, 8000)], 1)
+    inter = run_synthetic.synthetic_interactions(kg, n_user, n_item, n_ent, 30, rng)
+    parts = np.split(inter[rng.permutation(inter.shape[0])], [int(0.6 * len(inter)), int(0.8 * len(inter))])
+    csr = data_prep.build_csr(kg, n_ent, device="cuda:0")
+    adj_e, adj_r = data_prep.construct_adj(csr, n_ent, K, seed=1)
+    uts = data_prep.get_user_triplet_set(csr, data_prep.history_csr(parts[0], n_user, device="cuda:0"), n_user, P, Nm,
+                                         seed=2)
+    data = (n_user, n_item, n_ent, n_rel, parts[0], parts[1], parts[2], adj_e, adj_r, uts)
+    args = make_args(dim=16, neighbor_sample_size=K, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=256,
+                     lr=2e-2, l2_weight=1e-6, l2_agg_weight=1e-6)
+    args.n_epochs, args.tolerance, args.early_stop, args.save_final_model = 4, 1, 2, True
+    args.path = types.SimpleNamespace(emb=str(tmp_path / "emb"))
+    model, hist = harness.train(args, data, device="cuda:0", rng=np.random.default_rng(1))
+    assert 1 <= len(hist) <= 4 and hist[-1]["loss"] < hist[0]["loss"]
+    assert all(0.0 <= h["eval"]["auc"] <= 1.0 for h in hist)
+    assert os.path.exists(model._emb_path())                       # best-epoch checkpoint of the STWS tables
+    args.n_epochs = 1
+    _, hist2 = harness.train(args, data, show_topk=True, model=model, rng=np.random.default_rng(2))
+    assert len(hist2[0]["eval"]["recall"]) == 7 and all(0.0 <= x <= 1.0 for x in hist2[0]["test"]["ndcg"])

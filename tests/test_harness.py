@@ -107,3 +107,34 @@ def test_ranking_metric_definitions():
     assert abs(harness.recall_at_k(ranked, truth, 5) - 2 / 3) < 1e-12
     assert abs(harness.dcg_at_k([0, 1, 0, 0, 1], 5) - (1 / np.log2(3) + 1 / np.log2(6))) < 1e-12
     assert harness.ndcg_at_k([1, 1, 0], 3) == 1.0 and harness.ndcg_at_k([0, 0], 2) == 0.0
+
+
+def test_early_stop_rule():
+    """train_util.py:33-61: saves on every improvement, counts non-improving epochs only after
+    ``tolerance`` epochs, stops at ``early_stop`` of them in a row."""
+    from mvin_amd.harness import EarlyStop
+
+    class M(object):
+        path = None
+        saved = 0
+
+        def save_pretrain_emb_fuc(self, *a):
+            self.saved += 1
+
+    m = M()
+    st = EarlyStop(tolerance=2, early_stop=2, save_final_model=True)
+    scores = [0.5, 0.4, 0.6, 0.55, 0.58, 0.7]
+    stopped = []
+    for e, sc in enumerate(scores):
+        stopped.append(st.update(e, sc, m))
+        if stopped[-1]:
+            break
+    # epochs 0,1 are inside the tolerance window; best is set at epoch 2 (0.6); 3 and 4 do not improve -> stop at 4
+    assert stopped == [False, False, False, False, True]
+    assert st.best == 0.6 and m.saved == 0            # no path.emb: nothing written
+    import types
+    m.path = types.SimpleNamespace(emb="/tmp/x")
+    st2 = EarlyStop(tolerance=0, early_stop=3)
+    for e, s in enumerate([0.1, 0.2, 0.15, 0.3]):
+        st2.update(e, s, m)
+    assert m.saved == 3                                # improvements at epochs 0, 1, 3
