@@ -28,6 +28,9 @@ class GraphedScorer(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = model.forward_device(self.users, self.items, self.mh, self.mr, self.mt)
+        # the graph reads derived tables (relation logits, hoisted entity tables) that an optimizer step,
+        # set_adjacency or restore_pretrain_emb replaces: such a graph must be captured again
+        self._generation = getattr(model, "_generation", 0)
 
     def load(self, users, items, mem_h, mem_r, mem_t):
         """Copy a batch (device tensors) into the graph's static input buffers."""
@@ -40,6 +43,9 @@ class GraphedScorer(object):
 
     def replay(self):
         """Score whatever is in the static buffers; returns the (static) output namespace."""
+        if getattr(self.model, "_generation", 0) != self._generation:
+            raise RuntimeError("the model's parameters / adjacency changed since this graph was captured: "
+                               "build a new GraphedScorer")
         self.graph.replay()
         return self.out
 

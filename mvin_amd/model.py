@@ -111,6 +111,7 @@ class MVIN(object):
             return torch.from_numpy(np.asarray(a).astype(np.int32)).to(self.device).contiguous()
         self.adj_entity, self.adj_relation = conv(adj_entity), conv(adj_relation)
         self._hoisted = None
+        self._generation = getattr(self, "_generation", 0) + 1
 
     def _build_inputs(self):
         """model.py:49-64."""
@@ -224,6 +225,7 @@ class MVIN(object):
         for agg in self.aggregators:
             agg.invalidate()
         self._hoisted = None
+        self._generation = getattr(self, "_generation", 0) + 1   # captured hipGraphs of older generations are stale
 
     # ------------------------------------------------------------------ graph pieces
     def get_neighbors(self, seeds, levels=None):

@@ -31,3 +31,21 @@ def test_graph_replay_matches_eager(hip_lib):
         ref = model.forward_device(users, items, mh, mr, mt).scores
         torch.cuda.synchronize()
         assert torch.equal(got, ref)
+
+
+def test_stale_graph_is_refused(hip_lib):
+    """A captured graph reads derived tables that an optimizer step / new adjacency replaces."""
+    from mvin_amd.graph import GraphedScorer
+    from mvin_amd.model import MVIN
+    args = make_args(dim=16, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=8, batch_size=16)
+    adj_e, adj_r = synth.uniform_adjacency(100, 5, 4, seed=1)
+    model = MVIN(args, 20, 100, 5, adj_e, adj_r, device="cuda:0", seed=2, hoist=True)
+    scorer = GraphedScorer(model, 16)
+    scorer.replay()
+    model.set_adjacency(adj_e, adj_r)
+    with pytest.raises(RuntimeError, match="new GraphedScorer"):
+        scorer.replay()
+    scorer = GraphedScorer(model, 16)      # entity tables are rebuilt in the warm-up, outside the capture
+    a = scorer.replay().scores.clone()
+    b = model.forward_device(scorer.users, scorer.items, scorer.mh, scorer.mr, scorer.mt).scores
+    assert torch.equal(a, b)
