@@ -70,3 +70,15 @@ def test_ops_refuse_cpu_tensors(hip_lib):
     from mvin_amd import _lib, ops
     with pytest.raises(_lib.MvinHipError):
         ops.rel_score(torch.zeros(3, 8), torch.zeros(24, 1))
+
+
+def test_header_is_plain_c_and_cpp():
+    """include/mvin_hip.h is the whole boundary: it must compile as C99 and as C++11 on its own."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mvin_hip.h")
+    for cc, lang, std in (("gcc", "c", "-std=c99"), ("g++", "c++", "-std=c++11")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        r = subprocess.run([cc, "-fsyntax-only", "-x", lang, std, "-Wall", "-Werror", hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
