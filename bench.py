@@ -295,6 +295,26 @@ def main():
                          "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS,
                          "faithful_bytes_per_pair": bpp_faithful},
         }
+        if world == 1 and not a.no_cpu_baseline and a.hoist == "off" and not rowshard and model.hoist_supported():
+            # informational only, measured AFTER the timed region on the same inputs: the entity-table mode
+            #  has its own bytes per pair and is never `value`
+            hm = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                      params=params, device=dev, table_dtype=a.table_dtype, hoist=True)
+            for _ in range(2):
+                ho = hm.forward_device(users, items, mh, mr, mt)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                ho = hm.forward_device(users, items, mh, mr, mt)
+            torch.cuda.synchronize()
+            dth = (time.perf_counter() - t1) / 5
+            dev_err = (ho.scores - out.scores).abs().max().item()
+            rec["other_modes"] = {"entity_table_mode_cached": {
+                "value": a.batch / dth, "unit": "pairs/s", "ms_per_step": 1e3 * dth,
+                "max_abs_diff_vs_faithful_scores": dev_err,
+                "note": "per-entity tables hoist the pair-independent part of the two deepest levels "
+                        "(SURVEY 7.3-c route 2b): different algorithmic bytes per pair, reported separately"}}
+            del hm, ho
         if world == 1 and not a.no_cpu_baseline:
             cb, ref, Bc = cpu_baseline(a, margs, case, params)
             rec["cpu_baseline"] = cb
