@@ -135,7 +135,10 @@ static hipError_t launch_lm(const mvin_linear_args& a, hipStream_t st) {
     const size_t lds = ((size_t)kTM * (NE * D + 2) + (D / 16) * kTM) * sizeof(float);
     const int64_t ntiles = (a.rows + kTM - 1) / kTM;
     const int nz = a.nz > 0 ? a.nz : 1;
-    int64_t gx = (256 * 6 + nz - 1) / nz;    // ~6 workgroups per CU over all z
+    // workgroups per CU over all z, from a sweep at C3: one full round at the kernel's occupancy for the
+    // wide-input forms (4 waves/SIMD at NE = 3), 12 for NE = 1 (7 waves/SIMD; a second round hides the tail)
+    constexpr int kWgPerCu = NE == 1 ? 12 : 4;
+    int64_t gx = (256 * kWgPerCu + nz - 1) / nz;
     if (gx > ntiles) gx = ntiles;
     if (gx < 1) gx = 1;
     linear_mfma_kernel<D, NE><<<dim3((unsigned)gx, (unsigned)nz), kBlock, lds, st>>>(a);
