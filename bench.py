@@ -322,9 +322,20 @@ def main():
             err = np.abs(got - ref.scores.numpy())
             rec["parity_vs_cpu_sample"] = {"max_abs_err": float(err.max()),
                                            "within_1e-5rel_1e-6abs": bool((err <= 1e-5 * np.abs(ref.scores.numpy()) + 1e-6).all())}
-        print(json.dumps(rec), flush=True)
+    else:
+        rec = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rec is not None:
+        # the JSON line goes out LAST: RCCL writes a version banner through C stdio, which would otherwise be
+        # flushed after it at exit
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
