@@ -97,3 +97,20 @@ def test_bench_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes_per_pair(64, 32, 2) == 279300
     assert bench.algorithmic_bytes_per_pair(64, 64, 2) == 1098756
     assert bench.algorithmic_bytes_per_pair(128, 128, 3, s=2) == 558007812
+
+
+def test_algorithmic_bytes_per_pair_matches_survey_table():
+    """bench.py's roofline numerator is SURVEY.md 8(d)'s figure: T*D*s + (T-K^L)*K*8 + D*s + 4."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.algorithmic_bytes_per_pair
+    assert f(16, 8, 1) == 708                       # C1
+    assert f(32, 16, 2) == 37252                    # C2
+    assert f(64, 32, 2) == 279300                   # C3 (metric config)
+    assert f(64, 64, 2) == 1098756                  # C4
+    assert f(128, 128, 3, s=2) == 558007812         # C5 (bf16 table)
+    assert bench.HBM_PEAK_GBS == 8000.0
