@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 SHAPES = [
     dict(dim=64, neighbor_sample_size=32, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=12),   # fused + key_addr<16>
     dict(dim=128, neighbor_sample_size=16, h_hop=3, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=3),   # depth 3
+    dict(dim=128, neighbor_sample_size=32, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=5),   # 16-byte bf16 loads, one group per child
     dict(dim=8, neighbor_sample_size=3, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=5),       # per-level kernels
     dict(dim=32, neighbor_sample_size=8, h_hop=1, n_mix_hop=2, p_hop=2, n_memory=8, batch_size=6),
 ]
