@@ -105,10 +105,14 @@ def load_kg_triples(data_dir, cache_npy=False):
 
 def load_data(data_dir, neighbor_sample_size, p_hop, n_memory, device="cuda", new_load_data=False, ratio=1.0,
               seed=0, n_neighbor=16):
-    """:18-31.  Returns (n_user, n_item, n_entity, n_relation, train_data, eval_data, test_data,
-    adj_entity, adj_relation, user_triplet_set, item_set_most_pop, user_history_dict); adjacency
-    ([n_entity, K] int32) and ripple sets ([n_user, p_hop, 3, n_memory] int32, an all-zero block for
-    users without history) are device tensors, ready for MVIN(...) / harness.DeviceFeeder."""
+    """:18-31.  Returns the reference's 16-tuple, position for position (train.py:17-21 reads it by
+    index): (n_user, n_item, n_entity, n_relation, train_data, eval_data, test_data, adj_entity,
+    adj_relation, user_triplet_set, user_path, user_path_top_k, item_set_most_pop, user_history_dict,
+    entity_index_2_name, rela_index_2_name).  ``user_path`` / ``user_path_top_k`` are None in the
+    reference too (:301-306); the two name tables are {} unless the amazon case-study files are given
+    (:21-24, not read here).  Adjacency ([n_entity, K] int32) and ripple sets ([n_user, p_hop, 3,
+    n_memory] int32, an all-zero block for users without history) are device tensors, ready for
+    MVIN(...) / harness.DeviceFeeder."""
     from . import data_prep
     n_user, n_item, train, ev, test, hist, pop = load_rating(data_dir, new_load_data, ratio, seed)
     kg_np, n_entity, n_relation = load_kg_triples(data_dir)
@@ -117,4 +121,4 @@ def load_data(data_dir, neighbor_sample_size, p_hop, n_memory, device="cuda", ne
     adj_e, adj_r = data_prep.construct_adj(csr, n_rows, neighbor_sample_size, seed=seed + 1)
     hcsr = data_prep.history_csr(train, n_user, device=device)
     uts = data_prep.get_user_triplet_set(csr, hcsr, n_user, p_hop, n_memory, seed=seed + 2, n_neighbor=n_neighbor)
-    return (n_user, n_item, n_rows, n_relation, train, ev, test, adj_e, adj_r, uts, pop, hist)
+    return (n_user, n_item, n_rows, n_relation, train, ev, test, adj_e, adj_r, uts, None, None, pop, hist, {}, {})

@@ -289,12 +289,17 @@ class EarlyStop(object):
         return False
 
 
-def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=None, topk_batch=65536, hoist=True):
-    """train.py:16-109 on the GPU path.  ``data`` = the tuple of mvin_amd.data_io.load_data (or the
-    reference's own ``load_data`` prefix): (n_user, n_item, n_entity, n_relation, train, eval, test,
-    adj_entity, adj_relation, user_triplet_set, ...).  Per epoch: shuffle, full minibatches only
+def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=None, topk_batch=65536, hoist=True,
+          topk_early_stop=False):
+    """train.py:16-109 on the GPU path.  ``data`` = the 16-tuple of mvin_amd.data_io.load_data / the
+    reference's ``load_data`` (read by position exactly as train.py:17-21 does; a 10-tuple prefix
+    (..., user_triplet_set) is accepted for CTR runs).  Per epoch: shuffle, full minibatches only
     (:56-64), then CTR evaluation on train/eval/test with early stopping on the eval AUC (:87-103) or,
-    with ``show_topk``, top-K evaluation with early stopping on eval recall@k_list[2] (:67-86).
+    with ``show_topk``, top-K evaluation over the candidate set ``item_set_most_pop`` = data[12]
+    (:69-77 pass it where topk_eval's signature says item_set) scored on eval recall@k_list[2].
+    In top-K mode the reference NEVER stops early: :86 compares update_score's return value
+    ('EarlyStopping' or None) with True.  That is reproduced (the best-epoch save still happens);
+    ``topk_early_stop=True`` applies the evident intent instead (listed in INTEGRATION.md section 4).
     ``hoist``: evaluate through the entity-table mode (weights are frozen while an epoch is evaluated; the
     tables are dropped by every optimizer step and rebuilt by the first evaluation batch) -- 2-4x faster
     evaluation at the same tolerance; training steps always take the faithful kernels.
@@ -313,6 +318,8 @@ def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=
     if show_topk:
         user_list, train_rec, eval_rec, test_rec, item_set, k_list = topk_settings(train_data, eval_data, test_data,
                                                                                    n_item)
+        if len(data) > 12 and data[12] is not None:
+            item_set = set(int(i) for i in data[12])                            # item_set_most_pop, train.py:70,75
     history = []
     train_data = train_data.copy()
     for epoch in range(getattr(args, "n_epochs", 20)):
@@ -332,7 +339,7 @@ def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=
         history.append(rec)
         if log:
             log(rec)
-        if stop.update(epoch, score, model):
+        if stop.update(epoch, score, model) and (topk_early_stop or not show_topk):
             break
     return model, history
 

@@ -639,6 +639,6 @@ class MVIN(object):
         imp = out.importance_list
         imp0 = imp[0].cpu().numpy() if imp and imp[0] is not None else None
         imp1 = imp[1].cpu().numpy() if len(imp) > 1 and imp[1] is not None else 0
-        return (user.cpu().numpy(), np.asarray(feed_dict[self.labels]), item.cpu().numpy(),
+        return (user.cpu().numpy(), np.asarray(feed_dict[self.labels], dtype=np.float32), item.cpu().numpy(),   # fetched placeholder: float32 (model.py:52)
                 [e.cpu().numpy().astype(np.int64) for e in ents],
                 [r.cpu().numpy().astype(np.int64) for r in rels], imp0, imp1)

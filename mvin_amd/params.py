@@ -33,7 +33,11 @@ def xavier_uniform(rng, shape):
 
 def aggregator_keys(args):
     """(i, n) of every aggregator the graph builds: model.py:286-291 (wide_deep) or
-    :357-360 (legacy ``aggregate``: one per h_hop iteration, mix index fixed to 0)."""
+    :357-360 (legacy ``aggregate``: one per h_hop iteration, mix index fixed to 0).  With
+    ``PS_only`` the aggregation function is never called (model.py:142-144), so the reference graph
+    holds no aggregator variables at all (pinned by tests/test_ref_pins.py)."""
+    if getattr(args, "PS_only", False):
+        return []
     if args.wide_deep:
         return [(i, n) for n in range(args.n_mix_hop) for i in range(args.h_hop)]
     return [(i, 0) for i in range(args.h_hop)]

@@ -40,7 +40,7 @@ def test_from_reference_file_formats(hip_lib, tmp_path):
             for i, (u, it, l) in enumerate(part):
                 f.write(f"{i},{it},{l},{u}\n")
     K, P, Nm = 4, 2, 8
-    (nu, ni, ne, nr, train, ev, test, adj_e, adj_r, uts, pop, hist) = data_io.load_data(
+    (nu, ni, ne, nr, train, ev, test, adj_e, adj_r, uts, _, _, pop, hist, _, _) = data_io.load_data(
         str(tmp_path), K, P, Nm, device="cuda:0")
     assert (nu, ni, ne, nr) == (ratings[:, 0].max() + 1, ratings[:, 1].max() + 1, n_ent, n_rel)
     assert tuple(adj_e.shape) == (n_ent, K) and tuple(uts.shape) == (nu, P, 3, Nm)

@@ -1,0 +1,122 @@
+"""-m gpu: the HIP path (through the C ABI) against fixtures produced by the REFERENCE'S OWN CODE
+(tests/golden/ref/, see tests/golden/make_ref_fixtures.py and tests/test_ref_pins.py):
+
+  * model__*.npz: scores / sigmoid scores / attention outputs / level ids of model.py + aggregators.py run
+    unmodified over the numpy TF stand-in (wiring pinned to the reference; fp64 arithmetic of the fixture
+    is numpy's) -- on both HIP schedules (fused two-level kernel where it applies, per-level kernels);
+  * harness.npz: util.py's ctr_eval / topk_eval / case-study dump and train.py's feed assembly, run by the
+    reference itself -- against mvin_amd.harness driving the HIP model (host feeds and device feeds);
+  * data_loader.npz: the HIP CSR build equals the reference's construct_kg lists; the HIP samplers obey
+    the rules the reference's own (seeded) samples obey.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from parity import ATOL, RTOL, assert_close
+from test_ref_pins import MODEL_FIX, REF, check_adjacency_rule, check_ripple_rule, load_model_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fused", [None, False], ids=["default", "per_level"])
+@pytest.mark.parametrize("path", MODEL_FIX, ids=lambda p: os.path.basename(p)[7:-4])
+def test_hip_matches_reference_graph(path, fused, hip_lib):
+    from mvin_amd.model import MVIN
+    z, args, params, (mh, mr, mt) = load_model_fixture(path)
+    model = MVIN(args, int(z["n_user"]), int(z["n_entity"]), int(z["n_relation"]), z["adj_entity"], z["adj_relation"],
+                 params=params, device="cuda:0", fused=fused)
+    feed = {model.user_indices: z["users"], model.item_indices: z["items"], model.labels: z["labels"]}
+    for i in range(len(mh)):
+        feed[model.memories_h[i]], feed[model.memories_r[i]], feed[model.memories_t[i]] = mh[i], mr[i], mt[i]
+    items, sig = model.get_scores(None, feed)                         # the reference's own calling convention
+    np.testing.assert_array_equal(items, z["items"])
+    assert_close(sig, z["ref_scores_normalized_64"], "sigmoid scores vs reference graph")
+    dev = model.device
+    out = model.forward_device(torch.from_numpy(z["users"]).to(dev), torch.from_numpy(z["items"]).to(dev),
+                               [torch.from_numpy(m).to(dev) for m in mh], [torch.from_numpy(m).to(dev) for m in mr],
+                               [torch.from_numpy(m).to(dev) for m in mt], want_probs=True)
+    assert_close(out.scores.cpu().numpy(), z["ref_scores_64"], "scores vs reference graph (fp64)")
+    assert_close(out.scores.cpu().numpy(), z["ref_scores_32"], "scores vs reference graph (fp32)", rtol=RTOL, atol=2 * ATOL)
+    if args.PS_only:
+        return
+    users, labels, items2, ents, rels, imp0, imp1 = model.eval_case_study(None, feed)
+    assert labels.dtype == np.float32 and users.dtype == np.int64
+    L = args.n_mix_hop * args.h_hop
+    for i in range(L + 1):
+        np.testing.assert_array_equal(ents[i], z[f"ref_entities_{i}"])     # integer work: bit-exact
+    for i in range(L):
+        np.testing.assert_array_equal(rels[i], z[f"ref_relations_{i}"])
+    if "ref_importance_0" in z.files:
+        assert_close(imp0, z["ref_importance_0"], "importance_list_0", atol=1e-7)
+    else:
+        assert imp0 is None
+    if "ref_importance_1" in z.files:
+        assert_close(imp1, z["ref_importance_1"], "importance_list_1", atol=1e-7)
+    elif L == 1:
+        assert isinstance(imp1, int) and imp1 == 0                         # model.py:323
+
+
+def _harness_model():
+    from mirror_model import load_harness_fixture
+    from mvin_amd.model import MVIN
+    z, args, params, uts = load_harness_fixture()
+    model = MVIN(args, int(z["n_user"]), int(z["n_entity"]), int(z["n_relation"]), z["adj_entity"], z["adj_relation"],
+                 params=params, device="cuda:0")
+    return z, args, model, uts
+
+
+def test_harness_on_hip_matches_reference_loops(hip_lib):
+    from mvin_amd import harness
+    z, args, model, uts = _harness_model()
+    for name in ("train", "eval", "test"):
+        aucs, accs, f1s, auc, acc, f1 = harness.ctr_eval(args, model, z[f"{name}_data"], uts, args.batch_size)
+        np.testing.assert_allclose(np.array([aucs, accs, f1s]), z[f"ctr_{name}_lists"], atol=1e-9)
+        np.testing.assert_allclose([auc, acc, f1], z[f"ctr_{name}_means"], atol=1e-9)
+        dev = harness.ctr_eval_device(harness.DeviceFeeder(model, uts), z[f"{name}_data"], args.batch_size)
+        np.testing.assert_allclose(dev[3:], z[f"ctr_{name}_means"], atol=1e-9)
+    users, tr, ev, te, item_set, k_list = harness.topk_settings(z["train_data"], z["eval_data"], z["test_data"], int(z["n_item"]))
+    assert list(users) == z["topk_user_list"].tolist()
+    cand = set(z["topk_candidates"].tolist())
+    for mode in ("eval", "test"):
+        p, r, nd, _, _ = harness.topk_eval(args, uts, model, users, tr, ev, te, cand, k_list, args.batch_size, mode=mode)
+        np.testing.assert_allclose(np.array([p, r, nd]), z[f"topk_{mode}"], atol=1e-9)
+        p, r, nd, _, _ = harness.topk_eval_device(harness.DeviceFeeder(model, uts), users, tr, ev, te, cand, k_list,
+                                                  args.batch_size, mode=mode)
+        np.testing.assert_allclose(np.array([p, r, nd]), z[f"topk_{mode}"], atol=1e-9)
+
+
+def test_case_study_dump_on_hip_matches_reference_text(hip_lib, tmp_path):
+    from mirror_model import compare_case_study_text
+    from mvin_amd import harness
+    z, args, model, uts = _harness_model()
+    hist = {u: sorted(s) for u, s in harness.get_user_record(z["train_data"]).items()}
+    path = tmp_path / "case.log"
+    harness.ctr_eval_case_study(args, model, z["test_data"][:16], uts, hist, {"3": "Entity Three"}, {"0": "rel zero"},
+                                z["case_user_list"].tolist(), set(z["topk_candidates"].tolist()), args.batch_size, str(path))
+    assert compare_case_study_text(path.read_text(), str(z["case_study_text"]), atol=2e-6) > 0
+
+
+def test_hip_prep_against_reference_rules(hip_lib):
+    from mvin_amd import data_prep
+    z = np.load(os.path.join(REF, "data_loader.npz"))
+    n_entity, K = int(z["n_entity"]), int(z["K"])
+    csr = data_prep.build_csr(z["kg_np"], n_entity)
+    # construct_kg (:324-343): the device CSR holds the reference's per-entity lists in its insertion order
+    np.testing.assert_array_equal(csr[0].cpu().numpy(), z["csr_indptr"])
+    np.testing.assert_array_equal(csr[1].cpu().numpy(), z["csr_dst"])
+    np.testing.assert_array_equal(csr[2].cpu().numpy(), z["csr_rel"])
+    indptr, dst, rel = z["csr_indptr"], z["csr_dst"], z["csr_rel"]
+    for seed in (3, 4):
+        ae, ar = data_prep.construct_adj(csr, n_entity, K, seed=seed)
+        check_adjacency_rule(indptr, dst, rel, ae.cpu().numpy(), ar.cpu().numpy(), K)
+    P, Nm, nn = int(z["uts_p_hop"]), int(z["uts_n_memory"]), int(z["uts_n_neighbor"])
+    ptr, items = z["uts_hist_ptr"], z["uts_hist_items"]
+    n_user = len(z["uts_users"])
+    hist = (torch.from_numpy(ptr.astype(np.int64)).cuda(), torch.from_numpy(items.astype(np.int32)).cuda())
+    got = data_prep.get_user_triplet_set(csr, hist, n_user, P, Nm, seed=9, n_neighbor=nn).cpu().numpy()
+    assert got.shape == z["uts"].shape
+    for i in range(n_user):
+        check_ripple_rule(indptr, dst, rel, items[ptr[i]:ptr[i + 1]].tolist(), got[i], P, Nm, nn)
