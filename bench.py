@@ -12,9 +12,16 @@ dim=64, hop=2 (n_mix_hop=1), fan-out=32, fp32.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field):
   value     = pairs scored per second, whole job (all ranks), max-over-ranks time
-  roofline  = gather+attention kernel (mvin_gather_attn_fwd): algorithmic bytes per launch
-              (SURVEY.md 8(d) bytes(pair) x pairs per launch) / mean launch duration measured
-              with HIP events on the launch stream inside the timed steps
+  roofline  = the dominant kernel (gather_attn_l2_kernel, mvin_gather_attn_l2_fwd) in its HBM-BOUND
+              regime: the same kernel at the same D / K on a 4 GB entity table (16 M rows, uniform
+              adjacency, far larger than the 256 MB Infinity Cache), algorithmic bytes per launch
+              (SURVEY.md 8(d) bytes(pair) x pairs per launch) / mean launch duration measured live
+              with HIP events on the launch stream, against the 8 TB/s HBM peak (frac <= 1)
+    .timed_region = the same kernel as launched inside the timed steps on the metric workload, whose
+              27 MB table is L2 / Infinity-Cache resident: labelled bound "l2", algorithmic GB/s
+              against the 34.5 TB/s L2 aggregate, plus the measured HBM fraction from PMC traffic
+  batch_sweep  = whole-path pairs/s at the reference's own batch sizes (512, 4096,
+              16384), eager and as one hipGraph replay
   cpu_baseline = oracle/mirror_fp32.py (TF-graph-equivalent torch-CPU restatement) timed on
               this host's cores on a bounded sample of the same workload (rank 0, N=1 only)
 """
@@ -31,6 +38,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth (8 XCDs x 4 MiB), same guide, "L2 (per XCD)"
+HBM_LEG_ROWS = 16_000_000   # x 64 x 4 B = 4.1 GB: 16x the Infinity Cache, < 4 GiB (32-bit buffer offsets)
+HBM_LEG_PAIRS = 32768
 
 
 def algorithmic_bytes_per_pair(D, K, L, s=4):
@@ -71,7 +81,14 @@ def parse():
     ap.add_argument("--adj", choices=["kg", "uniform"], default="kg")
     ap.add_argument("--items", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--cpu-batch", type=int, default=512)
-    ap.add_argument("--cpu-iters", type=int, default=9)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 4 GB-table launch of the dominant kernel")
+    ap.add_argument("--hbm-leg-only", action="store_true",
+                    help="run ONLY the 4 GB-table leg and print its record (the command profiles/r2/*hbm_leg* were "
+                         "collected with: one kernel name, one regime per rocprofv3 run)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
+    ap.add_argument("--sweep", default="512,4096,16384")
     ap.add_argument("--n-entity", type=int, default=0,
                     help="override the entity count (synthetic large-table variant, e.g. 16000000 = 4 GB at dim 64; "
                          "implies --adj uniform)")
@@ -111,16 +128,97 @@ def cpu_baseline(args, margs, case, params):
             best_thr, best_t = thr, t
     torch.set_num_threads(best_thr)
     Bc = min(args.cpu_batch, len(case.users))
-    run(Bc)  # warm-up
+    for _ in range(args.cpu_warmup):
+        run(Bc)
     times = []
     for _ in range(args.cpu_iters):
         t, ref = run(Bc)
         times.append(t)
     med = float(np.median(times))
     return {"value": Bc / med, "unit": "pairs/s", "cores": best_thr, "kind": "port",
-            "sample": f"{args.cpu_iters} timed passes (median) of {Bc} pairs of the same workload, "
+            "sample": f"{args.cpu_warmup} warm-ups + {args.cpu_iters} timed passes (median) of {Bc} pairs of the same workload, "
                       f"torch-CPU fp32 op-by-op mirror of the TF graph (oracle/mirror_fp32.py); "
                       f"{best_thr} threads = fastest of a probe over thread counts on a {ncpu}-core host"}, ref, Bc
+
+
+def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0):
+    """The dominant kernel in its HBM-bound regime: mvin_gather_attn_l2_fwd (same template instance as
+    in the timed steps: same D, K, table dtype, projection + attention on) on a ``n_rows`` x D table far
+    larger than the Infinity Cache, uniform adjacency, ``pairs`` parents per launch.  Each launch is
+    bracketed by HIP events on the stream it is launched on (torch's current stream)."""
+    import torch
+    from mvin_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    dt = torch.bfloat16 if table_dtype == "bf16" else torch.float32
+    table = (torch.rand((n_rows, D), device=dev, generator=g) - 0.5).to(dt)
+    adj_e = torch.randint(0, n_rows, (n_rows, K), device=dev, generator=g, dtype=torch.int32)
+    adj_r = torch.randint(0, n_rel, (n_rows, K), device=dev, generator=g, dtype=torch.int32)
+    parents = torch.randint(0, n_rows, (pairs,), device=dev, generator=g, dtype=torch.int32)
+    t0 = torch.rand(n_rel, device=dev, generator=g)
+    W = (torch.rand((3, D, D), device=dev, generator=g) - 0.5) / D ** 0.5
+    q = torch.rand((pairs, D), device=dev, generator=g)
+    bias = torch.zeros(D, device=dev)
+    args = (table, adj_e, adj_r, parents, t0, t0, W[0], W[1], bias, bias, q, W[2], bias, pairs, 1, K, D, n_rel)
+    for _ in range(warmup):
+        ops.gather_attn_l2(*args)
+    evs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = ops.gather_attn_l2(*args)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())
+    ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    s_ = 2 if table_dtype == "bf16" else 4
+    bpp = algorithmic_bytes_per_pair(D, K, 2, s=s_)
+    del table, adj_e, adj_r
+    torch.cuda.empty_cache()
+    return {"avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
+            "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows, "table_bytes": n_rows * D * s_,
+            "launches": iters, "outputs_finite": finite}
+
+
+def pmc_record(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5):
+    """Whole get_scores path at the reference's own batch sizes: eager launches, and the
+    same pass replayed as one hipGraph (mvin_amd.graph.GraphedScorer)."""
+    import torch
+    from mvin_amd.graph import GraphedScorer
+    out = []
+    for B in sizes:
+        if B > users.shape[0]:
+            continue
+        sl = slice(0, B)
+        feed = (users[sl], items[sl], [m[sl] for m in mh], [m[sl] for m in mr], [m[sl] for m in mt])
+        rec = {"batch": B}
+        for mode in ("eager", "hipgraph"):
+            if mode == "hipgraph":
+                sc = GraphedScorer(model, B)
+                sc.load(*feed)
+                fn = sc.replay
+            else:
+                fn = lambda: model.forward_device(*feed)   # noqa: E731
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            rec[mode] = {"pairs_per_s": B / dt, "us_per_step": 1e6 * dt}
+        out.append(rec)
+    return out
 
 
 def main():
@@ -149,6 +247,12 @@ def main():
     from mvin_amd.config import make_args
     from mvin_amd.model import MVIN
     from mvin_amd.params import init_params
+
+    if a.hbm_leg_only:
+        leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, iters=max(a.steps, 1), warmup=a.warmup)
+        leg.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", frac=leg["achieved"] / HBM_PEAK_GBS)
+        print(json.dumps({"hbm_leg_only": leg}), flush=True)
+        return
 
     d = synth.DATASETS[a.dataset]
     if a.batch % world:
@@ -239,23 +343,23 @@ def main():
         hoisted = a.hoist != "off" and model.hoist_supported()
         from mvin_amd import ops as _ops
         used_l2 = bool(model.fused and a.hop >= 2 and _ops.gather_attn_l2_supported(a.dim, a.fanout))
+        pmc = pmc_record("pmc_latest.json")
         try:
-            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-                pmc = json.load(f)
-            same = (pmc.get("bench_args") == {"dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix,
-                                              "fanout": a.fanout, "adj": a.adj, "items": a.items, "batch": a.batch}
-                    and a.table_dtype == "f32")
+            same = (pmc is not None and a.table_dtype == "f32" and not a.n_entity and pmc.get("bench_args") == {
+                "dataset": a.dataset, "dim": a.dim, "hop": a.hop, "mix": a.mix, "fanout": a.fanout, "adj": a.adj,
+                "items": a.items, "batch": a.batch})
             if same and used_l2 and world == 1 and not hoisted:
                 traffic = pmc["gather_attn_l2_traffic_bytes_per_launch"] / pmc["gather_attn_l2_pairs_per_launch"] * Bl
-        except (OSError, KeyError, ValueError):
+        except (KeyError, ValueError):
             traffic = None
         L = a.hop * a.mix
-        bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L, s=2 if a.table_dtype == "bf16" else 4)
+        s_ = 2 if a.table_dtype == "bf16" else 4
+        bpp = algorithmic_bytes_per_pair(a.dim, a.fanout, L, s=s_)
         bpp_faithful = bpp
         if hoisted:
             # bytes this mode really needs per pair: K+1 fp32 rows of the hoisted tables + the adjacency row
             # per level-(L-2) node, + (mode 'step') the table build amortised over the rank's pairs
-            K, D, s_ = a.fanout, a.dim, (2 if a.table_dtype == "bf16" else 4)
+            K, D = a.fanout, a.dim
             bpp = K ** (L - 2) * ((K + 1) * D * 4 + 2 * K * 4) + D * 4 + 4
             if a.hoist == "step":
                 bpp += case.n_entity * (K * D * s_ + 2 * K * 4 + D * s_ + 4 * D * 4) / Bl
@@ -263,38 +367,70 @@ def main():
         kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = (bpp * Bl / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
         value = a.batch * a.steps / elapsed
+        table_bytes = case.n_entity * a.dim * s_
+        cache_resident = table_bytes <= 256 * 2 ** 20        # Infinity Cache (MI355X_MICROARCH.md)
+        kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
+                  "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if used_l2
+                 else "gather_attn_kernel (mvin_gather_attn_fwd)")
+        peak = L2_PEAK_GBS if cache_resident else HBM_PEAK_GBS
+        timed = {"bound": "l2" if cache_resident else "hbm", "kernel": kname, "achieved": achieved, "peak": peak,
+                 "unit": "GB/s", "frac": (achieved / peak) if achieved else None,
+                 "bytes_per_pair": bpp, "pairs_per_launch": Bl, "avg_launch_ms": kern_avg_ms,
+                 "table_bytes": table_bytes, "traffic": traffic,
+                 "hbm_frac_from_traffic": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                 if (traffic and kern_avg_ms) else None,
+                 "whole_path_algorithmic_gbs": value / world * bpp / 1e9,
+                 "faithful_bytes_per_pair": bpp_faithful,
+                 "note": ("launches inside the timed steps; the %.0f MB entity table is L2 / Infinity-Cache resident, so "
+                          "the algorithmic bytes are served on-chip: priced against the %.1f TB/s L2 aggregate, NOT the HBM "
+                          "peak; `traffic` = bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE + "
+                          "WRITE_SIZE, profiles/pmc_latest.json)" % (table_bytes / 1e6, L2_PEAK_GBS / 1e3))
+                 if cache_resident else "launches inside the timed steps; the table is far larger than the Infinity Cache"}
+        roofline = timed
+        if not a.no_hbm_leg and used_l2 and not hoisted and cache_resident and L == 2:
+            # the genuinely HBM-bound measurement of the SAME kernel instance, live, after the timed region
+            leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype)
+            pl = pmc_record("pmc_hbm_leg.json")
+            leg_traffic = None
+            if pl and all(pl.get(k) == v for k, v in (("dim", a.dim), ("fanout", a.fanout), ("table_rows", leg["table_rows"]),
+                                                      ("pairs_per_launch", leg["pairs_per_launch"]),
+                                                      ("table_dtype", a.table_dtype))):
+                leg_traffic = pl["traffic_bytes_per_launch"]
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": leg["achieved"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": leg["achieved"] / HBM_PEAK_GBS, "traffic": leg_traffic,
+                        "bytes_per_pair": leg["bytes_per_pair"], "pairs_per_launch": leg["pairs_per_launch"],
+                        "avg_launch_ms": leg["avg_launch_ms"], "table_bytes": leg["table_bytes"],
+                        "table_rows": leg["table_rows"], "launches": leg["launches"],
+                        "workload": "the timed region's kernel instance (same D, K, dtype, projection + attention on) on a "
+                                    "16 M-row synthetic entity table with uniform adjacency: 16x the Infinity Cache, so "
+                                    "every gathered row comes from HBM; measured after the timed region with HIP events "
+                                    "around each launch; `traffic` = 2*FETCH_SIZE + WRITE_SIZE per launch from "
+                                    "profiles/pmc_hbm_leg.json (rocprofv3 --pmc passes over `bench.py --hbm-leg-only`)",
+                        "timed_region": timed}
         rec = {
             "metric": "(user,item) pairs scored/sec @ dim=%d hop=%d fan-out=%d; %% HBM roofline"
                       % (a.dim, a.hop, a.fanout),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": a.table_dtype, "data": "synthetic",
             "config": {"workload": f"{a.dataset}-shaped tables (nE={case.n_entity}, nU={case.n_user}, "
                                    f"nR={case.n_relation}), dim={a.dim} hop={a.hop} n_mix_hop={a.mix} "
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
-                       "entity_table_dtype": a.table_dtype, "entity_table_mode": a.hoist,
+                       "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
                                        f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"
                                        if rowshard else
                                        (f"pairs split over {world} ranks; tables replicated" if world > 1
                                         else "single-gpu"))},
-            "roofline": {"bound": "hbm", "kernel": ("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
-                                                    "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
-                         else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if used_l2 else "gather_attn_kernel (mvin_gather_attn_fwd)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "traffic_note": "bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE+WRITE_SIZE, "
-                                         "profiles/pmc_latest.json); far below the algorithmic bytes because the 27 MB "
-                                         "table is L2/Infinity-Cache resident" if traffic else None,
-                         "bytes_per_pair": bpp, "pairs_per_launch": Bl,
-                         "avg_launch_ms": kern_avg_ms,
-                         "whole_path_frac": value / world * bpp / 1e9 / HBM_PEAK_GBS,
-                         "faithful_bytes_per_pair": bpp_faithful},
+            "roofline": roofline,
         }
+        if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard:
+            rec["batch_sweep"] = batch_sweep(model, users, items, mh, mr, mt, [int(x) for x in a.sweep.split(",") if x])
         if world == 1 and not a.no_cpu_baseline and a.hoist == "off" and not rowshard and model.hoist_supported():
             # informational only, measured AFTER the timed region on the same inputs: the entity-table mode
             #  has its own bytes per pair and is never `value`

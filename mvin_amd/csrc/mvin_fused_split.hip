@@ -1,0 +1,498 @@
+// Role-split variant of the fused two-level gather + attention kernel (gfx950) for D >= 64.
+//
+// Same arithmetic, arguments and outputs as gather_attn_l2_kernel (mvin_fused.hip; reference
+// model.py:251-305, aggregators.py:98-146) -- what changes is WHO does what inside a workgroup.
+// In the symmetric kernel every wave gathers rows, then multiplies (226 VGPRs: 48 resident weight
+// registers + 32 load registers -> 2 waves per SIMD, and the row loads stop while the wave multiplies).
+// Here a workgroup is NG "gather" waves + NM = D/16 "dense" waves and a software pipeline over the
+// 32-child tiles t of its parents; at step s
+//
+//   gather waves : tile s   : for each child, its K grandchild rows as 16-byte lane loads (one lane
+//                             group per child, 16 loads in flight per lane), S' = (1/K) sum_k p_k E[y_k]
+//                             and the raw child row  -> LDS tile sA[s & 1]
+//   dense waves  : tile s-1 : MFMA phases B and C of mvin_fused.hip on sA[(s-1) & 1] (weights resident
+//                             as B fragments, one 16-column tile per wave), nagg0 / nagg1 in registers
+//                  tile s+1 : its id work -- the children's adjacency rows (issued before the MFMAs,
+//                             consumed after them), softmax over K -> (id, weight) list sYP[(s+1) & 1]
+//                  parent of tile s+2: adjacency row -> child ids + attention weights p0 / p1 (ring of 4)
+//
+// so the row gathers never wait for a multiply or for an id fetch, and neither role carries the other's
+// registers: the kernel fits 128 VGPRs = 4 waves per SIMD (two 8-wave workgroups per CU at D = 64).
+// One workgroup barrier per step; the dense waves order phase B -> phase C among themselves through
+// an LDS counter (the gather waves do not take part).
+//
+// Supported: D in {64, 128}; K in {32, 64, 128}; fp32 or bf16 table.  Everything else stays on
+// gather_attn_l2_kernel.
+#include <cstdlib>
+
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int D, int KT, bool BF, int NG>
+struct SplitGeom {
+    static constexpr int TM = 32;                       // children per tile
+    static constexpr int NT = D / 16;                   // 16-column MFMA tiles = dense waves
+    static constexpr int NM = NT;
+    static constexpr int NW = NG + NM;
+    static constexpr int KS = D / 4;                    // MFMA k-steps per DxD matrix
+    static constexpr int LDA = 2 * D + 2;               // conflict-free A-fragment reads
+    static constexpr int LDZ = D + 2;
+    static constexpr int YLD = KT + 1;                  // (id, weight) row stride: lane groups read different rows
+    static constexpr bool WIDE = BF && D == 128;        // 8 bf16 per lane (16-byte loads)
+    static constexpr int EPL = WIDE ? 8 : 4;
+    static constexpr int LPRX = D / EPL;                // lanes per table row
+    static constexpr int RPWX = 64 / LPRX;              // lane groups (children) per gather wave-round
+    static constexpr int NPW = TM / NG;                 // children per gather wave per tile
+    static constexpr int NTILE = KT / TM;
+    static constexpr int NPL = (KT + 63) / 64;          // parent-row ids per lane (dense wave 0)
+    static constexpr int NCH = TM * KT / 4;             // int4 adjacency chunks per tile
+    static constexpr int CPL = (NCH + NM * 64 - 1) / (NM * 64);   // ... per dense lane
+    static constexpr int LPN = KT / 4;                  // lanes per child adjacency row
+    static constexpr int LPN_L2 = (LPN == 8) ? 3 : (LPN == 16) ? 4 : 5;
+    static_assert(NPW % RPWX == 0, "children per gather wave must be a multiple of its lane groups");
+    static_assert(KT == 32 || KT == 64 || KT == 128, "K");
+};
+
+size_t fused_split_lds_bytes(int D, int K, int nR) {
+    const size_t words = 2 * 32 * (size_t)(2 * D + 2) + 32 * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2;
+    return words * 4 + 2 * 32 * (size_t)(K + 1) * sizeof(int2);
+}
+
+template <int D, int KT, bool BF, int NG>
+__global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_kernel(FusedL2Args a) {
+    using G = SplitGeom<D, KT, BF, NG>;
+    constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nRp = (a.nR + 1) & ~1;
+    float* sA = smem;                                   // [2][TM][LDA]  {E[x1] raw | S'}
+    float* sZ = sA + 2 * TM * LDA;                      // [TM][LDZ]
+    float* sP0 = sZ + TM * LDZ;                         // [4][KT]  ring over parents
+    float* sP1 = sP0 + 4 * KT;                          // [4][KT]
+    float* sT0 = sP1 + 4 * KT;                          // [nRp]
+    float* sT1 = sT0 + nRp;                             // [nRp]
+    int* sX1 = reinterpret_cast<int*>(sT1 + nRp);       // [4][KT]
+    int* sCnt = sX1 + 4 * KT;                           // [2]
+    int2* sYP = reinterpret_cast<int2*>(sCnt + 2);      // [2][TM][YLD]   (even word offset: 8-byte aligned)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool is_dense = wave < NM;
+    const bool has_proj = a.W1 != nullptr;
+    const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
+    const float invK = 1.f / (float)KT;
+    const int64_t nloc = (a.P - blockIdx.x + gridDim.x - 1) / gridDim.x;    // parents of this workgroup
+    const int64_t S = nloc * G::NTILE;                                      // its tiles
+
+    for (int i = tid; i < a.nR; i += G::NW * 64) {
+        sT0[i] = has_att0 ? a.t0[i] : 0.f;
+        sT1[i] = has_att1 ? a.t1[i] : 0.f;
+    }
+    if (tid == 0) sCnt[0] = 0;
+    __syncthreads();
+
+    if (is_dense) {
+        // =====================================================================================
+        // dense waves: MFMA phases for tile s-1, id work for tile s+1 and the parent of tile s+2
+        // =====================================================================================
+        const int q16 = lane >> 4, l16 = lane & 15;
+        const int nt = wave;
+        const int col = 16 * nt + l16;
+        const int mlane = wave * 64 + lane;
+        const float c2scale = has_att0 ? invK : 1.f;    // (sum_k p_k)/K
+        float bW1[KS], bW2[KS], bA0[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kk = 4 * s + q16;
+            bW1[s] = has_proj ? a.W1[kk * D + col] : 0.f;
+            bW2[s] = has_proj ? a.W2[kk * D + col] : 0.f;
+            bA0[s] = a.A0[kk * D + col];
+        }
+        const float a0v = a.a0 ? a.a0[col] : 0.f;
+        const float b1v = (has_proj && a.b1) ? a.b1[col] : 0.f;
+        const float b2v = (has_proj && a.b2) ? a.b2[col] : 0.f;
+
+        auto parent_of = [&](int64_t i) -> int64_t { return blockIdx.x + i * gridDim.x; };
+        // parent adjacency row -> registers (dense wave 0: lane n handles children n, n+64, ...)
+        auto parent_load = [&](int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL]) {
+#pragma unroll
+            for (int i = 0; i < G::NPL; ++i) {
+                const int n = lane + 64 * i;
+                xs[i] = 0;
+                rr[i] = 0;
+                if (n < KT) {
+                    xs[i] = a.adj_e[x0 * KT + n];
+                    if (has_att0 || has_att1) rr[i] = a.adj_r[x0 * KT + n];
+                }
+            }
+        };
+        // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
+        auto parent_store = [&](int64_t pp, const int (&xs)[G::NPL], const int (&rr)[G::NPL], int slot) {
+            float s0[G::NPL], s1[G::NPL];
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < G::NPL; ++i) {
+                const int n = lane + 64 * i;
+                s0[i] = s1[i] = -INFINITY;
+                if (n < KT) {
+                    s0[i] = has_att0 ? sT0[rr[i]] : 0.f;
+                    s1[i] = has_att1 ? sT1[rr[i]] : 0.f;
+                    m0 = fmaxf(m0, s0[i]);
+                    m1 = fmaxf(m1, s1[i]);
+                }
+            }
+            m0 = wave_max(m0);
+            m1 = wave_max(m1);
+            float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::NPL; ++i) {
+                const int n = lane + 64 * i;
+                if (n < KT) {
+                    s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
+                    s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
+                    z0 += s0[i];
+                    z1 += s1[i];
+                }
+            }
+            z0 = wave_sum(z0);
+            z1 = wave_sum(z1);
+#pragma unroll
+            for (int i = 0; i < G::NPL; ++i) {
+                const int n = lane + 64 * i;
+                if (n < KT) {
+                    const float p0 = has_att0 ? s0[i] / z0 : 1.f;
+                    const float p1 = has_att1 ? s1[i] / z1 : 1.f;
+                    sX1[slot * KT + n] = xs[i];
+                    sP0[slot * KT + n] = p0;
+                    sP1[slot * KT + n] = p1;
+                    if (a.probs_parent && has_att0) a.probs_parent[pp * KT + n] = p0;
+                }
+            }
+        };
+        // int4 chunk `it` of the adjacency rows of the children of tile (slot, tile)
+        auto chunk_load = [&](int slot, int tile, int it, int4& ye, int4& re) {
+            const int item = it * (NM * 64) + mlane;
+            ye = make_int4(0, 0, 0, 0);
+            re = make_int4(0, 0, 0, 0);
+            if (item < G::NCH) {
+                const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
+                const int64_t xb = (int64_t)sX1[slot * KT + tile * TM + nl] * KT + 4 * ch;
+                ye = *reinterpret_cast<const int4*>(a.adj_e + xb);
+                if (has_att0) re = *reinterpret_cast<const int4*>(a.adj_r + xb);
+            }
+        };
+        // ... -> softmax over K inside the child's lane group -> (grandchild id, p_k / K) list
+        auto chunk_finish = [&](int64_t p, int tile, int it, int buf, const int4& ye, const int4& re) {
+            const int item = it * (NM * 64) + mlane;
+            const bool valid = item < G::NCH;
+            const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
+            float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f, sc3 = 0.f;
+            if (has_att0 && valid) {
+                sc0 = sT0[re.x];
+                sc1 = sT0[re.y];
+                sc2 = sT0[re.z];
+                sc3 = sT0[re.w];
+            }
+            const float m = group_max(fmaxf(fmaxf(sc0, sc1), fmaxf(sc2, sc3)), G::LPN_L2);
+            float e0 = 1.f, e1 = 1.f, e2 = 1.f, e3 = 1.f;
+            if (has_att0) {
+                e0 = expf(sc0 - m);
+                e1 = expf(sc1 - m);
+                e2 = expf(sc2 - m);
+                e3 = expf(sc3 - m);
+            }
+            const float z = group_sum((e0 + e1) + (e2 + e3), G::LPN_L2);
+            if (valid) {
+                if (has_att0) {
+                    e0 /= z;
+                    e1 /= z;
+                    e2 /= z;
+                    e3 /= z;
+                    if (a.probs_child)
+                        *reinterpret_cast<float4*>(a.probs_child + ((p * KT + tile * TM + nl) * KT + 4 * ch)) =
+                            make_float4(e0, e1, e2, e3);
+                }
+                int2* dst = sYP + ((size_t)buf * TM + nl) * YLD + 4 * ch;
+                dst[0] = make_int2(ye.x, __float_as_int(e0 * invK));
+                dst[1] = make_int2(ye.y, __float_as_int(e1 * invK));
+                dst[2] = make_int2(ye.z, __float_as_int(e2 * invK));
+                dst[3] = make_int2(ye.w, __float_as_int(e3 * invK));
+            }
+        };
+
+        // ---- pipeline fill: parents 0 and 1, id list of tile 0 ----
+        if (wave == 0) {
+            int xs[G::NPL], rr[G::NPL];
+            parent_load(a.parent_ids[parent_of(0)], xs, rr);
+            parent_store(parent_of(0), xs, rr, 0);
+            if (nloc > 1) {
+                parent_load(a.parent_ids[parent_of(1)], xs, rr);
+                parent_store(parent_of(1), xs, rr, 1);
+            }
+        }
+        __syncthreads();
+        {
+            int4 ye[G::CPL], re[G::CPL];
+#pragma unroll
+            for (int it = 0; it < G::CPL; ++it) chunk_load(0, 0, it, ye[it], re[it]);
+#pragma unroll
+            for (int it = 0; it < G::CPL; ++it) chunk_finish(parent_of(0), 0, it, 0, ye[it], re[it]);
+        }
+        __syncthreads();
+
+        float nacc0 = 0.f, nacc1 = 0.f;
+        float c1v = 0.f, c2v = 0.f, c1n = 0.f, c2n = 0.f;
+        int dense_iter = 0;
+        for (int64_t s = 0; s <= S; ++s) {
+            // ---------------- issue this step's id loads (they land under the MFMAs) ----------------
+            const int64_t i2 = (s + 2) / G::NTILE;
+            const bool do_parent = wave == 0 && (s + 2) % G::NTILE == 0 && i2 >= 2 && i2 < nloc;
+            int nxs[G::NPL], nrr[G::NPL];
+            if (do_parent) parent_load(a.parent_ids[parent_of(i2)], nxs, nrr);
+            const bool do_chunk = s + 1 < S;
+            const int64_t i1 = (s + 1) / G::NTILE;
+            const int tile1 = (int)((s + 1) % G::NTILE);
+            int4 ye[G::CPL], re[G::CPL];
+            if (do_chunk) {
+#pragma unroll
+                for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
+            }
+            const bool do_q = has_proj && s < S && s % G::NTILE == 0;
+            float qv[KS];
+            if (do_q) {
+                const float* qb = a.q + (parent_of(s / G::NTILE) / a.parents_per_pair) * D;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) qv[k] = qb[4 * k + q16];
+            }
+            // ---------------- dense phases of tile s-1 ----------------
+            if (s >= 1) {
+                const int64_t td = s - 1;
+                const int64_t id_ = td / G::NTILE;
+                const int tile = (int)(td % G::NTILE);
+                const int slot = (int)(id_ & 3);
+                const float* tA = sA + (td & 1) * TM * LDA;
+                const float* tP0 = sP0 + slot * KT + tile * TM;
+                const float* tP1 = sP1 + slot * KT + tile * TM;
+                if (tile == 0) {
+                    c1v = c1n;
+                    c2v = c2n;
+                    nacc0 = 0.f;
+                    nacc1 = 0.f;
+                }
+                // phase B: self1 = E[x1] W1 + c1 ; Z = self1 + S' W2 + c2 (model.py:277-283 applied after the sum)
+                f32x4 accE[2], accS[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    accE[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    accS[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                if (has_proj) {
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const float* ar = tA + (16 * m + l16) * LDA + 4 * k + q16;
+                            accE[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], bW1[k], accE[m], 0, 0, 0);
+                            accS[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[D], bW2[k], accS[m], 0, 0, 0);
+                        }
+                    }
+                }
+                float part = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * q16 + r;
+                        float s1v, zv;
+                        if (has_proj) {
+                            s1v = accE[m][r] + c1v;
+                            zv = s1v + (accS[m][r] + c2v);
+                        } else {
+                            s1v = tA[row * LDA + col];
+                            zv = s1v + tA[row * LDA + D + col];
+                        }
+                        part = fmaf(tP0[row], s1v, part);
+                        sZ[row * LDZ + col] = zv;
+                    }
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                nacc0 += part;
+                // every dense wave's columns of Z must be in LDS before any of them starts phase C
+                ++dense_iter;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_fetch_add(sCnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(sCnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NM * dense_iter)
+                    __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                // phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1 += sum_n p1[n] out1[n]
+                f32x4 acc2[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const float az = sZ[(16 * m + l16) * LDZ + 4 * k + q16];
+                        acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bA0[k], acc2[m], 0, 0, 0);
+                    }
+                }
+                part = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * m + 4 * q16 + r;
+                        const float o = fmaxf(acc2[m][r] + a0v, 0.f);
+                        part = fmaf(tP1[row], o, part);
+                    }
+                }
+                part += __shfl_xor(part, 16, kWave);
+                part += __shfl_xor(part, 32, kWave);
+                nacc1 += part;
+                if (tile == G::NTILE - 1 && q16 == 0) {
+                    const int64_t p = parent_of(id_);
+                    a.nagg0[p * D + col] = nacc0 * invK;
+                    a.nagg1[p * D + col] = nacc1 * invK;
+                }
+            }
+            // ---------------- finish the id work ----------------
+            if (do_chunk) {
+#pragma unroll
+                for (int it = 0; it < G::CPL; ++it)
+                    chunk_finish(parent_of(i1), tile1, it, (int)((s + 1) & 1), ye[it], re[it]);
+            }
+            if (do_parent) parent_store(parent_of(i2), nxs, nrr, (int)(i2 & 3));
+            if (do_q) {
+                // c_e[col] = q_b . W_e[:, col] + b_e[col]: the W columns are resident as B fragments
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    c1 = fmaf(qv[k], bW1[k], c1);
+                    c2 = fmaf(qv[k], bW2[k], c2);
+                }
+                c1 += __shfl_xor(c1, 16, kWave);
+                c1 += __shfl_xor(c1, 32, kWave);
+                c2 += __shfl_xor(c2, 16, kWave);
+                c2 += __shfl_xor(c2, 32, kWave);
+                c1n = c1 + b1v;
+                c2n = (c2 + b2v) * c2scale;
+            }
+            __syncthreads();
+        }
+    } else {
+        // =====================================================================================
+        // gather waves: tile s -> sA[s & 1]
+        // =====================================================================================
+        const int gw = wave - NM;
+        const int g = lane / G::LPRX, c = lane % G::LPRX;
+        const bool buf32 = !BF && a.table_bytes < (1ull << 32);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
+        const unsigned c16 = (unsigned)c * 16u;
+        auto row4 = [&](int id) -> float4 {
+            if (BF)
+                return bf16x4_to_f32(reinterpret_cast<const uint2*>(
+                    reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
+            if (buf32) {
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+                return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                                   __uint_as_float(raw[3]));
+            }
+            return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
+        };
+        auto load8 = [&](int id, float4& lo, float4& hi) {
+            const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
+            lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
+            hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
+        };
+        auto put = [&](float* dst, float4 lo, float4 hi) {
+            float* q = dst + G::EPL * c;
+            *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
+            *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
+            if constexpr (G::WIDE) {
+                *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
+                *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
+            }
+        };
+        __syncthreads();   // parents 0 / 1 in the ring
+        __syncthreads();   // id list of tile 0
+        for (int64_t s = 0; s <= S; ++s) {
+            if (s < S) {
+                const int slot = (int)((s / G::NTILE) & 3);
+                const int tile = (int)(s % G::NTILE);
+                const int buf = (int)(s & 1);
+#pragma unroll
+                for (int j = 0; j < G::NPW / G::RPWX; ++j) {
+                    const int nl = gw * G::NPW + j * G::RPWX + g;
+                    const int2* yp = sYP + ((size_t)buf * TM + nl) * YLD;
+                    float* arow = sA + ((size_t)buf * TM + nl) * LDA;
+                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
+                    float4 sv, sv1 = acc;
+                    if constexpr (G::WIDE) {
+#pragma unroll 8
+                        for (int k = 0; k < KT; ++k) {
+                            const int2 e = yp[k];
+                            float4 lo, hi;
+                            load8(e.x, lo, hi);
+                            acc = f4_fma(__int_as_float(e.y), lo, acc);
+                            acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
+                        }
+                        load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
+                    } else {
+#pragma unroll 16
+                        for (int k = 0; k < KT; ++k) {
+                            const int2 e = yp[k];
+                            acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                        }
+                        sv = row4(sX1[slot * KT + tile * TM + nl]);
+                    }
+                    put(arow, sv, sv1);
+                    put(arow + D, acc, acc1);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int D, int KT, bool BF, int NG>
+static hipError_t launch_split(const FusedL2Args& a, hipStream_t st) {
+    using G = SplitGeom<D, KT, BF, NG>;
+    const size_t lds = fused_split_lds_bytes(D, KT, a.nR);
+    auto kern = gather_attn_l2_split_kernel<D, KT, BF, NG>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const int per_cu = (G::NW * 64 <= 512 && 2 * lds <= 160 * 1024) ? 2 : 1;
+    const int64_t cap = 256 * per_cu;                   // persistent: one pipeline per resident workgroup
+    const int grid = (int)(a.P < cap ? a.P : cap);
+    kern<<<grid, G::NW * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+bool fused_split_supported(int D, int K) {
+    return (D == 64 || D == 128) && (K == 32 || K == 64 || K == 128);
+}
+
+template <int D, bool BF, int NG>
+static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
+    switch (a.K) {
+        case 32: return launch_split<D, 32, BF, NG>(a, st);
+        case 64: return launch_split<D, 64, BF, NG>(a, st);
+        case 128: return launch_split<D, 128, BF, NG>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
+    if (D == 64) return table_bf16 ? launch_split_k<64, true, 4>(a, st) : launch_split_k<64, false, 4>(a, st);
+    if (D == 128) return table_bf16 ? launch_split_k<128, true, 8>(a, st) : launch_split_k<128, false, 8>(a, st);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mvin

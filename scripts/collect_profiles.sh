@@ -1,9 +1,13 @@
 #!/bin/bash
-# Run ON the GPU box (via gpurun): rocprofv3 evidence for the default bench.py workload.
-#   1. kernel trace + stats           -> gpurun_out/prof_<tag>/stats
-#   2. PMC passes, one counter each   -> gpurun_out/prof_<tag>/pmc_<COUNTER>   (never combined with
-#      sys/hip/hsa traces; FETCH_SIZE and WRITE_SIZE per MI355X_MICROARCH.md's HBM recipe)
-#   3. scripts/summarize_pmc.py       -> gpurun_out/prof_<tag>/pmc.json
+# Run ON the GPU box (via gpurun): rocprofv3 evidence for the bench.py numbers.
+#   A. the metric workload (timed region of the default bench.py; --no-hbm-leg --no-sweep so that the
+#      kernel-name averages describe ONE regime):
+#        kernel trace + stats        -> gpurun_out/prof_<tag>/stats
+#        PMC passes, one counter each-> gpurun_out/prof_<tag>/pmc_<COUNTER>  (never combined with
+#        sys/hip/hsa traces; FETCH_SIZE and WRITE_SIZE per MI355X_MICROARCH.md's HBM recipe)
+#   B. the HBM-bound leg of the dominant kernel (`bench.py --hbm-leg-only`: 4 GB table), same passes
+#        -> gpurun_out/prof_<tag>/hbm_stats, hbm_pmc_<COUNTER>
+#   C. scripts/summarize_pmc.py      -> pmc.json (A) and pmc_hbm_leg.json (B)
 # usage: scripts/collect_profiles.sh <tag> [bench.py args...]
 set -u
 tag=${1:-latest}; shift || true
@@ -11,14 +15,22 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-bargs="--steps 5 --warmup 1 --no-cpu-baseline $*"
+bargs="--steps 5 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-sweep $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" $bargs > "$out/bench_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" $bargs > "$out/bench_pmc_$c.log" 2>&1
 done
+hargs="--hbm-leg-only --steps 10 --warmup 3 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hbm_stats" -- python "$root/bench.py" $hargs > "$out/bench_hbm_stats.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/hbm_pmc_$c" -- python "$root/bench.py" $hargs > "$out/bench_hbm_pmc_$c.log" 2>&1
+done
 cd "$root"
 python scripts/summarize_pmc.py "$out" $bargs
-f=$(ls "$out"/stats/*/*kernel_stats.csv | head -1)
-cp "$f" "$out/kernel_stats.csv"
+python scripts/summarize_pmc.py --hbm-leg "$out" $hargs
+f=$(ls "$out"/stats/*/*kernel_stats.csv | head -1); cp "$f" "$out/kernel_stats.csv"
+f=$(ls "$out"/hbm_stats/*/*kernel_stats.csv | head -1); cp "$f" "$out/hbm_leg_kernel_stats.csv"
 grep '^{' "$out/bench_stats.log" | tail -1 > "$out/bench.json"
-head -12 "$out/kernel_stats.csv" | cut -c1-160
+grep '^{' "$out/bench_hbm_stats.log" | tail -1 > "$out/hbm_leg_bench.json"
+head -8 "$out/kernel_stats.csv" | cut -c1-160
+head -4 "$out/hbm_leg_kernel_stats.csv" | cut -c1-160

@@ -13,6 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
+    hbm = "--hbm-leg" in sys.argv
+    if hbm:
+        sys.argv.remove("--hbm-leg")
     out = sys.argv[1]
     saved = sys.argv
     sys.argv = ["bench.py"] + saved[2:]
@@ -20,8 +23,9 @@ def main():
     a = bench.parse()
     sys.argv = saved
     kernels = {}
+    prefix = "hbm_pmc_" if hbm else "pmc_"
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        for path in glob.glob(os.path.join(out, f"pmc_{c}", "*", "*counter_collection.csv")):
+        for path in glob.glob(os.path.join(out, f"{prefix}{c}", "*", "*counter_collection.csv")):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     if row["Counter_Name"] != c:
@@ -37,6 +41,23 @@ def main():
             v = v[len(v) // 6:] if len(v) > 6 else v     # drop the warm-up launches' share
             summ[name][c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
     fused = [k for k in summ if "gather_attn_l2_kernel" in k]
+    if hbm:
+        k = summ[fused[0]]
+        rec = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py "
+                          + " ".join(saved[2:]) + " (separate passes: FETCH_SIZE, WRITE_SIZE)",
+               "dim": a.dim, "fanout": a.fanout, "table_dtype": a.table_dtype, "table_rows": bench.HBM_LEG_ROWS,
+               "pairs_per_launch": bench.HBM_LEG_PAIRS,
+               "algorithmic_bytes_per_launch": bench.algorithmic_bytes_per_pair(
+                   a.dim, a.fanout, 2, 2 if a.table_dtype == "bf16" else 4) * bench.HBM_LEG_PAIRS,
+               "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950 correction: read bytes = 2*FETCH_SIZE*1024 "
+                        "(MI355X_MICROARCH.md, HBM section)",
+               "kernel": fused[0], "counters": k,
+               "traffic_bytes_per_launch": (2 * k["FETCH_SIZE"]["mean_per_launch"]
+                                            + k["WRITE_SIZE"]["mean_per_launch"]) * 1024}
+        with open(os.path.join(out, "pmc_hbm_leg.json"), "w") as f:
+            json.dump(rec, f, indent=1)
+        print(json.dumps({k: rec[k] for k in ("traffic_bytes_per_launch", "algorithmic_bytes_per_launch")}))
+        return
     rec = {
         "command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py "
                    + " ".join(saved[2:]) + " (separate passes: FETCH_SIZE, WRITE_SIZE; scripts/collect_profiles.sh)",
