@@ -24,6 +24,7 @@
 // Supported: D in {64, 128}; K in {32, 64, 128}; fp32 or bf16 table.  Everything else stays on
 // gather_attn_l2_kernel.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mvin_kernels.h"
 
@@ -31,6 +32,9 @@ namespace mvin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// waves per SIMD the register budget is cut for: two 8-wave workgroups per CU (128 VGPRs), or one of 12 (168)
+constexpr int split_minw(int D, int NG) { return ((NG + D / 16) * 64 <= 512) ? 4 : 3; }
 
 template <int D, int KT, bool BF, int NG>
 struct SplitGeom {
@@ -53,17 +57,19 @@ struct SplitGeom {
     static constexpr int CPL = (NCH + NM * 64 - 1) / (NM * 64);   // ... per dense lane
     static constexpr int LPN = KT / 4;                  // lanes per child adjacency row
     static constexpr int LPN_L2 = (LPN == 8) ? 3 : (LPN == 16) ? 4 : 5;
+    static constexpr int MINW = split_minw(D, NG);
     static_assert(NPW % RPWX == 0, "children per gather wave must be a multiple of its lane groups");
     static_assert(KT == 32 || KT == 64 || KT == 128, "K");
 };
 
 size_t fused_split_lds_bytes(int D, int K, int nR) {
-    const size_t words = 2 * 32 * (size_t)(2 * D + 2) + 32 * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2;
+    const size_t words = 2 * 32 * (size_t)(2 * D + 2) + 32 * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2
+                         + 4 * (size_t)D;
     return words * 4 + 2 * 32 * (size_t)(K + 1) * sizeof(int2);
 }
 
-template <int D, int KT, bool BF, int NG>
-__global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_kernel(FusedL2Args a) {
+template <int D, int KT, bool BF, int NG, int UNR>
+__global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_attn_l2_split_kernel(FusedL2Args a) {
     using G = SplitGeom<D, KT, BF, NG>;
     constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -76,7 +82,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
     float* sT1 = sT0 + nRp;                             // [nRp]
     int* sX1 = reinterpret_cast<int*>(sT1 + nRp);       // [4][KT]
     int* sCnt = sX1 + 4 * KT;                           // [2]
-    int2* sYP = reinterpret_cast<int2*>(sCnt + 2);      // [2][TM][YLD]   (even word offset: 8-byte aligned)
+    float* sQ = reinterpret_cast<float*>(sCnt + 2);     // [4][D]  query vector of the parent's pair (ring)
+    int2* sYP = reinterpret_cast<int2*>(sQ + 4 * D);    // [2][TM][YLD]   (even word offset: 8-byte aligned)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -117,7 +124,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
 
         auto parent_of = [&](int64_t i) -> int64_t { return blockIdx.x + i * gridDim.x; };
         // parent adjacency row -> registers (dense wave 0: lane n handles children n, n+64, ...)
-        auto parent_load = [&](int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL]) {
+        auto parent_load = [&](int64_t pp, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[D / 64]) {
+            const int64_t x0 = a.parent_ids[pp];
+            if (has_proj) {
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i) qr[i] = a.q[(pp / a.parents_per_pair) * D + lane + 64 * i];
+            }
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
                 const int n = lane + 64 * i;
@@ -130,7 +142,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
             }
         };
         // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
-        auto parent_store = [&](int64_t pp, const int (&xs)[G::NPL], const int (&rr)[G::NPL], int slot) {
+        auto parent_store = [&](int64_t pp, const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[D / 64],
+                                int slot) {
+            if (has_proj) {
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i) sQ[slot * D + lane + 64 * i] = qr[i];
+            }
             float s0[G::NPL], s1[G::NPL];
             float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
@@ -226,11 +243,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
         // ---- pipeline fill: parents 0 and 1, id list of tile 0 ----
         if (wave == 0) {
             int xs[G::NPL], rr[G::NPL];
-            parent_load(a.parent_ids[parent_of(0)], xs, rr);
-            parent_store(parent_of(0), xs, rr, 0);
+            float qr[D / 64];
+            parent_load(parent_of(0), xs, rr, qr);
+            parent_store(parent_of(0), xs, rr, qr, 0);
             if (nloc > 1) {
-                parent_load(a.parent_ids[parent_of(1)], xs, rr);
-                parent_store(parent_of(1), xs, rr, 1);
+                parent_load(parent_of(1), xs, rr, qr);
+                parent_store(parent_of(1), xs, rr, qr, 1);
             }
         }
         __syncthreads();
@@ -244,28 +262,22 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
         __syncthreads();
 
         float nacc0 = 0.f, nacc1 = 0.f;
-        float c1v = 0.f, c2v = 0.f, c1n = 0.f, c2n = 0.f;
+        float c1v = 0.f, c2v = 0.f;
         int dense_iter = 0;
         for (int64_t s = 0; s <= S; ++s) {
             // ---------------- issue this step's id loads (they land under the MFMAs) ----------------
             const int64_t i2 = (s + 2) / G::NTILE;
             const bool do_parent = wave == 0 && (s + 2) % G::NTILE == 0 && i2 >= 2 && i2 < nloc;
             int nxs[G::NPL], nrr[G::NPL];
-            if (do_parent) parent_load(a.parent_ids[parent_of(i2)], nxs, nrr);
+            float nq[D / 64];
+            if (do_parent) parent_load(parent_of(i2), nxs, nrr, nq);
             const bool do_chunk = s + 1 < S;
             const int64_t i1 = (s + 1) / G::NTILE;
             const int tile1 = (int)((s + 1) % G::NTILE);
             int4 ye[G::CPL], re[G::CPL];
-            if (do_chunk) {
+            if (do_chunk && s == 0) {   // no dense work in step 0: issue right away
 #pragma unroll
                 for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
-            }
-            const bool do_q = has_proj && s < S && s % G::NTILE == 0;
-            float qv[KS];
-            if (do_q) {
-                const float* qb = a.q + (parent_of(s / G::NTILE) / a.parents_per_pair) * D;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) qv[k] = qb[4 * k + q16];
             }
             // ---------------- dense phases of tile s-1 ----------------
             if (s >= 1) {
@@ -277,10 +289,25 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
                 const float* tP0 = sP0 + slot * KT + tile * TM;
                 const float* tP1 = sP1 + slot * KT + tile * TM;
                 if (tile == 0) {
-                    c1v = c1n;
-                    c2v = c2n;
                     nacc0 = 0.f;
                     nacc1 = 0.f;
+                    if (has_proj) {
+                        // c_e[col] = q_b . W_e[:, col] + b_e[col] (model.py:277-279 on the broadcast query): the W
+                        // columns are resident as B fragments, q_b sits in the parent ring
+                        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) {
+                            const float qv = sQ[slot * D + 4 * k + q16];
+                            c1 = fmaf(qv, bW1[k], c1);
+                            c2 = fmaf(qv, bW2[k], c2);
+                        }
+                        c1 += __shfl_xor(c1, 16, kWave);
+                        c1 += __shfl_xor(c1, 32, kWave);
+                        c2 += __shfl_xor(c2, 16, kWave);
+                        c2 += __shfl_xor(c2, 32, kWave);
+                        c1v = c1 + b1v;
+                        c2v = (c2 + b2v) * c2scale;
+                    }
                 }
                 // phase B: self1 = E[x1] W1 + c1 ; Z = self1 + S' W2 + c2 (model.py:277-283 applied after the sum)
                 f32x4 accE[2], accS[2];
@@ -321,6 +348,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
                 part += __shfl_xor(part, 16, kWave);
                 part += __shfl_xor(part, 32, kWave);
                 nacc0 += part;
+                // the next tile's adjacency chunks are issued between the phases: their registers are live
+                // only while phase C's 8 accumulators are (phase B holds 16), and they land under its MFMAs
+                if (do_chunk) {
+#pragma unroll
+                    for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
+                }
                 // every dense wave's columns of Z must be in LDS before any of them starts phase C
                 ++dense_iter;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -365,22 +398,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
                 for (int it = 0; it < G::CPL; ++it)
                     chunk_finish(parent_of(i1), tile1, it, (int)((s + 1) & 1), ye[it], re[it]);
             }
-            if (do_parent) parent_store(parent_of(i2), nxs, nrr, (int)(i2 & 3));
-            if (do_q) {
-                // c_e[col] = q_b . W_e[:, col] + b_e[col]: the W columns are resident as B fragments
-                float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    c1 = fmaf(qv[k], bW1[k], c1);
-                    c2 = fmaf(qv[k], bW2[k], c2);
-                }
-                c1 += __shfl_xor(c1, 16, kWave);
-                c1 += __shfl_xor(c1, 32, kWave);
-                c2 += __shfl_xor(c2, 16, kWave);
-                c2 += __shfl_xor(c2, 32, kWave);
-                c1n = c1 + b1v;
-                c2n = (c2 + b2v) * c2scale;
-            }
+            if (do_parent) parent_store(parent_of(i2), nxs, nrr, nq, (int)(i2 & 3));
             __syncthreads();
         }
     } else {
@@ -393,82 +411,94 @@ __global__ __launch_bounds__((NG + D / 16) * 64, 4) void gather_attn_l2_split_ke
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
         const unsigned c16 = (unsigned)c * 16u;
-        auto row4 = [&](int id) -> float4 {
-            if (BF)
-                return bf16x4_to_f32(reinterpret_cast<const uint2*>(
-                    reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
-            if (buf32) {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
-                return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
-                                   __uint_as_float(raw[3]));
-            }
-            return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
-        };
-        auto load8 = [&](int id, float4& lo, float4& hi) {
-            const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
-            lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
-            hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
-        };
-        auto put = [&](float* dst, float4 lo, float4 hi) {
-            float* q = dst + G::EPL * c;
-            *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
-            *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
-            if constexpr (G::WIDE) {
-                *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
-                *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
+        // addressing mode resolved OUTSIDE the loops (a per-load wave-uniform branch keeps every load in its
+        // own basic block): 0 = bf16 rows, 1 = fp32 through the buffer descriptor, 2 = fp32, 64-bit addresses
+        auto run = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            auto row4 = [&](int id) -> float4 {
+                if constexpr (MODE == 0) {
+                    return bf16x4_to_f32(reinterpret_cast<const uint2*>(
+                        reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
+                } else if constexpr (MODE == 1) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+                    return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                                       __uint_as_float(raw[3]));
+                } else {
+                    return reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.table) + (int64_t)id * D)[c];
+                }
+            };
+            auto load8 = [&](int id, float4& lo, float4& hi) {
+                const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
+                lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
+                hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
+            };
+            auto put = [&](float* dst, float4 lo, float4 hi) {
+                float* q = dst + G::EPL * c;
+                *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
+                *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
+                if constexpr (G::WIDE) {
+                    *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
+                    *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
+                }
+            };
+            for (int64_t s = 0; s <= S; ++s) {
+                if (s < S) {
+                    const int slot = (int)((s / G::NTILE) & 3);
+                    const int tile = (int)(s % G::NTILE);
+                    const int buf = (int)(s & 1);
+#pragma unroll
+                    for (int j = 0; j < G::NPW / G::RPWX; ++j) {
+                        const int nl = gw * G::NPW + j * G::RPWX + g;
+                        const int2* yp = sYP + ((size_t)buf * TM + nl) * YLD;
+                        float* arow = sA + ((size_t)buf * TM + nl) * LDA;
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
+                        float4 sv, sv1 = acc;
+                        if constexpr (G::WIDE) {
+#pragma unroll 8
+                            for (int k = 0; k < KT; ++k) {
+                                const int2 e = yp[k];
+                                float4 lo, hi;
+                                load8(e.x, lo, hi);
+                                acc = f4_fma(__int_as_float(e.y), lo, acc);
+                                acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
+                            }
+                            load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
+                        } else {
+#pragma unroll UNR
+                            for (int k = 0; k < KT; ++k) {
+                                const int2 e = yp[k];
+                                acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
+                            }
+                            sv = row4(sX1[slot * KT + tile * TM + nl]);
+                        }
+                        put(arow, sv, sv1);
+                        put(arow + D, acc, acc1);
+                    }
+                }
+                __syncthreads();
             }
         };
         __syncthreads();   // parents 0 / 1 in the ring
         __syncthreads();   // id list of tile 0
-        for (int64_t s = 0; s <= S; ++s) {
-            if (s < S) {
-                const int slot = (int)((s / G::NTILE) & 3);
-                const int tile = (int)(s % G::NTILE);
-                const int buf = (int)(s & 1);
-#pragma unroll
-                for (int j = 0; j < G::NPW / G::RPWX; ++j) {
-                    const int nl = gw * G::NPW + j * G::RPWX + g;
-                    const int2* yp = sYP + ((size_t)buf * TM + nl) * YLD;
-                    float* arow = sA + ((size_t)buf * TM + nl) * LDA;
-                    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
-                    float4 sv, sv1 = acc;
-                    if constexpr (G::WIDE) {
-#pragma unroll 8
-                        for (int k = 0; k < KT; ++k) {
-                            const int2 e = yp[k];
-                            float4 lo, hi;
-                            load8(e.x, lo, hi);
-                            acc = f4_fma(__int_as_float(e.y), lo, acc);
-                            acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
-                        }
-                        load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
-                    } else {
-#pragma unroll 16
-                        for (int k = 0; k < KT; ++k) {
-                            const int2 e = yp[k];
-                            acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
-                        }
-                        sv = row4(sX1[slot * KT + tile * TM + nl]);
-                    }
-                    put(arow, sv, sv1);
-                    put(arow + D, acc, acc1);
-                }
-            }
-            __syncthreads();
+        if constexpr (BF) {
+            run(std::integral_constant<int, 0>{});
+        } else {
+            if (buf32) run(std::integral_constant<int, 1>{});
+            else run(std::integral_constant<int, 2>{});
         }
     }
 }
 
-template <int D, int KT, bool BF, int NG>
+template <int D, int KT, bool BF, int NG, int UNR = 16>
 static hipError_t launch_split(const FusedL2Args& a, hipStream_t st) {
     using G = SplitGeom<D, KT, BF, NG>;
     const size_t lds = fused_split_lds_bytes(D, KT, a.nR);
-    auto kern = gather_attn_l2_split_kernel<D, KT, BF, NG>;
+    auto kern = gather_attn_l2_split_kernel<D, KT, BF, NG, UNR>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int per_cu = (G::NW * 64 <= 512 && 2 * lds <= 160 * 1024) ? 2 : 1;
+    const int per_cu = (G::MINW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
     const int64_t cap = 256 * per_cu;                   // persistent: one pipeline per resident workgroup
     const int grid = (int)(a.P < cap ? a.P : cap);
     kern<<<grid, G::NW * 64, lds, st>>>(a);
@@ -482,7 +512,13 @@ bool fused_split_supported(int D, int K) {
 template <int D, bool BF, int NG>
 static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
     switch (a.K) {
-        case 32: return launch_split<D, 32, BF, NG>(a, st);
+        case 32: {
+            // experiment knob: rows in flight per lane in the gather loop (default 16)
+            static const char* u = getenv("MVIN_SPLIT_UNR");
+            if (u && atoi(u) == 8) return launch_split<D, 32, BF, NG, 8>(a, st);
+            if (u && atoi(u) == 32) return launch_split<D, 32, BF, NG, 32>(a, st);
+            return launch_split<D, 32, BF, NG>(a, st);
+        }
         case 64: return launch_split<D, 64, BF, NG>(a, st);
         case 128: return launch_split<D, 128, BF, NG>(a, st);
         default: return hipErrorInvalidValue;
@@ -491,7 +527,7 @@ static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
 
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
     if (D == 64) return table_bf16 ? launch_split_k<64, true, 4>(a, st) : launch_split_k<64, false, 4>(a, st);
-    if (D == 128) return table_bf16 ? launch_split_k<128, true, 8>(a, st) : launch_split_k<128, false, 8>(a, st);
+    if (D == 128) return table_bf16 ? launch_split_k<128, true, 4>(a, st) : launch_split_k<128, false, 4>(a, st);
     return hipErrorInvalidValue;
 }
 

@@ -196,5 +196,7 @@ hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, h
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
+bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)
+hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 
 }  // namespace mvin
