@@ -38,6 +38,11 @@ extern "C" {
 int mvin_abi_version(void);
 const char* mvin_last_error(void);
 
+/* Development aid, not part of the reference-facing path: with MVIN_SPLIT_DBG=4 in the environment workgroup 0
+ * of the role-split fused kernel stamps s_memtime at its phase boundaries; this copies the stamps
+ * ([2 roles][64 steps][8 slots] int64) to `host_dst` (synchronous).  scripts/trace_split.py prints them. */
+int mvin_debug_read_trace(long long* host_dst, size_t n);
+
 /* Number of int32 elements of the flattened id lists mvin_expand_ids writes:
  * entities levels 0..levels (B * sum_{e<=levels} K^e) and relations levels 0..levels-1
  * (B * sum_{1<=e<=levels} K^e).  Level e of `ent_out` starts at B*sum_{i<e}K^i and is

@@ -1,5 +1,6 @@
 // extern "C" boundary of libmvin_hip.so (see include/mvin_hip.h).  Argument validation,
 // per-thread error string, kernel launches.  No allocation, no synchronisation, no state.
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -42,6 +43,11 @@ size_t geom_sum(int B, int K, int from, int to) {  // B * sum_{e=from..to} K^e
 extern "C" {
 
 int mvin_abi_version(void) { return MVIN_ABI_VERSION; }
+
+int mvin_debug_read_trace(long long* host_dst, size_t n) {
+    if (!host_dst) return -1;
+    return (int)mvin::split_read_trace(host_dst, n);
+}
 
 const char* mvin_last_error(void) { return g_last_error.c_str(); }
 
@@ -183,12 +189,17 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
     f.probs_child = probs_child;
     f.P = (int64_t)B * parents_per_pair;
     f.table_bytes = (uint64_t)n_entity * (uint64_t)D * (table_bf16 ? 2 : 4);
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
     f.parents_per_pair = parents_per_pair;
     f.K = K;
     f.nR = nR;
     int l = 0;
     while ((4 << l) < K) ++l;
     f.lpn_log2 = l;
+    {
+        static const char* dbg = getenv("MVIN_SPLIT_DBG");
+        f.dbg = dbg ? atoi(dbg) : 0;
+    }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
 }
 

@@ -602,7 +602,7 @@ hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hi
     // MVIN_L2_SPLIT=0 keeps the symmetric kernel below for A/B measurements
     static const char* split_env = getenv("MVIN_L2_SPLIT");
     static const bool use_split = !(split_env && split_env[0] == '0');
-    if (use_split && fused_split_supported(D, a.K)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
+    if (use_split && fused_split_applies(a, D)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
     static const bool no_small = getenv("MVIN_L2_NOSMALL") != nullptr;
     const bool small = a.K <= 16 && !no_small;
     if (table_bf16) {

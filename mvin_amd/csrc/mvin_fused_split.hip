@@ -33,6 +33,11 @@ namespace mvin {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Development aid (FusedL2Args::dbg & 4, env MVIN_SPLIT_DBG): workgroup 0 stamps s_memtime at the phase
+// boundaries of its first steps; read back with mvin_debug_read_trace (scripts/trace_split.py).
+constexpr int kTraceSteps = 64, kTraceSlots = 8;
+__device__ long long g_split_trace[2 * kTraceSteps * kTraceSlots];
+
 // waves per SIMD the register budget is cut for: two 8-wave workgroups per CU (128 VGPRs), or one of 12 (168)
 constexpr int split_minw(int D, int NG) { return ((NG + D / 16) * 64 <= 512) ? 4 : 3; }
 
@@ -64,11 +69,11 @@ struct SplitGeom {
 
 size_t fused_split_lds_bytes(int D, int K, int nR) {
     const size_t words = 2 * 32 * (size_t)(2 * D + 2) + 32 * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2
-                         + 4 * (size_t)D;
+                         + 4 * (size_t)D + 4 * (size_t)D;
     return words * 4 + 2 * 32 * (size_t)(K + 1) * sizeof(int2);
 }
 
-template <int D, int KT, bool BF, int NG, int UNR>
+template <int D, int KT, bool BF, int NG, int UNR, bool TRACE>
 __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_attn_l2_split_kernel(FusedL2Args a) {
     using G = SplitGeom<D, KT, BF, NG>;
     constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
@@ -83,7 +88,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
     int* sX1 = reinterpret_cast<int*>(sT1 + nRp);       // [4][KT]
     int* sCnt = sX1 + 4 * KT;                           // [2]
     float* sQ = reinterpret_cast<float*>(sCnt + 2);     // [4][D]  query vector of the parent's pair (ring)
-    int2* sYP = reinterpret_cast<int2*>(sQ + 4 * D);    // [2][TM][YLD]   (even word offset: 8-byte aligned)
+    float* sBias = sQ + 4 * D;                          // [3][D]  a0 | b1 | b2 (LDS, not registers: a spilled
+                                                        //         register's reload would wait for every id load)
+    int2* sYP = reinterpret_cast<int2*>(sBias + 4 * D); // [2][TM][YLD]   (even word offset: 8-byte aligned)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -93,12 +100,24 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
     const float invK = 1.f / (float)KT;
     const int64_t nloc = (a.P - blockIdx.x + gridDim.x - 1) / gridDim.x;    // parents of this workgroup
     const int64_t S = nloc * G::NTILE;                                      // its tiles
+    auto stamp = [&](int64_t s, int slot) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NM) && s >= 8 && s < 8 + kTraceSteps)
+                g_split_trace[((wave == 0 ? 0 : 1) * kTraceSteps + (s - 8)) * kTraceSlots + slot] = __builtin_readcyclecounter();
+        }
+    };
+    const int dbg = TRACE ? a.dbg : 0;                  // the skip-work knobs exist in the traced build only
 
     for (int i = tid; i < a.nR; i += G::NW * 64) {
         sT0[i] = has_att0 ? a.t0[i] : 0.f;
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
     if (tid == 0) sCnt[0] = 0;
+    for (int i = tid; i < D; i += G::NW * 64) {
+        sBias[i] = a.a0 ? a.a0[i] : 0.f;
+        sBias[D + i] = (has_proj && a.b1) ? a.b1[i] : 0.f;
+        sBias[2 * D + i] = (has_proj && a.b2) ? a.b2[i] : 0.f;
+    }
     __syncthreads();
 
     if (is_dense) {
@@ -118,33 +137,46 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
             bW2[s] = has_proj ? a.W2[kk * D + col] : 0.f;
             bA0[s] = a.A0[kk * D + col];
         }
-        const float a0v = a.a0 ? a.a0[col] : 0.f;
-        const float b1v = (has_proj && a.b1) ? a.b1[col] : 0.f;
-        const float b2v = (has_proj && a.b2) ? a.b2[col] : 0.f;
 
         auto parent_of = [&](int64_t i) -> int64_t { return blockIdx.x + i * gridDim.x; };
+        // adjacency rows and the two output rows through buffer descriptors: 32-bit per-lane offsets instead of
+        // loop-invariant 64-bit per-lane pointers (those were what the register allocator spilled, and a spill
+        // reload's vmcnt(0) waits for every id load in flight).  The launcher guarantees both are < 4 GiB.
+        const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(a.adj_r), 0, (int)a.adj_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t out0 = __builtin_amdgcn_make_buffer_rsrc(a.nagg0, 0, (int)(a.P * D * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t out1 = __builtin_amdgcn_make_buffer_rsrc(a.nagg1, 0, (int)(a.P * D * 4), 0x00020000);
         // parent adjacency row -> registers (dense wave 0: lane n handles children n, n+64, ...)
-        auto parent_load = [&](int64_t pp, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[D / 64]) {
-            const int64_t x0 = a.parent_ids[pp];
-            if (has_proj) {
+        const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.q), 0, (int)((a.P / a.parents_per_pair) * D * 4), 0x00020000);
+        auto parent_load = [&](int64_t pp, int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[D / 64]) {
+            // adjacency row first: x0 was fetched a step ago, and the wait for it must not cover younger loads
 #pragma unroll
-                for (int i = 0; i < D / 64; ++i) qr[i] = a.q[(pp / a.parents_per_pair) * D + lane + 64 * i];
-            }
+            for (int i = 0; i < D / 64; ++i) qr[i] = 0.f;
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
                 const int n = lane + 64 * i;
                 xs[i] = 0;
                 rr[i] = 0;
                 if (n < KT) {
-                    xs[i] = a.adj_e[x0 * KT + n];
-                    if (has_att0 || has_att1) rr[i] = a.adj_r[x0 * KT + n];
+                    const unsigned off = ((unsigned)x0 * KT + n) * 4u;
+                    xs[i] = __builtin_amdgcn_raw_buffer_load_b32(adjE, off, 0, 0);
+                    if (has_att0 || has_att1) rr[i] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
                 }
+            }
+            if (has_proj) {
+                const unsigned qoff = ((unsigned)pp / (unsigned)a.parents_per_pair) * (unsigned)D;
+#pragma unroll
+                for (int i = 0; i < D / 64; ++i)
+                    qr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(qsrc, (qoff + lane + 64 * i) * 4u, 0, 0));
             }
         };
         // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
-        auto parent_store = [&](int64_t pp, const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[D / 64],
-                                int slot) {
-            if (has_proj) {
+        auto parent_store = [&](const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[D / 64], int slot,
+                                bool commit) {
+            if (has_proj && commit) {
 #pragma unroll
                 for (int i = 0; i < D / 64; ++i) sQ[slot * D + lane + 64 * i] = qr[i];
             }
@@ -161,8 +193,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                     m1 = fmaxf(m1, s1[i]);
                 }
             }
-            m0 = wave_max(m0);
-            m1 = wave_max(m1);
+            constexpr int PL2 = (KT >= 64) ? 6 : 5;     // lanes holding children: 64 (KT >= 64) or 32
+            m0 = group_max(m0, PL2);
+            m1 = group_max(m1, PL2);
             float z0 = 0.f, z1 = 0.f;
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
@@ -174,18 +207,17 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                     z1 += s1[i];
                 }
             }
-            z0 = wave_sum(z0);
-            z1 = wave_sum(z1);
+            z0 = group_sum(z0, PL2);
+            z1 = group_sum(z1, PL2);
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
                 const int n = lane + 64 * i;
-                if (n < KT) {
+                if (n < KT && commit) {
                     const float p0 = has_att0 ? s0[i] / z0 : 1.f;
                     const float p1 = has_att1 ? s1[i] / z1 : 1.f;
                     sX1[slot * KT + n] = xs[i];
                     sP0[slot * KT + n] = p0;
                     sP1[slot * KT + n] = p1;
-                    if (a.probs_parent && has_att0) a.probs_parent[pp * KT + n] = p0;
                 }
             }
         };
@@ -196,13 +228,17 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
             re = make_int4(0, 0, 0, 0);
             if (item < G::NCH) {
                 const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
-                const int64_t xb = (int64_t)sX1[slot * KT + tile * TM + nl] * KT + 4 * ch;
-                ye = *reinterpret_cast<const int4*>(a.adj_e + xb);
-                if (has_att0) re = *reinterpret_cast<const int4*>(a.adj_r + xb);
+                const unsigned off = ((unsigned)sX1[slot * KT + tile * TM + nl] * KT + 4 * ch) * 4u;
+                const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, off, 0, 0);
+                ye = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
+                if (has_att0) {
+                    const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, off, 0, 0);
+                    re = make_int4((int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3]);
+                }
             }
         };
         // ... -> softmax over K inside the child's lane group -> (grandchild id, p_k / K) list
-        auto chunk_finish = [&](int64_t p, int tile, int it, int buf, const int4& ye, const int4& re) {
+        auto chunk_finish = [&](int tile, int it, int buf, const int4& ye, const int4& re) {
             const int item = it * (NM * 64) + mlane;
             const bool valid = item < G::NCH;
             const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
@@ -228,9 +264,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                     e1 /= z;
                     e2 /= z;
                     e3 /= z;
-                    if (a.probs_child)
-                        *reinterpret_cast<float4*>(a.probs_child + ((p * KT + tile * TM + nl) * KT + 4 * ch)) =
-                            make_float4(e0, e1, e2, e3);
                 }
                 int2* dst = sYP + ((size_t)buf * TM + nl) * YLD + 4 * ch;
                 dst[0] = make_int2(ye.x, __float_as_int(e0 * invK));
@@ -244,11 +277,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         if (wave == 0) {
             int xs[G::NPL], rr[G::NPL];
             float qr[D / 64];
-            parent_load(parent_of(0), xs, rr, qr);
-            parent_store(parent_of(0), xs, rr, qr, 0);
+            parent_load(parent_of(0), a.parent_ids[parent_of(0)], xs, rr, qr);
+            parent_store(xs, rr, qr, 0, true);
             if (nloc > 1) {
-                parent_load(parent_of(1), xs, rr, qr);
-                parent_store(parent_of(1), xs, rr, qr, 1);
+                parent_load(parent_of(1), a.parent_ids[parent_of(1)], xs, rr, qr);
+                parent_store(xs, rr, qr, 1, true);
             }
         }
         __syncthreads();
@@ -257,28 +290,40 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
 #pragma unroll
             for (int it = 0; it < G::CPL; ++it) chunk_load(0, 0, it, ye[it], re[it]);
 #pragma unroll
-            for (int it = 0; it < G::CPL; ++it) chunk_finish(parent_of(0), 0, it, 0, ye[it], re[it]);
+            for (int it = 0; it < G::CPL; ++it) chunk_finish(0, it, 0, ye[it], re[it]);
         }
         __syncthreads();
 
         float nacc0 = 0.f, nacc1 = 0.f;
         float c1v = 0.f, c2v = 0.f;
+        // The id loads of a step are issued and consumed UNCONDITIONALLY, by every dense wave, on clamped indices
+        // (results are dropped where a step has nothing to prepare; only wave 0 commits the parent data).  With
+        // conditional issue / consume pairs the compiler's waitcnt pass must assume a load may still be pending at
+        // the loop back-edge and puts a vmcnt(0) in front of the next step's first load -- which then waits for
+        // whatever was issued just before it (measured: ~3000 cycles per step).
+        // The entity id of the parent to prepare is a wave-uniform scalar load taken one step ahead.
+        auto clampi = [&](int64_t i) -> int64_t { return i < nloc ? i : nloc - 1; };
+        int x0n = a.parent_ids[parent_of(clampi(2 / G::NTILE))];
         int dense_iter = 0;
         for (int64_t s = 0; s <= S; ++s) {
+            stamp(s, 0);
             // ---------------- issue this step's id loads (they land under the MFMAs) ----------------
-            const int64_t i2 = (s + 2) / G::NTILE;
-            const bool do_parent = wave == 0 && (s + 2) % G::NTILE == 0 && i2 >= 2 && i2 < nloc;
-            int nxs[G::NPL], nrr[G::NPL];
-            float nq[D / 64];
-            if (do_parent) parent_load(parent_of(i2), nxs, nrr, nq);
-            const bool do_chunk = s + 1 < S;
-            const int64_t i1 = (s + 1) / G::NTILE;
-            const int tile1 = (int)((s + 1) % G::NTILE);
+            const int64_t i2r = (s + 2) / G::NTILE;
+            const int64_t i2 = clampi(i2r);
+            const bool commit_parent = wave == 0 && (s + 2) % G::NTILE == 0 && i2r >= 2 && i2r < nloc;
+            const int64_t t1 = s + 1 < S ? s + 1 : S - 1;
+            const int64_t i1 = t1 / G::NTILE;
+            const int tile1 = (int)(t1 % G::NTILE);
             int4 ye[G::CPL], re[G::CPL];
-            if (do_chunk && s == 0) {   // no dense work in step 0: issue right away
+            constexpr bool CHUNK_EARLY = G::CPL <= 2;   // few registers: issue before phase B (more cover)
+            if constexpr (CHUNK_EARLY) {
 #pragma unroll
                 for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
             }
+            int nxs[G::NPL], nrr[G::NPL];
+            float nq[D / 64];
+            parent_load(parent_of(i2), x0n, nxs, nrr, nq);
+            x0n = a.parent_ids[parent_of(clampi((s + 3) / G::NTILE))];
             // ---------------- dense phases of tile s-1 ----------------
             if (s >= 1) {
                 const int64_t td = s - 1;
@@ -287,7 +332,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 const int slot = (int)(id_ & 3);
                 const float* tA = sA + (td & 1) * TM * LDA;
                 const float* tP0 = sP0 + slot * KT + tile * TM;
-                const float* tP1 = sP1 + slot * KT + tile * TM;
                 if (tile == 0) {
                     nacc0 = 0.f;
                     nacc1 = 0.f;
@@ -305,8 +349,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         c1 += __shfl_xor(c1, 32, kWave);
                         c2 += __shfl_xor(c2, 16, kWave);
                         c2 += __shfl_xor(c2, 32, kWave);
-                        c1v = c1 + b1v;
-                        c2v = (c2 + b2v) * c2scale;
+                        c1v = c1 + sBias[D + col];
+                        c2v = (c2 + sBias[2 * D + col]) * c2scale;
                     }
                 }
                 // phase B: self1 = E[x1] W1 + c1 ; Z = self1 + S' W2 + c2 (model.py:277-283 applied after the sum)
@@ -316,7 +360,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                     accE[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     accS[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                if (has_proj) {
+                if (has_proj && !(dbg & 1)) {
 #pragma unroll
                     for (int k = 0; k < KS; ++k) {
 #pragma unroll
@@ -348,12 +392,20 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 part += __shfl_xor(part, 16, kWave);
                 part += __shfl_xor(part, 32, kWave);
                 nacc0 += part;
-                // the next tile's adjacency chunks are issued between the phases: their registers are live
-                // only while phase C's 8 accumulators are (phase B holds 16), and they land under its MFMAs
-                if (do_chunk) {
+                stamp(s, 1);
+            }
+            // many chunks per lane: issued between the phases -- their registers are live only while phase C's 8
+            // accumulators are (phase B holds 16), and they land under its MFMAs
+            if constexpr (!CHUNK_EARLY) {
 #pragma unroll
-                    for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
-                }
+                for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
+            }
+            if (s >= 1) {
+                const int64_t td = s - 1;
+                const int64_t id_ = td / G::NTILE;
+                const int tile = (int)(td % G::NTILE);
+                const int slot = (int)(id_ & 3);
+                const float* tP1 = sP1 + slot * KT + tile * TM;
                 // every dense wave's columns of Z must be in LDS before any of them starts phase C
                 ++dense_iter;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -361,10 +413,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 while (__hip_atomic_load(sCnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NM * dense_iter)
                     __builtin_amdgcn_s_sleep(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                stamp(s, 2);
                 // phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1 += sum_n p1[n] out1[n]
                 f32x4 acc2[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(dbg & 1))
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
 #pragma unroll
@@ -373,7 +427,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bA0[k], acc2[m], 0, 0, 0);
                     }
                 }
-                part = 0.f;
+                float part = 0.f;
+                const float a0v = sBias[col];
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -388,18 +443,20 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 nacc1 += part;
                 if (tile == G::NTILE - 1 && q16 == 0) {
                     const int64_t p = parent_of(id_);
-                    a.nagg0[p * D + col] = nacc0 * invK;
-                    a.nagg1[p * D + col] = nacc1 * invK;
+                    const unsigned off = ((unsigned)p * D + col) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nacc0 * invK), out0, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nacc1 * invK), out1, off, 0, 0);
                 }
             }
+            stamp(s, 3);
             // ---------------- finish the id work ----------------
-            if (do_chunk) {
 #pragma unroll
-                for (int it = 0; it < G::CPL; ++it)
-                    chunk_finish(parent_of(i1), tile1, it, (int)((s + 1) & 1), ye[it], re[it]);
-            }
-            if (do_parent) parent_store(parent_of(i2), nxs, nrr, nq, (int)(i2 & 3));
+            for (int it = 0; it < G::CPL; ++it) chunk_finish(tile1, it, (int)((s + 1) & 1), ye[it], re[it]);
+            stamp(s, 4);
+            parent_store(nxs, nrr, nq, (int)(i2r & 3), commit_parent);
+            stamp(s, 5);
             __syncthreads();
+            stamp(s, 6);
         }
     } else {
         // =====================================================================================
@@ -442,7 +499,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 }
             };
             for (int64_t s = 0; s <= S; ++s) {
-                if (s < S) {
+                stamp(s, 0);
+                if (s < S && !(dbg & 2)) {
                     const int slot = (int)((s / G::NTILE) & 3);
                     const int tile = (int)(s % G::NTILE);
                     const int buf = (int)(s & 1);
@@ -454,6 +512,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
                         float4 sv, sv1 = acc;
                         if constexpr (G::WIDE) {
+                            load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
 #pragma unroll 8
                             for (int k = 0; k < KT; ++k) {
                                 const int2 e = yp[k];
@@ -462,20 +521,22 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                                 acc = f4_fma(__int_as_float(e.y), lo, acc);
                                 acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
                             }
-                            load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
                         } else {
+                            sv = row4(sX1[slot * KT + tile * TM + nl]);     // first: lands under the K row loads
 #pragma unroll UNR
                             for (int k = 0; k < KT; ++k) {
                                 const int2 e = yp[k];
                                 acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
                             }
-                            sv = row4(sX1[slot * KT + tile * TM + nl]);
                         }
                         put(arow, sv, sv1);
                         put(arow + D, acc, acc1);
+                        stamp(s, 1 + j);
                     }
                 }
+                stamp(s, 5);
                 __syncthreads();
+                stamp(s, 6);
             }
         };
         __syncthreads();   // parents 0 / 1 in the ring
@@ -489,11 +550,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
     }
 }
 
-template <int D, int KT, bool BF, int NG, int UNR = 16>
+template <int D, int KT, bool BF, int NG, int UNR = 16, bool TRACE = false>
 static hipError_t launch_split(const FusedL2Args& a, hipStream_t st) {
     using G = SplitGeom<D, KT, BF, NG>;
     const size_t lds = fused_split_lds_bytes(D, KT, a.nR);
-    auto kern = gather_attn_l2_split_kernel<D, KT, BF, NG, UNR>;
+    auto kern = gather_attn_l2_split_kernel<D, KT, BF, NG, UNR, TRACE>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -509,6 +570,13 @@ bool fused_split_supported(int D, int K) {
     return (D == 64 || D == 128) && (K == 32 || K == 64 || K == 128);
 }
 
+// ... and for these arguments: no attention outputs requested (eval_case_study keeps the symmetric kernel),
+// adjacency tables and output rows addressable with 32-bit byte offsets
+bool fused_split_applies(const FusedL2Args& a, int D) {
+    return fused_split_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 &&
+           a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31);
+}
+
 template <int D, bool BF, int NG>
 static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
     switch (a.K) {
@@ -517,12 +585,20 @@ static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
             static const char* u = getenv("MVIN_SPLIT_UNR");
             if (u && atoi(u) == 8) return launch_split<D, 32, BF, NG, 8>(a, st);
             if (u && atoi(u) == 32) return launch_split<D, 32, BF, NG, 32>(a, st);
+            if constexpr (D == 64 && !BF) {
+                if (a.dbg) return launch_split<D, 32, BF, NG, 16, true>(a, st);     // MVIN_SPLIT_DBG: traced build
+            }
             return launch_split<D, 32, BF, NG>(a, st);
         }
         case 64: return launch_split<D, 64, BF, NG>(a, st);
         case 128: return launch_split<D, 128, BF, NG>(a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t split_read_trace(long long* host_dst, size_t n) {
+    const size_t have = sizeof(g_split_trace) / sizeof(long long);
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_split_trace), (n < have ? n : have) * sizeof(long long));
 }
 
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {

@@ -102,7 +102,9 @@ struct FusedL2Args {
     float* probs_child;          // [P*K, K] or NULL
     int64_t P;
     uint64_t table_bytes;        // nE * D * 4 (buffer descriptor range)
+    uint64_t adj_bytes;          // nE * K * 4: size of adj_e / adj_r (0: unknown)
     int parents_per_pair, K, nR, lpn_log2;
+    int dbg;                     // timing experiments only (MVIN_SPLIT_DBG): 1 = skip the MFMAs, 2 = skip the row loads
 };
 
 // ---- backward (mvin_bwd.hip) ----
@@ -197,6 +199,8 @@ hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)
+bool fused_split_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
+hipError_t split_read_trace(long long* host_dst, size_t n);   // development aid, see mvin_fused_split.hip
 
 }  // namespace mvin
