@@ -38,6 +38,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTraceSteps = 64, kTraceSlots = 8;
 __device__ long long g_split_trace[2 * kTraceSteps * kTraceSlots];
 
+// Sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), every lane gets the total: two VALU lane
+// swaps (gfx950 v_permlane32_swap / v_permlane16_swap) instead of two ds_bpermute round trips through the LDS.
+__device__ __forceinline__ float rows_sum(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // {[lo,lo], [hi,hi]}
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned yy = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane16_swap(yy, yy, false, false);    // {[r0,r0,r2,r2], [r1,r1,r3,r3]}
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // waves per SIMD the register budget is cut for: two 8-wave workgroups per CU (128 VGPRs), or one of 12 (168)
 constexpr int split_minw(int D, int NG) { return ((NG + D / 16) * 64 <= 512) ? 4 : 3; }
 
@@ -145,74 +156,60 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<int32_t*>(a.adj_r), 0, (int)a.adj_bytes, 0x00020000);
+            const_cast<int32_t*>(a.adj_r), 0, a.adj_r ? (int)a.adj_bytes : 0, 0x00020000);   // none: ids read as 0
         const __amdgpu_buffer_rsrc_t out0 = __builtin_amdgcn_make_buffer_rsrc(a.nagg0, 0, (int)(a.P * D * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t out1 = __builtin_amdgcn_make_buffer_rsrc(a.nagg1, 0, (int)(a.P * D * 4), 0x00020000);
         // parent adjacency row -> registers (dense wave 0: lane n handles children n, n+64, ...)
+        // (no projection: zero records -> every load returns 0 without touching memory)
         const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.q), 0, (int)((a.P / a.parents_per_pair) * D * 4), 0x00020000);
+            const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
         auto parent_load = [&](int64_t pp, int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[D / 64]) {
-            // adjacency row first: x0 was fetched a step ago, and the wait for it must not cover younger loads
-#pragma unroll
-            for (int i = 0; i < D / 64; ++i) qr[i] = 0.f;
+            // no branch around any load or its use (see the note at the step loop): lane n holds child n % KT, so at
+            // KT = 32 the upper half-wave duplicates the lower one
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
-                const int n = lane + 64 * i;
-                xs[i] = 0;
-                rr[i] = 0;
-                if (n < KT) {
-                    const unsigned off = ((unsigned)x0 * KT + n) * 4u;
-                    xs[i] = __builtin_amdgcn_raw_buffer_load_b32(adjE, off, 0, 0);
-                    if (has_att0 || has_att1) rr[i] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
-                }
+                const unsigned off = ((unsigned)x0 * KT + ((lane + 64 * i) & (KT - 1))) * 4u;
+                xs[i] = __builtin_amdgcn_raw_buffer_load_b32(adjE, off, 0, 0);
+                rr[i] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
             }
-            if (has_proj) {
-                const unsigned qoff = ((unsigned)pp / (unsigned)a.parents_per_pair) * (unsigned)D;
+            const unsigned qoff = ((unsigned)pp / (unsigned)a.parents_per_pair) * (unsigned)D;
 #pragma unroll
-                for (int i = 0; i < D / 64; ++i)
-                    qr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(qsrc, (qoff + lane + 64 * i) * 4u, 0, 0));
-            }
+            for (int i = 0; i < D / 64; ++i)
+                qr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(qsrc, (qoff + lane + 64 * i) * 4u, 0, 0));
         };
         // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
         auto parent_store = [&](const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[D / 64], int slot,
                                 bool commit) {
-            if (has_proj && commit) {
+            if (commit) {
 #pragma unroll
                 for (int i = 0; i < D / 64; ++i) sQ[slot * D + lane + 64 * i] = qr[i];
             }
             float s0[G::NPL], s1[G::NPL];
             float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < G::NPL; ++i) {
-                const int n = lane + 64 * i;
-                s0[i] = s1[i] = -INFINITY;
-                if (n < KT) {
-                    s0[i] = has_att0 ? sT0[rr[i]] : 0.f;
-                    s1[i] = has_att1 ? sT1[rr[i]] : 0.f;
-                    m0 = fmaxf(m0, s0[i]);
-                    m1 = fmaxf(m1, s1[i]);
-                }
+            for (int i = 0; i < G::NPL; ++i) {          // sT0 / sT1 hold zeros without attention: uniform weights
+                s0[i] = sT0[rr[i]];
+                s1[i] = sT1[rr[i]];
+                m0 = fmaxf(m0, s0[i]);
+                m1 = fmaxf(m1, s1[i]);
             }
-            constexpr int PL2 = (KT >= 64) ? 6 : 5;     // lanes holding children: 64 (KT >= 64) or 32
+            constexpr int PL2 = (KT >= 64) ? 6 : 5;     // lanes holding distinct children: 64 (KT >= 64) or 32
             m0 = group_max(m0, PL2);
             m1 = group_max(m1, PL2);
             float z0 = 0.f, z1 = 0.f;
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
-                const int n = lane + 64 * i;
-                if (n < KT) {
-                    s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
-                    s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
-                    z0 += s0[i];
-                    z1 += s1[i];
-                }
+                s0[i] = has_att0 ? expf(s0[i] - m0) : 1.f;
+                s1[i] = has_att1 ? expf(s1[i] - m1) : 1.f;
+                z0 += s0[i];
+                z1 += s1[i];
             }
             z0 = group_sum(z0, PL2);
             z1 = group_sum(z1, PL2);
 #pragma unroll
             for (int i = 0; i < G::NPL; ++i) {
-                const int n = lane + 64 * i;
-                if (n < KT && commit) {
+                const int n = (lane + 64 * i) & (KT - 1);
+                if (commit) {
                     const float p0 = has_att0 ? s0[i] / z0 : 1.f;
                     const float p1 = has_att1 ? s1[i] / z1 : 1.f;
                     sX1[slot * KT + n] = xs[i];
@@ -223,32 +220,22 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         };
         // int4 chunk `it` of the adjacency rows of the children of tile (slot, tile)
         auto chunk_load = [&](int slot, int tile, int it, int4& ye, int4& re) {
-            const int item = it * (NM * 64) + mlane;
-            ye = make_int4(0, 0, 0, 0);
-            re = make_int4(0, 0, 0, 0);
-            if (item < G::NCH) {
-                const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
-                const unsigned off = ((unsigned)sX1[slot * KT + tile * TM + nl] * KT + 4 * ch) * 4u;
-                const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, off, 0, 0);
-                ye = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
-                if (has_att0) {
-                    const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, off, 0, 0);
-                    re = make_int4((int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3]);
-                }
-            }
+            // unconditional (lanes beyond the tile's chunk count repeat earlier chunks and drop the result)
+            const int item = (it * (NM * 64) + mlane) & (G::NCH - 1);
+            const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
+            const unsigned off = ((unsigned)sX1[slot * KT + tile * TM + nl] * KT + 4 * ch) * 4u;
+            const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, off, 0, 0);
+            ye = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
+            const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, off, 0, 0);
+            re = make_int4((int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3]);
         };
         // ... -> softmax over K inside the child's lane group -> (grandchild id, p_k / K) list
         auto chunk_finish = [&](int tile, int it, int buf, const int4& ye, const int4& re) {
             const int item = it * (NM * 64) + mlane;
             const bool valid = item < G::NCH;
             const int nl = item >> G::LPN_L2, ch = item & (G::LPN - 1);
-            float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f, sc3 = 0.f;
-            if (has_att0 && valid) {
-                sc0 = sT0[re.x];
-                sc1 = sT0[re.y];
-                sc2 = sT0[re.z];
-                sc3 = sT0[re.w];
-            }
+            // sT0 holds zeros without attention; the duplicate lanes hold valid relation ids too
+            const float sc0 = sT0[re.x], sc1 = sT0[re.y], sc2 = sT0[re.z], sc3 = sT0[re.w];
             const float m = group_max(fmaxf(fmaxf(sc0, sc1), fmaxf(sc2, sc3)), G::LPN_L2);
             float e0 = 1.f, e1 = 1.f, e2 = 1.f, e3 = 1.f;
             if (has_att0) {
@@ -259,17 +246,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
             }
             const float z = group_sum((e0 + e1) + (e2 + e3), G::LPN_L2);
             if (valid) {
-                if (has_att0) {
-                    e0 /= z;
-                    e1 /= z;
-                    e2 /= z;
-                    e3 /= z;
-                }
+                const float r = has_att0 ? invK / z : invK;     // p_k / K = e_k * (1 / (K z)): one division per lane
                 int2* dst = sYP + ((size_t)buf * TM + nl) * YLD + 4 * ch;
-                dst[0] = make_int2(ye.x, __float_as_int(e0 * invK));
-                dst[1] = make_int2(ye.y, __float_as_int(e1 * invK));
-                dst[2] = make_int2(ye.z, __float_as_int(e2 * invK));
-                dst[3] = make_int2(ye.w, __float_as_int(e3 * invK));
+                dst[0] = make_int2(ye.x, __float_as_int(e0 * r));
+                dst[1] = make_int2(ye.y, __float_as_int(e1 * r));
+                dst[2] = make_int2(ye.z, __float_as_int(e2 * r));
+                dst[3] = make_int2(ye.w, __float_as_int(e3 * r));
             }
         };
 
@@ -295,7 +277,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         __syncthreads();
 
         float nacc0 = 0.f, nacc1 = 0.f;
-        float c1v = 0.f, c2v = 0.f;
         // The id loads of a step are issued and consumed UNCONDITIONALLY, by every dense wave, on clamped indices
         // (results are dropped where a step has nothing to prepare; only wave 0 commits the parent data).  With
         // conditional issue / consume pairs the compiler's waitcnt pass must assume a load may still be pending at
@@ -335,24 +316,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 if (tile == 0) {
                     nacc0 = 0.f;
                     nacc1 = 0.f;
-                    if (has_proj) {
-                        // c_e[col] = q_b . W_e[:, col] + b_e[col] (model.py:277-279 on the broadcast query): the W
-                        // columns are resident as B fragments, q_b sits in the parent ring
-                        float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-                        for (int k = 0; k < KS; ++k) {
-                            const float qv = sQ[slot * D + 4 * k + q16];
-                            c1 = fmaf(qv, bW1[k], c1);
-                            c2 = fmaf(qv, bW2[k], c2);
-                        }
-                        c1 += __shfl_xor(c1, 16, kWave);
-                        c1 += __shfl_xor(c1, 32, kWave);
-                        c2 += __shfl_xor(c2, 16, kWave);
-                        c2 += __shfl_xor(c2, 32, kWave);
-                        c1v = c1 + sBias[D + col];
-                        c2v = (c2 + sBias[2 * D + col]) * c2scale;
-                    }
                 }
+                // the query is already in the tile rows (the gather waves store E[x1] + q and S' + (sum_k p_k / K) q,
+                // model.py:277: (entity_vectors + transfer_o) . W + b), so only the biases remain
+                const float c1v = sBias[D + col];
+                const float c2v = sBias[2 * D + col] * c2scale;
                 // phase B: self1 = E[x1] W1 + c1 ; Z = self1 + S' W2 + c2 (model.py:277-283 applied after the sum)
                 f32x4 accE[2], accS[2];
 #pragma unroll
@@ -389,9 +357,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         sZ[row * LDZ + col] = zv;
                     }
                 }
-                part += __shfl_xor(part, 16, kWave);
-                part += __shfl_xor(part, 32, kWave);
-                nacc0 += part;
+                nacc0 += rows_sum(part);
                 stamp(s, 1);
             }
             // many chunks per lane: issued between the phases -- their registers are live only while phase C's 8
@@ -438,9 +404,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         part = fmaf(tP1[row], o, part);
                     }
                 }
-                part += __shfl_xor(part, 16, kWave);
-                part += __shfl_xor(part, 32, kWave);
-                nacc1 += part;
+                nacc1 += rows_sum(part);
                 if (tile == G::NTILE - 1 && q16 == 0) {
                     const int64_t p = parent_of(id_);
                     const unsigned off = ((unsigned)p * D + col) * 4u;
@@ -463,6 +427,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         // gather waves: tile s -> sA[s & 1]
         // =====================================================================================
         const int gw = wave - NM;
+        const float c2scale = has_att0 ? invK : 1.f;    // (sum_k p_k) / K
         const int g = lane / G::LPRX, c = lane % G::LPRX;
         const bool buf32 = !BF && a.table_bytes < (1ull << 32);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -529,8 +494,14 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                                 acc = f4_fma(__int_as_float(e.y), row4(e.x), acc);
                             }
                         }
-                        put(arow, sv, sv1);
-                        put(arow + D, acc, acc1);
+                        // this lane's elements of the pair's query (zeros without the projection), read after the row
+                        // loop so that they are not live across it
+                        const float* qrow = sQ + slot * D + G::EPL * c;
+                        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 q0 = has_proj ? *reinterpret_cast<const float4*>(qrow) : zero4;
+                        const float4 q1 = (has_proj && G::WIDE) ? *reinterpret_cast<const float4*>(qrow + 4) : zero4;
+                        put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                      // E[x1] + q
+                        put(arow + D, f4_fma(c2scale, q0, acc), f4_fma(c2scale, q1, acc1));      // S' + (sum p / K) q
                         stamp(s, 1 + j);
                     }
                 }
@@ -584,7 +555,6 @@ static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
             // experiment knob: rows in flight per lane in the gather loop (default 16)
             static const char* u = getenv("MVIN_SPLIT_UNR");
             if (u && atoi(u) == 8) return launch_split<D, 32, BF, NG, 8>(a, st);
-            if (u && atoi(u) == 32) return launch_split<D, 32, BF, NG, 32>(a, st);
             if constexpr (D == 64 && !BF) {
                 if (a.dbg) return launch_split<D, 32, BF, NG, 16, true>(a, st);     // MVIN_SPLIT_DBG: traced build
             }
