@@ -88,6 +88,9 @@ def parse():
                     help="run ONLY the 4 GB-table leg and print its record (the command profiles/r2/*hbm_leg* were "
                          "collected with: one kernel name, one regime per rocprofv3 run)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
+    ap.add_argument("--feed", choices=["pairs", "users"], default="pairs",
+                    help="pairs: per-pair ripple-set arrays [B, n_memory] resident in HBM (the reference's feed_dict "
+                         "contents); users: user_triplet_set resident, pairs grouped by user inside key addressing")
     ap.add_argument("--sweep", default="512,4096,16384")
     ap.add_argument("--n-entity", type=int, default=0,
                     help="override the entity count (synthetic large-table variant, e.g. 16000000 = 4 GB at dim 64; "
@@ -431,6 +434,24 @@ def main():
         }
         if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard:
             rec["batch_sweep"] = batch_sweep(model, users, items, mh, mr, mt, [int(x) for x in a.sweep.split(",") if x])
+        if world == 1 and a.hoist == "off" and not rowshard and a.feed == "pairs":
+            # the same pass fed the way harness.DeviceFeeder feeds it: user_triplet_set on the device, pairs grouped
+            # by user inside key addressing (a user's rows are read once per batch instead of once per pair)
+            uts_d = torch.from_numpy(case.user_triplet_set).to(dev)
+            for _ in range(2):
+                go = model.forward_users(users, items, uts_d)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                go = model.forward_users(users, items, uts_d)
+            torch.cuda.synchronize()
+            dtg = (time.perf_counter() - t1) / 5
+            rec.setdefault("other_modes", {})["user_grouped_feed"] = {
+                "value": a.batch / dtg, "unit": "pairs/s", "ms_per_step": 1e3 * dtg,
+                "max_abs_diff_vs_per_pair_feed_scores": (go.scores - out.scores).abs().max().item(),
+                "note": "MVIN.forward_users: key addressing groups the batch's pairs by user (mvin_key_addressing_"
+                        "grouped_fwd); same scores, 2*P*Nm rows per USER instead of per pair"}
+            del go, uts_d
         if world == 1 and not a.no_cpu_baseline and a.hoist == "off" and not rowshard and model.hoist_supported():
             # informational only, measured AFTER the timed region on the same inputs: the entity-table mode
             #  has its own bytes per pair and is never `value`
@@ -445,11 +466,11 @@ def main():
             torch.cuda.synchronize()
             dth = (time.perf_counter() - t1) / 5
             dev_err = (ho.scores - out.scores).abs().max().item()
-            rec["other_modes"] = {"entity_table_mode_cached": {
+            rec.setdefault("other_modes", {})["entity_table_mode_cached"] = {
                 "value": a.batch / dth, "unit": "pairs/s", "ms_per_step": 1e3 * dth,
                 "max_abs_diff_vs_faithful_scores": dev_err,
                 "note": "per-entity tables hoist the pair-independent part of the two deepest levels "
-                        "(SURVEY 7.3-c route 2b): different algorithmic bytes per pair, reported separately"}}
+                        "(SURVEY 7.3-c route 2b): different algorithmic bytes per pair, reported separately"}
             del hm, ho
         if world == 1 and not a.no_cpu_baseline:
             cb, ref, Bc = cpu_baseline(a, margs, case, params)

@@ -179,6 +179,23 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
                             float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
 
+/* The same reads for pairs GROUPED BY USER (the feeds of train.py:117-120 / util.py:208-230 give every pair its
+ * user's ripple sets, so all pairs of one user gather the same rows).  `uts` = user_triplet_set on the device,
+ * [n_user, max(1,P), 3, Nm] int32 (h | r | t per hop, data_loader_user_set.py:392-441).  The batch's pairs are
+ * described in user order: segment s = pairs pair_index[seg_ptr[s] .. seg_ptr[s+1]) of user seg_user[s]
+ * (pair_index: position in the caller's batch, i.e. row of `items` and of `out`).  One workgroup stages a
+ * user's 2*P*Nm rows in LDS once, forms V[pair, r, :] = E[item] . R_KGE[r] with MFMA per 16 pairs (no [B,nR,D]
+ * tensor) and runs the attention reads of mvin_key_addressing_fwd from LDS.  out as in mvin_key_addressing_fwd.
+ * items are int64 (items_i64) or int32 (items_i32).  nseg_dev (optional, device) holds the actual segment count
+ * when the caller built the segments on the device without a host sync; nseg is then an upper bound (array
+ * sizes).  -3: shape outside the LDS budget. */
+int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                    const int32_t* uts, const int32_t* seg_user, const int32_t* seg_ptr,
+                                    const int32_t* nseg_dev, const int32_t* pair_index, const int64_t* items_i64,
+                                    const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR, int n_entity, int n_user,
+                                    float* out, int64_t ldo, int table_bf16, void* stream);
+int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
+
 /* out[r, :] = softmax(x[r, :]) over n columns (tf.nn.softmax, model.py:189 / :223).  Building block of the
  * SHARED-USER form of MVIN._key_addressing (one user scored against many items, as util.py:145-181 does for
  * top-K evaluation): with one ripple set for the whole batch the reads become dense products,

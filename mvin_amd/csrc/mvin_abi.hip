@@ -305,6 +305,49 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 
+int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR) {
+    return mvin::key_addr_grouped_supported(D, P, Nm, nR) ? 1 : 0;
+}
+
+int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                    const int32_t* uts, const int32_t* seg_user, const int32_t* seg_ptr,
+                                    const int32_t* nseg_dev, const int32_t* pair_index, const int64_t* items_i64,
+                                    const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR,
+                                    int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream) {
+    const char* who = "mvin_key_addressing_grouped_fwd";
+    if (!entity_emb || !uts || !seg_user || !seg_ptr || !pair_index || !out) return fail(-1, "%s: null pointer", who);
+    if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
+    if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
+    if (P == 0 && !w) return fail(-2, "%s: nothing to do (P == 0 and w == NULL)", who);
+    if (P > 0 && !relation_kge) return fail(-1, "%s: hops need relation_kge", who);
+    if (nseg <= 0 || B <= 0 || Nm <= 0 || n_entity <= 0 || n_user <= 0 || nR <= 0)
+        return fail(-2, "%s: bad sizes nseg=%d B=%d Nm=%d n_entity=%d n_user=%d nR=%d", who, nseg, B, Nm, n_entity, n_user, nR);
+    const int n_o = P + (w ? 1 : 0);
+    if (ldo < (int64_t)n_o * D || (ldo & 3)) return fail(-2, "%s: ldo=%lld", who, (long long)ldo);
+    if (!mvin::key_addr_grouped_supported(D, P, Nm, nR))
+        return fail(-3, "%s: unsupported shape D=%d P=%d Nm=%d nR=%d (D in {16,32,64,128}; rows + V tile must fit 160 KB "
+                    "of LDS)", who, D, P, Nm, nR);
+    mvin::KeyAddrGroupedArgs k{};
+    k.E = entity_emb;
+    k.R = relation_kge;
+    k.w = w;
+    k.uts = uts;
+    k.seg_user = seg_user;
+    k.seg_ptr = seg_ptr;
+    k.nseg_dev = nseg_dev;
+    k.pair_index = pair_index;
+    k.items64 = items_i64;
+    k.items32 = items_i32;
+    k.out = out;
+    k.ldo = ldo;
+    k.nseg = nseg;
+    k.P = P;
+    k.Nm = Nm;
+    k.D = D;
+    k.nR = nR;
+    return hip_result(mvin::launch_key_addr_grouped(k, table_bf16, (hipStream_t)stream), who);
+}
+
 int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                         const int32_t* node_ids, const float* rel_score, const float* rowbias, int64_t nodes,
                         int nodes_per_group, int K, int D, int n_entity, int nR, int relu, float* out,

@@ -70,6 +70,22 @@ struct KeyAddrArgs {
     uint64_t table_bytes;      // size of E in bytes (0: unknown -> 64-bit addressing)
 };
 
+struct KeyAddrGroupedArgs {
+    const void* E;             // [nE, D]
+    const float* R;            // [nR, D, D] relation_emb_KGE_matrix
+    const float* w;            // [D] h-set logit weights or NULL
+    const int32_t* uts;        // [nU, max(1,P), 3, Nm]
+    const int32_t* seg_user;   // [nseg]
+    const int32_t* seg_ptr;    // [nseg + 1]
+    const int32_t* nseg_dev;   // [1] actual number of segments (<= nseg) or NULL
+    const int32_t* pair_index; // [B]
+    const int64_t* items64;    // [B] (or items32)
+    const int32_t* items32;
+    float* out;                // [B, ldo]
+    int64_t ldo;
+    int nseg, P, Nm, D, nR, NRL;
+};
+
 struct GatherMixArgs {
     const void* table;         // [nE, D] fp32 or bf16
     const int32_t* adj_e;      // [nE, K]
@@ -193,6 +209,8 @@ hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, co
                                    int K, uint64_t seed, int32_t* adj_e, int32_t* adj_r, hipStream_t st);
 hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
+bool key_addr_grouped_supported(int D, int P, int Nm, int nR);
+hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);

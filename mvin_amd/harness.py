@@ -84,8 +84,7 @@ class DeviceFeeder(object):
         dev = self.model.device
         u = torch.as_tensor(np.asarray(users) if not torch.is_tensor(users) else users).to(dev).long()
         it = torch.as_tensor(np.asarray(items) if not torch.is_tensor(items) else items).to(dev).long()
-        mh, mr, mt = self.memories(u)
-        return self.model.forward_device(u, it, mh, mr, mt).scores_normalized
+        return self.model.forward_users(u, it, self.uts).scores_normalized     # feeds assembled inside the kernels
 
 
     def scores_user(self, user, items):

@@ -532,19 +532,51 @@ class MVIN(object):
         return item_emb, scores, sig, []
 
     # ------------------------------------------------------------------ forward
+    def forward_users(self, user_indices, item_indices, user_triplet_set, want_probs=False):
+        """The same pass when the caller holds ``user_triplet_set`` on the device ([n_user, max(1,P), 3, n_memory]
+        int32, data_loader_user_set.py:392-441) instead of per-pair ripple-set arrays: the feed assembly of
+        train.py:117-120 (memories_x[i] = user_triplet_set[user][i][x]) happens inside the key-addressing kernel,
+        which groups the batch's pairs by user and reads each user's rows once (``_key_addressing_grouped``)."""
+        return self.forward_device(user_indices, item_indices, None, None, None, want_probs=want_probs,
+                                   uts=user_triplet_set)
+
+    def _key_addressing_grouped(self, user, item, uts):
+        """model.py:161-240 with the pairs grouped by user (mvin_key_addressing_grouped_fwd) -> user_o [B,D]."""
+        a, D, P = self.args, self.dim, self.p_hop
+        n_o = P + 1 if a.PS_O_ft else P
+        o_cat = torch.empty((item.shape[0], n_o * D), dtype=torch.float32, device=self.device)
+        w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
+        groups = ops.group_pairs_by_user(user)
+        ops.key_addressing_grouped(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, uts, groups, item, P,
+                                   o_cat, n_o * D, self.n_relation)
+        return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
+
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,
-                       want_probs=False):
+                       want_probs=False, uts=None):
         """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
         [B, n_memory] per hop).  Returns a namespace of device tensors.
         Shared-user form: ripple sets given as ONE [n_memory] list per hop (and ``user_indices`` a
-        single id or [B]) score one user against ``item_indices`` -- see ``_key_addressing_shared``."""
+        single id or [B]) score one user against ``item_indices`` -- see ``_key_addressing_shared``.
+        ``uts`` (instead of the memories): see ``forward_users``."""
         a = self.args
         if not item_indices.is_cuda:
             raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
         item32 = item_indices.contiguous()   # int64 (reference dtype) or int32: kernels take both
         user32 = user_indices.contiguous()
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
-        shared = memories_h[0].dim() == 1      # one user's ripple sets for the whole batch
+        grouped = False
+        if uts is not None:
+            if user32.numel() == 1 and item32.shape[0] > 1:
+                user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
+            grouped = (need_ps and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
+                       and ops.key_addressing_grouped_supported(self.dim, self.p_hop, self.n_memory, self.n_relation))
+            if need_ps and not grouped:     # outside the grouped kernel: assemble the per-pair feeds on the device
+                sel = uts[user32.long()]
+                P_ = sel.shape[1]
+                memories_h = [sel[:, i, 0].contiguous() for i in range(P_)]
+                memories_r = [sel[:, i, 1].contiguous() for i in range(P_)]
+                memories_t = [sel[:, i, 2].contiguous() for i in range(P_)]
+        shared = (not grouped) and memories_h is not None and memories_h[0].dim() == 1   # one user's sets for the batch
         if shared and user32.numel() == 1:
             user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
         if shared and (self.n_memory % 4 != 0 or self.n_memory > 256):
@@ -554,6 +586,8 @@ class MVIN(object):
             shared = False
         if not need_ps:
             ps = None
+        elif grouped:
+            ps = self._key_addressing_grouped(user32, item32, uts)
         elif shared:
             ps = self._key_addressing_shared(item32, [m_.contiguous() for m_ in memories_h],
                                              [m_.contiguous() for m_ in memories_r],

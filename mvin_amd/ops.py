@@ -280,6 +280,48 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     return out
 
 
+def key_addressing_grouped_supported(D, P, Nm, nR):
+    return bool(_lib.load().mvin_key_addressing_grouped_supported(D, P, Nm, nR))
+
+
+def group_pairs_by_user(users):
+    """Segments of a batch in user order, built on the device with static shapes (no host sync, graph-capturable):
+    returns (seg_user [B] int32, seg_ptr [B+2] int32, nseg [1] int32, pair_index [B] int32); only the first
+    nseg entries of seg_user / nseg+1 of seg_ptr are meaningful."""
+    B = users.shape[0]
+    su, perm = torch.sort(users)
+    start = torch.ones(B, dtype=torch.bool, device=users.device)
+    start[1:] = su[1:] != su[:-1]
+    seg_id = torch.cumsum(start, 0) - 1
+    nseg = (seg_id[-1:] + 1).to(I32)
+    pos = torch.arange(B, dtype=I32, device=users.device)
+    seg_ptr = torch.full((B + 2,), B, dtype=I32, device=users.device)
+    seg_ptr.scatter_(0, torch.where(start, seg_id, torch.full_like(seg_id, B + 1)), pos)
+    seg_user = su[seg_ptr[:B].clamp(max=B - 1).long()].to(I32)
+    return seg_user, seg_ptr, nseg, perm.to(I32)
+
+
+def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, out, ldo, nR):
+    """mvin_key_addressing_grouped_fwd: the attention reads of a batch whose pairs are grouped by user
+    (``groups`` = group_pairs_by_user(users)); fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...]."""
+    lib = _lib.load()
+    bf = _chk_table(entity_emb, "entity_emb")
+    _chk(relation_kge, F32, "relation_kge"), _chk(w, F32, "w"), _chk(out, F32, "out"), _chk(uts, I32, "uts")
+    seg_user, seg_ptr, nseg, perm = groups
+    B = items.shape[0]
+    n_user, Ph, three, Nm = uts.shape
+    D = entity_emb.shape[1]
+    i64 = items if items.dtype == torch.int64 else None
+    i32 = items if items.dtype == I32 else None
+    if i64 is None and i32 is None:
+        raise TypeError("items must be int64 or int32")
+    _lib.check(lib.mvin_key_addressing_grouped_fwd(_p(entity_emb), _p(relation_kge), _p(w), _p(uts), _p(seg_user),
+                                                   _p(seg_ptr), _p(nseg), _p(perm), _p(i64), _p(i32), B, B, P, Nm, D, nR,
+                                                   entity_emb.shape[0], n_user, _p(out), ldo, bf, _stream()),
+               "mvin_key_addressing_grouped_fwd")
+    return out
+
+
 # ------------------------------------------------------------------------------- training ops
 def _fill_linear_args(a, srcs, ids, Dout, rows, nz, sum_sources):
     nsrc = len(srcs)

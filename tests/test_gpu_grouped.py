@@ -1,0 +1,88 @@
+"""-m gpu: key addressing with the pairs grouped by user (mvin_key_addressing_grouped_fwd, MVIN.forward_users)
+against the per-pair kernel fed with the same users' ripple sets and against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import synth
+from mvin_amd.config import make_args
+from mvin_amd.params import init_params
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (dim, K, H, P, Nm, nR, n_user, B, ablation, table_dtype)
+    (64, 4, 2, 2, 64, 9, 40, 700, "all", "f32"),          # C3 key-addressing shape, ~17 pairs per user
+    (64, 4, 2, 1, 16, 39, 11, 333, "all", "f32"),          # amazon-book shape: nR > P*Nm (relation compaction)
+    (16, 4, 1, 2, 8, 5, 300, 257, "all", "f32"),           # most users appear once; B not a multiple of 16
+    (32, 4, 2, 2, 12, 6, 5, 100, "no_ps_o_ft", "f32"),     # Nm not a multiple of the rows per wave, no h-set
+    (128, 4, 2, 1, 16, 7, 9, 90, "all", "f32"),
+    (64, 4, 2, 2, 32, 9, 13, 200, "ps_only", "f32"),
+    (64, 4, 2, 2, 32, 9, 13, 200, "no_kg_eh_uo", "f32"),
+    (64, 4, 2, 2, 64, 9, 21, 300, "all", "bf16"),
+    (128, 4, 2, 1, 16, 39, 9, 150, "all", "bf16"),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "d%dP%dNm%dnR%d_%s_%s" % (c[0], c[3], c[4], c[5], c[8], c[9]))
+def test_grouped_matches_per_pair_and_oracle(case, hip_lib):
+    from mvin_amd.model import MVIN
+    from oracle import mirror_fp32
+    D, K, H, P, Nm, nR, n_user, B, abl, tdt = case
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    n_entity = 500
+    rng = np.random.default_rng(D + Nm + B)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=3)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    users[:3] = users[0]                                    # a run of equal users at the front of the batch
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0", table_dtype=tdt)
+    dev = model.device
+    u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
+    uts_d = torch.from_numpy(uts).to(dev)
+    got = model.forward_users(u_d, i_d, uts_d)
+    mh, mr, mt = synth.memories_for(uts, users)
+    ref_dev = model.forward_device(u_d, i_d, [torch.from_numpy(m).to(dev) for m in mh],
+                                   [torch.from_numpy(m).to(dev) for m in mr], [torch.from_numpy(m).to(dev) for m in mt])
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-5, atol=1e-6) if tdt == "f32" else dict(rtol=1e-5, atol=2e-6)
+    assert_close(got.user_o.cpu().numpy(), ref_dev.user_o.cpu().numpy(), "user_o grouped vs per-pair kernel", **tol)
+    assert_close(got.scores.cpu().numpy(), ref_dev.scores.cpu().numpy(), "scores grouped vs per-pair kernel", **tol)
+    if tdt == "f32":
+        ref = mirror_fp32.forward(args, params, adj_e, adj_r, users, items, mh, mr, mt)
+        assert_close(got.user_o.cpu().numpy(), ref.user_o.numpy(), "user_o vs fp32 mirror")
+        assert_close(got.scores.cpu().numpy(), ref.scores.numpy(), "scores vs fp32 mirror")
+
+
+def test_grouping_is_a_permutation_with_segments(hip_lib):
+    from mvin_amd import ops
+    users = torch.tensor([5, 1, 5, 5, 2, 1, 9, 9, 0], device="cuda:0")
+    seg_user, seg_ptr, nseg, perm = ops.group_pairs_by_user(users)
+    n = int(nseg.item())
+    assert n == 5
+    assert seg_user[:n].tolist() == [0, 1, 2, 5, 9]
+    assert seg_ptr[:n + 1].tolist() == [0, 1, 3, 4, 7, 9]
+    assert sorted(perm.tolist()) == list(range(9))
+    for s in range(n):
+        assert all(int(users[perm[p]]) == seg_user[s] for p in range(int(seg_ptr[s]), int(seg_ptr[s + 1])))
+
+
+def test_device_feeder_uses_the_grouped_path(hip_lib):
+    from mvin_amd import harness
+    from mvin_amd.model import MVIN
+    args = make_args(dim=64, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=32, batch_size=64)
+    n_user, n_entity, nR = 20, 300, 6
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, 4, seed=1)
+    uts = synth.ripple_sets(n_user, n_entity, nR, 2, 32, seed=2)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, device="cuda:0", seed=3)
+    feeder = harness.DeviceFeeder(model, uts)
+    rng = np.random.default_rng(0)
+    users, items = rng.integers(0, n_user, 100), rng.integers(0, n_entity, 100)
+    a = feeder.scores(users, items).cpu().numpy()
+    mh, mr, mt = feeder.memories(torch.from_numpy(users).to(model.device))
+    b = model.forward_device(torch.from_numpy(users).to(model.device), torch.from_numpy(items).to(model.device),
+                             mh, mr, mt).scores_normalized.cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
