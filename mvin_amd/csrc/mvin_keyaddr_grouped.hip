@@ -22,7 +22,7 @@ namespace mvin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGW = 8;       // waves per workgroup
+constexpr int kGW = 16;      // waves per workgroup: one pair of a 16-pair tile each
 constexpr int kGT = 16;      // pairs per tile (one MFMA row tile)
 
 struct KaGroupedLds {
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
         // `vsel(m)` gives the LDS address of the D-vector multiplying key row m
         float* lg = sLg + (size_t)wave * Nm;
         auto attend = [&](const float* keys, const float* vals, auto vsel) -> float4 {
+#pragma unroll 4
             for (int m0 = 0; m0 < Nm; m0 += RPW) {
                 const int m = m0 + g;
                 float d = 0.f;
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
             z = wave_sum(z);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
             for (int m0 = 0; m0 < Nm; m0 += RPW) {
                 const int m = m0 + g;
                 if (m < Nm) acc = f4_fma(lg[m], *reinterpret_cast<const float4*>(vals + (size_t)m * D + 4 * c), acc);
@@ -183,18 +185,28 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
             // V[pair, rl, :] = E[item_pair] . R_KGE[sList[rl]]: wave -> (column tile, relations rl0, rl0+step, ...)
             if (P > 0) {
                 constexpr int STEP = kGW / NT > 0 ? kGW / NT : 1;
+                constexpr int RB = (KS <= 16) ? 2 : 1;          // relations whose B fragments are in flight together
                 const int nt = wave % NT;
-                for (int rl = wave / NT; rl < nrl; rl += STEP) {
-                    const float* Rr = a.R + (size_t)sList[rl] * D * D + 16 * nt + l16;
-                    float bfrag[KS];
+                for (int rl0 = wave / NT; rl0 < nrl; rl0 += RB * STEP) {
+                    float bfrag[RB][KS];
 #pragma unroll
-                    for (int k = 0; k < KS; ++k) bfrag[k] = Rr[(size_t)(4 * k + q16) * D];
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < RB; ++j) {
+                        const int rl = rl0 + j * STEP;
+                        const float* Rr = a.R + (size_t)sList[rl < nrl ? rl : rl0] * D * D + 16 * nt + l16;
 #pragma unroll
-                    for (int k = 0; k < KS; ++k)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sEi[l16 * LDE + 4 * k + q16], bfrag[k], acc, 0, 0, 0);
+                        for (int k = 0; k < KS; ++k) bfrag[j][k] = Rr[(size_t)(4 * k + q16) * D];
+                    }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sV[((size_t)(4 * q16 + i) * NRL + rl) * D + 16 * nt + l16] = acc[i];
+                    for (int j = 0; j < RB; ++j) {
+                        const int rl = rl0 + j * STEP;
+                        if (rl >= nrl) break;
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < KS; ++k)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sEi[l16 * LDE + 4 * k + q16], bfrag[j][k], acc, 0, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sV[((size_t)(4 * q16 + i) * NRL + rl) * D + 16 * nt + l16] = acc[i];
+                    }
                 }
             }
             __syncthreads();
