@@ -88,7 +88,7 @@ def parse():
                     help="run ONLY the 4 GB-table leg and print its record (the command profiles/r2/*hbm_leg* were "
                          "collected with: one kernel name, one regime per rocprofv3 run)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
-    ap.add_argument("--feed", choices=["pairs", "users"], default="pairs",
+    ap.add_argument("--feed", choices=["pairs", "users"], default="users",
                     help="pairs: per-pair ripple-set arrays [B, n_memory] resident in HBM (the reference's feed_dict "
                          "contents); users: user_triplet_set resident, pairs grouped by user inside key addressing")
     ap.add_argument("--sweep", default="512,4096,16384")
@@ -273,28 +273,41 @@ def main():
     sl = slice(rank * Bl, (rank + 1) * Bl)
     params = init_params(margs, case.n_user, case.n_entity, case.n_relation, seed=a.seed)
     rowshard = a.shard == "rowshard" or (a.shard == "auto" and world > 1)
-    mparams = params
-    if rowshard:  # the model's entity table becomes the sharded table's working copy
-        mparams = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
-    model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=mparams, device=dev, table_dtype=a.table_dtype,
-                 hoist={"off": False, "cached": True, "step": "step"}[a.hoist])
-    runner = model
-    if rowshard:
+    hoist_kw = {"off": False, "cached": True, "step": "step"}[a.hoist]
+    if rowshard:  # the model lives in shard space; its entity table is the sharded table's working copy
         from mvin_amd.dist import ShardedMVIN, shard_rows
         shard = shard_rows(torch.from_numpy(params["entity_emb_matrix"]), rank, world)
-        if a.table_dtype == "bf16":
-            shard = shard.to(torch.bfloat16)
-        runner = ShardedMVIN(model, shard, rank, world, is_shard=True, always_collective=a.force_collectives)
+        runner = ShardedMVIN.build(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity,
+                                   case.adj_relation, params, shard, rank, world, device=dev,
+                                   table_dtype=a.table_dtype, hoist=hoist_kw, always_collective=a.force_collectives)
+        model = runner.model
+    else:
+        model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                     params=params, device=dev, table_dtype=a.table_dtype, hoist=hoist_kw)
+        runner = model
     users = torch.from_numpy(case.users[sl]).to(dev)
     items = torch.from_numpy(case.items[sl]).to(dev)
-    mh = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_h]
-    mr = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r]
-    mt = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t]
+    by_user = a.feed == "users"
+    if by_user:   # user_triplet_set resident; the per-pair ripple sets are assembled inside key addressing
+        uts_d = torch.from_numpy(case.user_triplet_set).to(dev)
+        if rowshard:
+            runner.set_user_triplet_set(uts_d)
+        mh = mr = mt = None
+    else:
+        mh = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_h]
+        mr = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r]
+        mt = [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t]
+
+    def pair_feed():
+        m = synth.memories_for(case.user_triplet_set, case.users[sl])
+        return [[torch.from_numpy(x).to(dev) for x in lst] for lst in m]
 
     scorer = None
     if a.graph and not rowshard:
         from mvin_amd.graph import GraphedScorer
+        if by_user:
+            mh, mr, mt = pair_feed()
+            by_user = False
         scorer = GraphedScorer(model, Bl)
         scorer.load(users, items, mh, mr, mt)
     overlap = rowshard and not a.no_overlap
@@ -305,15 +318,19 @@ def main():
     def step():
         if scorer is not None:
             return scorer.replay()
+        if not rowshard:
+            if by_user:
+                return model.forward_users(users, items, uts_d)
+            return model.forward_device(users, items, mh, mr, mt)
         if not overlap:
-            return runner.forward_device(users, items, mh, mr, mt)
+            return runner.forward_device(users, items, mh, mr, mt, global_batch=a.batch)
         # every step scores one batch AND performs one row exchange (for the following batch),
         # on two streams; the same synthetic batch is re-used, the exchange is not skipped
         i = state["i"]
         if i == 0:
-            runner.prefetch(0, items, mh, mt)
+            runner.prefetch(0, users, items, mh, mt, global_batch=a.batch)
         out = runner.forward_prefetched(i % 2, users, items, mh, mr, mt)
-        runner.prefetch((i + 1) % 2, items, mh, mt)
+        runner.prefetch((i + 1) % 2, users, items, mh, mt, global_batch=a.batch)
         state["i"] = i + 1
         return out
 
@@ -424,8 +441,12 @@ def main():
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
-                       "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (blocks) "
-                                       f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(Bl) else 'sparse'} regime)"
+                       "feed": ("user_triplet_set [n_user, P, 3, n_memory] + (user, item) ids resident in HBM; the per-pair "
+                                "ripple sets of train.py:117-120 are assembled inside key addressing, which groups the "
+                                "batch's pairs by user" if a.feed == "users" and scorer is None else
+                                "per-pair ripple-set arrays [B, n_memory] + (user, item) ids resident in HBM"),
+                       "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (owner = id mod {world}) "
+                                       f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(a.batch) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"
                                        if rowshard else
                                        (f"pairs split over {world} ranks; tables replicated" if world > 1
@@ -433,36 +454,46 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard:
-            rec["batch_sweep"] = batch_sweep(model, users, items, mh, mr, mt, [int(x) for x in a.sweep.split(",") if x])
-        if world == 1 and a.hoist == "off" and not rowshard and a.feed == "pairs":
-            # the same pass fed the way harness.DeviceFeeder feeds it: user_triplet_set on the device, pairs grouped
-            # by user inside key addressing (a user's rows are read once per batch instead of once per pair)
-            uts_d = torch.from_numpy(case.user_triplet_set).to(dev)
+            smh, smr, smt = (mh, mr, mt) if mh is not None else pair_feed()   # per-pair feeds: the reference's own
+            rec["batch_sweep"] = batch_sweep(model, users, items, smh, smr, smt, [int(x) for x in a.sweep.split(",") if x])
+        if world == 1 and a.hoist == "off" and not rowshard and scorer is None:
+            # the same pass with the OTHER feed, after the timed region
+            if by_user:
+                pmh, pmr, pmt = pair_feed()
+                alt = lambda: model.forward_device(users, items, pmh, pmr, pmt)          # noqa: E731
+                key, note = "per_pair_feed", ("per-pair ripple-set arrays [B, n_memory] resident in HBM (the contents "
+                                              "of the reference's feed_dict): key addressing gathers 2*P*Nm rows per "
+                                              "PAIR (mvin_key_addressing_fwd)")
+            else:
+                uts_alt = torch.from_numpy(case.user_triplet_set).to(dev)
+                alt = lambda: model.forward_users(users, items, uts_alt)                  # noqa: E731
+                key, note = "user_grouped_feed", ("MVIN.forward_users: user_triplet_set resident, key addressing groups "
+                                                  "the batch's pairs by user (mvin_key_addressing_grouped_fwd)")
             for _ in range(2):
-                go = model.forward_users(users, items, uts_d)
+                go = alt()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(5):
-                go = model.forward_users(users, items, uts_d)
+                go = alt()
             torch.cuda.synchronize()
             dtg = (time.perf_counter() - t1) / 5
-            rec.setdefault("other_modes", {})["user_grouped_feed"] = {
+            rec.setdefault("other_modes", {})[key] = {
                 "value": a.batch / dtg, "unit": "pairs/s", "ms_per_step": 1e3 * dtg,
-                "max_abs_diff_vs_per_pair_feed_scores": (go.scores - out.scores).abs().max().item(),
-                "note": "MVIN.forward_users: key addressing groups the batch's pairs by user (mvin_key_addressing_"
-                        "grouped_fwd); same scores, 2*P*Nm rows per USER instead of per pair"}
-            del go, uts_d
+                "max_abs_diff_vs_timed_feed_scores": (go.scores - out.scores).abs().max().item(), "note": note}
+            del go
         if world == 1 and not a.no_cpu_baseline and a.hoist == "off" and not rowshard and model.hoist_supported():
             # informational only, measured AFTER the timed region on the same inputs: the entity-table mode
             #  has its own bytes per pair and is never `value`
             hm = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
                       params=params, device=dev, table_dtype=a.table_dtype, hoist=True)
+            hstep = ((lambda: hm.forward_users(users, items, uts_d)) if by_user
+                     else (lambda: hm.forward_device(users, items, mh, mr, mt)))
             for _ in range(2):
-                ho = hm.forward_device(users, items, mh, mr, mt)
+                ho = hstep()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(5):
-                ho = hm.forward_device(users, items, mh, mr, mt)
+                ho = hstep()
             torch.cuda.synchronize()
             dth = (time.perf_counter() - t1) / 5
             dev_err = (ho.scores - out.scores).abs().max().item()

@@ -203,6 +203,12 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
  * instead of 2*Nm row gathers per pair. */
 int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
 
+/* Row movers of the multi-GPU layer (mvin_amd/dist.py; no reference counterpart -- the reference is single
+ * device): out[i, :] = table[ids[i], :] (gather) and table[ids[i], :] = rows[i, :] (scatter; ids distinct),
+ * rows of `row_bytes` bytes (a multiple of 4: fp32 or bf16 entity rows move untouched). */
+int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream);
+int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, const void* rows, void* stream);
+
 /* Entity-table ("hoisted") mode building block -- an inference-side re-association of
  * model.py:295-305 / aggregators.py:118-146 at the two deepest levels (SURVEY.md 7.3-c route 2b):
  *   out[i, :] = (1/K) sum_k w_k * f(table[adj_entity[x_i, k], :] + rowbias[i / nodes_per_group, :])

@@ -305,6 +305,20 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 
+int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream) {
+    const char* who = "mvin_gather_rows";
+    if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(-2, "%s: n=%lld row_bytes=%d", who, (long long)n, row_bytes);
+    if (n > 0 && (!table || !ids || !out)) return fail(-1, "%s: null pointer", who);
+    return hip_result(mvin::launch_move_rows(const_cast<void*>(table), ids, n, row_bytes, out, false, (hipStream_t)stream), who);
+}
+
+int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, const void* rows, void* stream) {
+    const char* who = "mvin_scatter_rows";
+    if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(-2, "%s: n=%lld row_bytes=%d", who, (long long)n, row_bytes);
+    if (n > 0 && (!table || !ids || !rows)) return fail(-1, "%s: null pointer", who);
+    return hip_result(mvin::launch_move_rows(table, ids, n, row_bytes, const_cast<void*>(rows), true, (hipStream_t)stream), who);
+}
+
 int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR) {
     return mvin::key_addr_grouped_supported(D, P, Nm, nR) ? 1 : 0;
 }

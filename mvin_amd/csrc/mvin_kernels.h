@@ -212,6 +212,8 @@ int key_addr_nj(int Nm, int D);
 bool key_addr_grouped_supported(int D, int P, int Nm, int nR);
 hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
+hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, void* rows, bool scatter,
+                            hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);

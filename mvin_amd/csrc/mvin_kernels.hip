@@ -453,4 +453,29 @@ hipError_t launch_ripple(const RippleArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- raw row movers (multi-GPU exchange): 4-byte words, one row per lane group ----
+template <bool SCATTER>
+__global__ __launch_bounds__(kBlock) void move_rows_kernel(uint32_t* __restrict__ table, const int32_t* __restrict__ ids,
+                                                           int64_t n, int words, uint32_t* __restrict__ rows) {
+    const int64_t total = n * words;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / words;
+        const int w = (int)(i - r * words);
+        const int64_t t = (int64_t)ids[r] * words + w;
+        if (SCATTER) table[t] = rows[i];
+        else rows[i] = table[t];
+    }
+}
+
+hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, void* rows, bool scatter,
+                            hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int words = row_bytes / 4;
+    const int64_t nblk = (n * words + kBlock - 1) / kBlock;
+    const int grid = (int)(nblk < 256 * 32 ? nblk : 256 * 32);
+    if (scatter) move_rows_kernel<true><<<grid, kBlock, 0, st>>>((uint32_t*)table, ids, n, words, (uint32_t*)rows);
+    else move_rows_kernel<false><<<grid, kBlock, 0, st>>>((uint32_t*)table, ids, n, words, (uint32_t*)rows);
+    return hipGetLastError();
+}
+
 }  // namespace mvin

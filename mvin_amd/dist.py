@@ -5,58 +5,111 @@ table row-sharded across the ranks of a node, cross-shard rows fetched with all-
 The reference has no distributed code at all; this is new design
 mandated by BASELINE.json's north_star.  Layout:
 
-  * contiguous row blocks: n_local = ceil(nE / world), owner(x) = x // n_local; every shard is
-    padded to n_local rows so all exchanges have static sizes;
-  * adjacency (int32, [nE,K]), the relation table, the KGE relation matrices, the user table
-    and all dense weights are replicated (a few MB);
+  * cyclic row ownership, owner(x) = x mod W (item ids occupy [0, n_item) and the
+    Zipf-hot rows are items, so contiguous blocks would put them all on the first ranks).  Rank r
+    stores rows r, r+W, r+2W, ... as one contiguous shard of n_local = ceil(nE / W) rows (zero padded).
+  * SHARD SPACE: the sharded model works on relabelled entity ids  pi(x) = (x mod W) * n_local + x div W,
+    in which rank r's shard is the contiguous block [r*n_local, (r+1)*n_local).  The adjacency tables
+    are relabelled once at construction (rows permuted, entries mapped), a device-resident
+    user_triplet_set once, and a batch's item ids (and per-pair ripple sets, if fed that way) by one
+    elementwise op per step.  Every kernel then runs unchanged on a WORKING TABLE of W*n_local rows
+    addressed by shard-space id, and an all-gather of the shards IS that table (no transpose pass).
+  * adjacency (int32), the relation table, the KGE relation matrices, the user table and all dense
+    weights are replicated (a few MB);
   * every rank scores its own slice of the batch (pairs are independent: no reduction);
-  * every step a rank brings the rows its pairs touch into a WORKING TABLE addressed by global
-    entity id (so the scoring kernels run unchanged), in one of two regimes:
+  * every step a rank brings the rows its pairs touch into the working table, in one of two regimes:
 
-    dense  (batch footprint >= table: B*K^L row references vs nE rows -- every benchmark
-            config): ONE all_to_all_single in which each rank sends its shard to every peer
-            (RCCL lowers it to grouped P2P send/recv over all 7 xGMI links at once, no ring),
-            i.e. each row crosses the fabric once per rank per step, no id traffic, no host sync;
-    sparse (small batches / tables much larger than a batch's footprint): the touched rows
-            are marked through the replicated adjacency (tree levels 0..L + ripple-set heads and
-            tails, deduplicated level by level), then all-to-all (counts) -> all-to-all-v (ids)
-            -> owner-side HIP row gather -> all-to-all-v (rows) -> scatter into the working table.
+    dense  (batch footprint >= table: B*K^L row references vs nE rows -- every benchmark config):
+            every rank receives every shard.  Over RCCL this is ONE grouped send/recv
+            (torch.distributed.all_to_all on W views of the SAME local shard -- no W-fold send
+            staging -- and W slices of the working table): direct P2P on all 7 xGMI links at once,
+            no ring, static sizes, no host sync.  Other backends (gloo in the CPU tests):
+            all_gather_into_tensor, same result.
+    sparse (small batches / tables much larger than a batch's footprint): the touched rows are marked
+            through the replicated adjacency (tree levels 0..L + ripple-set heads and tails,
+            deduplicated level by level), then all-to-all (counts) -> all-to-all-v (ids) -> owner-side
+            HIP row gather (mvin_gather_rows, fp32 or bf16 rows) -> all-to-all-v (rows) -> HIP scatter
+            into the working table.
 
-The working table is full-size address space but scratch: it is refilled every step (the
-exchange is never skipped or cached across steps), and a second working table lets the exchange
-for step i+1 run on a side stream while step i is scored.
+Memory per rank: the shard (1/W of the table) + one working table (two with the pipeline, so that
+the exchange for step i+1 runs on a side stream while step i is scored).  The working table is
+scratch: it is refilled every step (the exchange is never skipped or cached across steps).
+
+The regime must be the SAME on every rank (the two regimes issue different collectives): it is a
+function of the GLOBAL batch size only (``global_batch`` argument, default local batch * W, i.e. equal
+slices), never of a rank's own slice; MVIN_DIST_CHECK=1 verifies the agreement with an all-reduce.
 """
+import os
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
-def shard_bounds(n_entity, rank, world):
-    n_local = -(-n_entity // world)
-    lo = min(n_entity, rank * n_local)
-    return lo, min(n_entity, lo + n_local), n_local
+def n_local_rows(n_entity, world):
+    return -(-n_entity // world)
+
+
+def to_shard_space(ids, n_entity, world):
+    """pi(x) = (x mod W) * n_local + x div W (torch tensor or numpy array, any integer dtype)."""
+    if world == 1:
+        return ids
+    nl = n_local_rows(n_entity, world)
+    return (ids % world) * nl + ids // world
+
+
+def from_shard_space(pids, n_entity, world):
+    if world == 1:
+        return pids
+    nl = n_local_rows(n_entity, world)
+    return (pids % nl) * world + pids // nl
 
 
 def shard_rows(table, rank, world):
-    """Rows owned by ``rank`` (contiguous block partition), zero-padded to n_local rows."""
-    lo, hi, n_local = shard_bounds(table.shape[0], rank, world)
-    out = torch.zeros((n_local, table.shape[1]), dtype=table.dtype, device=table.device)
-    out[:hi - lo] = table[lo:hi]
+    """Rows owned by ``rank`` (x mod W == rank, ascending), zero-padded to n_local rows."""
+    nl = n_local_rows(table.shape[0], world)
+    mine = table[rank::world]
+    out = torch.zeros((nl, table.shape[1]), dtype=table.dtype, device=table.device)
+    out[:mine.shape[0]] = mine
     return out
 
 
-def mark_needed(n_entity, adj_entity, items, levels, extra_ids=()):
-    """Boolean mask [nE] of the entity rows a batch touches: the K-ary tree below each item down
+def permute_adjacency(adj_entity, adj_relation, n_entity, world):
+    """The fixed-fan-out adjacency in shard space: row pi(x) holds pi(adj_entity[x]) / adj_relation[x];
+    padding rows are zero (= entity 0 / relation 0, like entities absent from the KG,
+    data_loader_user_set.py:377-380).  numpy in, numpy int32 out."""
+    adj_entity, adj_relation = np.asarray(adj_entity), np.asarray(adj_relation)
+    nl = n_local_rows(n_entity, world)
+    K = adj_entity.shape[1]
+    pe = np.zeros((world * nl, K), dtype=np.int32)
+    pr = np.zeros((world * nl, K), dtype=np.int32)
+    pos = to_shard_space(np.arange(n_entity, dtype=np.int64), n_entity, world)
+    pe[pos] = to_shard_space(adj_entity[:n_entity].astype(np.int64), n_entity, world)
+    pr[pos] = adj_relation[:n_entity]
+    return pe, pr
+
+
+def permute_ripple_sets(uts, n_entity, world):
+    """user_triplet_set [n_user, P, 3, Nm] with heads and tails relabelled (relations untouched)."""
+    out = uts.clone() if torch.is_tensor(uts) else np.array(uts, copy=True)
+    out[:, :, 0] = to_shard_space(uts[:, :, 0], n_entity, world)
+    out[:, :, 2] = to_shard_space(uts[:, :, 2], n_entity, world)
+    return out
+
+
+def mark_needed(n_rows, adj_entity, items, levels, extra_ids=()):
+    """Boolean mask [n_rows] of the entity rows a batch touches: the K-ary tree below each item down
     to ``levels`` (model.py:243-256, through the replicated adjacency) plus ``extra_ids``
     (ripple-set heads and tails).  Level sets are deduplicated level by level, so the work is
-    bounded by nE*K per level instead of B*K^L."""
+    bounded by nE*K per level instead of B*K^L.  Ids and adjacency in the same id space."""
     dev = adj_entity.device
-    need = torch.zeros(n_entity, dtype=torch.bool, device=dev)
-    frontier = torch.zeros(n_entity, dtype=torch.bool, device=dev)
+    need = torch.zeros(n_rows, dtype=torch.bool, device=dev)
+    frontier = torch.zeros(n_rows, dtype=torch.bool, device=dev)
     frontier[items.long()] = True
     need |= frontier
     for _ in range(levels):
         cur = frontier.nonzero(as_tuple=True)[0]
-        frontier = torch.zeros(n_entity, dtype=torch.bool, device=dev)
+        frontier = torch.zeros(n_rows, dtype=torch.bool, device=dev)
         frontier[adj_entity[cur].reshape(-1).long()] = True
         need |= frontier
     for ids in extra_ids:
@@ -64,59 +117,84 @@ def mark_needed(n_entity, adj_entity, items, levels, extra_ids=()):
     return need
 
 
-class ShardedEntityTable(object):
-    """Row-sharded entity table + per-step all-to-all row fetch into a working table."""
+def hip_row_gather(table, idx_int32):
+    """Owner-side row gather on the GPU (mvin_gather_rows: fp32 or bf16 rows, moved untouched)."""
+    from . import ops
+    return ops.gather_rows(table, idx_int32.contiguous())
 
-    def __init__(self, local_rows, n_entity, rank, world, row_gather, group=None, always_collective=False):
+
+def hip_row_scatter(table, idx_int32, rows):
+    from . import ops
+    return ops.scatter_rows(table, idx_int32.contiguous(), rows.contiguous())
+
+
+def _torch_row_scatter(table, idx_int32, rows):
+    table.index_copy_(0, idx_int32.long(), rows)
+    return table
+
+
+class ShardedEntityTable(object):
+    """Row-sharded entity table + per-step row fetch into a working table (all ids in shard space)."""
+
+    def __init__(self, local_rows, n_entity, rank, world, row_gather=None, row_scatter=None, group=None,
+                 always_collective=False):
         """``local_rows``: this rank's padded shard ([n_local, D], see shard_rows).
-        ``row_gather(table, idx_int32) -> rows``: the owner-side gather of the sparse regime
-        (the HIP gather kernel in production: ``hip_row_gather``)."""
+        ``row_gather(table, idx_int32) -> rows`` / ``row_scatter(table, idx_int32, rows)``: the row movers of
+        the sparse regime (the HIP kernels by default; the CPU tests inject torch indexing)."""
         self.n_entity, self.rank, self.world = n_entity, rank, world
-        self.lo, self.hi, self.n_local = shard_bounds(n_entity, rank, world)
+        self.n_local = n_local_rows(n_entity, world)
+        self.lo = rank * self.n_local
         if local_rows.shape[0] != self.n_local:
             raise ValueError(f"shard must have n_local={self.n_local} rows (padded), got {local_rows.shape[0]}")
         self.local = local_rows.contiguous()
         self.group = group
         self.always_collective = always_collective   # run the collectives even when world == 1 (tests)
-        self.row_gather = row_gather
+        on_gpu = self.local.is_cuda
+        self.row_gather = row_gather or (hip_row_gather if on_gpu else (lambda t, i: t[i.long()]))
+        self.row_scatter = row_scatter or (hip_row_scatter if on_gpu else _torch_row_scatter)
         self.dim = local_rows.shape[1]
         self.work = self.new_work_table()
-        self._send = None
         self.last_stats = {}
 
     def refresh(self):
-        """Call after the shard's rows changed in place (e.g. a training step)."""
-        self._send = None
+        """Call after the shard's rows changed in place (kept for API symmetry: nothing is staged)."""
 
     def new_work_table(self):
-        """A working table: world*n_local rows (>= nE), addressed by global entity id."""
+        """A working table: W*n_local rows (>= nE), addressed by shard-space id."""
         return torch.zeros((self.world * self.n_local, self.dim), dtype=self.local.dtype, device=self.local.device)
+
+    def bytes_per_rank(self, n_work_tables=1):
+        row = self.dim * self.local.element_size()
+        return {"shard": self.n_local * row, "working_tables": n_work_tables * self.world * self.n_local * row}
 
     # ---- dense regime ---------------------------------------------------------------------
     def fetch_all(self, work=None):
-        """Every rank sends its shard to every peer in one all-to-all (direct P2P on all links)."""
+        """Every rank receives every shard; shard r lands at rows [r*n_local, (r+1)*n_local)."""
         work = self.work if work is None else work
         W = self.world
         if W == 1 and not self.always_collective:
             work.copy_(self.local)
+        elif dist.get_backend(self.group) == "nccl":
+            # grouped P2P (ncclGroupStart; W x send/recv; ncclGroupEnd): every peer pair uses its own xGMI link.
+            # The W inputs are the SAME tensor -- nothing is replicated on the sender.
+            dist.all_to_all(list(work.view(W, self.n_local, self.dim).unbind(0)), [self.local] * W, group=self.group)
         else:
-            if self._send is None:   # the shard laid out once per destination (rebuilt by refresh())
-                self._send = self.local.unsqueeze(0).expand(W, self.n_local, self.dim).contiguous()
-            dist.all_to_all_single(work, self._send.view(W * self.n_local, self.dim), group=self.group)
+            dist.all_gather_into_tensor(work, self.local, group=self.group)
         self.last_stats = {"mode": "dense", "requested": self.n_entity,
-                           "remote": self.n_entity - (self.hi - self.lo)}
+                           "remote": self.n_entity - len(range(self.rank, self.n_entity, W))}
         return work
 
     # ---- sparse regime --------------------------------------------------------------------
     def fetch(self, need_mask, work=None):
-        """Make ``work[x]`` valid for every x with need_mask[x] (default: ``self.work``)."""
+        """Make ``work[p]`` valid for every shard-space id p with need_mask[p] (default: ``self.work``)."""
         work = self.work if work is None else work
         W = self.world
         dev = self.local.device
         ids = need_mask.nonzero(as_tuple=True)[0]            # sorted: already grouped by owner block
         send_counts = torch.bincount(ids // self.n_local, minlength=W)
         if W == 1 and not self.always_collective:
-            work.index_copy_(0, ids, self.row_gather(self.local, ids.to(torch.int32)))
+            i32 = ids.to(torch.int32)
+            self.row_scatter(work, i32, self.row_gather(self.local, i32))
             self.last_stats = {"mode": "sparse", "requested": int(ids.numel()), "remote": 0}
             return work
         recv_counts = torch.empty_like(send_counts)
@@ -127,35 +205,58 @@ class ShardedEntityTable(object):
         out_rows = self.row_gather(self.local, (want - self.lo).to(torch.int32))
         got = torch.empty((ids.numel(), self.dim), dtype=self.local.dtype, device=dev)
         dist.all_to_all_single(got, out_rows, output_split_sizes=sc, input_split_sizes=rc, group=self.group)
-        work.index_copy_(0, ids, got)
+        self.row_scatter(work, ids.to(torch.int32), got)
         self.last_stats = {"mode": "sparse", "requested": int(ids.numel()),
                            "remote": int(ids.numel()) - sc[self.rank], "served": int(want.numel())}
         return work
 
 
-def hip_row_gather(table, idx_int32):
-    """Owner-side row gather on the GPU: mvin_linear_fwd in its identity/gather form."""
-    from . import ops
-    if table.dtype != torch.float32:   # bf16 shard: rows move as bf16 (pure data movement)
-        return table.index_select(0, idx_int32.long())
-    return ops.linear([table], None, table.shape[1], ids=[idx_int32.contiguous()])
-
-
 class ShardedMVIN(object):
     """MVIN scoring with the entity table row-sharded over the ranks of ``group``.
 
-    ``model`` is an mvin_amd.model.MVIN whose ``entity_emb_matrix`` is replaced by a working
-    table of a ShardedEntityTable; every forward first brings in the rows the local pairs need."""
+    Build with ``ShardedMVIN.build(...)``: it creates an mvin_amd.model.MVIN that lives in shard space
+    (relabelled adjacency, W*n_local entity rows) and whose ``entity_emb_matrix`` is the working table
+    of a ShardedEntityTable; every forward first brings in the rows the local pairs need.  Callers keep
+    passing ORIGINAL entity ids (items, ripple sets, user_triplet_set)."""
 
-    def __init__(self, model, full_entity_table_or_shard, rank, world, group=None, row_gather=None,
-                 is_shard=False, always_collective=False, regime="auto"):
-        self.model, self.rank, self.world = model, rank, world
-        local = full_entity_table_or_shard if is_shard else shard_rows(full_entity_table_or_shard, rank, world)
-        self.table = ShardedEntityTable(local.to(model.device), model.n_entity, rank, world,
-                                        row_gather or hip_row_gather, group, always_collective)
+    def __init__(self, model, shard, n_entity, rank, world, group=None, row_gather=None, row_scatter=None,
+                 always_collective=False, regime="auto"):
+        self.model, self.rank, self.world, self.n_entity = model, rank, world, n_entity
+        self.table = ShardedEntityTable(shard.to(model.device), n_entity, rank, world, row_gather, row_scatter,
+                                        group, always_collective)
+        if model.n_entity != self.table.work.shape[0]:
+            raise ValueError("the model must be built in shard space: n_entity = W * n_local rows (ShardedMVIN.build)")
         self.regime = regime
+        self.group = group
         model.entity_emb_matrix = self.table.work
         self._bufs = None
+        self._uts = None
+        self._check = os.environ.get("MVIN_DIST_CHECK") == "1"
+
+    @classmethod
+    def build(cls, args, n_user, n_entity, n_relation, adj_entity, adj_relation, params, shard, rank, world,
+              device=None, table_dtype="f32", **kw):
+        """``params``: the replicated parameters (an ``entity_emb_matrix`` entry is ignored);
+        ``shard``: this rank's rows (shard_rows(full_table, rank, world)), fp32 or bf16."""
+        from .model import MVIN
+        mkw = {k: kw.pop(k) for k in ("hoist", "fused", "seed") if k in kw}
+        pe, pr = permute_adjacency(adj_entity, adj_relation, n_entity, world)
+        rows = pe.shape[0]
+        p = dict(params, entity_emb_matrix=np.zeros((rows, shard.shape[1]), dtype=np.float32))
+        model = MVIN(args, n_user, rows, n_relation, pe, pr, params=p, device=device, table_dtype=table_dtype, **mkw)
+        if shard.dtype != model.entity_emb_matrix.dtype:
+            shard = shard.to(model.entity_emb_matrix.dtype)
+        return cls(model, shard, n_entity, rank, world, **kw)
+
+    # ---- id spaces ------------------------------------------------------------------------
+    def ids(self, x):
+        return to_shard_space(x, self.n_entity, self.world)
+
+    def set_user_triplet_set(self, uts):
+        """Register a device-resident user_triplet_set (original ids): relabelled once, then
+        ``forward_users`` needs no per-step id work beyond the item ids."""
+        self._uts = permute_ripple_sets(uts.to(self.model.device), self.n_entity, self.world).contiguous()
+        return self._uts
 
     def _depth(self):
         m = self.model
@@ -163,34 +264,65 @@ class ShardedMVIN(object):
             return 0
         return m.n_mix_hop * m.h_hop if m.args.wide_deep else m.h_hop
 
-    def is_dense(self, batch):
-        """Static regime choice (no device sync): row references of the batch vs table rows."""
+    def is_dense(self, global_batch):
+        """Regime from the GLOBAL batch only (identical on every rank; no device sync): row references of the
+        batch's per-rank share vs table rows."""
         if self.regime != "auto":
             return self.regime == "dense"
         m = self.model
-        refs = batch * (sum(m.n_neighbor ** e for e in range(self._depth() + 1)) + 2 * m.n_memory * max(1, m.p_hop))
-        return refs >= m.n_entity
+        per_rank = -(-int(global_batch) // self.world)
+        refs = per_rank * (sum(m.n_neighbor ** e for e in range(self._depth() + 1)) + 2 * m.n_memory * max(1, m.p_hop))
+        return refs >= self.n_entity
 
-    def needed(self, item_indices, memories_h, memories_t):
+    def _regime(self, local_batch, global_batch):
+        dense = self.is_dense(local_batch * self.world if global_batch is None else global_batch)
+        if self._check and (self.world > 1 or self.table.always_collective):
+            t = torch.tensor([int(dense), -int(dense)], device=self.model.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if int(t[0]) != -int(t[1]):
+                raise RuntimeError("ranks chose different exchange regimes: pass the same global_batch everywhere")
+        return dense
+
+    def needed(self, item_p, heads_tails_p):
         m = self.model
-        extra = []
-        need_ps = m.args.PS_only or (not m.args.HO_only) or m.args.User_orient_kg_eh
-        if need_ps:
-            extra += list(memories_h[:max(1, m.p_hop)])
-            extra += list(memories_t[:m.p_hop])
-        return mark_needed(m.n_entity, m.adj_entity, item_indices, self._depth(), extra)
+        return mark_needed(self.table.work.shape[0], m.adj_entity, item_p, self._depth(), heads_tails_p)
 
-    def _exchange(self, work, item_indices, memories_h, memories_t):
-        if self.is_dense(item_indices.shape[0]):
+    def _ripple_ids(self, users, mem_h_p, mem_t_p):
+        m = self.model
+        need_ps = m.args.PS_only or (not m.args.HO_only) or m.args.User_orient_kg_eh
+        if not need_ps:
+            return []
+        if mem_h_p is not None:
+            return list(mem_h_p[:max(1, m.p_hop)]) + list(mem_t_p[:m.p_hop])
+        sel = self._uts[users.long()]
+        return [sel[:, :, 0], sel[:, :m.p_hop, 2]]
+
+    def _exchange(self, work, users, item_p, mem_h_p, mem_t_p, global_batch):
+        if self._regime(item_p.shape[0], global_batch):
             self.table.fetch_all(work)
         else:
-            self.table.fetch(self.needed(item_indices, memories_h, memories_t), work)
+            self.table.fetch(self.needed(item_p, self._ripple_ids(users, mem_h_p, mem_t_p)), work)
 
-    def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t, **kw):
-        """Exchange, then score (serialised on the current stream)."""
-        self._exchange(self.table.work, item_indices, memories_h, memories_t)
+    def _map_feed(self, item_indices, memories_h, memories_t):
+        item_p = self.ids(item_indices)
+        if memories_h is None:
+            return item_p, None, None
+        return item_p, [self.ids(t) for t in memories_h], [self.ids(t) for t in memories_t]
+
+    def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t, global_batch=None, **kw):
+        """Exchange, then score (serialised on the current stream).  Original entity ids in."""
+        item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
+        self._exchange(self.table.work, user_indices, item_p, mh_p, mt_p, global_batch)
         self.model.entity_emb_matrix = self.table.work
-        return self.model.forward_device(user_indices, item_indices, memories_h, memories_r, memories_t, **kw)
+        if memories_h is None:
+            return self.model.forward_users(user_indices, item_p, self._uts, **kw)
+        return self.model.forward_device(user_indices, item_p, mh_p, memories_r, mt_p, **kw)
+
+    def forward_users(self, user_indices, item_indices, global_batch=None, **kw):
+        """The same with the ripple sets taken from the registered user_triplet_set (set_user_triplet_set)."""
+        if self._uts is None:
+            raise RuntimeError("call set_user_triplet_set(uts) first")
+        return self.forward_device(user_indices, item_indices, None, None, None, global_batch=global_batch, **kw)
 
     # ---- double-buffered pipeline: exchange for batch i+1 overlaps the scoring of batch i ----
     def enable_pipeline(self):
@@ -199,7 +331,7 @@ class ShardedMVIN(object):
         self._ready = [None, None]      # event: rows of buffer b are in place (side stream)
         self._free = [None, None]       # event: the scoring that read buffer b is done (main stream)
 
-    def prefetch(self, buf, item_indices, memories_h, memories_t):
+    def prefetch(self, buf, user_indices, item_indices, memories_h=None, memories_t=None, global_batch=None):
         """Start the row exchange for a batch into working table ``buf`` on the side stream."""
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self._side):
@@ -207,7 +339,8 @@ class ShardedMVIN(object):
                 self._side.wait_stream(main)
             else:
                 self._side.wait_event(self._free[buf])
-            self._exchange(self._bufs[buf], item_indices, memories_h, memories_t)
+            item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
+            self._exchange(self._bufs[buf], user_indices, item_p, mh_p, mt_p, global_batch)
             ev = torch.cuda.Event()
             ev.record(self._side)
             self._ready[buf] = ev
@@ -217,7 +350,11 @@ class ShardedMVIN(object):
         main = torch.cuda.current_stream()
         main.wait_event(self._ready[buf])
         self.model.entity_emb_matrix = self._bufs[buf]
-        out = self.model.forward_device(user_indices, item_indices, memories_h, memories_r, memories_t, **kw)
+        item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
+        if memories_h is None:
+            out = self.model.forward_users(user_indices, item_p, self._uts, **kw)
+        else:
+            out = self.model.forward_device(user_indices, item_p, mh_p, memories_r, mt_p, **kw)
         done = torch.cuda.Event()
         done.record(main)
         self._free[buf] = done

@@ -280,6 +280,27 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     return out
 
 
+def gather_rows(table, ids):
+    """mvin_gather_rows: out[i] = table[ids[i]] for rows of any 4-byte-multiple width (fp32 / bf16 entity rows)."""
+    _chk(ids, I32, "ids")
+    if not table.is_cuda or not table.is_contiguous():
+        raise _lib.MvinHipError("table: expected a contiguous CUDA/ROCm tensor")
+    out = torch.empty((ids.shape[0], table.shape[1]), dtype=table.dtype, device=table.device)
+    _lib.check(_lib.load().mvin_gather_rows(_p(table), _p(ids), ids.shape[0], table.shape[1] * table.element_size(),
+                                            _p(out), _stream()), "mvin_gather_rows")
+    return out
+
+
+def scatter_rows(table, ids, rows):
+    """mvin_scatter_rows: table[ids[i]] = rows[i] (distinct ids)."""
+    _chk(ids, I32, "ids")
+    if rows.dtype != table.dtype or not rows.is_contiguous() or not table.is_contiguous():
+        raise TypeError("rows/table: same dtype, contiguous")
+    _lib.check(_lib.load().mvin_scatter_rows(_p(table), _p(ids), ids.shape[0], table.shape[1] * table.element_size(),
+                                             _p(rows), _stream()), "mvin_scatter_rows")
+    return table
+
+
 def key_addressing_grouped_supported(D, P, Nm, nR):
     return bool(_lib.load().mvin_key_addressing_grouped_supported(D, P, Nm, nR))
 

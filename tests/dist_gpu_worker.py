@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mvin_amd import synth  # noqa: E402
 from mvin_amd.config import make_args  # noqa: E402
 from mvin_amd.dist import ShardedMVIN, shard_rows  # noqa: E402
+from mvin_amd import synth as _synth  # noqa: E402,F401
 from mvin_amd.model import MVIN  # noqa: E402
 from mvin_amd.params import init_params  # noqa: E402
 
@@ -38,24 +39,34 @@ def main():
     ref = ref_model.forward_device(*feed).scores
     full = torch.from_numpy(params["entity_emb_matrix"])
     zeroed = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
+    build = lambda regime, **kw: ShardedMVIN.build(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity,
+                                                   case.adj_relation, params, shard_rows(full, rank, world), rank, world,
+                                                   device=dev, regime=regime, **kw)
+    uts = torch.from_numpy(_synth.ripple_sets(case.n_user, case.n_entity, case.n_relation, 2, 16, seed=63)).to(dev)
+    mhu, mru, mtu = _synth.memories_for(uts.cpu().numpy(), case.users[sl])
+    ref_u = ref_model.forward_device(feed[0], feed[1], [torch.from_numpy(m).to(dev) for m in mhu],
+                                     [torch.from_numpy(m).to(dev) for m in mru],
+                                     [torch.from_numpy(m).to(dev) for m in mtu]).scores
     for regime in ("dense", "sparse"):
-        sh = ShardedMVIN(mk(zeroed), shard_rows(full, rank, world), rank, world, is_shard=True, regime=regime)
+        sh = build(regime)
         got = sh.forward_device(*feed).scores
         assert torch.equal(got, ref), f"rank {rank} {regime}: sharded scores differ from replicated"
         st = sh.table.last_stats
         assert st["mode"] == regime and st["remote"] > 0, st
         sh.enable_pipeline()
-        sh.prefetch(0, feed[1], feed[2], feed[4])
+        sh.prefetch(0, feed[0], feed[1], feed[2], feed[4])
         for i in range(3):
             out = sh.forward_prefetched(i % 2, *feed)
-            sh.prefetch((i + 1) % 2, feed[1], feed[2], feed[4])
+            sh.prefetch((i + 1) % 2, feed[0], feed[1], feed[2], feed[4])
             assert torch.equal(out.scores, ref), f"rank {rank} {regime}: pipelined step {i} differs"
+        # the user_triplet_set feed (relabelled once): same scores as the per-pair arrays of the same users
+        sh.set_user_triplet_set(uts)
+        got_u = sh.forward_users(feed[0], feed[1]).scores
+        assert torch.allclose(got_u, ref_u, rtol=1e-5, atol=1e-6), f"rank {rank} {regime}: forward_users differs"
         torch.cuda.synchronize()
     # entity-table mode on top of the sharded table: the per-entity tables must be rebuilt whenever an
     # exchange refills the working table (tracked through the tensor version counter)
-    hm = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=zeroed,
-              device=dev, hoist=True)
-    sh = ShardedMVIN(hm, shard_rows(full, rank, world), rank, world, is_shard=True, regime="dense")
+    sh = build("dense", hoist=True)
     got = sh.forward_device(*feed).scores
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), f"rank {rank}: hoisted sharded scores differ"
     sh.table.local.mul_(1.5)

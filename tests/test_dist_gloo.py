@@ -1,6 +1,6 @@
-"""CPU, world_size=2 over gloo: the row-sharded entity table and its all-to-all row fetch
-(mvin_amd/dist.py).  The owner-side gather is injected (torch indexing here; the HIP gather
-kernel in production), everything else is the production code path."""
+"""CPU, world_size=2 over gloo: the row-sharded entity table (cyclic ownership x mod W, shard-space ids)
+and its row fetch (mvin_amd/dist.py).  The row movers are torch indexing here (the HIP kernels in
+production), everything else is the production code path."""
 import os
 import socket
 
@@ -12,7 +12,8 @@ import torch.multiprocessing as mp
 
 from mvin_amd import synth
 from mvin_amd.config import make_args
-from mvin_amd.dist import ShardedEntityTable, mark_needed, shard_rows
+from mvin_amd.dist import (ShardedEntityTable, from_shard_space, mark_needed, n_local_rows, permute_adjacency,
+                           permute_ripple_sets, shard_rows, to_shard_space)
 from mvin_amd.params import init_params
 
 
@@ -39,38 +40,43 @@ def _worker(rank, world, port, ret):
         params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=41)
         full = torch.from_numpy(params["entity_emb_matrix"])
         sl = slice(rank * 3, rank * 3 + 3)                                             # my pairs
-        items = torch.from_numpy(case.items[sl])
-        mh = [torch.from_numpy(m[sl]) for m in case.memories_h]
-        mt = [torch.from_numpy(m[sl]) for m in case.memories_t]
-        adj_e = torch.from_numpy(case.adj_entity.astype(np.int32))
-        need = mark_needed(case.n_entity, adj_e, items, 2, extra_ids=mh + mt)
-        table = ShardedEntityTable(shard_rows(full, rank, world), case.n_entity, rank, world, _torch_gather)
-        assert table.local.shape[0] == -(-case.n_entity // world)          # padded block
+        nE, nl = case.n_entity, n_local_rows(case.n_entity, world)
+        pi = lambda x: to_shard_space(x, nE, world)
+        items_p = pi(torch.from_numpy(case.items[sl]))
+        mh_p = [pi(torch.from_numpy(m[sl]).long()) for m in case.memories_h]
+        mt_p = [pi(torch.from_numpy(m[sl]).long()) for m in case.memories_t]
+        pe, pr = permute_adjacency(case.adj_entity, case.adj_relation, nE, world)
+        adj_p = torch.from_numpy(pe)
+        full_p = torch.zeros((world * nl, full.shape[1]))                    # the table in shard space
+        full_p[pi(torch.arange(nE))] = full
+        need = mark_needed(world * nl, adj_p, items_p, 2, extra_ids=mh_p + mt_p)
+        table = ShardedEntityTable(shard_rows(full, rank, world), nE, rank, world, _torch_gather)
+        assert table.local.shape[0] == nl and torch.equal(table.local[:len(range(rank, nE, world))], full[rank::world])
         # ---- sparse regime: only the touched rows move ----
         work = table.fetch(need)
         idx = need.nonzero(as_tuple=True)[0]
-        assert torch.equal(work[idx], full[idx]), "fetched rows differ from the owners' rows"
+        assert torch.equal(work[idx], full_p[idx]), "fetched rows differ from the owners' rows"
         assert table.last_stats["requested"] == idx.numel() and table.last_stats["remote"] > 0
         rest = torch.ones(work.shape[0], dtype=torch.bool)
         rest[idx] = False
         assert not work[rest].any()                                        # untouched rows never written
-        # the marked set covers everything the scoring path reads: scores from the working
-        # table == scores from the full table
+        # the marked set covers everything the scoring path reads: scores in shard space from the working
+        # table == scores from the full table in the original id space
         sargs = make_args(**dict(vars(args), batch_size=3))
         feed = (case.users[sl], case.items[sl], [m[sl] for m in case.memories_h],
                 [m[sl] for m in case.memories_r], [m[sl] for m in case.memories_t])
         ref = mirror_fp32.forward(sargs, params, case.adj_entity, case.adj_relation, *feed)
-        got = mirror_fp32.forward(sargs, dict(params, entity_emb_matrix=work[:case.n_entity].numpy()), case.adj_entity,
-                                  case.adj_relation, *feed)
+        feed_p = (case.users[sl], items_p.numpy(), [m.numpy() for m in mh_p], feed[3], [m.numpy() for m in mt_p])
+        got = mirror_fp32.forward(sargs, dict(params, entity_emb_matrix=work.numpy()), pe, pr, *feed_p)
         assert torch.equal(ref.scores, got.scores)
         # a second fetch with a different need set reuses the working table
         need2 = torch.zeros_like(need)
         need2[[1, 2, 50 + rank]] = True
         work = table.fetch(need2)
-        assert torch.equal(work[:case.n_entity][need2], full[need2])
-        # ---- dense regime: one all-to-all brings every shard ----
+        assert torch.equal(work[need2], full_p[need2])
+        # ---- dense regime: every rank receives every shard ----
         w2 = table.fetch_all(table.new_work_table())
-        assert torch.equal(w2[:case.n_entity], full) and not w2[case.n_entity:].any()
+        assert torch.equal(w2, full_p)
         assert table.last_stats["mode"] == "dense"
         ret[rank] = "ok"
     except Exception as e:  # noqa: BLE001
@@ -88,13 +94,30 @@ def test_sharded_table_all_to_all_fetch_world2():
     assert dict(ret) == {0: "ok", 1: "ok"}
 
 
-def test_single_rank_fetch_and_block_partition():
+def test_cyclic_partition_and_shard_space():
     full = torch.arange(11 * 4, dtype=torch.float32).view(11, 4) + 1
     for world in (1, 2, 3, 8):
+        nl = n_local_rows(11, world)
         shards = [shard_rows(full, r, world) for r in range(world)]
-        n_local = -(-11 // world)
-        assert all(s.shape == (n_local, 4) for s in shards)
-        assert torch.equal(torch.cat(shards)[:11], full) and not torch.cat(shards)[11:].any()
+        assert all(s.shape == (nl, 4) for s in shards)
+        x = torch.arange(11)
+        p = to_shard_space(x, 11, world)
+        assert torch.equal(from_shard_space(p, 11, world), x) and len(set(p.tolist())) == 11
+        assert torch.equal(p // nl, x % world)                     # owner(x) = x mod W is a contiguous block
+        assert torch.equal(torch.cat(shards)[p], full)             # all-gather of the shards = the table in shard space
+    # adjacency and ripple sets relabelled consistently
+    rng = np.random.default_rng(0)
+    adj_e, adj_r = rng.integers(0, 11, (11, 3)), rng.integers(0, 4, (11, 3))
+    pe, pr = permute_adjacency(adj_e, adj_r, 11, 4)
+    for x in range(11):
+        px = int(to_shard_space(np.int64(x), 11, 4))
+        assert from_shard_space(pe[px].astype(np.int64), 11, 4).tolist() == adj_e[x].tolist()
+        assert pr[px].tolist() == adj_r[x].tolist()
+    uts = rng.integers(0, 11, (5, 2, 3, 4)).astype(np.int32)
+    pu = permute_ripple_sets(uts, 11, 4)
+    assert np.array_equal(pu[:, :, 1], uts[:, :, 1])
+    assert np.array_equal(from_shard_space(pu[:, :, 0].astype(np.int64), 11, 4), uts[:, :, 0])
+    # single rank: shard space is the identity
     t = ShardedEntityTable(full.clone(), 11, 0, 1, _torch_gather)
     need = torch.zeros(11, dtype=torch.bool)
     need[[0, 3, 10]] = True

@@ -36,11 +36,9 @@ def test_sharded_scores_equal_replicated(collective, regime, hip_lib, nccl_world
     dev = torch.device("cuda:0")
     ref_model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
                      params=params, device=dev)
-    zeroed = dict(params, entity_emb_matrix=np.zeros_like(params["entity_emb_matrix"]))
-    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
-                 params=zeroed, device=dev)
-    sh = ShardedMVIN(model, torch.from_numpy(params["entity_emb_matrix"]), 0, 1, always_collective=collective,
-                     regime=regime)
+    sh = ShardedMVIN.build(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                           params, torch.from_numpy(params["entity_emb_matrix"]), 0, 1, device=dev,
+                           always_collective=collective, regime=regime)
     feed = (torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
             [torch.from_numpy(m).to(dev) for m in case.memories_h],
             [torch.from_numpy(m).to(dev) for m in case.memories_r],
@@ -52,11 +50,11 @@ def test_sharded_scores_equal_replicated(collective, regime, hip_lib, nccl_world
     assert st["mode"] == regime
     if regime == "sparse":
         assert 0 < st["requested"] < case.n_entity      # only the touched rows were fetched
-        untouched = ~sh.needed(feed[1], feed[2], feed[4])
+        untouched = ~sh.needed(feed[1], list(feed[2]) + list(feed[4]))
         assert not sh.table.work[:case.n_entity][untouched].any()
     # pipelined form (exchange on a side stream into a second working table): same scores
     sh.enable_pipeline()
-    sh.prefetch(1, feed[1], feed[2], feed[4])
+    sh.prefetch(1, feed[0], feed[1], feed[2], feed[4])
     got2 = sh.forward_prefetched(1, *feed)
     torch.cuda.synchronize()
     assert torch.equal(got2.scores, ref.scores)
@@ -93,3 +91,31 @@ def test_bench_two_ranks_one_gpu(hip_lib):
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0
     assert rec["config"]["pairs_per_gpu_per_step"] == 2048
     assert "row-sharded" in rec["config"]["parallelism"] and rec["roofline"]["achieved"] > 0
+
+
+def test_row_movers_fp32_and_bf16(hip_lib):
+    from mvin_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    for dt in (torch.float32, torch.bfloat16):
+        table = torch.rand((1000, 64), device=dev, generator=g).to(dt)
+        ids = torch.randperm(1000, device=dev, generator=g)[:300].to(torch.int32)
+        rows = ops.gather_rows(table, ids)
+        assert torch.equal(rows, table[ids.long()])
+        dst = torch.zeros_like(table)
+        ops.scatter_rows(dst, ids, rows)
+        assert torch.equal(dst[ids.long()], rows) and int((dst != 0).any(dim=1).sum()) <= 300
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL wants one device per rank")
+def test_bench_two_ranks_over_rccl(hip_lib):
+    """bench.py --gpus 2 under the driver's torchrun line with the PRODUCTION transport (RCCL): self-skips on the
+    1-GPU boxes, so that the scaling run is not the first time RCCL sees two ranks wherever two GPUs exist."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _run_ranks([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8192"],
+                   2, extra_env={"MVIN_DIST_BACKEND": "nccl", "MVIN_DIST_CHECK": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and "row-sharded" in rec["config"]["parallelism"]
