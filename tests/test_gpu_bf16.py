@@ -83,3 +83,33 @@ def test_c5_shape_two_paths_agree(hip_lib):
     c = run(mk(ae, ar, True), case).scores.cpu().numpy()
     assert_close(c, a, "child permutation at C5 shape", rtol=1e-5, atol=1e-6)
     del d
+
+
+@pytest.mark.parametrize("name", ["c5_h2", "c5_full_h3"])
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlevel"])
+def test_c5_against_the_fp64_oracle(name, fused, hip_lib):
+    """BASELINE config C5 (amazon-book-shaped, D=128, K=128, bf16 table) against oracle/equations_fp64.py: at
+    depth 2 (16 513 rows per pair) and at the FULL depth 3 (2 113 665 rows per pair, B=1).  The expected scores
+    were computed in the build container (tests/golden/make_c5_fixture.py) from inputs that are regenerated
+    here from the same seeds (checked by a CRC of the inputs); on both HIP paths."""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_c5_fixture as fx
+    from mvin_amd.model import MVIN
+    exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_expected.json")))[name]
+    args, case, params = fx.build_case(name)
+    assert fx.checksum(case, params) == exp["inputs_crc32"], "regenerated inputs differ from the fixture's"
+    assert case.users.tolist() == exp["users"] and case.items.tolist() == exp["items"]
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                 params=params, device="cuda:0", fused=fused, table_dtype="bf16")
+    # the kernels read exactly the values the oracle was given
+    rounded = fx.bf16_round(params["entity_emb_matrix"])
+    assert np.array_equal(model.entity_emb_matrix.float().cpu().numpy(), rounded)
+    got = run(model, case).scores.cpu().numpy()
+    assert_close(got, np.array(exp["scores_fp64"]), f"{name} vs fp64 oracle", rtol=1e-5, atol=2e-6)
+    if name == "c5_h2":   # small enough for the op-by-op fp32 mirror too
+        ref = mirror_fp32.forward(args, dict(params, entity_emb_matrix=rounded), case.adj_entity, case.adj_relation,
+                                  case.users, case.items, case.memories_h, case.memories_r, case.memories_t)
+        assert_close(got, ref.scores.numpy(), "c5_h2 vs fp32 mirror")
