@@ -203,6 +203,21 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
  * instead of 2*Nm row gathers per pair. */
 int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
 
+/* Everything of MVIN.aggregate_delta_whole (model.py:259-324) above mvin_gather_attn_l2_fwd for the shape
+ * n_mix_hop = 1, h_hop = 2 (tree depth 2), in one launch:
+ *   ev0 = (E[item] + q) W0 + b0  (W0 == NULL: ev0 = E[item], User_orient off)        model.py:270-283
+ *   out0 = relu((ev0 + nagg0) A0 + a0) ; out2 = relu((out0 + nagg1) A1 + a1)          aggregators.py:108-116
+ *   item_emb = [ev0 | out0 | out2] Wmix + bmix                                        model.py:310-315
+ *   scores = sum_d user_o * item_emb ; sig = sigmoid(scores)                          model.py:158-159
+ * nagg0 / nagg1 [B, D]: the outputs of mvin_gather_attn_l2_fwd with parents_per_pair = 1.  D in {16, 32, 64}
+ * (-3 otherwise: use mvin_linear_fwd per stage).  item_emb and sig may be NULL. */
+int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int32_t* items_i32, const float* q,
+                     const float* user_o, const float* nagg0, const float* nagg1, const float* W0, const float* b0,
+                     const float* A0, const float* a0, const float* A1, const float* a1, const float* Wmix,
+                     const float* bmix, int64_t B, int D, int n_entity, float* item_emb, float* scores, float* sig,
+                     int table_bf16, void* stream);
+int mvin_l2_tail_supported(int D);
+
 /* Row movers of the multi-GPU layer (mvin_amd/dist.py; no reference counterpart -- the reference is single
  * device): out[i, :] = table[ids[i], :] (gather) and table[ids[i], :] = rows[i, :] (scatter; ids distinct),
  * rows of `row_bytes` bytes (a multiple of 4: fp32 or bf16 entity rows move untouched). */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mvin_abi_version": (C.c_int, []),
     "mvin_last_error": (C.c_char_p, []),
     "mvin_debug_read_trace": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "mvin_l2_tail_fwd": (C.c_int, [C.c_void_p] * 15 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]),
+    "mvin_l2_tail_supported": (C.c_int, [C.c_int]),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

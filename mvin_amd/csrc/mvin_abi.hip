@@ -305,6 +305,43 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 
+int mvin_l2_tail_supported(int D) { return mvin::l2_tail_supported(D) ? 1 : 0; }
+
+int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int32_t* items_i32, const float* q,
+                     const float* user_o, const float* nagg0, const float* nagg1, const float* W0, const float* b0,
+                     const float* A0, const float* a0, const float* A1, const float* a1, const float* Wmix,
+                     const float* bmix, int64_t B, int D, int n_entity, float* item_emb, float* scores, float* sig,
+                     int table_bf16, void* stream) {
+    const char* who = "mvin_l2_tail_fwd";
+    if (!mvin::l2_tail_supported(D)) return fail(-3, "%s: unsupported D=%d (16, 32, 64)", who, D);
+    if (!entity_emb || !user_o || !nagg0 || !nagg1 || !A0 || !A1 || !Wmix || !scores) return fail(-1, "%s: null pointer", who);
+    if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
+    if (W0 && !q) return fail(-1, "%s: the projection needs q", who);
+    if (B <= 0 || n_entity <= 0) return fail(-2, "%s: bad sizes B=%lld n_entity=%d", who, (long long)B, n_entity);
+    mvin::TailArgs t{};
+    t.E = entity_emb;
+    t.items64 = items_i64;
+    t.items32 = items_i32;
+    t.q = q;
+    t.user_o = user_o;
+    t.nagg0 = nagg0;
+    t.nagg1 = nagg1;
+    t.W0 = W0;
+    t.b0 = b0;
+    t.A0 = A0;
+    t.a0 = a0;
+    t.A1 = A1;
+    t.a1 = a1;
+    t.Wmix = Wmix;
+    t.bmix = bmix;
+    t.item_emb = item_emb;
+    t.scores = scores;
+    t.sig = sig;
+    t.B = B;
+    t.table_bf16 = table_bf16;
+    return hip_result(mvin::launch_l2_tail(t, D, (hipStream_t)stream), who);
+}
+
 int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream) {
     const char* who = "mvin_gather_rows";
     if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(-2, "%s: n=%lld row_bytes=%d", who, (long long)n, row_bytes);

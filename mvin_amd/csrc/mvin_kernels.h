@@ -86,6 +86,29 @@ struct KeyAddrGroupedArgs {
     int nseg, P, Nm, D, nR, NRL;
 };
 
+struct TailArgs {
+    const void* E;             // [nE, D] fp32 or bf16
+    const int64_t* items64;    // [B] (or items32)
+    const int32_t* items32;
+    const float* q;            // [B, D] query (transfer_o[0]); unused without the projection
+    const float* user_o;       // [B, D]
+    const float* nagg0;        // [B, D] from mvin_gather_attn_l2_fwd
+    const float* nagg1;
+    const float* W0;           // [D, D] level-0 projection or NULL (User_orient off)
+    const float* b0;
+    const float* A0;           // aggregator (0,0)
+    const float* a0;
+    const float* A1;           // aggregator (1,0)
+    const float* a1;
+    const float* Wmix;         // [3D, D] mix-hop combiner
+    const float* bmix;
+    float* item_emb;           // [B, D] or NULL
+    float* scores;             // [B]
+    float* sig;                // [B] or NULL
+    int64_t B;
+    int table_bf16;
+};
+
 struct GatherMixArgs {
     const void* table;         // [nE, D] fp32 or bf16
     const int32_t* adj_e;      // [nE, K]
@@ -216,6 +239,8 @@ hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_
                             hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
+bool l2_tail_supported(int D);
+hipError_t launch_l2_tail(const TailArgs& a, int D, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)

@@ -1,0 +1,185 @@
+// Everything of MVIN.aggregate_delta_whole above the fused two-level kernel, for the metric shape
+// (wide_deep, n_mix_hop = 1, h_hop = 2: L = 2), in ONE launch per batch instead of four:
+//   ev0    = (E[item] + q) W_0 + b_0                      user-oriented projection of level 0, model.py:270-283
+//   out0   = relu((ev0  + nagg0) A_0 + a_0)               aggregator (0,0) at hop 0, aggregators.py:108-116
+//   out2   = relu((out0 + nagg1) A_1 + a_1)               aggregator (1,0) at hop 0
+//   item   = [ev0 | out0 | out2] Wmix + bmix              mix-hop combiner, model.py:310-315
+//   score  = sum_d user_o[d] item[d] ; sigmoid            model.py:158-159
+// nagg0 / nagg1 are the neighbor aggregates mvin_gather_attn_l2_fwd returns per pair.
+// One workgroup of D/16 waves walks 32-row tiles; all six D x D weight blocks stay resident as B fragments of
+// v_mfma_f32_16x16x4_f32 (6 * D/4 registers per wave), the five intermediates of a tile live in LDS
+// (row stride D+2: conflict-free A-fragment reads).  D in {16, 32, 64}.
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
+    constexpr int NT = D / 16, KS = D / 4, LD = D + 2, TM = 32, NTHR = NT * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                   // [TM][LD]  E[item] + q, then Z2 = out0 + nagg1
+    float* sE0 = sX + TM * LD;          // ev0
+    float* sZ1 = sE0 + TM * LD;         // ev0 + nagg0, then out2
+    float* sO0 = sZ1 + TM * LD;         // out0
+    float* sSc = sO0 + TM * LD;         // [NT][TM] per-slab partial scores
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q16 = lane >> 4, l16 = lane & 15;
+    const int col = 16 * wave + l16;
+    const bool proj = a.W0 != nullptr;
+
+    float bW0[KS], bA0[KS], bA1[KS], bC0[KS], bC1[KS], bC2[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const size_t o = (size_t)(4 * s + q16) * D + col;
+        bW0[s] = proj ? a.W0[o] : 0.f;
+        bA0[s] = a.A0[o];
+        bA1[s] = a.A1[o];
+        bC0[s] = a.Wmix[o];
+        bC1[s] = a.Wmix[(size_t)D * D + o];
+        bC2[s] = a.Wmix[(size_t)2 * D * D + o];
+    }
+    const float b0v = (proj && a.b0) ? a.b0[col] : 0.f;
+    const float a0v = a.a0 ? a.a0[col] : 0.f;
+    const float a1v = a.a1 ? a.a1[col] : 0.f;
+    const float bcv = a.bmix ? a.bmix[col] : 0.f;
+
+    // acc[m] += A(tile rows of `src`) . B fragment
+    auto mma = [&](const float* src, const float (&bf)[KS], f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(src[(16 * m + l16) * LD + 4 * s + q16], bf[s], acc[m], 0, 0, 0);
+        }
+    };
+    const int64_t ntiles = (a.B + TM - 1) / TM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TM;
+        __syncthreads();                                    // previous tile's buffers consumed
+        // ---- X = E[item] + q ----
+        for (int idx = tid; idx < TM * (D / 4); idx += NTHR) {
+            const int row = idx / (D / 4), c = idx - row * (D / 4);
+            const int64_t r = r0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < a.B) {
+                const int64_t it = a.items64 ? a.items64[r] : (int64_t)a.items32[r];
+                v = load_row4(a.E, a.table_bf16, it, D, c);
+                if (proj) {
+                    const float4 qv = reinterpret_cast<const float4*>(a.q + r * D)[c];
+                    v.x += qv.x;
+                    v.y += qv.y;
+                    v.z += qv.z;
+                    v.w += qv.w;
+                }
+            }
+            float* dst = sX + row * LD + 4 * c;
+            *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
+            *reinterpret_cast<float2*>(dst + 2) = make_float2(v.z, v.w);
+        }
+        __syncthreads();
+        // ---- ev0 ; Z1 = ev0 + nagg0 ----
+        {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (proj) mma(sX, bW0, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * m + 4 * q16 + r;
+                    const int64_t gr = r0 + row;
+                    const float e0 = proj ? acc[m][r] + b0v : sX[row * LD + col];
+                    const float n0 = gr < a.B ? a.nagg0[gr * D + col] : 0.f;
+                    sE0[row * LD + col] = e0;
+                    sZ1[row * LD + col] = e0 + n0;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- out0 = relu(Z1 A0 + a0) ; Z2 = out0 + nagg1 (into sX) ----
+        {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mma(sZ1, bA0, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * m + 4 * q16 + r;
+                    const int64_t gr = r0 + row;
+                    const float o0 = fmaxf(acc[m][r] + a0v, 0.f);
+                    const float n1 = gr < a.B ? a.nagg1[gr * D + col] : 0.f;
+                    sO0[row * LD + col] = o0;
+                    sX[row * LD + col] = o0 + n1;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- out2 = relu(Z2 A1 + a1) (into sZ1) ----
+        {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mma(sX, bA1, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sZ1[(16 * m + 4 * q16 + r) * LD + col] = fmaxf(acc[m][r] + a1v, 0.f);
+            }
+        }
+        __syncthreads();
+        // ---- item = [ev0 | out0 | out2] Wmix + bmix ; score ----
+        {
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mma(sE0, bC0, acc);
+            mma(sO0, bC1, acc);
+            mma(sZ1, bC2, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * m + 4 * q16 + r;
+                    const int64_t gr = r0 + row;
+                    const float v = acc[m][r] + bcv;
+                    float part = 0.f;
+                    if (gr < a.B) {
+                        if (a.item_emb) a.item_emb[gr * D + col] = v;
+                        part = a.user_o[gr * D + col] * v;
+                    }
+                    part = group_sum(part, 4);              // the slab's 16 columns of this row
+                    if (l16 == 0) sSc[wave * TM + row] = part;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < TM && r0 + tid < a.B) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) s += sSc[w * TM + tid];      // fixed order: deterministic
+            a.scores[r0 + tid] = s;
+            if (a.sig) a.sig[r0 + tid] = 1.f / (1.f + expf(-s));
+        }
+    }
+}
+
+bool l2_tail_supported(int D) { return D == 16 || D == 32 || D == 64; }
+
+template <int D>
+static hipError_t launch_tail_d(const TailArgs& a, hipStream_t st) {
+    constexpr int NT = D / 16;
+    const size_t lds = (size_t)(4 * 32 * (D + 2) + NT * 32) * 4;
+    const int64_t ntiles = (a.B + 31) / 32;
+    const int64_t cap = 256 * (D == 64 ? 4 : 8);
+    l2_tail_kernel<D><<<(int)(ntiles < cap ? ntiles : cap), NT * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_l2_tail(const TailArgs& a, int D, hipStream_t st) {
+    switch (D) {
+        case 16: return launch_tail_d<16>(a, st);
+        case 32: return launch_tail_d<32>(a, st);
+        case 64: return launch_tail_d<64>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin

@@ -444,7 +444,11 @@ class MVIN(object):
         use_l2 = use_hoist or (self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K))
         top = L - 1 if use_l2 else L          # levels 0..top-1 are materialised
         ents, rels = self.get_neighbors(item32, levels=top - 1)
-        ev, c = self._project_levels(ents, q, top, need_c=() if use_l2 else (L,))
+        # depth-2 trees: everything above the fused kernel (level-0 projection, both hop-0 aggregators, the
+        # combiner and the score) is ONE launch (mvin_l2_tail_fwd) instead of four
+        use_tail = (use_l2 and not use_hoist and L == 2 and M == 1 and self.fused is not False
+                    and ops.l2_tail_supported(D))
+        ev, c = (None, {}) if use_tail else self._project_levels(ents, q, top, need_c=() if use_l2 else (L,))
         nagg = pp = pc = None
         if use_hoist:
             if self._profile is not None:
@@ -472,6 +476,19 @@ class MVIN(object):
                 e1.record()
                 self._profile.append((e0, e1))
             nagg = (n0, n1)
+            if use_tail:
+                item_emb, scores, sig = ops.l2_tail(
+                    self.entity_emb_matrix, item32, q if uo else None, user_o, n0, n1,
+                    self.transfer_matrix_list[0] if uo else None, self.transfer_matrix_bias[0] if uo else None,
+                    a0.weights, a0.bias, a1.weights, a1.bias, self.enti_transfer_matrix_list[0],
+                    self.enti_transfer_bias_list[0])
+                importance = []
+                if want_probs and a0.User_orient_rela:
+                    importance = [pp.view(B, 1, K) if pp is not None else None,
+                                  pc.view(B, K, K) if pc is not None else None]
+                elif want_probs:
+                    importance = [None, None]
+                return item_emb, scores, sig, importance
         importance = []
         out = None
         for n in range(M):

@@ -280,6 +280,31 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     return out
 
 
+def l2_tail_supported(D):
+    return bool(_lib.load().mvin_l2_tail_supported(D))
+
+
+def l2_tail(entity_emb, items, q, user_o, nagg0, nagg1, W0, b0, A0, a0, A1, a1, Wmix, bmix):
+    """mvin_l2_tail_fwd: projection of level 0, both hop-0 aggregators, the mix-hop combiner and the score in one
+    launch (depth-2 trees).  Returns (item_emb [B,D], scores [B], sigmoid [B])."""
+    bf = _chk_table(entity_emb, "entity_emb")
+    for t, nm in ((q, "q"), (user_o, "user_o"), (nagg0, "nagg0"), (nagg1, "nagg1"), (W0, "W0"), (b0, "b0"), (A0, "A0"),
+                  (a0, "a0"), (A1, "A1"), (a1, "a1"), (Wmix, "Wmix"), (bmix, "bmix")):
+        _chk(t, F32, nm)
+    B, D = user_o.shape
+    dev = user_o.device
+    i64 = items if items.dtype == torch.int64 else None
+    i32 = items if items.dtype == I32 else None
+    item_emb = torch.empty((B, D), dtype=F32, device=dev)
+    scores = torch.empty((B,), dtype=F32, device=dev)
+    sig = torch.empty((B,), dtype=F32, device=dev)
+    _lib.check(_lib.load().mvin_l2_tail_fwd(_p(entity_emb), _p(i64), _p(i32), _p(q), _p(user_o), _p(nagg0), _p(nagg1),
+                                            _p(W0), _p(b0), _p(A0), _p(a0), _p(A1), _p(a1), _p(Wmix), _p(bmix), B, D,
+                                            entity_emb.shape[0], _p(item_emb), _p(scores), _p(sig), bf, _stream()),
+               "mvin_l2_tail_fwd")
+    return item_emb, scores, sig
+
+
 def gather_rows(table, ids):
     """mvin_gather_rows: out[i] = table[ids[i]] for rows of any 4-byte-multiple width (fp32 / bf16 entity rows)."""
     _chk(ids, I32, "ids")
