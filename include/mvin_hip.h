@@ -218,6 +218,54 @@ int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int
                      int table_bf16, void* stream);
 int mvin_l2_tail_supported(int D);
 
+/* The whole get_scores pass (model.py:125-159, default wiring: preference sets AND high-order part, query =
+ * user_o, wide_deep, n_mix_hop = 1, h_hop = 2) enqueued by ONE native call: at the reference's own batch sizes
+ * (512 / 1024, src/bash/mvin_*.sh) the pass is a handful of short kernels and the host-side cost of issuing them
+ * one foreign call at a time dominates.  Sequence (each step is the entry point of the same name):
+ *   mvin_linear_fwd (V = E[item] . R_KGE[r]) -> mvin_key_addressing_fwd -> mvin_linear_fwd (user MLP, :232-236)
+ *   -> mvin_expand_ids (level 0) -> mvin_gather_attn_l2_fwd -> mvin_l2_tail_fwd.
+ * All pointers are device pointers except mem_h / mem_r / mem_t (host arrays of max(1,P) device pointers).
+ * Workspace and outputs are caller-owned.  Returns the first failing step's code. */
+typedef struct {
+    const void* entity_emb;        /* [nE, D] fp32 or bf16 */
+    const int32_t* adj_entity;     /* [nE, K] */
+    const int32_t* adj_relation;
+    const float* relation_kge;     /* [nR, D, D] */
+    const float* h_set_w;          /* [D] or NULL (PS_O_ft off) */
+    const float* user_mlp_W;       /* [(P + (h_set_w != NULL)) * D, D] */
+    const float* user_mlp_b;
+    const float* t0;               /* [nR] relation logits of aggregator (0,0) / (1,0) or NULL (User_orient_rela off) */
+    const float* t1;
+    const float* W0;               /* projections of levels 0, 1, 2 or all NULL (User_orient off) */
+    const float* b0;
+    const float* W1;
+    const float* b1;
+    const float* W2;
+    const float* b2;
+    const float* A0;
+    const float* a0;
+    const float* A1;
+    const float* a1;
+    const float* Wmix;             /* [3D, D] */
+    const float* bmix;
+    const int64_t* items;          /* [B] */
+    const int32_t* const* mem_h;
+    const int32_t* const* mem_r;
+    const int32_t* const* mem_t;
+    float* V;                      /* workspace [B, nR, D] */
+    float* o_cat;                  /* workspace [B, (P + (h_set_w != NULL)) * D] */
+    int32_t* parents;              /* workspace [B] */
+    float* nagg0;                  /* workspace [B, D] */
+    float* nagg1;
+    float* user_o;                 /* out [B, D] */
+    float* item_emb;               /* out [B, D] */
+    float* scores;                 /* out [B] */
+    float* sig;                    /* out [B] */
+    int64_t B;
+    int D, K, P, Nm, n_entity, n_relation, table_bf16;
+} mvin_score_l2_args;
+int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
+
 /* Row movers of the multi-GPU layer (mvin_amd/dist.py; no reference counterpart -- the reference is single
  * device): out[i, :] = table[ids[i], :] (gather) and table[ids[i], :] = rows[i, :] (scatter; ids distinct),
  * rows of `row_bytes` bytes (a multiple of 4: fp32 or bf16 entity rows move untouched). */

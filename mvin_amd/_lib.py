@@ -43,6 +43,15 @@ class LinearArgs(C.Structure):
     ]
 
 
+class ScoreL2Args(C.Structure):
+    """mvin_score_l2_args (include/mvin_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "entity_emb", "adj_entity", "adj_relation", "relation_kge", "h_set_w", "user_mlp_W", "user_mlp_b", "t0", "t1",
+        "W0", "b0", "W1", "b1", "W2", "b2", "A0", "a0", "A1", "a1", "Wmix", "bmix", "items", "mem_h", "mem_r", "mem_t",
+        "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
+        ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16")]
+
+
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
 SIGNATURES = {
     "mvin_abi_version": (C.c_int, []),
@@ -50,6 +59,7 @@ SIGNATURES = {
     "mvin_debug_read_trace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mvin_l2_tail_fwd": (C.c_int, [C.c_void_p] * 15 + [C.c_int64, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p]),
     "mvin_l2_tail_supported": (C.c_int, [C.c_int]),
+    "mvin_score_l2_fwd": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),

@@ -342,6 +342,62 @@ int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int
     return hip_result(mvin::launch_l2_tail(t, D, (hipStream_t)stream), who);
 }
 
+int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
+    const char* who = "mvin_score_l2_fwd";
+    if (!a) return fail(-1, "%s: null args", who);
+    if (a->P < 1 || a->P > 8) return fail(-2, "%s: P=%d (1..8)", who, a->P);
+    if (!a->V || !a->o_cat || !a->parents || !a->nagg0 || !a->nagg1 || !a->user_o || !a->scores || !a->items)
+        return fail(-1, "%s: null workspace / output / items", who);
+    const int D = a->D, nR = a->n_relation;
+    const int n_o = a->P + (a->h_set_w ? 1 : 0);
+    // V[b, r, :] = E[item_b] . R_KGE[r]   (model.py:214-220 re-associated: (R h).v == h.(v R))
+    mvin_linear_args l{};
+    l.src[0] = reinterpret_cast<const float*>(a->entity_emb);
+    l.ids[0] = reinterpret_cast<const int32_t*>(a->items);
+    l.ids64 = 1;
+    l.src_bf16 = a->table_bf16 ? 1 : 0;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = a->B;
+    l.W = a->relation_kge;
+    l.rows_per_group = 1;
+    l.out = a->V;
+    l.ldo = (int64_t)nR * D;
+    l.nz = nR;
+    l.w_zstride = (int64_t)D * D;
+    l.out_zstride = D;
+    int rc = mvin_linear_fwd(&l, stream);
+    if (rc) return rc;
+    rc = mvin_key_addressing_fwd(a->entity_emb, a->V, a->h_set_w, a->mem_h, a->mem_r, a->mem_t, a->P, (int)a->B, a->Nm, D,
+                                 nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+    if (rc) return rc;
+    mvin_linear_args u{};                     // user_o = o_cat . user_mlp + bias (model.py:232-236)
+    u.src[0] = a->o_cat;
+    u.nsrc = 1;
+    u.Dsrc = n_o * D;
+    u.Dout = D;
+    u.rows = a->B;
+    u.W = a->user_mlp_W;
+    u.bias = a->user_mlp_b;
+    u.rows_per_group = 1;
+    u.out = a->user_o;
+    u.ldo = D;
+    u.nz = 1;
+    rc = mvin_linear_fwd(&u, stream);
+    if (rc) return rc;
+    rc = mvin_expand_ids(a->adj_entity, a->adj_relation, a->items, nullptr, (int)a->B, a->K, 0, a->n_entity, a->parents,
+                         nullptr, stream);
+    if (rc) return rc;
+    rc = mvin_gather_attn_l2_fwd(a->entity_emb, a->adj_entity, a->adj_relation, a->parents, a->t0, a->t1, a->W1, a->W2,
+                                 a->b1, a->b2, a->W1 ? a->user_o : nullptr, a->A0, a->a0, (int)a->B, 1, a->K, D,
+                                 a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr, a->table_bf16, stream);
+    if (rc) return rc;
+    return mvin_l2_tail_fwd(a->entity_emb, a->items, nullptr, a->W0 ? a->user_o : nullptr, a->user_o, a->nagg0, a->nagg1,
+                            a->W0, a->b0, a->A0, a->a0, a->A1, a->a1, a->Wmix, a->bmix, a->B, D, a->n_entity, a->item_emb,
+                            a->scores, a->sig, a->table_bf16, stream);
+}
+
 int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream) {
     const char* who = "mvin_gather_rows";
     if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(-2, "%s: n=%lld row_bytes=%d", who, (long long)n, row_bytes);

@@ -175,6 +175,8 @@ class MVIN(object):
                 self._agg[(i, n)] = agg
                 self.aggregators.append(agg)
         self._profile = None
+        self._native_l2_state = None
+        self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
 
     def _build_train(self):
         """model.py:378-414 (loss + Adam): the backward path is a later row of the scope
@@ -557,6 +559,78 @@ class MVIN(object):
         return self.forward_device(user_indices, item_indices, None, None, None, want_probs=want_probs,
                                    uts=user_triplet_set)
 
+    # ------------------------------------------------------------------ native whole-pass schedule
+    def _native_l2_ok(self, item, memories_h, want_probs):
+        """The pass can be enqueued by ONE native call (mvin_score_l2_fwd): default wiring, depth-2 trees."""
+        a = self.args
+        return (self.fused is not False and not want_probs and not self.hoist and self._profile is None
+                and a.wide_deep and not a.PS_only and not a.HO_only and a.User_orient_kg_eh
+                and self.n_mix_hop == 1 and self.h_hop == 2 and self.p_hop >= 1
+                and item.dtype == torch.int64 and memories_h[0].dim() == 2
+                and ops.l2_tail_supported(self.dim) and ops.gather_attn_l2_supported(self.dim, self.n_neighbor)
+                and ops.key_addressing_supported(self.n_memory, self.dim)
+                and item.shape[0] <= self.native_l2_max_batch)
+
+    def _score_l2_native(self, item, mem_h, mem_r, mem_t):
+        """model.py:125-159 through mvin_score_l2_fwd.  The argument block (every weight pointer) is built once and
+        kept until a parameter tensor is replaced; per call only the batch pointers change."""
+        from . import _lib
+        import ctypes as C
+        a, D, P, B = self.args, self.dim, self.p_hop, item.shape[0]
+        a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
+        t0 = a0.relation_scores() if a0.User_orient_rela else None
+        t1 = a1.relation_scores() if a1.User_orient_rela else None
+        uo = a.User_orient
+        key = (self._generation, self.entity_emb_matrix.data_ptr(), t0.data_ptr() if t0 is not None else 0,
+               t1.data_ptr() if t1 is not None else 0)
+        st = self._native_l2_state
+        if st is None or st["key"] != key:
+            s = _lib.ScoreL2Args()
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            s.entity_emb, s.adj_entity, s.adj_relation = ptr(self.entity_emb_matrix), ptr(self.adj_entity), ptr(self.adj_relation)
+            s.relation_kge = ptr(self.relation_emb_KGE_matrix)
+            s.h_set_w = ptr(self.h_emb_item_mlp_matrix) if a.PS_O_ft else None
+            s.user_mlp_W, s.user_mlp_b = ptr(self.user_mlp_matrix), ptr(self.user_mlp_bias)
+            s.t0, s.t1 = ptr(t0), ptr(t1)
+            for e in range(3):
+                setattr(s, f"W{e}", ptr(self.transfer_matrix_list[e]) if uo else None)
+                setattr(s, f"b{e}", ptr(self.transfer_matrix_bias[e]) if uo else None)
+            s.A0, s.a0, s.A1, s.a1 = ptr(a0.weights), ptr(a0.bias), ptr(a1.weights), ptr(a1.bias)
+            s.Wmix, s.bmix = ptr(self.enti_transfer_matrix_list[0]), ptr(self.enti_transfer_bias_list[0])
+            s.D, s.K, s.P, s.Nm = D, self.n_neighbor, P, self.n_memory
+            s.n_entity, s.n_relation = self.n_entity, self.n_relation
+            s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
+            # every tensor whose address sits in the block is kept alive with it; rebinding a parameter attribute
+            # needs invalidate(), exactly as for the cached relation logits
+            keep = (t0, t1, self.entity_emb_matrix, self.adj_entity, self.adj_relation, self.relation_emb_KGE_matrix,
+                    self.h_emb_item_mlp_matrix, self.user_mlp_matrix, self.user_mlp_bias, list(self.transfer_matrix_list),
+                    list(self.transfer_matrix_bias), a0.weights, a0.bias, a1.weights, a1.bias,
+                    self.enti_transfer_matrix_list[0], self.enti_transfer_bias_list[0])
+            st = self._native_l2_state = {"key": key, "args": s, "keep": keep, "ws": {}, "arr": (C.c_void_p * P)}
+        s = st["args"]
+        n_o = P + (1 if a.PS_O_ft else 0)
+        ws = st["ws"].get(B)
+        if ws is None:        # workspace reused across calls of the same batch size (the stream orders the reuse)
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
+            ws = st["ws"][B] = (f(B, self.n_relation, D), f(B, n_o * D), torch.empty(B, dtype=torch.int32, device=self.device),
+                                f(B, D), f(B, D))
+            if len(st["ws"]) > 4:
+                st["ws"].pop(next(iter(st["ws"])))
+        user_o = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        item_emb = torch.empty((B, D), dtype=torch.float32, device=self.device)
+        scores = torch.empty((B,), dtype=torch.float32, device=self.device)
+        sig = torch.empty((B,), dtype=torch.float32, device=self.device)
+        ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
+        s.items = item.data_ptr()
+        s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
+        s.V, s.o_cat, s.parents, s.nagg0, s.nagg1 = (w.data_ptr() for w in ws)
+        s.user_o, s.item_emb, s.scores, s.sig = user_o.data_ptr(), item_emb.data_ptr(), scores.data_ptr(), sig.data_ptr()
+        s.B = B
+        _lib.check(_lib.load().mvin_score_l2_fwd(C.byref(s), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "mvin_score_l2_fwd")
+        return SimpleNamespace(scores=scores, scores_normalized=sig, user_o=user_o, item_embeddings=item_emb,
+                               importance_list=[])
+
     def _key_addressing_grouped(self, user, item, uts):
         """model.py:161-240 with the pairs grouped by user (mvin_key_addressing_grouped_fwd) -> user_o [B,D]."""
         a, D, P = self.args, self.dim, self.p_hop
@@ -594,6 +668,10 @@ class MVIN(object):
                 memories_r = [sel[:, i, 1].contiguous() for i in range(P_)]
                 memories_t = [sel[:, i, 2].contiguous() for i in range(P_)]
         shared = (not grouped) and memories_h is not None and memories_h[0].dim() == 1   # one user's sets for the batch
+        if not grouped and not shared and memories_h is not None and self._native_l2_ok(item32, memories_h, want_probs) \
+                and all(m_.dtype == torch.int32 and m_.is_contiguous() for lst in (memories_h, memories_r, memories_t)
+                        for m_ in lst[:self.p_hop]):
+            return self._score_l2_native(item32, memories_h, memories_r, memories_t)
         if shared and user32.numel() == 1:
             user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
         if shared and (self.n_memory % 4 != 0 or self.n_memory > 256):
