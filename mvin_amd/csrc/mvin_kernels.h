@@ -234,6 +234,8 @@ hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
 bool key_addr_grouped_supported(int D, int P, int Nm, int nR);
 hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
+bool key_addr_dense_supported(int D, int P, int Nm, int nR);     // dense (all-MFMA) variant, mvin_keyaddr_dense.hip
+hipError_t launch_key_addr_dense(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, void* rows, bool scatter,
                             hipStream_t st);

@@ -1,0 +1,352 @@
+// MVIN._key_addressing (model.py:161-240) for pairs grouped by user, in its DENSE form: with a user's ripple
+// sets fixed for all of the user's pairs, every step of the attention reads is a small matrix product, and all
+// of them run on v_mfma_f32_16x16x4_f32 (exact fp32).  Same interface as key_addr_grouped_kernel
+// (mvin_keyaddr_grouped.hip); this is the variant the launcher prefers whenever its LDS footprint fits.
+//
+// Per user segment (one workgroup of 16 waves):
+//   stage   : uts[u] ids; head rows h_m and tail rows t_m of every hop -> LDS (sH, sT), once
+//   U       : U_m = R_KGE[r_m] . h_m for every memory m -- the reference's own association, model.py:214-216
+//             (tf.matmul(r_emb, h_expanded)) -- as row tiles of 16 memories that share a relation (the memories
+//             are bucketed by relation in LDS; a bucket is padded to whole tiles): A = h rows, B = R_KGE[r]^T
+//             fragments straight from L1/L2, result -> sU in (hop, m) order
+//   h-set   : o_hset = sum_m softmax_m(h0_m . w_h) h0_m (:162-197), once per user (one wave, VALU)
+//   per tile of 16 pairs:
+//     logits : L[pair, m] = E[item_pair] . U_m                       (:219-220)   MFMA, A = item rows, B = sU^T
+//     softmax: over the Nm memories of each hop (:223)               one wave per pair
+//     reads  : o[pair, hop] = sum_m p[pair, m] t_m                   (:229)       MFMA, A = p, B = sT
+// Nothing of size [B, nR, D] or [B, Nm, D, D] exists; a user's 2*P*Nm rows are read once per batch.
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDW = 16;      // waves per workgroup
+constexpr int kDT = 16;      // pairs per tile
+
+struct KaDenseLds {
+    size_t h, u, t, ei, l, z, hset, lg, idh, idt, rel, rank, bidx, cnt, off, tile_rel, tile_row, orig, total;
+    int NmP, PN, maxtiles;
+};
+
+static KaDenseLds ka_dense_layout(int D, int P, int Nm, int nR) {
+    KaDenseLds L{};
+    const int Ph = P > 0 ? P : 1;
+    L.NmP = (Nm + 15) & ~15;
+    L.PN = P * L.NmP;
+    const int nrl = nR < P * Nm ? nR : P * Nm;
+    L.maxtiles = L.PN / 16 + (nrl > 0 ? nrl : 1);          // every bucket wastes less than one tile
+    size_t o = 0;
+    auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };
+    L.h = take((size_t)Ph * L.NmP * (D + 2));
+    L.u = take((size_t)L.PN * (D + 2));
+    L.t = take((size_t)L.PN * (D + 16));
+    L.ei = take((size_t)kDT * (D + 2));
+    L.l = take((size_t)kDT * (L.PN + 2));
+    L.z = take((size_t)kDT * (P > 0 ? P : 1));
+    L.hset = take(D);
+    L.lg = take(L.NmP);
+    L.idh = take((size_t)Ph * L.NmP);
+    L.idt = take((size_t)Ph * L.NmP);
+    L.rel = take((size_t)Ph * L.NmP);
+    L.rank = take((size_t)Ph * L.NmP);
+    L.bidx = take((size_t)L.maxtiles * 16);
+    L.cnt = take(nR);
+    L.off = take(nR);
+    L.tile_rel = take(L.maxtiles);
+    L.tile_row = take(L.maxtiles);
+    L.orig = take(kDT + 4);
+    L.total = o * 4;
+    return L;
+}
+
+template <int D, bool BF>
+__global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int LPR = D / 4, RPW = 64 / LPR, NT = D / 16, KS = D / 4, LDH = D + 2, LDT = D + 16, NTHR = kDW * 64;
+    constexpr int LPR_L2 = (LPR == 4) ? 2 : (LPR == 8) ? 3 : (LPR == 16) ? 4 : 5;
+    const int P = a.P, Nm = a.Nm, Ph = P > 0 ? P : 1, NmP = L.NmP, PN = L.PN, LDL = PN + 2;
+    float* sH = smem + L.h;
+    float* sU = smem + L.u;
+    float* sT = smem + L.t;
+    float* sEi = smem + L.ei;
+    float* sL = smem + L.l;
+    float* sZ = smem + L.z;
+    float* sHset = smem + L.hset;
+    float* sLg = smem + L.lg;
+    int* sIdH = reinterpret_cast<int*>(smem + L.idh);
+    int* sIdT = reinterpret_cast<int*>(smem + L.idt);
+    int* sRel = reinterpret_cast<int*>(smem + L.rel);
+    int* sRank = reinterpret_cast<int*>(smem + L.rank);
+    int* sBidx = reinterpret_cast<int*>(smem + L.bidx);
+    int* sCnt = reinterpret_cast<int*>(smem + L.cnt);
+    int* sOff = reinterpret_cast<int*>(smem + L.off);
+    int* sTileRel = reinterpret_cast<int*>(smem + L.tile_rel);
+    int* sTileRow = reinterpret_cast<int*>(smem + L.tile_row);
+    int* sOrig = reinterpret_cast<int*>(smem + L.orig);      // [kDT] original pair index (-1: padding), [kDT] = #tiles
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane / LPR, c = lane % LPR;
+    const int q16 = lane >> 4, l16 = lane & 15;
+    const bool has_set = a.w != nullptr;
+    const int slot0 = has_set ? 1 : 0;
+
+    const int nseg = a.nseg_dev ? *a.nseg_dev : a.nseg;
+    // The item row of a pair hangs on three dependent loads (pair_index -> items -> E row).  A tile's rows are
+    // therefore fetched one tile AHEAD into registers (tile 0: before the segment's own id -> row chain starts),
+    // and the next segment's descriptor is read while the current one is processed.
+    auto item_row = [&](int t0, int p1, float4& e, int& orig) {
+        e = make_float4(0.f, 0.f, 0.f, 0.f);
+        orig = -1;
+        if (tid < kDT * LPR && t0 < p1) {
+            const int p = t0 + tid / LPR;
+            const int o = a.pair_index[p < p1 ? p : p1 - 1];
+            const int64_t item = a.items64 ? a.items64[o] : (int64_t)a.items32[o];
+            e = load_row4(a.E, BF, item, D, tid % LPR);
+            orig = p < p1 ? o : -1;
+        }
+    };
+    int nu = 0, np0 = 0, np1 = 0;
+    if ((int)blockIdx.x < nseg) {
+        nu = a.seg_user[blockIdx.x];
+        np0 = a.seg_ptr[blockIdx.x];
+        np1 = a.seg_ptr[blockIdx.x + 1];
+    }
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+        const int u = nu, p0 = np0, p1 = np1;
+        if (seg + (int)gridDim.x < nseg) {
+            nu = a.seg_user[seg + gridDim.x];
+            np0 = a.seg_ptr[seg + gridDim.x];
+            np1 = a.seg_ptr[seg + gridDim.x + 1];
+        }
+        float4 e_next;
+        int orig_next;
+        item_row(p0, p1, e_next, orig_next);
+        __syncthreads();                                     // previous segment fully consumed
+        for (int i = tid; i < a.nR; i += NTHR) sCnt[i] = 0;
+        for (int i = tid; i < L.maxtiles * 16; i += NTHR) sBidx[i] = -1;
+        __syncthreads();
+        // ---- ids (row i = hop * NmP + m; padding rows m >= Nm stay zero), rank of every memory inside its relation ----
+        const int32_t* ub = a.uts + (int64_t)u * Ph * 3 * Nm;
+        for (int i = tid; i < Ph * NmP; i += NTHR) {
+            const int hop = i / NmP, m = i - hop * NmP;
+            int idh = -1, idt = -1, r = 0, rk = 0;
+            if (m < Nm) {
+                idh = ub[(hop * 3 + 0) * Nm + m];
+                if (hop < P) {
+                    idt = ub[(hop * 3 + 2) * Nm + m];
+                    r = ub[(hop * 3 + 1) * Nm + m];
+                    rk = atomicAdd(&sCnt[r], 1);
+                }
+            }
+            sIdH[i] = idh;
+            sIdT[i] = idt;
+            sRel[i] = r;
+            sRank[i] = rk;
+        }
+        __syncthreads();
+        // ---- buckets padded to whole 16-row tiles: offsets + the tile table (wave 0) ----
+        if (wave == 0) {
+            int base = 0, ntile = 0;
+            for (int r0 = 0; r0 < a.nR; r0 += 64) {
+                const int r = r0 + lane;
+                const int cnt = r < a.nR ? sCnt[r] : 0;
+                const int tiles = (cnt + 15) >> 4;
+                int incl = tiles;                            // inclusive scan of `tiles` over the 64 lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int v = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += v;
+                }
+                const int first = ntile + incl - tiles;
+                if (r < a.nR) sOff[r] = first * 16;
+                for (int j = 0; j < tiles; ++j) {
+                    sTileRel[first + j] = r;
+                    sTileRow[first + j] = (first + j) * 16;
+                }
+                ntile += __shfl(incl, 63, 64);
+                base += 0;
+            }
+            if (lane == 0) sOrig[kDT] = ntile;
+        }
+        __syncthreads();
+        const int ntile = sOrig[kDT];
+        // ---- rows -> LDS; bucket index table ----
+        for (int i = wave * RPW + g; i < Ph * NmP; i += kDW * RPW) {
+            const int idh = sIdH[i], idt = sIdT[i];
+            float4 h = make_float4(0.f, 0.f, 0.f, 0.f), t = h;
+            if (idh >= 0) h = load_row4(a.E, BF, idh, D, c);
+            if (idt >= 0) t = load_row4(a.E, BF, idt, D, c);
+            float* dh = sH + (size_t)i * LDH + 4 * c;
+            *reinterpret_cast<float2*>(dh) = make_float2(h.x, h.y);
+            *reinterpret_cast<float2*>(dh + 2) = make_float2(h.z, h.w);
+            if (i < PN) {
+                *reinterpret_cast<float4*>(sT + (size_t)i * LDT + 4 * c) = t;
+                if (c == 0 && idt >= 0) sBidx[sOff[sRel[i]] + sRank[i]] = i;
+            }
+        }
+        __syncthreads();
+        // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
+        if (has_set && wave == kDW - 1) {
+            const float4 w4 = reinterpret_cast<const float4*>(a.w)[c];
+            for (int m0 = 0; m0 < NmP; m0 += RPW) {
+                const int m = m0 + g;
+                const float* hr = sH + (size_t)m * LDH + 4 * c;
+                float d = fmaf(hr[0], w4.x, fmaf(hr[1], w4.y, fmaf(hr[2], w4.z, hr[3] * w4.w)));
+                d = group_sum(d, LPR_L2);
+                if (c == 0) sLg[m] = m < Nm ? d : -INFINITY;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            float mx = -INFINITY;
+            for (int m = lane; m < NmP; m += 64) mx = fmaxf(mx, sLg[m]);
+            mx = wave_max(mx);
+            float z = 0.f;
+            for (int m = lane; m < NmP; m += 64) {
+                const float e = m < Nm ? expf(sLg[m] - mx) : 0.f;
+                sLg[m] = e;
+                z += e;
+            }
+            z = wave_sum(z);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int m0 = 0; m0 < NmP; m0 += RPW) {
+                const int m = m0 + g;
+                const float* hr = sH + (size_t)m * LDH + 4 * c;
+                acc = f4_fma(sLg[m], make_float4(hr[0], hr[1], hr[2], hr[3]), acc);
+            }
+            acc = group_xor_sum(acc, LPR);
+            const float inv = 1.f / z;
+            if (g == 0) *reinterpret_cast<float4*>(sHset + 4 * c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        } else if (P > 0) {
+            const int nw = has_set ? kDW - 1 : kDW;
+            for (int task = wave; task < ntile * NT; task += nw) {
+                const int tl = task / NT, nt = task - tl * NT;
+                const int row0 = sTileRow[tl];
+                const float* Rr = a.R + (size_t)sTileRel[tl] * D * D + (size_t)(16 * nt + l16) * D + q16;   // R[r][n][k]
+                float bfrag[KS];
+#pragma unroll
+                for (int k = 0; k < KS; ++k) bfrag[k] = Rr[4 * k];
+                const int ia = sBidx[row0 + l16];
+                const float* ar = sH + (size_t)(ia >= 0 ? ia : 0) * LDH + q16;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], bfrag[k], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int io = sBidx[row0 + 4 * q16 + i];
+                    if (io >= 0) sU[(size_t)io * LDH + 16 * nt + l16] = acc[i];
+                }
+            }
+            // padding memories: U rows never written by a tile must read as zero
+            for (int i = tid; i < PN * NT; i += (has_set ? (kDW - 1) : kDW) * 64) {
+                const int row = i / NT, nt = i - row * NT;
+                if (sIdT[row] < 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) sU[(size_t)row * LDH + 16 * nt + j] = 0.f;
+                }
+            }
+        }
+        // ---- the user's pairs, 16 at a time ----
+        for (int t0 = p0; t0 < p1; t0 += kDT) {
+            __syncthreads();                                 // sU / sHset complete; previous tile consumed
+            if (tid < kDT * LPR) {
+                const int i = tid / LPR, cc = tid % LPR;
+                float* dst = sEi + i * LDH + 4 * cc;
+                *reinterpret_cast<float2*>(dst) = make_float2(e_next.x, e_next.y);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(e_next.z, e_next.w);
+                if (cc == 0) sOrig[i] = orig_next;
+            }
+            item_row(t0 + kDT, p1, e_next, orig_next);       // the next tile's rows land under this tile's work
+            __syncthreads();
+            // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
+            for (int mt = wave; mt < PN / 16; mt += kDW) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* ar = sEi + l16 * LDH + q16;
+                const float* br = sU + (size_t)(16 * mt + l16) * LDH + q16;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], br[4 * k], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sL[(size_t)(4 * q16 + i) * LDL + 16 * mt + l16] = acc[i];
+            }
+            __syncthreads();
+            // softmax over the Nm memories of every (pair, hop) (:223): un-normalised weights back to sL, 1/sum to sZ
+            for (int task = wave; task < kDT * P; task += kDW) {
+                const int pi = task / P, hop = task - pi * P;
+                float* row = sL + (size_t)pi * LDL + hop * NmP;
+                float mx = -INFINITY;
+                for (int m = lane; m < Nm; m += 64) mx = fmaxf(mx, row[m]);
+                mx = wave_max(mx);
+                float z = 0.f;
+                for (int m = lane; m < NmP; m += 64) {
+                    const float e = m < Nm ? expf(row[m] - mx) : 0.f;
+                    row[m] = e;
+                    z += e;
+                }
+                z = wave_sum(z);
+                if (lane == 0) sZ[pi * P + hop] = 1.f / z;
+            }
+            __syncthreads();
+            // reads o[pair, hop, :] = sum_m p[pair, m] t_m : one (hop, 16-column tile) per task
+            for (int task = wave; task < P * NT; task += kDW) {
+                const int hop = task / NT, nt = task - hop * NT;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* ar = sL + (size_t)l16 * LDL + hop * NmP + q16;
+                const float* br = sT + (size_t)(hop * NmP + q16) * LDT + 16 * nt + l16;
+                for (int k = 0; k < NmP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], br[(size_t)4 * k * LDT], acc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pi = 4 * q16 + i;
+                    const int orig = sOrig[pi];
+                    if (orig >= 0)
+                        a.out[(int64_t)orig * a.ldo + (size_t)(slot0 + hop) * D + 16 * nt + l16] = acc[i] * sZ[pi * P + hop];
+                }
+            }
+            if (has_set) {
+                for (int i = tid; i < kDT * LPR; i += NTHR) {
+                    const int pi = i / LPR, cc = i - pi * LPR;
+                    const int orig = sOrig[pi];
+                    if (orig >= 0)
+                        *reinterpret_cast<float4*>(a.out + (int64_t)orig * a.ldo + 4 * cc) = *reinterpret_cast<const float4*>(sHset + 4 * cc);
+                }
+            }
+        }
+    }
+}
+
+bool key_addr_dense_supported(int D, int P, int Nm, int nR) {
+    const bool dok = D == 16 || D == 32 || D == 64 || D == 128;
+    return dok && Nm >= 1 && Nm <= 256 && P >= 0 && P <= 8 && nR >= 1 && nR <= 4096 &&
+           ka_dense_layout(D, P, Nm, nR).total <= 160 * 1024;
+}
+
+template <int D>
+static hipError_t launch_kad(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
+    const KaDenseLds L = ka_dense_layout(D, a.P, a.Nm, a.nR);
+    const int cap = 256;                                     // 16 waves: one workgroup per CU
+    const int grid = a.nseg < cap ? a.nseg : cap;
+    hipError_t e = hipSuccess;
+    if (table_bf16) {
+        auto k = key_addr_dense_kernel<D, true>;
+        if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+        if (e != hipSuccess) return e;
+        k<<<grid, kDW * 64, L.total, st>>>(a, L);
+    } else {
+        auto k = key_addr_dense_kernel<D, false>;
+        if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+        if (e != hipSuccess) return e;
+        k<<<grid, kDW * 64, L.total, st>>>(a, L);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_key_addr_dense(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
+    switch (a.D) {
+        case 16: return launch_kad<16>(a, table_bf16, st);
+        case 32: return launch_kad<32>(a, table_bf16, st);
+        case 64: return launch_kad<64>(a, table_bf16, st);
+        case 128: return launch_kad<128>(a, table_bf16, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin

@@ -16,6 +16,8 @@
 // key_addr_kernel up to fp32 summation order.
 //
 // Supported: D in {16, 32, 64, 128}, Nm <= 256, rows + V tile within the 160 KB LDS (launcher checks).
+#include <cstdlib>
+
 #include "mvin_kernels.h"
 
 namespace mvin {
@@ -234,6 +236,7 @@ size_t key_addr_grouped_lds_bytes(int D, int P, int Nm, int nR) {
 
 bool key_addr_grouped_supported(int D, int P, int Nm, int nR) {
     const bool dok = D == 16 || D == 32 || D == 64 || D == 128;
+    if (key_addr_dense_supported(D, P, Nm, nR)) return true;
     return dok && Nm >= 1 && Nm <= 256 && P >= 0 && P <= 8 && nR >= 1 && nR <= 4096 &&
            key_addr_grouped_lds_bytes(D, P, Nm, nR) <= 160 * 1024;
 }
@@ -262,6 +265,10 @@ static hipError_t launch_kag(KeyAddrGroupedArgs a, int table_bf16, hipStream_t s
 }
 
 hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
+    // the dense (all-MFMA) form whenever its LDS footprint fits; MVIN_KA_DENSE=0 keeps this file's kernel (A/B)
+    static const char* dense_env = getenv("MVIN_KA_DENSE");
+    if (!(dense_env && dense_env[0] == '0') && key_addr_dense_supported(a.D, a.P, a.Nm, a.nR))
+        return launch_key_addr_dense(a, table_bf16, st);
     switch (a.D) {
         case 16: return launch_kag<16>(a, table_bf16, st);
         case 32: return launch_kag<32>(a, table_bf16, st);

@@ -4,7 +4,7 @@
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$root"; mkdir -p gpurun_out; out=gpurun_out/bench_variants.jsonl; : > $out
 run() {
-  line=$(python bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | grep '^{' | tail -1)
+  line=$(python bench.py --no-cpu-baseline --no-hbm-leg --no-sweep --steps 10 --warmup 3 "$@" 2>/dev/null | grep '^{' | tail -1)
   [ -n "$line" ] && python - "$line" "$*" >> $out <<'PY'
 import json, sys
 r = json.loads(sys.argv[1]); r["variant_args"] = sys.argv[2]; print(json.dumps(r))
@@ -13,7 +13,8 @@ PY
 C2="--dataset MovieLens-1M --dim 32 --fanout 16"
 C4="--dataset amazon-book_20core --dim 64 --fanout 64 --batch 32768"
 C5="--dataset amazon-book_20core --dim 128 --hop 3 --fanout 128 --table-dtype bf16"
-run                                             # C3 default
+run                                             # C3 default (feed: user_triplet_set resident)
+run --feed pairs                                # C3, per-pair ripple-set arrays resident
 run --batch 262144
 run --batch 262144 --adj uniform --items uniform   # worst-case locality
 run --batch 16384
@@ -22,7 +23,11 @@ run --batch 512 --graph
 run --n-entity 16000000 --batch 32768           # 4 GB table: HBM-bound
 run $C2 --batch 524288
 run $C4
+run $C4 --feed pairs
 run $C5 --batch 64 --steps 3 --warmup 1
+MVIN_L2_SPLIT=0 run --feed pairs                # symmetric fused kernel (round-1 design) for A/B
+MVIN_L2_SPLIT=0 run $C4 --feed pairs
+MVIN_L2_SPLIT=0 run $C5 --batch 64 --steps 3 --warmup 1
 # entity-table mode (separate mode, own bytes per pair)
 run --batch 262144 --hoist cached
 run --batch 262144 --hoist step
@@ -38,5 +43,5 @@ python - <<'PY'
 import json
 for l in open("gpurun_out/bench_variants.jsonl"):
     r = json.loads(l)
-    print(f'{r["variant_args"]:75s} {r["value"]:14.1f} pairs/s  {r["ms_per_step"]:9.3f} ms  kernel {r["roofline"]["avg_launch_ms"]} ms  {r["roofline"]["achieved"]} GB/s')
+    print(f'{r["variant_args"]:75s} {r["value"]:14.1f} pairs/s  {r["ms_per_step"]:9.3f} ms  kernel {r["roofline"]["avg_launch_ms"]} ms  {r["roofline"]["achieved"]} GB/s ({r["roofline"]["bound"]})')
 PY

@@ -40,7 +40,7 @@ def main():
         for c, v in cs.items():
             v = v[len(v) // 6:] if len(v) > 6 else v     # drop the warm-up launches' share
             summ[name][c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-    fused = [k for k in summ if "gather_attn_l2_kernel" in k]
+    fused = [k for k in summ if "gather_attn_l2" in k]
     if hbm:
         k = summ[fused[0]]
         rec = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py "

@@ -61,6 +61,7 @@ def main():
             assert torch.equal(out.scores, ref), f"rank {rank} {regime}: pipelined step {i} differs"
         # the user_triplet_set feed (relabelled once): same scores as the per-pair arrays of the same users
         sh.set_user_triplet_set(uts)
+        sh.model.group_min_pairs_per_user = 0
         got_u = sh.forward_users(feed[0], feed[1]).scores
         assert torch.allclose(got_u, ref_u, rtol=1e-5, atol=1e-6), f"rank {rank} {regime}: forward_users differs"
         torch.cuda.synchronize()

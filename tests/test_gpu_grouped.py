@@ -40,6 +40,7 @@ def test_grouped_matches_per_pair_and_oracle(case, hip_lib):
     items = rng.integers(0, n_entity, B, dtype=np.int64)
     params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
     model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0", table_dtype=tdt)
+    model.group_min_pairs_per_user = 0                     # always take the grouped kernel here
     dev = model.device
     u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
     uts_d = torch.from_numpy(uts).to(dev)
@@ -78,6 +79,7 @@ def test_device_feeder_uses_the_grouped_path(hip_lib):
     adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, 4, seed=1)
     uts = synth.ripple_sets(n_user, n_entity, nR, 2, 32, seed=2)
     model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, device="cuda:0", seed=3)
+    model.group_min_pairs_per_user = 0
     feeder = harness.DeviceFeeder(model, uts)
     rng = np.random.default_rng(0)
     users, items = rng.integers(0, n_user, 100), rng.integers(0, n_entity, 100)
