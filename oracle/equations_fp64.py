@@ -1,6 +1,6 @@
 """From-the-equations numpy fp64 restatement of the MVIN scoring path (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED (see oracle/__init__.py).  Written independently of
+Pinned to the reference's wiring by tests/golden/ref (see oracle/__init__.py); TF arithmetic unpinned.  Written independently of
 oracle/mirror_fp32.py: one (user,item) pair at a time, no batch axis, no
 tile/concat -- the attention score is formed from the three slices of
 ``urh_weights`` and the tree is walked level by level with explicit child

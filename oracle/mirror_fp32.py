@@ -1,6 +1,6 @@
 """Op-by-op torch-CPU fp32 mirror of the reference TF1.x graph (TEST INFRASTRUCTURE).
 
-PARITY UNPINNED (see oracle/__init__.py): restatement, not the reference.
+Restatement, not the reference; pinned to the reference's wiring by tests/golden/ref (oracle/__init__.py).
 
 Every function cites the reference lines it follows (paths relative to
 /root/reference/src/model/MVIN/).  The mirror keeps TF's op order and TF's

@@ -2,7 +2,7 @@
 src/model/MVIN/model.py:378-412 on top of oracle/mirror_fp32.py, gradients by torch
 autograd, and tf.train.AdamOptimizer's update rule (model.py:414).
 
-PARITY UNPINNED (see oracle/__init__.py): a restatement, checked against finite differences
+Loss pieces pinned to the reference graph (tests/golden/ref, oracle/__init__.py); gradients are a restatement, checked against finite differences
 in tests/test_train_oracle.py.
 
 Loss (model.py:379-412), with B = batch size:

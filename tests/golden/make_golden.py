@@ -2,7 +2,7 @@
 
     python tests/golden/make_golden.py
 
-PARITY UNPINNED: the reference has no tests / golden vectors for this path and its
+SELF-GENERATED vectors (the reference-produced ones are tests/golden/ref/, make_ref_fixtures.py): the reference has no tests / golden vectors for this path and its
 TensorFlow-1.x implementation cannot be imported in this image, so these vectors come from
 the repo's own two restatements (oracle/mirror_fp32.py, oracle/equations_fp64.py), which must
 agree with each other before a fixture is written.  A fixture is data only: args, inputs
