@@ -184,6 +184,7 @@ class Trainer(object):
 
         # ================================================================ forward
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
+        self._ka_bwd_ran = False
         n_o = P + 1 if a.PS_O_ft else P
         ps = None
         if need_ps:
@@ -209,6 +210,7 @@ class Trainer(object):
                 d = G.get(ps)
                 if d is None:
                     return
+                self._ka_bwd_ran = True      # mvin_key_addressing_bwd adds the 2*l2*(h, t) regulariser rows
                 ops.linear_wgrad([o_cat], d, dP["user_mlp_matrix"], db=dP["user_mlp_bias"])
                 do_cat = torch.empty_like(o_cat)
                 for s in range(n_o):  # d o_s = d . Wu[sD:(s+1)D]^T
@@ -432,7 +434,9 @@ class Trainer(object):
             for ids in (memories_h[hop], memories_t[hop]):
                 rows = self._lookup(E, ids.reshape(-1))
                 ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
-                if not need_ps:   # otherwise mvin_key_addressing_bwd already added 2*l2*rows
+                # mvin_key_addressing_bwd adds 2*l2*rows when it ran -- it does not when ps was built but never
+                # consumed (HO_only + User_orient_kg_eh without User_orient: q has no consumer)
+                if not getattr(self, "_ka_bwd_ran", False):
                     ops.scatter_add_rows(dP["entity_emb_matrix"], ids.reshape(-1), rows, alpha=2.0 * l2w)
             cnt = torch.bincount(memories_r[hop].reshape(-1).long(), minlength=nR).to(F32)
             ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
