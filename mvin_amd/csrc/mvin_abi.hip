@@ -46,7 +46,8 @@ int mvin_abi_version(void) { return MVIN_ABI_VERSION; }
 
 int mvin_debug_read_trace(long long* host_dst, size_t n) {
     if (!host_dst) return -1;
-    return (int)mvin::split_read_trace(host_dst, n);
+    static const bool ka = getenv("MVIN_KA_TRACE") != nullptr;     // which kernel's stamps
+    return (int)(ka ? mvin::ka_read_trace(host_dst, n) : mvin::split_read_trace(host_dst, n));
 }
 
 const char* mvin_last_error(void) { return g_last_error.c_str(); }

@@ -52,6 +52,29 @@ __device__ __forceinline__ float group_max(float v, int l2) {
     return v;
 }
 
+// ---- whole-wave reductions without the LDS crossbar: DPP inside the 16-lane rows, then the gfx950 lane swaps
+// (v_permlane16_swap / v_permlane32_swap) across rows; every lane gets the result ----
+__device__ __forceinline__ float rows_combine_sum(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned yy = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(yy, yy, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+__device__ __forceinline__ float rows_combine_max(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned yy = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(yy, yy, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+__device__ __forceinline__ float wave_sum_fast(float v) { return rows_combine_sum(group_sum(v, 4)); }
+__device__ __forceinline__ float wave_max_fast(float v) { return rows_combine_max(group_max(v, 4)); }
+
 // ---- entity-table rows: fp32 (16-byte lane loads) or bf16 (8-byte lane loads, widened to fp32
 // exactly: bf16 -> f32 is a 16-bit shift) ------------------------------------------------------
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {

@@ -248,6 +248,7 @@ hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hi
 bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)
 bool fused_split_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
-hipError_t split_read_trace(long long* host_dst, size_t n);   // development aid, see mvin_fused_split.hip
+hipError_t split_read_trace(long long* host_dst, size_t n);
+hipError_t ka_read_trace(long long* host_dst, size_t n);   // development aid, see mvin_fused_split.hip
 
 }  // namespace mvin

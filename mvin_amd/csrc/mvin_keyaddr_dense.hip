@@ -15,13 +15,17 @@
 //     softmax: over the Nm memories of each hop (:223)               one wave per pair
 //     reads  : o[pair, hop] = sum_m p[pair, m] t_m                   (:229)       MFMA, A = p, B = sT
 // Nothing of size [B, nR, D] or [B, Nm, D, D] exists; a user's 2*P*Nm rows are read once per batch.
+#include <cstdlib>
+
 #include "mvin_kernels.h"
 
 namespace mvin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDW = 16;      // waves per workgroup
+// development aid (MVIN_KA_TRACE=1, scripts/trace_keyaddr.py): workgroup 0 stamps s_memtime at its phase boundaries
+__device__ long long g_ka_trace[64 * 16];
+constexpr int kDW = 12;      // waves per workgroup (168 VGPRs each: room for the resident R_KGE fragments)
 constexpr int kDT = 16;      // pairs per tile
 
 struct KaDenseLds {
@@ -60,7 +64,7 @@ static KaDenseLds ka_dense_layout(int D, int P, int Nm, int nR) {
     return L;
 }
 
-template <int D, bool BF>
+template <int D, bool BF, bool TRACE>
 __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LPR = D / 4, RPW = 64 / LPR, NT = D / 16, KS = D / 4, LDH = D + 2, LDT = D + 16, NTHR = kDW * 64;
@@ -112,7 +116,54 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
         np0 = a.seg_ptr[blockIdx.x];
         np1 = a.seg_ptr[blockIdx.x + 1];
     }
-    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    // R_KGE fragments RESIDENT in registers when the model has few enough relations: (relation r, column tile nt)
+    // number q = r*NT + nt belongs to wave q % (kDW-1), slot q / (kDW-1) (the last wave does the h-set read).  Every workgroup
+    // of the chip needs all of R_KGE (147 KB at C3) for every user; fetched per tile those loads ran at ~6 k
+    // cycles each (hot lines of a tiny table behind 4 000 waves, L1 too small to hold it next to the row traffic).
+    // The contraction index is permuted (MFMA step s, slot q16 stands for k = KS*q16 + s; A and B agree) so that a
+    // lane's KS fragment values of R[r][n][.] are contiguous: KS/4 16-byte loads.
+    constexpr int RES = (KS <= 16) ? 4 : 0;
+    const bool resident = RES > 0 && a.nR * NT <= RES * (kDW - 1) && P > 0;
+    float rb[RES > 0 ? RES : 1][KS];
+    auto load_bfrag = [&](int r, int nt, float (&bf)[KS]) {
+        const float* Rr = a.R + (size_t)r * D * D + (size_t)(16 * nt + l16) * D + KS * q16;   // R[r][n][k]
+#pragma unroll
+        for (int k = 0; k < KS; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(Rr + k);
+            bf[k] = v.x;
+            bf[k + 1] = v.y;
+            bf[k + 2] = v.z;
+            bf[k + 3] = v.w;
+        }
+    };
+    if (resident && wave < kDW - 1) {
+#pragma unroll
+        for (int sl = 0; sl < RES; ++sl) {
+            const int q = wave + (kDW - 1) * sl;
+            if (q < a.nR * NT) load_bfrag(q / NT, q % NT, rb[sl]);
+        }
+    }
+    // U tile: rows sBidx[row0 .. row0+15] of sH times the fragment -> sU
+    auto u_tile = [&](int row0, int nt, const float (&bf)[KS]) {
+        const int ia = sBidx[row0 + l16];
+        const float* ar = sH + (size_t)(ia >= 0 ? ia : 0) * LDH + KS * q16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[k], bf[k], acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int io = sBidx[row0 + 4 * q16 + i];
+            if (io >= 0) sU[(size_t)io * LDH + 16 * nt + l16] = acc[i];
+        }
+    };
+    int iter = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 0 && tid == 0 && iter >= 4 && iter < 68) g_ka_trace[(iter - 4) * 16 + slot] = __builtin_readcyclecounter();
+        }
+    };
+    for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x, ++iter) {
+        stamp(0);
         const int u = nu, p0 = np0, p1 = np1;
         if (seg + (int)gridDim.x < nseg) {
             nu = a.seg_user[seg + gridDim.x];
@@ -145,6 +196,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             sRank[i] = rk;
         }
         __syncthreads();
+        stamp(1);
         // ---- buckets padded to whole 16-row tiles: offsets + the tile table (wave 0) ----
         if (wave == 0) {
             int base = 0, ntile = 0;
@@ -171,6 +223,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
         }
         __syncthreads();
         const int ntile = sOrig[kDT];
+        stamp(2);
         // ---- rows -> LDS; bucket index table ----
         for (int i = wave * RPW + g; i < Ph * NmP; i += kDW * RPW) {
             const int idh = sIdH[i], idt = sIdT[i];
@@ -186,6 +239,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             }
         }
         __syncthreads();
+        stamp(3);
         // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
         if (has_set && wave == kDW - 1) {
             const float4 w4 = reinterpret_cast<const float4*>(a.w)[c];
@@ -199,14 +253,14 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             float mx = -INFINITY;
             for (int m = lane; m < NmP; m += 64) mx = fmaxf(mx, sLg[m]);
-            mx = wave_max(mx);
+            mx = wave_max_fast(mx);
             float z = 0.f;
             for (int m = lane; m < NmP; m += 64) {
                 const float e = m < Nm ? expf(sLg[m] - mx) : 0.f;
                 sLg[m] = e;
                 z += e;
             }
-            z = wave_sum(z);
+            z = wave_sum_fast(z);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int m0 = 0; m0 < NmP; m0 += RPW) {
@@ -219,24 +273,27 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             if (g == 0) *reinterpret_cast<float4*>(sHset + 4 * c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         } else if (P > 0) {
             const int nw = has_set ? kDW - 1 : kDW;
-            for (int task = wave; task < ntile * NT; task += nw) {
-                const int tl = task / NT, nt = task - tl * NT;
-                const int row0 = sTileRow[tl];
-                const float* Rr = a.R + (size_t)sTileRel[tl] * D * D + (size_t)(16 * nt + l16) * D + q16;   // R[r][n][k]
-                float bfrag[KS];
+            if (resident) {
+                if (wave < kDW - 1) {
 #pragma unroll
-                for (int k = 0; k < KS; ++k) bfrag[k] = Rr[4 * k];
-                const int ia = sBidx[row0 + l16];
-                const float* ar = sH + (size_t)(ia >= 0 ? ia : 0) * LDH + q16;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], bfrag[k], acc, 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int io = sBidx[row0 + 4 * q16 + i];
-                    if (io >= 0) sU[(size_t)io * LDH + 16 * nt + l16] = acc[i];
+                    for (int sl = 0; sl < RES; ++sl) {
+                        const int q = wave + (kDW - 1) * sl;
+                        if (q < a.nR * NT) {
+                            const int r = q / NT, nt = q % NT;
+                            const int tiles = (sCnt[r] + 15) >> 4, row0 = sOff[r];
+                            for (int j = 0; j < tiles; ++j) u_tile(row0 + 16 * j, nt, rb[sl]);
+                        }
+                    }
+                }
+            } else {
+                for (int task = wave; task < ntile * NT; task += nw) {
+                    const int tl = task / NT, nt = task - tl * NT;
+                    float bfrag[KS];
+                    load_bfrag(sTileRel[tl], nt, bfrag);
+                    u_tile(sTileRow[tl], nt, bfrag);
                 }
             }
+            stamp(9);
             // padding memories: U rows never written by a tile must read as zero
             for (int i = tid; i < PN * NT; i += (has_set ? (kDW - 1) : kDW) * 64) {
                 const int row = i / NT, nt = i - row * NT;
@@ -246,6 +303,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
                 }
             }
         }
+        stamp(4);
         // ---- the user's pairs, 16 at a time ----
         for (int t0 = p0; t0 < p1; t0 += kDT) {
             __syncthreads();                                 // sU / sHset complete; previous tile consumed
@@ -258,6 +316,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             }
             item_row(t0 + kDT, p1, e_next, orig_next);       // the next tile's rows land under this tile's work
             __syncthreads();
+            if (t0 == p0) stamp(5);
             // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
             for (int mt = wave; mt < PN / 16; mt += kDW) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -269,23 +328,25 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
                 for (int i = 0; i < 4; ++i) sL[(size_t)(4 * q16 + i) * LDL + 16 * mt + l16] = acc[i];
             }
             __syncthreads();
+            if (t0 == p0) stamp(6);
             // softmax over the Nm memories of every (pair, hop) (:223): un-normalised weights back to sL, 1/sum to sZ
             for (int task = wave; task < kDT * P; task += kDW) {
                 const int pi = task / P, hop = task - pi * P;
                 float* row = sL + (size_t)pi * LDL + hop * NmP;
                 float mx = -INFINITY;
                 for (int m = lane; m < Nm; m += 64) mx = fmaxf(mx, row[m]);
-                mx = wave_max(mx);
+                mx = wave_max_fast(mx);
                 float z = 0.f;
                 for (int m = lane; m < NmP; m += 64) {
                     const float e = m < Nm ? expf(row[m] - mx) : 0.f;
                     row[m] = e;
                     z += e;
                 }
-                z = wave_sum(z);
+                z = wave_sum_fast(z);
                 if (lane == 0) sZ[pi * P + hop] = 1.f / z;
             }
             __syncthreads();
+            if (t0 == p0) stamp(7);
             // reads o[pair, hop, :] = sum_m p[pair, m] t_m : one (hop, 16-column tile) per task
             for (int task = wave; task < P * NT; task += kDW) {
                 const int hop = task / NT, nt = task - hop * NT;
@@ -301,6 +362,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
                         a.out[(int64_t)orig * a.ldo + (size_t)(slot0 + hop) * D + 16 * nt + l16] = acc[i] * sZ[pi * P + hop];
                 }
             }
+            if (t0 == p0) stamp(8);
             if (has_set) {
                 for (int i = tid; i < kDT * LPR; i += NTHR) {
                     const int pi = i / LPR, cc = i - pi * LPR;
@@ -326,17 +388,23 @@ static hipError_t launch_kad(const KeyAddrGroupedArgs& a, int table_bf16, hipStr
     const int grid = a.nseg < cap ? a.nseg : cap;
     hipError_t e = hipSuccess;
     if (table_bf16) {
-        auto k = key_addr_dense_kernel<D, true>;
+        auto k = key_addr_dense_kernel<D, true, false>;
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
         k<<<grid, kDW * 64, L.total, st>>>(a, L);
     } else {
-        auto k = key_addr_dense_kernel<D, false>;
+        static const bool trace = getenv("MVIN_KA_TRACE") != nullptr;
+        auto k = (D == 64 && trace) ? key_addr_dense_kernel<D, false, true> : key_addr_dense_kernel<D, false, false>;
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
         k<<<grid, kDW * 64, L.total, st>>>(a, L);
     }
     return hipGetLastError();
+}
+
+hipError_t ka_read_trace(long long* host_dst, size_t n) {
+    const size_t have = sizeof(g_ka_trace) / sizeof(long long);
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_ka_trace), (n < have ? n : have) * sizeof(long long));
 }
 
 hipError_t launch_key_addr_dense(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {

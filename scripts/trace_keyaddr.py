@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Phase timeline of the dense grouped key-addressing kernel (development aid): MVIN_KA_TRACE=1, GPU box."""
+import ctypes as C, os, sys
+import numpy as np, torch
+os.environ["MVIN_KA_TRACE"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mvin_amd import _lib, ops, synth
+dev = torch.device("cuda:0"); B, D, P, Nm, nR = 524288, 64, 2, 64, 9
+d = synth.DATASETS["last-fm_50core"]
+g = torch.Generator(device=dev); g.manual_seed(0)
+E = torch.rand((d["n_entity"], D), device=dev, generator=g) - 0.5
+R = torch.rand((nR, D, D), device=dev, generator=g) - 0.5
+w = torch.rand(D, device=dev, generator=g)
+uts = torch.from_numpy(synth.ripple_sets(d["n_user"], d["n_entity"], nR, P, Nm, seed=3)).to(dev)
+users = torch.randint(0, d["n_user"], (B,), device=dev, generator=g)
+items = torch.randint(0, d["n_entity"], (B,), device=dev, generator=g)
+out = torch.empty((B, 3 * D), device=dev)
+groups = ops.group_pairs_by_user(users)
+for _ in range(3):
+    ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, 3 * D, nR)
+torch.cuda.synchronize()
+buf = np.zeros(64 * 16, dtype=np.int64)
+assert _lib.load().mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+full = buf.reshape(64, 16).astype(np.float64)
+print("U tiles of wave 0 done (cycles since 'rows->LDS'):", round(float(np.mean(full[8:56, 9] - full[8:56, 3]))))
+t = full[:, :9]
+names = ["top", "ids+rank", "tile table", "rows->LDS", "U + hset", "tile0: Ei", "tile0: logits", "tile0: softmax", "tile0: reads"]
+print("cycles per segment:", round(float(np.mean(np.diff(t[4:60, 0])))))
+dd = np.diff(t[4:60], axis=1)
+for i in range(8):
+    print("   %-14s -> %-14s %8.0f" % (names[i], names[i + 1], dd[:, i].mean()))
