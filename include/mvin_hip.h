@@ -144,6 +144,11 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                             int table_bf16, void* stream);
 int mvin_gather_attn_l2_supported(int D, int K);
+/* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
+ * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
+ * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
+ * probs, adjacency and outputs below 2 GiB).  n_parents = B * parents_per_pair.  For tests and benchmarks. */
+int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);
 
 /* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
  * other than the deepest hop; aggregators.py:98-152, model.py:295-305):

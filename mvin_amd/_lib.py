@@ -78,6 +78,7 @@ SIGNATURES = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
                                           _c_f32p, C.c_int, C.c_void_p]),
     "mvin_gather_attn_l2_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_gather_attn_l2_variant": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "mvin_agg_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_key_addressing_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p),

@@ -152,6 +152,17 @@ int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const 
 
 int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supported(D, K) ? 1 : 0; }
 
+int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs) {
+    if (!mvin::fused_l2_supported(D, K)) return 0;
+    mvin::FusedL2Args f{};
+    f.K = K;
+    f.P = n_parents;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    float probe = 0.f;
+    if (want_probs) f.probs_parent = f.probs_child = &probe;     // only tested for presence
+    return mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D) ? 2 : 1;
+}
+
 int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
                             const float* W2, const float* b1, const float* b2, const float* q,

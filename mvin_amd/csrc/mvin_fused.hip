@@ -597,12 +597,16 @@ bool fused_l2_supported(int D, int K) {
     return dok && kok;
 }
 
-hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
-    // D >= 64, K in {32, 64, 128}: the role-split pipeline (gather waves + dense waves);
-    // MVIN_L2_SPLIT=0 keeps the symmetric kernel below for A/B measurements
+bool fused_l2_split_in_use() {
     static const char* split_env = getenv("MVIN_L2_SPLIT");
     static const bool use_split = !(split_env && split_env[0] == '0');
-    if (use_split && fused_split_applies(a, D)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
+    return use_split;
+}
+
+hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
+    // D >= 32, K in {16 (D = 32), 32, 64, 128}: the role-split pipeline (gather waves + dense waves);
+    // MVIN_L2_SPLIT=0 keeps the symmetric kernel below for A/B measurements
+    if (fused_l2_split_in_use() && fused_split_applies(a, D)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
     static const bool no_small = getenv("MVIN_L2_NOSMALL") != nullptr;
     const bool small = a.K <= 16 && !no_small;
     if (table_bf16) {

@@ -54,7 +54,8 @@ constexpr int split_minw(int D, int NG) { return ((NG + D / 16) * 64 <= 512) ? 4
 
 template <int D, int KT, bool BF, int NG>
 struct SplitGeom {
-    static constexpr int TM = 32;                       // children per tile
+    static constexpr int TM = KT < 32 ? KT : 32;        // children per tile (one parent per tile at K = 16)
+    static constexpr int RT = TM / 16;                  // 16-row MFMA tiles per tile
     static constexpr int NT = D / 16;                   // 16-column MFMA tiles = dense waves
     static constexpr int NM = NT;
     static constexpr int NW = NG + NM;
@@ -72,16 +73,17 @@ struct SplitGeom {
     static constexpr int NCH = TM * KT / 4;             // int4 adjacency chunks per tile
     static constexpr int CPL = (NCH + NM * 64 - 1) / (NM * 64);   // ... per dense lane
     static constexpr int LPN = KT / 4;                  // lanes per child adjacency row
-    static constexpr int LPN_L2 = (LPN == 8) ? 3 : (LPN == 16) ? 4 : 5;
+    static constexpr int LPN_L2 = (LPN == 4) ? 2 : (LPN == 8) ? 3 : (LPN == 16) ? 4 : 5;
     static constexpr int MINW = split_minw(D, NG);
     static_assert(NPW % RPWX == 0, "children per gather wave must be a multiple of its lane groups");
-    static_assert(KT == 32 || KT == 64 || KT == 128, "K");
+    static_assert(KT == 16 || KT == 32 || KT == 64 || KT == 128, "K");
 };
 
 size_t fused_split_lds_bytes(int D, int K, int nR) {
-    const size_t words = 2 * 32 * (size_t)(2 * D + 2) + 32 * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2
+    const size_t tm = K < 32 ? K : 32;
+    const size_t words = 2 * tm * (size_t)(2 * D + 2) + tm * (size_t)(D + 2) + 12 * (size_t)K + 2 * (size_t)((nR + 1) & ~1) + 2
                          + 4 * (size_t)D + 4 * (size_t)D;
-    return words * 4 + 2 * 32 * (size_t)(K + 1) * sizeof(int2);
+    return words * 4 + 2 * tm * (size_t)(K + 1) * sizeof(int2);
 }
 
 template <int D, int KT, bool BF, int NG, int UNR, bool TRACE>
@@ -163,7 +165,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         // (no projection: zero records -> every load returns 0 without touching memory)
         const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
-        auto parent_load = [&](int64_t pp, int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[D / 64]) {
+        auto parent_load = [&](int64_t pp, int64_t x0, int (&xs)[G::NPL], int (&rr)[G::NPL], float (&qr)[(D + 63) / 64]) {
             // no branch around any load or its use (see the note at the step loop): lane n holds child n % KT, so at
             // KT = 32 the upper half-wave duplicates the lower one
 #pragma unroll
@@ -174,15 +176,16 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
             }
             const unsigned qoff = ((unsigned)pp / (unsigned)a.parents_per_pair) * (unsigned)D;
 #pragma unroll
-            for (int i = 0; i < D / 64; ++i)
+            for (int i = 0; i < (D + 63) / 64; ++i)
                 qr[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(qsrc, (qoff + lane + 64 * i) * 4u, 0, 0));
         };
         // ... -> child ids + attention weights of aggregator (0,.) / (1,.) over the K children
-        auto parent_store = [&](const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[D / 64], int slot,
+        auto parent_store = [&](const int (&xs)[G::NPL], const int (&rr)[G::NPL], const float (&qr)[(D + 63) / 64], int slot,
                                 bool commit) {
             if (commit) {
 #pragma unroll
-                for (int i = 0; i < D / 64; ++i) sQ[slot * D + lane + 64 * i] = qr[i];
+                for (int i = 0; i < (D + 63) / 64; ++i)
+                    if (lane + 64 * i < D) sQ[slot * D + lane + 64 * i] = qr[i];
             }
             float s0[G::NPL], s1[G::NPL];
             float m0 = -INFINITY, m1 = -INFINITY;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 m0 = fmaxf(m0, s0[i]);
                 m1 = fmaxf(m1, s1[i]);
             }
-            constexpr int PL2 = (KT >= 64) ? 6 : 5;     // lanes holding distinct children: 64 (KT >= 64) or 32
+            constexpr int PL2 = (KT >= 64) ? 6 : (KT == 32) ? 5 : 4;     // lanes holding distinct children: 64, 32 or 16
             m0 = group_max(m0, PL2);
             m1 = group_max(m1, PL2);
             float z0 = 0.f, z1 = 0.f;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         // ---- pipeline fill: parents 0 and 1, id list of tile 0 ----
         if (wave == 0) {
             int xs[G::NPL], rr[G::NPL];
-            float qr[D / 64];
+            float qr[(D + 63) / 64];
             parent_load(parent_of(0), a.parent_ids[parent_of(0)], xs, rr, qr);
             parent_store(xs, rr, qr, 0, true);
             if (nloc > 1) {
@@ -302,7 +305,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 for (int it = 0; it < G::CPL; ++it) chunk_load((int)(i1 & 3), tile1, it, ye[it], re[it]);
             }
             int nxs[G::NPL], nrr[G::NPL];
-            float nq[D / 64];
+            float nq[(D + 63) / 64];
             parent_load(parent_of(i2), x0n, nxs, nrr, nq);
             x0n = a.parent_ids[parent_of(clampi((s + 3) / G::NTILE))];
             // ---------------- dense phases of tile s-1 ----------------
@@ -322,9 +325,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 const float c1v = sBias[D + col];
                 const float c2v = sBias[2 * D + col] * c2scale;
                 // phase B: self1 = E[x1] W1 + c1 ; Z = self1 + S' W2 + c2 (model.py:277-283 applied after the sum)
-                f32x4 accE[2], accS[2];
+                f32x4 accE[G::RT], accS[G::RT];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < G::RT; ++m) {
                     accE[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     accS[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
@@ -332,7 +335,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
 #pragma unroll
                     for (int k = 0; k < KS; ++k) {
 #pragma unroll
-                        for (int m = 0; m < 2; ++m) {
+                        for (int m = 0; m < G::RT; ++m) {
                             const float* ar = tA + (16 * m + l16) * LDA + 4 * k + q16;
                             accE[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[0], bW1[k], accE[m], 0, 0, 0);
                             accS[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[D], bW2[k], accS[m], 0, 0, 0);
@@ -341,7 +344,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 }
                 float part = 0.f;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < G::RT; ++m) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * q16 + r;
@@ -381,14 +384,14 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
                 stamp(s, 2);
                 // phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1 += sum_n p1[n] out1[n]
-                f32x4 acc2[2];
+                f32x4 acc2[G::RT];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < G::RT; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (!(dbg & 1))
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
+                    for (int m = 0; m < G::RT; ++m) {
                         const float az = sZ[(16 * m + l16) * LDZ + 4 * k + q16];
                         acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(az, bA0[k], acc2[m], 0, 0, 0);
                     }
@@ -396,7 +399,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 float part = 0.f;
                 const float a0v = sBias[col];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < G::RT; ++m) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 16 * m + 4 * q16 + r;
@@ -530,7 +533,8 @@ static hipError_t launch_split(const FusedL2Args& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const int per_cu = (G::MINW == 4 && 2 * lds <= 160 * 1024) ? 2 : 1;
+    int per_cu = G::MINW == 4 ? 16 / G::NW : 1;         // 4 waves per SIMD: 16 waves per CU
+    while (per_cu > 1 && per_cu * lds > 160 * 1024) --per_cu;
     const int64_t cap = 256 * per_cu;                   // persistent: one pipeline per resident workgroup
     const int grid = (int)(a.P < cap ? a.P : cap);
     kern<<<grid, G::NW * 64, lds, st>>>(a);
@@ -538,6 +542,7 @@ static hipError_t launch_split(const FusedL2Args& a, hipStream_t st) {
 }
 
 bool fused_split_supported(int D, int K) {
+    if (D == 32) return K == 16 || K == 32 || K == 64 || K == 128;
     return (D == 64 || D == 128) && (K == 32 || K == 64 || K == 128);
 }
 
@@ -572,6 +577,10 @@ hipError_t split_read_trace(long long* host_dst, size_t n) {
 }
 
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
+    if (D == 32) {
+        if (a.K == 16) return table_bf16 ? launch_split<32, 16, true, 2>(a, st) : launch_split<32, 16, false, 2>(a, st);
+        return table_bf16 ? launch_split_k<32, true, 4>(a, st) : launch_split_k<32, false, 4>(a, st);
+    }
     if (D == 64) return table_bf16 ? launch_split_k<64, true, 4>(a, st) : launch_split_k<64, false, 4>(a, st);
     if (D == 128) return table_bf16 ? launch_split_k<128, true, 4>(a, st) : launch_split_k<128, false, 4>(a, st);
     return hipErrorInvalidValue;

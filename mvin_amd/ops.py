@@ -204,6 +204,11 @@ def gather_attn_l2_supported(D, K):
     return bool(_lib.load().mvin_gather_attn_l2_supported(D, K))
 
 
+def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False):
+    """0 = unsupported, 1 = symmetric fused kernel, 2 = role-split pipeline (include/mvin_hip.h)."""
+    return int(_lib.load().mvin_gather_attn_l2_variant(D, K, n_parents, n_entity, int(bool(want_probs))))
+
+
 def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0,
                    B, parents_per_pair, K, D, nR, want_probs=False):
     """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  Returns
