@@ -175,9 +175,12 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
  *   o_hset = sum_m softmax_m(E[mem_h[0][b,m]] . w[0:D])_m * E[mem_h[0][b,m]]                 (:162-197)
  *   o_hop  = sum_m softmax_m(E[mem_h[hop][b,m]] . V[b, mem_r[hop][b,m], :])_m * E[mem_t[hop][b,m]]  (:210-230)
  * mem_h/mem_r/mem_t are HOST arrays of max(1,P) device pointers ([B, Nm] int32 each).  Every table
- * row is read once (head rows stay in registers between the logit and the weighted-sum pass).
- * Returns -3 when Nm/D exceed the register-resident kernel (ceil(Nm / (64/ceil_pow2(D/4))) > 16);
- * callers then use mvin_ripple_attn_fwd per read. */
+ * row is read once.  Two kernels sit behind the entry point: a streaming LDS-DMA pipeline (P >= 1, Nm <= 64,
+ * D in {16,32,64,128}, nR*D*4 <= 3072: rows go global -> LDS without VGPR staging, the h-set read is one
+ * online-softmax pass) and a register-resident one (head rows stay in VGPRs between the logit and the
+ * weighted-sum pass; ceil(Nm / (64/ceil_pow2(D/4))) <= 16).  Returns -3 when neither takes the shape;
+ * callers then use mvin_ripple_attn_fwd per read.  mvin_key_addressing_supported(Nm, D) answers for the
+ * register-resident kernel alone (it does not know nR): sufficient, not necessary. */
 int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,

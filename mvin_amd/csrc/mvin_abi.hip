@@ -289,8 +289,6 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     if (bad_dim(D)) return fail(-2, "%s: D=%d (need %%4==0, 4..%d)", who, D, MVIN_MAX_DIM);
     const int n_o = P + (w ? 1 : 0);
     if (ldo < (int64_t)n_o * D || (ldo & 3)) return fail(-2, "%s: ldo=%lld", who, (long long)ldo);
-    if (mvin::key_addr_nj(Nm, D) > 16)
-        return fail(-3, "%s: unsupported shape Nm=%d D=%d for the register-resident kernel", who, Nm, D);
     mvin::KeyAddrArgs k{};
     k.E = entity_emb;
     k.V = V;
@@ -314,6 +312,9 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     k.nR = nR;
     k.lpr_log2 = mvin::lpr_log2_for(D);
     k.table_bytes = (uint64_t)n_entity * D * (table_bf16 ? 2 : 4);
+    if (!mvin::key_addr_stream_supported(k, table_bf16) && mvin::key_addr_nj(Nm, D) > 16)
+        return fail(-3, "%s: unsupported shape Nm=%d D=%d (streaming kernel: Nm <= 64 and nR*D*4 <= 3072; "
+                    "register-resident kernel: ceil(Nm / (64 / lanes per row)) <= 16)", who, Nm, D);
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
 }
 

@@ -237,6 +237,8 @@ hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, 
 bool key_addr_dense_supported(int D, int P, int Nm, int nR);     // dense (all-MFMA) variant, mvin_keyaddr_dense.hip
 hipError_t launch_key_addr_dense(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
+bool key_addr_stream_supported(const KeyAddrArgs& a, int table_bf16);       // LDS-DMA streaming variant, mvin_keyaddr_stream.hip
+hipError_t launch_key_addr_stream(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, void* rows, bool scatter,
                             hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);

@@ -208,6 +208,9 @@ int key_addr_nj(int Nm, int D) {
 }
 
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st) {
+    // per-pair ripple sets with P >= 1 hops, Nm <= 64 and a small V block: the streaming (LDS-DMA) pipeline;
+    // MVIN_KA_STREAM=0 keeps the register-resident kernel below for A/B measurements
+    if (key_addr_stream_supported(a, table_bf16)) return launch_key_addr_stream(a, table_bf16, st);
     const int nj = key_addr_nj(a.Nm, a.D);
     const int64_t nblk = (a.B + 3) / 4;
     const int64_t cap = 256 * 8;
