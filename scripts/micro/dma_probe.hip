@@ -119,6 +119,47 @@ __global__ __launch_bounds__(64) void fixed_m0_kernel(const float* table, const 
     sink[blockIdx.x * 64 + lane] = acc;
 }
 
+// the register path for comparison: 8 independent 16-byte loads per lane per round (4 random 256-byte rows per
+// wave-instruction, as the gather waves of mvin_fused_split.hip issue them), summed
+template <int LPR>     // lanes per row: 8 = 128-byte rows (D=32 fp32), 16 = 256-byte rows, 32 = 512-byte rows
+__global__ __launch_bounds__(64) void reg_kernel(const float* table, const int* ids, int nrows, int iters, long long* cyc, float* sink) {
+    const int lane = threadIdx.x, g = lane / LPR, c = lane % LPR;
+    const int* my = ids + (size_t)blockIdx.x * iters * 16;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int it = 0; it < iters; it += 2) {
+        const int* p = my + it * 16;
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const float4*>(table + (size_t)p[(k * 4 + g) & 31] * (LPR * 4) + c * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            acc.x += v[k].x;
+            acc.y += v[k].y;
+            acc.z += v[k].z;
+            acc.w += v[k].w;
+        }
+    }
+    sink[blockIdx.x * 64 + lane] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int LPR>
+static void run_reg(const float* table, const int* ids, int nrows, int iters, int waves_per_cu, long long* cyc, float* sink) {
+    const int grid = 256 * waves_per_cu;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    reg_kernel<LPR><<<grid, 64>>>(table, ids, nrows, iters, cyc, sink);
+    hipEventRecord(e0);
+    reg_kernel<LPR><<<grid, 64>>>(table, ids, nrows, iters, cyc, sink);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double bytes = (double)grid * iters * 4 * 1024;
+    printf("register loads, %d-byte rows, 8 in flight  waves/CU=%2d: %.3f ms  %.2f TB/s  %.1f B/clk/CU\n", LPR * 16, waves_per_cu, ms, bytes / ms / 1e9,
+           bytes / 256 / (ms * 1e-3 * 2.4e9));
+}
+
 static void run_fixed(const float* table, const int* ids, int nrows, int iters, int waves_per_cu, long long* cyc, float* sink) {
     const int grid = 256 * waves_per_cu;
     hipEvent_t e0, e1;
@@ -200,5 +241,17 @@ int main() {
         if (w <= 4) run_rate<16, true>(table, ids, nrows, iters, w, cyc, sink);
     }
     for (int w : {1, 2, 4, 8, 12, 16}) run_fixed(table, ids, nrows, iters, w, cyc, sink);
+    for (int w : {4, 8, 16}) run_reg<16>(table, ids, nrows, iters, w, cyc, sink);
+    // the same with the row ids folded into a small range: L1-resident (64 rows = 16 KB) and L2-resident (8192 rows = 2 MB)
+    for (int range : {64, 8192}) {
+        std::vector<int> h2(hid.size());
+        for (size_t i = 0; i < hid.size(); ++i) h2[i] = hid[i] % range;
+        hipMemcpy(ids, h2.data(), h2.size() * 4, hipMemcpyHostToDevice);
+        printf("-- rows drawn from the first %d rows (%d KB)\n", range, range / 4);
+        for (int w : {2, 4, 8, 16}) run_fixed(table, ids, nrows, iters, w, cyc, sink);
+        for (int w : {4, 8, 16}) run_reg<16>(table, ids, nrows, iters, w, cyc, sink);
+        run_reg<8>(table, ids, nrows, iters, 16, cyc, sink);
+        run_reg<32>(table, ids, nrows, iters, 16, cyc, sink);
+    }
     return 0;
 }
