@@ -84,6 +84,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 4 GB-table launch of the dominant kernel")
+    ap.add_argument("--no-probe", action="store_true", help="skip the gather-only probe of the timed region's access stream")
     ap.add_argument("--hbm-leg-only", action="store_true",
                     help="run ONLY the 4 GB-table leg and print its record (the command profiles/r2/*hbm_leg* were "
                          "collected with: one kernel name, one regime per rocprofv3 run)")
@@ -182,6 +183,37 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     return {"avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
             "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows, "table_bytes": n_rows * D * s_,
             "launches": iters, "outputs_finite": finite}
+
+
+PROBE_PAIRS = 131072
+
+
+def gather_probe(model, items, K, D, s_, iters=10, warmup=3):
+    """A reference point for the timed region's kernel: mvin_probe_gather_l2 reads exactly the table rows
+    mvin_gather_attn_l2_fwd must gather for these pairs (same entity table, same adjacency; the first
+    PROBE_PAIRS pairs of the batch) with the same 16-byte lane loads, ids one round ahead, and only sums them.
+    Timed with HIP events after the timed region; its bytes are the gathered rows alone."""
+    import torch
+    from mvin_amd import ops
+    n = min(items.shape[0], PROBE_PAIRS)
+    ents, _ = model.get_neighbors(items[:n])                   # mvin_expand_ids: levels 0..2 of these pairs
+    l1, l2 = ents[1].contiguous().view(-1), ents[2].contiguous().view(-1)
+    sums = torch.empty(n, dtype=torch.float32, device=items.device)
+    for _ in range(warmup):
+        ops.probe_gather_l2(model.entity_emb_matrix, l1, l2, K, sums)
+    evs = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.probe_gather_l2(model.entity_emb_matrix, l1, l2, K, sums)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = float(np.mean([x.elapsed_time(y) for x, y in evs]))
+    row_bytes = (K + K * K) * D * s_
+    return {"avg_launch_ms": ms, "pairs_per_launch": n, "row_bytes_per_pair": row_bytes,
+            "achieved": row_bytes * n / (ms * 1e-3) / 1e9, "unit": "GB/s", "launches": iters,
+            "checksum_finite": bool(torch.isfinite(sums).all())}
 
 
 def pmc_record(name):
@@ -407,6 +439,22 @@ def main():
                           "peak; `traffic` = bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE + "
                           "WRITE_SIZE, profiles/pmc_latest.json)" % (table_bytes / 1e6, L2_PEAK_GBS / 1e3))
                  if cache_resident else "launches inside the timed steps; the table is far larger than the Infinity Cache"}
+        if used_l2 and not hoisted and L == 2 and world == 1 and not a.no_probe and kern_avg_ms:
+            gp = gather_probe(model, items, a.fanout, a.dim, s_)
+            rows_gbs = gp["row_bytes_per_pair"] * Bl / (kern_avg_ms * 1e-3) / 1e9     # the fused kernel, rows only
+            gp["fused_kernel_rows_gbs"] = rows_gbs
+            gp["fused_kernel_frac_of_probe"] = rows_gbs / gp["achieved"]
+            gp["note"] = ("mvin_probe_gather_l2: the K + K*K table rows per pair of the timed region's own pairs, read once each with "
+                          "the same 16-byte lane loads by a PLAIN gather-and-sum kernel (one wave per parent, 8 loads in flight, ids "
+                          "from the expanded level lists one round ahead) -- a reference point, not an upper bound; "
+                          "fused_kernel_frac_of_probe = the full kernel's row bytes per second (adjacency chase, softmax, "
+                          "projections, MFMA epilogues on top) over the probe's.  Idealised gather ceilings of this part "
+                          "(scripts/micro/dma_probe.hip, profiles/r2/d_gather_ceiling_dma_probe.txt; 16-byte lanes, ids preloaded): "
+                          "26 TB/s for L1-resident rows, 24 TB/s L2-resident, 8.8 TB/s for uniformly random rows of a 27 MB table "
+                          "(Infinity Cache)")
+            gp["gather_ceiling_gbs"] = {"l1_resident": 26000.0, "l2_resident": 24000.0, "infinity_cache_uniform_27mb": 8800.0,
+                                        "source": "profiles/r2/d_gather_ceiling_dma_probe.txt"}
+            timed["gather_only_probe"] = gp
         roofline = timed
         if not a.no_hbm_leg and used_l2 and not hoisted and cache_resident and L == 2:
             # the genuinely HBM-bound measurement of the SAME kernel instance, live, after the timed region

@@ -149,6 +149,14 @@ int mvin_gather_attn_l2_supported(int D, int K);
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
  * probs, adjacency and outputs below 2 GiB).  n_parents = B * parents_per_pair.  For tests and benchmarks. */
 int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);
+/* Measurement aid: the row gathers of mvin_gather_attn_l2_fwd and nothing else, written the plain way (one wave per
+ * parent, 8 loads in flight per lane).  child_ids [n_parents, K] and grandchild_ids [n_parents, K*K] are levels 1 and 2
+ * of mvin_expand_ids for the parents; every listed row is read once (the same 16-byte lane loads, ids fetched one round
+ * ahead) and all its elements are added into sums[p].  bench.py times it on the timed region's own entity table and
+ * pairs as a reference point for the fused kernel's row rate.  Row bytes (D * 4, or D * 2 with table_bf16) in
+ * {64, 128, 256, 512}. */
+int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int32_t* grandchild_ids, int64_t n_parents, int K,
+                         int D, int n_entity, int table_bf16, float* sums, void* stream);
 
 /* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
  * other than the deepest hop; aggregators.py:98-152, model.py:295-305):

@@ -152,6 +152,18 @@ int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const 
 
 int mvin_gather_attn_l2_supported(int D, int K) { return mvin::fused_l2_supported(D, K) ? 1 : 0; }
 
+int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int32_t* grandchild_ids, int64_t n_parents, int K,
+                         int D, int n_entity, int table_bf16, float* sums, void* stream) {
+    const char* who = "mvin_probe_gather_l2";
+    if (!table || !child_ids || !grandchild_ids || !sums) return fail(-1, "%s: null pointer", who);
+    if (n_parents <= 0 || K <= 0 || n_entity <= 0) return fail(-2, "%s: bad sizes", who);
+    const int rb = D * (table_bf16 ? 2 : 4);
+    if (!(rb == 64 || rb == 128 || rb == 256 || (rb == 512 && !table_bf16)))
+        return fail(-3, "%s: row bytes %d (64, 128, 256 or 512)", who, rb);
+    return hip_result(mvin::launch_gather_probe_l2(table, child_ids, grandchild_ids, n_parents, K, D, table_bf16, sums,
+                                                   (hipStream_t)stream), who);
+}
+
 int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs) {
     if (!mvin::fused_l2_supported(D, K)) return 0;
     mvin::FusedL2Args f{};

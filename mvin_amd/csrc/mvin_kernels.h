@@ -249,6 +249,8 @@ bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)
 bool fused_split_applies(const FusedL2Args& a, int D);
+hipError_t launch_gather_probe_l2(const void* table, const int32_t* ids1, const int32_t* ids2, int64_t n_parents, int K,
+                                  int D, int table_bf16, float* sums, hipStream_t st);   // mvin_probe.hip
 bool fused_l2_split_in_use();                   // false under MVIN_L2_SPLIT=0
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 hipError_t split_read_trace(long long* host_dst, size_t n);

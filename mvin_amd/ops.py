@@ -204,6 +204,23 @@ def gather_attn_l2_supported(D, K):
     return bool(_lib.load().mvin_gather_attn_l2_supported(D, K))
 
 
+def probe_gather_l2(table, child_ids, grandchild_ids, K, sums=None):
+    """mvin_probe_gather_l2: read the K child rows and K*K grandchild rows of every parent (id lists = levels 1 and 2
+    of expand_ids) and add them up; returns sums [n_parents] (measurement aid, include/mvin_hip.h)."""
+    bf = _chk_table(table, "table")
+    _chk(child_ids, I32, "child_ids"), _chk(grandchild_ids, I32, "grandchild_ids")
+    n = child_ids.numel() // K
+    if grandchild_ids.numel() != n * K * K:
+        raise ValueError("grandchild_ids must hold K*K ids per parent")
+    if sums is None:
+        sums = torch.empty(n, dtype=F32, device=table.device)
+    else:
+        _chk(sums, F32, "sums")
+    _lib.check(_lib.load().mvin_probe_gather_l2(_p(table), _p(child_ids), _p(grandchild_ids), n, K, table.shape[1],
+                                                table.shape[0], bf, _p(sums), _stream()), "mvin_probe_gather_l2")
+    return sums
+
+
 def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False):
     """0 = unsupported, 1 = symmetric fused kernel, 2 = role-split pipeline (include/mvin_hip.h)."""
     return int(_lib.load().mvin_gather_attn_l2_variant(D, K, n_parents, n_entity, int(bool(want_probs))))

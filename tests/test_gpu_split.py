@@ -126,3 +126,27 @@ def test_split_kernel_dataset_sized(name, hip_lib):
     out2 = model.forward_device(*feed(slice(5, 5 + n)), want_probs=False)
     assert torch.equal(out2.scores, out.scores[5:5 + n])
     del CONFIGS
+
+
+@pytest.mark.parametrize("table", ["f32", "bf16"])
+@pytest.mark.parametrize("dk", [(16, 8), (32, 16), (64, 32), (128, 5)], ids=lambda dk: "D%dK%d" % dk)
+def test_gather_only_probe_reads_the_rows_of_the_fused_kernel(dk, table, hip_lib):
+    """mvin_probe_gather_l2 (bench.py's empirical ceiling for the fused kernel's row gathers): per parent the sum of
+    every element of its K child rows and K*K grandchild rows."""
+    D, K = dk
+    if table == "bf16" and D == 16:
+        pytest.skip("32-byte rows")
+    rng = np.random.default_rng(D + K)
+    nE, P = 3000, 777
+    E = torch.from_numpy(rng.normal(size=(nE, D)).astype(np.float32)).cuda()
+    if table == "bf16":
+        E = E.to(torch.bfloat16)
+    adj = torch.from_numpy(rng.integers(0, nE, (nE, K)).astype(np.int32)).cuda()
+    parents = torch.from_numpy(rng.integers(0, nE, P).astype(np.int32)).cuda()
+    x1 = adj[parents.long()].long()                      # [P, K]
+    y = adj[x1].long()                                   # [P, K, K]
+    got = ops.probe_gather_l2(E, x1.to(torch.int32).contiguous(), y.to(torch.int32).contiguous(), K)
+    torch.cuda.synchronize()
+    Ed = E.double()
+    ref = Ed[x1].sum((1, 2)) + Ed[y].sum((1, 2, 3))
+    assert_close(got.cpu().numpy(), ref.cpu().numpy(), "probe sums", rtol=1e-4, atol=1e-2)
