@@ -374,12 +374,23 @@ def main():
     for _ in range(a.warmup):
         out = step()
     barrier()
-    model._profile = []
+    # The dominant kernel is timed with HIP events around its launches inside the timed steps (model._profile).  At
+    # small batches the pass is ONE native call (mvin_score_l2_fwd, no event hooks inside): there the timed steps run
+    # un-instrumented and the kernel time comes from the same K steps repeated with the hooks on, after the clock stops.
+    one_call = (scorer is None and not rowshard and Bl <= model.native_l2_max_batch
+                and not (by_user and Bl >= model.group_min_pairs_per_user * case.n_user)     # grouped: Python schedule
+                and model._native_l2_ok(items, None if by_user else mh, False))
+    model._profile = None if one_call else []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if one_call:
+        model._profile = []
+        for _ in range(a.steps):
+            step()
+        barrier()
     prof = model._profile
     model._profile = None
     if world > 1:
@@ -430,6 +441,9 @@ def main():
                  "unit": "GB/s", "frac": (achieved / peak) if achieved else None,
                  "bytes_per_pair": bpp, "pairs_per_launch": Bl, "avg_launch_ms": kern_avg_ms,
                  "table_bytes": table_bytes, "traffic": traffic,
+                 "kernel_timing": ("HIP events around the kernel's launches in a repeat of the same steps after the timed "
+                                   "region (the timed steps are one native call each, mvin_score_l2_fwd: no hooks inside)"
+                                   if one_call else "HIP events around the kernel's launches inside the timed steps"),
                  "hbm_frac_from_traffic": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                  if (traffic and kern_avg_ms) else None,
                  "whole_path_algorithmic_gbs": value / world * bpp / 1e9,

@@ -194,6 +194,13 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
                             float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_supported(int Nm, int D);
+/* The same reads with the feed assembly of train.py:117-120 inside the kernel: pair b uses the ripple sets of user
+ * users[b] straight out of user_triplet_set `uts` [n_user, max(1,P), 3, Nm] int32 on the device (h, r, t lists per hop;
+ * data_loader_user_set.py:392-441) -- no per-pair [B, Nm] arrays exist.  One of users_i64 / users_i32 is given.  For
+ * batches whose users repeat, mvin_key_addressing_grouped_fwd reads a user's rows once instead. */
+int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
+                                  const int64_t* users_i64, const int32_t* users_i32, int P, int B, int Nm, int D, int nR,
+                                  int n_entity, float* out, int64_t ldo, int table_bf16, void* stream);
 
 /* The same reads for pairs GROUPED BY USER (the feeds of train.py:117-120 / util.py:208-230 give every pair its
  * user's ripple sets, so all pairs of one user gather the same rows).  `uts` = user_triplet_set on the device,
@@ -238,7 +245,7 @@ int mvin_l2_tail_supported(int D);
  * user_o, wide_deep, n_mix_hop = 1, h_hop = 2) enqueued by ONE native call: at the reference's own batch sizes
  * (512 / 1024, src/bash/mvin_*.sh) the pass is a handful of short kernels and the host-side cost of issuing them
  * one foreign call at a time dominates.  Sequence (each step is the entry point of the same name):
- *   mvin_linear_fwd (V = E[item] . R_KGE[r]) -> mvin_key_addressing_fwd -> mvin_linear_fwd (user MLP, :232-236)
+ *   mvin_linear_fwd (V = E[item] . R_KGE[r]) -> mvin_key_addressing_fwd (or _users_fwd) -> mvin_linear_fwd (user MLP, :232-236)
  *   -> mvin_expand_ids (level 0) -> mvin_gather_attn_l2_fwd -> mvin_l2_tail_fwd.
  * All pointers are device pointers except mem_h / mem_r / mem_t (host arrays of max(1,P) device pointers).
  * Workspace and outputs are caller-owned.  Returns the first failing step's code. */
@@ -268,6 +275,8 @@ typedef struct {
     const int32_t* const* mem_h;
     const int32_t* const* mem_r;
     const int32_t* const* mem_t;
+    const int32_t* uts;            /* user_triplet_set [n_user, P, 3, Nm] + users [B]: instead of mem_h / mem_r / mem_t */
+    const int64_t* users;          /*   (mvin_key_addressing_users_fwd); NULL = the per-pair arrays above */
     float* V;                      /* workspace [B, nR, D] */
     float* o_cat;                  /* workspace [B, (P + (h_set_w != NULL)) * D] */
     int32_t* parents;              /* workspace [B] */

@@ -287,16 +287,17 @@ int mvin_key_addressing_supported(int Nm, int D) {
     return (!bad_dim(D) && Nm > 0 && mvin::key_addr_nj(Nm, D) <= 16) ? 1 : 0;
 }
 
-int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
-                            const int32_t* const* mem_h, const int32_t* const* mem_r,
-                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
-                            float* out, int64_t ldo, int table_bf16, void* stream) {
-    const char* who = "mvin_key_addressing_fwd";
+// shared body of the two key-addressing entry points: ripple sets as per-pair arrays, or user_triplet_set + user ids
+static int key_addressing_impl(const char* who, const void* entity_emb, const float* V, const float* w,
+                               const int32_t* const* mem_h, const int32_t* const* mem_r, const int32_t* const* mem_t,
+                               const int32_t* uts, const int64_t* users64, const int32_t* users32, int P, int B, int Nm,
+                               int D, int nR, int n_entity, float* out, int64_t ldo, int table_bf16, void* stream) {
     if (n_entity <= 0) return fail(-2, "%s: n_entity=%d", who, n_entity);
-    if (!entity_emb || !mem_h || !out) return fail(-1, "%s: null pointer", who);
+    if (!entity_emb || !out || (!uts && !mem_h)) return fail(-1, "%s: null pointer", who);
+    if (uts && !users64 && !users32) return fail(-1, "%s: user_triplet_set given without user ids", who);
     if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
     if (P == 0 && !w) return fail(-2, "%s: nothing to do (P == 0 and w == NULL)", who);
-    if (P > 0 && (!V || !mem_r || !mem_t || nR <= 0)) return fail(-1, "%s: hops need V, mem_r, mem_t, nR", who);
+    if (P > 0 && (!V || nR <= 0 || (!uts && (!mem_r || !mem_t)))) return fail(-1, "%s: hops need V, mem_r, mem_t, nR", who);
     if (B <= 0 || Nm <= 0) return fail(-2, "%s: bad sizes B=%d Nm=%d", who, B, Nm);
     if (bad_dim(D)) return fail(-2, "%s: D=%d (need %%4==0, 4..%d)", who, D, MVIN_MAX_DIM);
     const int n_o = P + (w ? 1 : 0);
@@ -305,8 +306,11 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
     k.E = entity_emb;
     k.V = V;
     k.w = w;
+    k.uts = uts;
+    k.users64 = users64;
+    k.users32 = users32;
     const int nh = P > 0 ? P : 1;
-    for (int i = 0; i < nh; ++i) {
+    for (int i = 0; i < nh && !uts; ++i) {
         if (!mem_h[i]) return fail(-1, "%s: null mem_h[%d]", who, i);
         k.mem_h[i] = mem_h[i];
         if (i < P) {
@@ -328,6 +332,21 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
         return fail(-3, "%s: unsupported shape Nm=%d D=%d (streaming kernel: Nm <= 64 and nR*D*4 <= 3072; "
                     "register-resident kernel: ceil(Nm / (64 / lanes per row)) <= 16)", who, Nm, D);
     return hip_result(mvin::launch_key_addr(k, table_bf16, (hipStream_t)stream), who);
+}
+
+int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
+                            const int32_t* const* mem_h, const int32_t* const* mem_r,
+                            const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
+                            float* out, int64_t ldo, int table_bf16, void* stream) {
+    return key_addressing_impl("mvin_key_addressing_fwd", entity_emb, V, w, mem_h, mem_r, mem_t, nullptr, nullptr, nullptr, P,
+                               B, Nm, D, nR, n_entity, out, ldo, table_bf16, stream);
+}
+
+int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
+                                  const int64_t* users_i64, const int32_t* users_i32, int P, int B, int Nm, int D, int nR,
+                                  int n_entity, float* out, int64_t ldo, int table_bf16, void* stream) {
+    return key_addressing_impl("mvin_key_addressing_users_fwd", entity_emb, V, w, nullptr, nullptr, nullptr, uts, users_i64,
+                               users_i32, P, B, Nm, D, nR, n_entity, out, ldo, table_bf16, stream);
 }
 
 int mvin_l2_tail_supported(int D) { return mvin::l2_tail_supported(D) ? 1 : 0; }
@@ -373,6 +392,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (a->P < 1 || a->P > 8) return fail(-2, "%s: P=%d (1..8)", who, a->P);
     if (!a->V || !a->o_cat || !a->parents || !a->nagg0 || !a->nagg1 || !a->user_o || !a->scores || !a->items)
         return fail(-1, "%s: null workspace / output / items", who);
+    if (a->uts && !a->users) return fail(-1, "%s: user_triplet_set given without user ids", who);
     const int D = a->D, nR = a->n_relation;
     const int n_o = a->P + (a->h_set_w ? 1 : 0);
     // V[b, r, :] = E[item_b] . R_KGE[r]   (model.py:214-220 re-associated: (R h).v == h.(v R))
@@ -394,8 +414,12 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     l.out_zstride = D;
     int rc = mvin_linear_fwd(&l, stream);
     if (rc) return rc;
-    rc = mvin_key_addressing_fwd(a->entity_emb, a->V, a->h_set_w, a->mem_h, a->mem_r, a->mem_t, a->P, (int)a->B, a->Nm, D,
-                                 nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+    if (a->uts)
+        rc = mvin_key_addressing_users_fwd(a->entity_emb, a->V, a->h_set_w, a->uts, a->users, nullptr, a->P, (int)a->B, a->Nm,
+                                           D, nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+    else
+        rc = mvin_key_addressing_fwd(a->entity_emb, a->V, a->h_set_w, a->mem_h, a->mem_r, a->mem_t, a->P, (int)a->B, a->Nm, D,
+                                     nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
     if (rc) return rc;
     mvin_linear_args u{};                     // user_o = o_cat . user_mlp + bias (model.py:232-236)
     u.src[0] = a->o_cat;

@@ -68,7 +68,26 @@ struct KeyAddrArgs {
     int64_t B;
     int P, Nm, D, nR, lpr_log2;
     uint64_t table_bytes;      // size of E in bytes (0: unknown -> 64-bit addressing)
+    // users feed (instead of mem_h / mem_r / mem_t): pair b reads the lists of user users[b] straight out of
+    // user_triplet_set [nU, max(1,P), 3, Nm] (the feed assembly of train.py:117-120 inside the kernel)
+    const int32_t* uts;
+    const int64_t* users64;
+    const int32_t* users32;
 };
+
+// the three id lists (heads, relations, tails) of pair b at `hop`
+struct KeyAddrLists {
+    const int32_t *h, *r, *t;
+};
+__device__ __forceinline__ KeyAddrLists key_addr_lists(const KeyAddrArgs& a, int64_t b, int hop) {
+    if (a.uts) {
+        const int64_t u = a.users64 ? a.users64[b] : (int64_t)a.users32[b];
+        const int32_t* base = a.uts + ((u * (a.P > 0 ? a.P : 1) + hop) * 3) * (int64_t)a.Nm;
+        return {base, base + a.Nm, base + 2 * a.Nm};
+    }
+    const int64_t o = b * a.Nm;
+    return {a.mem_h[hop] + o, hop < a.P ? a.mem_r[hop] + o : nullptr, hop < a.P ? a.mem_t[hop] + o : nullptr};
+}
 
 struct KeyAddrGroupedArgs {
     const void* E;             // [nE, D]

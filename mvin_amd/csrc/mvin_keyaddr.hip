@@ -45,9 +45,10 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
             const bool do_set = hop == 0 && a.w != nullptr;
             if (!do_hop && !do_set) continue;
             const char* vb = reinterpret_cast<const char*>(a.V + b * a.nR * (int64_t)D);   // wave-uniform base
-            const int32_t* mh = a.mem_h[hop] + b * Nm;
-            const int32_t* mr = do_hop ? a.mem_r[hop] + b * Nm : nullptr;
-            const int32_t* mt = do_hop ? a.mem_t[hop] + b * Nm : nullptr;
+            const KeyAddrLists lists = key_addr_lists(a, b, hop);
+            const int32_t* mh = lists.h;
+            const int32_t* mr = do_hop ? lists.r : nullptr;
+            const int32_t* mt = do_hop ? lists.t : nullptr;
             // ids: one coalesced load per list, then distributed to the row groups by bpermute
             const int lm = lane < Nm ? lane : Nm - 1;
             const int idh = mh[lm];

@@ -104,9 +104,10 @@ __global__ __launch_bounds__(64) void key_addr_stream_kernel(KeyAddrArgs a) {
     const float* sV = reinterpret_cast<const float*>(smem + kWinV);
 
     auto issue_ids = [&](int64_t b, int hop) {
-        dma4_at<kWinIds - 4096>(reinterpret_cast<const char*>(a.mem_h[hop] + b * Nm + lm));
-        dma4_at<kWinIds - 4096 + 256>(reinterpret_cast<const char*>(a.mem_r[hop] + b * Nm + lm));
-        dma4_at<kWinIds - 4096 + 512>(reinterpret_cast<const char*>(a.mem_t[hop] + b * Nm + lm));
+        const KeyAddrLists l = key_addr_lists(a, b, hop);      // users feed: one uniform load of users[b] (drains the DMA queue:
+        dma4_at<kWinIds - 4096>(reinterpret_cast<const char*>(l.h + lm));            // only the last tail stage is in flight here)
+        dma4_at<kWinIds - 4096 + 256>(reinterpret_cast<const char*>(l.r + lm));
+        dma4_at<kWinIds - 4096 + 512>(reinterpret_cast<const char*>(l.t + lm));
     };
     auto issue_v = [&](int64_t b) {      // always three pieces (a constant for the wait counts); tail lanes re-read the end
         const char* src = reinterpret_cast<const char*>(a.V + b * a.nR * (int64_t)D);

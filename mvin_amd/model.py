@@ -562,17 +562,18 @@ class MVIN(object):
 
     # ------------------------------------------------------------------ native whole-pass schedule
     def _native_l2_ok(self, item, memories_h, want_probs):
-        """The pass can be enqueued by ONE native call (mvin_score_l2_fwd): default wiring, depth-2 trees."""
+        """The pass can be enqueued by ONE native call (mvin_score_l2_fwd): default wiring, depth-2 trees.
+        ``memories_h`` None = the users feed (user_triplet_set + user ids)."""
         a = self.args
         return (self.fused is not False and not want_probs and not self.hoist and self._profile is None
                 and a.wide_deep and not a.PS_only and not a.HO_only and a.User_orient_kg_eh
                 and self.n_mix_hop == 1 and self.h_hop == 2 and self.p_hop >= 1
-                and item.dtype == torch.int64 and memories_h[0].dim() == 2
+                and item.dtype == torch.int64 and (memories_h is None or memories_h[0].dim() == 2)
                 and ops.l2_tail_supported(self.dim) and ops.gather_attn_l2_supported(self.dim, self.n_neighbor)
                 and ops.key_addressing_supported(self.n_memory, self.dim)
                 and item.shape[0] <= self.native_l2_max_batch)
 
-    def _score_l2_native(self, item, mem_h, mem_r, mem_t):
+    def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None):
         """model.py:125-159 through mvin_score_l2_fwd.  The argument block (every weight pointer) is built once and
         kept until a parameter tensor is replaced; per call only the batch pointers change."""
         from . import _lib
@@ -621,9 +622,14 @@ class MVIN(object):
         item_emb = torch.empty((B, D), dtype=torch.float32, device=self.device)
         scores = torch.empty((B,), dtype=torch.float32, device=self.device)
         sig = torch.empty((B,), dtype=torch.float32, device=self.device)
-        ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
         s.items = item.data_ptr()
-        s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
+        if uts is not None:       # users feed: the kernel reads the lists of users[b] out of user_triplet_set
+            s.uts, s.users = uts.data_ptr(), users.data_ptr()
+            s.mem_h = s.mem_r = s.mem_t = None
+        else:
+            ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
+            s.uts = s.users = None
+            s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
         s.V, s.o_cat, s.parents, s.nagg0, s.nagg1 = (w.data_ptr() for w in ws)
         s.user_o, s.item_emb, s.scores, s.sig = user_o.data_ptr(), item_emb.data_ptr(), scores.data_ptr(), sig.data_ptr()
         s.B = B
@@ -666,7 +672,12 @@ class MVIN(object):
             grouped = (need_ps and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
                        and item32.shape[0] >= self.group_min_pairs_per_user * uts.shape[0]
                        and ops.key_addressing_grouped_supported(self.dim, self.p_hop, self.n_memory, self.n_relation))
-            if need_ps and not grouped:     # outside the grouped kernel: assemble the per-pair feeds on the device
+            if (need_ps and not grouped and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
+                    and uts.shape[1] == self.p_hop and uts.shape[3] == self.n_memory and user32.dtype == torch.int64
+                    and user32.shape[0] == item32.shape[0] and self._native_l2_ok(item32, None, want_probs)):
+                # one native call; key addressing indexes user_triplet_set by users[b] itself
+                return self._score_l2_native(item32, None, None, None, uts=uts, users=user32)
+            if need_ps and not grouped:     # any other wiring: assemble the per-pair feeds on the device
                 sel = uts[user32.long()]
                 P_ = sel.shape[1]
                 memories_h = [sel[:, i, 0].contiguous() for i in range(P_)]

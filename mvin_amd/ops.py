@@ -302,6 +302,25 @@ def key_addressing(entity_emb, V, w, mem_h, mem_r, mem_t, P, out, ldo, nR):
     return out
 
 
+def key_addressing_users(entity_emb, V, w, uts, users, P, out, ldo, nR):
+    """mvin_key_addressing_users_fwd: key_addressing() with pair b reading the ripple sets of users[b] out of the
+    device-resident user_triplet_set ``uts`` [n_user, max(1,P), 3, Nm] int32 (no per-pair [B, Nm] arrays)."""
+    lib = _lib.load()
+    bf = _chk_table(entity_emb, "entity_emb")
+    _chk(V, F32, "V"), _chk(w, F32, "w"), _chk(out, F32, "out"), _chk(uts, I32, "uts")
+    if users.dtype not in (torch.int64, I32):
+        raise TypeError("users: int64 or int32")
+    _chk(users, users.dtype, "users")
+    if uts.dim() != 4 or uts.shape[1] != max(1, P) or uts.shape[2] != 3:
+        raise ValueError("uts must be [n_user, max(1,P), 3, Nm]")
+    B, Nm, D = users.shape[0], uts.shape[3], entity_emb.shape[1]
+    u64, u32 = (_p(users), None) if users.dtype == torch.int64 else (None, _p(users))
+    _lib.check(lib.mvin_key_addressing_users_fwd(_p(entity_emb), _p(V), _p(w), _p(uts), u64, u32, P, B, Nm, D, nR,
+                                                 entity_emb.shape[0], _p(out), ldo, bf, _stream()),
+               "mvin_key_addressing_users_fwd")
+    return out
+
+
 def l2_tail_supported(D):
     return bool(_lib.load().mvin_l2_tail_supported(D))
 

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Build container: copy the summaries scripts/collect_all.sh <tag> left under gpurun_out/ into profiles/r2/<prefix>_*
+# (gpurun_out/ is scratch; profiles/ is what is committed and judged).
+tag=$1; p=$2
+root=$(cd "$(dirname "$0")/.." && pwd); cd "$root"
+g=gpurun_out; d=profiles/r2; mkdir -p $d
+cp $g/prof_$tag/kernel_stats.csv $d/${p}_c3_B524288_kernel_stats.csv
+cp $g/prof_$tag/bench.json $d/${p}_c3_B524288_bench.json
+cp $g/prof_$tag/pmc.json $d/${p}_c3_B524288_pmc.json
+cp $g/prof_$tag/hbm_leg_kernel_stats.csv $d/${p}_hbm_leg_kernel_stats.csv
+cp $g/prof_$tag/hbm_leg_bench.json $d/${p}_hbm_leg_bench.json
+cp $g/prof_$tag/pmc_hbm_leg.json $d/${p}_hbm_leg_pmc.json
+cp $g/prof_$tag/pmc.json profiles/pmc_latest.json
+cp $g/prof_$tag/pmc_hbm_leg.json profiles/pmc_hbm_leg.json
+cp $g/pmc_$tag/counters.json $d/${p}_c3_sq_tcp_tcc_counters.json
+for v in c3_pairs c2 c4 c5; do
+  f=$(ls $g/ks_${tag}_$v/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp "$f" $d/${p}_${v}_kernel_stats.csv
+done
+cp $g/bench_variants.jsonl $d/${p}_bench_variants.jsonl
+cp $g/bench_default_$tag.json $d/${p}_default_bench.json
+cp $g/dma_probe_$tag.txt $d/${p}_gather_ceiling_dma_probe.txt
+ls -la $d | grep " ${p}_"

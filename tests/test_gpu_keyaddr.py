@@ -89,3 +89,33 @@ def test_fallback_kernel_large_v_block_and_many_memories(hip_lib):
     """Shapes the streaming kernel does not take go to the register-resident one: nR * D * 4 > 3 KB, Nm > 64."""
     run_case(64, 16, 1, 39, 33, False, True, seed=7)            # amazon-book-like: 39 relations
     run_case(32, 100, 2, 12, 9, False, True, seed=8)
+
+
+@pytest.mark.parametrize("udtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("shape", [(64, 64, 2, 9), (32, 64, 2, 12), (64, 16, 1, 39), (32, 100, 2, 12), (64, 5, 3, 9)],
+                         ids=lambda s: "D%dNm%dP%dR%d" % s)
+def test_users_feed_equals_per_pair_arrays(shape, udtype, hip_lib):
+    """mvin_key_addressing_users_fwd (pair b reads user_triplet_set[users[b]]) against mvin_key_addressing_fwd fed
+    with the arrays train.py:117-120 would assemble: same kernels, same arithmetic -> identical bits."""
+    D, Nm, P, nR = shape
+    rng = np.random.default_rng(D + Nm + P)
+    dev, nE, nU, B = "cuda:0", 900, 37, 301
+    E = torch.from_numpy((rng.normal(size=(nE, D)) * 0.5).astype(np.float32)).to(dev)
+    w = torch.from_numpy(rng.normal(size=D).astype(np.float32)).to(dev)
+    V = torch.from_numpy(rng.normal(size=(B, nR, D)).astype(np.float32)).to(dev)
+    uts = np.empty((nU, P, 3, Nm), dtype=np.int32)
+    uts[:, :, 0] = rng.integers(0, nE, (nU, P, Nm))
+    uts[:, :, 1] = rng.integers(0, nR, (nU, P, Nm))
+    uts[:, :, 2] = rng.integers(0, nE, (nU, P, Nm))
+    users = rng.integers(0, nU, B)
+    uts_d, users_d = torch.from_numpy(uts).to(dev), torch.from_numpy(users).to(dev).to(udtype)
+    n_o = P + 1
+    a = torch.full((B, n_o * D), float("nan"), dtype=torch.float32, device=dev)
+    b = torch.full_like(a, float("nan"))
+    ops.key_addressing_users(E, V, w, uts_d, users_d, P, a, n_o * D, nR)
+    sel = uts_d[users_d.long()]
+    mk = lambda x: [sel[:, i, x].contiguous() for i in range(P)]
+    ops.key_addressing(E, V, w, mk(0), mk(1), mk(2), P, b, n_o * D, nR)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
