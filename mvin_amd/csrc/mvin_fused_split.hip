@@ -1,11 +1,11 @@
-// Role-split variant of the fused two-level gather + attention kernel (gfx950) for D >= 64.
+// Role-split variant of the fused two-level gather + attention kernel (gfx950) for D >= 32.
 //
 // Same arithmetic, arguments and outputs as gather_attn_l2_kernel (mvin_fused.hip; reference
 // model.py:251-305, aggregators.py:98-146) -- what changes is WHO does what inside a workgroup.
 // In the symmetric kernel every wave gathers rows, then multiplies (226 VGPRs: 48 resident weight
 // registers + 32 load registers -> 2 waves per SIMD, and the row loads stop while the wave multiplies).
 // Here a workgroup is NG "gather" waves + NM = D/16 "dense" waves and a software pipeline over the
-// 32-child tiles t of its parents; at step s
+// tiles t (min(K, 32) children) of its parents; at step s
 //
 //   gather waves : tile s   : for each child, its K grandchild rows as 16-byte lane loads (one lane
 //                             group per child, 16 loads in flight per lane), S' = (1/K) sum_k p_k E[y_k]
@@ -21,8 +21,8 @@
 // One workgroup barrier per step; the dense waves order phase B -> phase C among themselves through
 // an LDS counter (the gather waves do not take part).
 //
-// Supported: D in {64, 128}; K in {32, 64, 128}; fp32 or bf16 table.  Everything else stays on
-// gather_attn_l2_kernel.
+// Supported: D in {32, 64, 128}; K in {32, 64, 128}, and K = 16 at D = 32 (BASELINE config C2: one parent per
+// 16-child tile, 2 + 2 waves); fp32 or bf16 table.  Everything else stays on gather_attn_l2_kernel.
 #include <cstdlib>
 #include <type_traits>
 
