@@ -4,6 +4,8 @@
 // They mirror the forward kernels: what the forward gathers, the backward scatter-adds
 // (atomic float adds on table rows); softmax backward is a wave-level reduction; weight
 // gradients are row-reductions of outer products.  Correctness-first versions.
+#include <cstdlib>
+
 #include "mvin_kernels.h"
 
 namespace mvin {
@@ -178,6 +180,93 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(WgradArgs a) {
         if (e < nent && acc[q] != 0.f) atomicAdd(dW + (size_t)(i0 + e / Dout) * Dout + e % Dout, acc[q]);
     }
     if (a.db && blockIdx.y == 0 && tid < Dout && accb != 0.f) atomicAdd(a.db + (size_t)z * a.db_zstride + tid, accb);
+}
+
+// The same weight gradient on the matrix cores, for Din = TI*16 and Dout = TJ*16 with TI*TJ <= 64 (every D x D and
+// concat-of-3 shape of the path at D in {16, 32, 64}): dW = X^T . dY as v_mfma_f32_16x16x4_f32 with A = X^T (a 32-row
+// tile of X in LDS, read column-wise: 16 consecutive floats per row group), B = dY, the [TI x TJ] output tiles dealt to
+// the four waves and kept in registers over the block's row tiles, one atomic per entry at the end.  The VALU kernel
+// above reads two LDS words per fma (LDS-bound) and runs on at most 64 workgroups per weight slab.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) {
+    constexpr int Din = TI * 16, Dout = TJ * 16, NT = TI * TJ, NTW = (NT + 3) / 4;
+    constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din;      // row stride = 16 mod 32 words: the four row groups of an
+    constexpr int ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;   // A / B fragment read hit disjoint banks
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                 // [32][ldx]
+    float* sY = sX + kTM * ldx;       // [32][ldy]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, q16 = lane >> 4;
+    const int z = blockIdx.z;
+    f32x4w acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    const float* dY = a.dY + (size_t)z * a.dy_zstride;
+    const int c4 = a.lin.Dsrc >> 2;
+    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * kTM;
+        for (int s = 0; s < a.lin.nsrc; ++s) {
+            const float* src = a.lin.src[s];
+            const int32_t* ids = a.lin.ids[s];
+            for (int idx = tid; idx < kTM * c4; idx += kBlock) {
+                const int row = idx / c4, c = idx - row * c4;
+                const int64_t r = r0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < a.lin.rows) {
+                    const int64_t srow = !ids ? r : (a.lin.ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r]);
+                    v = reinterpret_cast<const float4*>(src + srow * a.lin.Dsrc)[c];
+                }
+                float4* dst = reinterpret_cast<float4*>(sX + row * ldx + (a.lin.sum_sources ? 0 : s * a.lin.Dsrc) + c * 4);
+                if (a.lin.sum_sources && s > 0) {
+                    const float4 o = *dst;
+                    v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+                }
+                *dst = v;
+            }
+            if (a.lin.sum_sources && s + 1 < a.lin.nsrc) __syncthreads();    // (same thread -> same cell: ordering only)
+        }
+        for (int idx = tid; idx < kTM * Dout; idx += kBlock) {
+            const int row = idx / Dout, j = idx - row * Dout;
+            const int64_t r = r0 + row;
+            float v = 0.f;
+            if (r < a.lin.rows) {
+                v = dY[r * a.ldy + j];
+                if (a.mask) v = a.mask[(size_t)z * a.mask_zstride + r * a.ldm + j] > 0.f ? v : 0.f;
+            }
+            sY[row * ldy + j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int tt = wave + 4 * t;
+            if (tt < NT) {
+                const int ti = tt / TJ, tj = tt - ti * TJ;
+#pragma unroll
+                for (int ks = 0; ks < kTM / 4; ++ks)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(sX[(4 * ks + q16) * ldx + 16 * ti + l16],
+                                                                 sY[(4 * ks + q16) * ldy + 16 * tj + l16], acc[t], 0, 0, 0);
+            }
+        }
+        if (a.db && tid < Dout)
+            for (int row = 0; row < kTM; ++row) accb += sY[row * ldy + tid];
+        __syncthreads();
+    }
+    float* dW = a.dW + (size_t)z * a.dw_zstride;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tt = wave + 4 * t;
+        if (tt < NT) {
+            const int ti = tt / TJ, tj = tt - ti * TJ;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (acc[t][r] != 0.f) atomicAdd(dW + (size_t)(16 * ti + 4 * q16 + r) * Dout + 16 * tj + l16, acc[t][r]);
+        }
+    }
+    if (a.db && tid < Dout && accb != 0.f) atomicAdd(a.db + (size_t)z * a.db_zstride + tid, accb);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -500,8 +589,34 @@ hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64,
     return hipGetLastError();
 }
 
+template <int TI, int TJ>
+static hipError_t launch_wgrad_mfma(const WgradArgs& a, hipStream_t st) {
+    constexpr int Din = TI * 16, Dout = TJ * 16;
+    constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din, ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;
+    const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
+    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
+    int64_t cap = 512 / nz;
+    if (cap < 1) cap = 1;
+    const int gx = (int)(ntiles < 1 ? 1 : ntiles < cap ? ntiles : cap);
+    const size_t lds = (size_t)kTM * (ldx + ldy) * sizeof(float);
+    linear_wgrad_mfma_kernel<TI, TJ><<<dim3(gx, 1, nz), kBlock, lds, st>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st) {
     const int Din = a.lin.sum_sources ? a.lin.Dsrc : a.lin.nsrc * a.lin.Dsrc;
+    static const bool no_mfma = getenv("MVIN_WGRAD_VALU") != nullptr;
+    if (!no_mfma && (a.lin.Dsrc & 3) == 0) {
+        const int ti = Din / 16, tj = a.lin.Dout / 16;
+        if (Din % 16 == 0 && a.lin.Dout % 16 == 0) {
+#define MVIN_WG(TIV, TJV) if (ti == TIV && tj == TJV) return launch_wgrad_mfma<TIV, TJV>(a, st);
+            MVIN_WG(1, 1) MVIN_WG(2, 1) MVIN_WG(3, 1) MVIN_WG(4, 1)
+            MVIN_WG(2, 2) MVIN_WG(4, 2) MVIN_WG(6, 2) MVIN_WG(8, 2)
+            MVIN_WG(4, 4) MVIN_WG(8, 4) MVIN_WG(12, 4) MVIN_WG(16, 4)
+            MVIN_WG(8, 8)
+#undef MVIN_WG
+        }
+    }
     a.IB = 4096 / a.lin.Dout;
     if (a.IB < 1) a.IB = 1;
     if (a.IB > Din) a.IB = Din;

@@ -438,7 +438,9 @@ class Trainer(object):
                 # consumed (HO_only + User_orient_kg_eh without User_orient: q has no consumer)
                 if not getattr(self, "_ka_bwd_ran", False):
                     ops.scatter_add_rows(dP["entity_emb_matrix"], ids.reshape(-1), rows, alpha=2.0 * l2w)
-            cnt = torch.bincount(memories_r[hop].reshape(-1).long(), minlength=nR).to(F32)
+            rid = memories_r[hop].reshape(-1).long()        # occurrences per relation, without bincount's host sync
+            cnt = torch.zeros(nR, dtype=F32, device=rid.device).scatter_add_(0, rid, torch.ones(rid.shape[0], dtype=F32,
+                                                                                              device=rid.device))
             ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
                         beta=1.0, D=D * D)
             ops.eltwise(7, nR * D * D, R.view(-1), z=cnt, accum=loss_acc, alpha=l2w, D=D * D)   # no host sync
