@@ -226,10 +226,13 @@ class Trainer(object):
                     # V[b,r,:] = E[item_b] . R[r]  =>  dR[r] += E[item]^T dV[:,r] ; dE[item] += sum_r dV[:,r] R[r]^T
                     ops.linear_wgrad([E], dV, dP["relation_emb_KGE_matrix"], ids=[item], rows=B, nz=nR, ldy=nR * D,
                                      dy_zstride=D, dw_zstride=D * D)
-                    ditem = zeros(B, D)
-                    for r in range(nR):
-                        tmp = ops.linear([dV[:, r, :].contiguous()], self._T(R[r]), D)
-                        ops.axpby(1.0, tmp.view(-1), 1.0, ditem.view(-1))
+                    if nR * D <= 4096:   # one product: ditem[b, i] = sum_{r, j} dV[b, r, j] R[r, i, j]
+                        ditem = ops.linear([dV.view(B, nR * D)], R.permute(0, 2, 1).reshape(nR * D, D).contiguous(), D)
+                    else:
+                        ditem = zeros(B, D)
+                        for r in range(nR):
+                            tmp = ops.linear([dV[:, r, :].contiguous()], self._T(R[r]), D)
+                            ops.axpby(1.0, tmp.view(-1), 1.0, ditem.view(-1))
                     ops.scatter_add_rows(dP["entity_emb_matrix"], item, ditem)
             tape.append(bwd_ps)
 
