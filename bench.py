@@ -52,8 +52,8 @@ def algorithmic_bytes_per_pair(D, K, L, s=4):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dataset", default="last-fm_50core")
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--hop", type=int, default=2)
