@@ -413,12 +413,17 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Ef = reinterpret_cast<const float*>(a.f.E);   // training keeps the tables in fp32
 
-    for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < a.f.B; b += (int64_t)gridDim.x * 4) {
-        for (int hop = 0; hop < nhop; ++hop) {
+    // one wave per (pair, read): the P hop reads and the h-set read of a pair are independent, and at the reference's
+    // batch sizes (512 / 1024 pairs) a wave per PAIR leaves most of the chip idle behind one long dependent chain
+    const int nread = a.f.P + (a.f.w ? 1 : 0);
+    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < a.f.B * nread; u += (int64_t)gridDim.x * 4) {
+        const int64_t b = u / nread;
+        const int rd = (int)(u - b * nread);
+        {
+            const bool is_set = rd == a.f.P;          // reads 0..P-1: hops; read P: the h-set read (rows of hop 0)
+            const int hop = is_set ? 0 : rd;
             const int32_t* mh = a.f.mem_h[hop] + b * Nm;
-            for (int pass = 0; pass < 2; ++pass) {   // pass 0: hop read, pass 1: h-set read (hop 0 only)
-                const bool is_set = pass == 1;
-                if (is_set ? !(hop == 0 && a.f.w) : !(hop < a.f.P)) continue;
+            {
                 const int32_t* mr = is_set ? nullptr : a.f.mem_r[hop] + b * Nm;
                 const int32_t* mv = is_set ? mh : a.f.mem_t[hop] + b * Nm;   // value rows
                 const float4 dvo = cact ? reinterpret_cast<const float4*>(
@@ -647,7 +652,7 @@ hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const floa
 
 hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a, hipStream_t st) {
     const size_t lds = (size_t)4 * 2 * a.f.Nm * sizeof(float);
-    key_addr_bwd_kernel<<<blocks_for(a.f.B, 4), kBlock, lds, st>>>(a);
+    key_addr_bwd_kernel<<<blocks_for(a.f.B * (a.f.P + (a.f.w ? 1 : 0)), 4), kBlock, lds, st>>>(a);
     return hipGetLastError();
 }
 
