@@ -218,6 +218,13 @@ int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relatio
                                     const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR, int n_entity, int n_user,
                                     float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
+/* The batch in user order for mvin_key_addressing_grouped_fwd, built on the device (counting sort by user id, int
+ * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
+ * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair
+ * at each position (order inside a segment unspecified).  workspace: 2 * n_user int32.  Ids outside [0, n_user) are
+ * dropped (the reference's TF gather would raise InvalidArgument). */
+int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,
+                             int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, void* stream);
 
 /* out[r, :] = softmax(x[r, :]) over n columns (tf.nn.softmax, model.py:189 / :223).  Building block of the
  * SHARED-USER form of MVIN._key_addressing (one user scored against many items, as util.py:145-181 does for

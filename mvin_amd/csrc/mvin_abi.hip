@@ -461,6 +461,16 @@ int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes,
     return hip_result(mvin::launch_move_rows(table, ids, n, row_bytes, const_cast<void*>(rows), true, (hipStream_t)stream), who);
 }
 
+int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,
+                             int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, void* stream) {
+    const char* who = "mvin_group_pairs_by_user";
+    if ((!users_i64 && !users_i32) || !workspace || !seg_user || !seg_ptr || !nseg || !pair_index)
+        return fail(-1, "%s: null pointer", who);
+    if (B <= 0 || B > 0x7fffffff || n_user <= 0) return fail(-2, "%s: bad sizes B=%lld n_user=%d", who, (long long)B, n_user);
+    return hip_result(mvin::launch_group_pairs(users_i64, users_i32, B, n_user, workspace, workspace + n_user, seg_user, seg_ptr,
+                                               nseg, pair_index, (hipStream_t)stream), who);
+}
+
 int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR) {
     return mvin::key_addr_grouped_supported(D, P, Nm, nR) ? 1 : 0;
 }

@@ -1,0 +1,95 @@
+// The batch in user order, for the grouped form of key addressing (mvin_key_addressing_grouped_fwd): a counting
+// sort by user id entirely on the device (no host sync, graph-capturable) --
+//   count[u]      = pairs of user u in the batch                          (int atomics)
+//   seg_user[s]   = the s-th user that occurs, in increasing id order ;  seg_ptr[s] = first position of its pairs
+//   pair_index[p] = original index of the pair at position p              (order inside a segment: arbitrary;
+//                                                                          per-pair results do not depend on it)
+// Replaces torch.sort + seven elementwise / scan / scatter launches (0.27 ms per 524 288 pairs) by three small kernels.
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+__global__ void group_count_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
+                                   int32_t* __restrict__ count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = u64 ? u64[i] : (int64_t)u32[i];
+        if (u >= 0 && u < n_user) atomicAdd(count + u, 1);
+    }
+}
+
+// one workgroup: exclusive scans of count[] (-> offs[]) and of (count[] > 0) (-> segment numbers), chunk by chunk
+__global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t* __restrict__ count, int n_user, int64_t B,
+                                                          int32_t* __restrict__ offs, int32_t* __restrict__ seg_user,
+                                                          int32_t* __restrict__ seg_ptr, int32_t* __restrict__ nseg) {
+    __shared__ int sC[16], sS[16];
+    __shared__ int carryC, carryS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        carryC = 0;
+        carryS = 0;
+    }
+    __syncthreads();
+    for (int base = 0; base < n_user; base += 1024) {
+        const int u = base + tid;
+        const int c = u < n_user ? count[u] : 0;
+        const int s = c > 0 ? 1 : 0;
+        int ic = c, is = s;                                   // inclusive scans inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tc = __shfl_up(ic, o, kWave), ts = __shfl_up(is, o, kWave);
+            if (lane >= o) {
+                ic += tc;
+                is += ts;
+            }
+        }
+        if (lane == 63) {
+            sC[wave] = ic;
+            sS[wave] = is;
+        }
+        __syncthreads();
+        int wc = carryC, ws = carryS;
+        for (int w = 0; w < wave; ++w) {
+            wc += sC[w];
+            ws += sS[w];
+        }
+        const int ec = wc + ic - c, es = ws + is - s;         // exclusive
+        if (u < n_user) {
+            offs[u] = ec;
+            if (c > 0) {
+                seg_user[es] = u;
+                seg_ptr[es] = ec;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            carryC = ec + c;
+            carryS = es + s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        nseg[0] = carryS;
+        seg_ptr[carryS] = carryC;                             // = number of pairs with a valid user id
+    }
+}
+
+__global__ void group_scatter_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
+                                     int32_t* __restrict__ offs, int32_t* __restrict__ pair_index) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = u64 ? u64[i] : (int64_t)u32[i];
+        if (u >= 0 && u < n_user) pair_index[atomicAdd(offs + u, 1)] = (int32_t)i;
+    }
+}
+
+hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B, int n_user, int32_t* count, int32_t* offs,
+                              int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(count, 0, (size_t)n_user * sizeof(int32_t), st);
+    if (e != hipSuccess) return e;
+    const int blocks = (int)((B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048);
+    group_count_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, count);
+    group_scan_kernel<<<1, 1024, 0, st>>>(count, n_user, B, offs, seg_user, seg_ptr, nseg);
+    group_scatter_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, offs, pair_index);
+    return hipGetLastError();
+}
+
+}  // namespace mvin

@@ -644,7 +644,7 @@ class MVIN(object):
         n_o = P + 1 if a.PS_O_ft else P
         o_cat = torch.empty((item.shape[0], n_o * D), dtype=torch.float32, device=self.device)
         w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
-        groups = ops.group_pairs_by_user(user)
+        groups = ops.group_pairs_by_user(user, n_user=uts.shape[0])
         ops.key_addressing_grouped(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, uts, groups, item, P,
                                    o_cat, n_o * D, self.n_relation)
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)

@@ -371,11 +371,23 @@ def key_addressing_grouped_supported(D, P, Nm, nR):
     return bool(_lib.load().mvin_key_addressing_grouped_supported(D, P, Nm, nR))
 
 
-def group_pairs_by_user(users):
+def group_pairs_by_user(users, n_user=None):
     """Segments of a batch in user order, built on the device with static shapes (no host sync, graph-capturable):
     returns (seg_user [B] int32, seg_ptr [B+2] int32, nseg [1] int32, pair_index [B] int32); only the first
-    nseg entries of seg_user / nseg+1 of seg_ptr are meaningful."""
+    nseg entries of seg_user / nseg+1 of seg_ptr are meaningful.  With ``n_user`` (ids in [0, n_user)):
+    mvin_group_pairs_by_user, a counting sort in three small kernels; without: torch.sort + scans."""
     B = users.shape[0]
+    if n_user is not None and users.is_cuda and users.dtype in (torch.int64, I32) and users.is_contiguous():
+        dev = users.device
+        ws = torch.empty(2 * n_user, dtype=I32, device=dev)
+        seg_user = torch.empty(B, dtype=I32, device=dev)
+        seg_ptr = torch.empty(B + 2, dtype=I32, device=dev)
+        nseg = torch.empty(1, dtype=I32, device=dev)
+        pair_index = torch.empty(B, dtype=I32, device=dev)
+        u64, u32 = (_p(users), None) if users.dtype == torch.int64 else (None, _p(users))
+        _lib.check(_lib.load().mvin_group_pairs_by_user(u64, u32, B, n_user, _p(ws), _p(seg_user), _p(seg_ptr), _p(nseg),
+                                                        _p(pair_index), _stream()), "mvin_group_pairs_by_user")
+        return seg_user, seg_ptr, nseg, pair_index
     su, perm = torch.sort(users)
     start = torch.ones(B, dtype=torch.bool, device=users.device)
     start[1:] = su[1:] != su[:-1]

@@ -71,6 +71,26 @@ def test_grouping_is_a_permutation_with_segments(hip_lib):
         assert all(int(users[perm[p]]) == seg_user[s] for p in range(int(seg_ptr[s]), int(seg_ptr[s + 1])))
 
 
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("B,n_user", [(9, 10), (1, 5), (5000, 37), (70000, 3000), (1025, 1025), (4096, 100000)])
+def test_native_grouping_matches_the_sort_based_one(B, n_user, dtype, hip_lib):
+    """mvin_group_pairs_by_user (counting sort, three kernels) against the torch.sort-based grouping: same users,
+    same segment boundaries, and every segment holds the same SET of pairs (order inside a segment is free)."""
+    from mvin_amd import ops
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(B + n_user)
+    users = torch.randint(0, n_user, (B,), device="cuda:0", generator=g).to(dtype)
+    su_a, sp_a, ns_a, pi_a = ops.group_pairs_by_user(users, n_user=n_user)
+    su_b, sp_b, ns_b, pi_b = ops.group_pairs_by_user(users.long())
+    n = int(ns_b.item())
+    assert int(ns_a.item()) == n
+    assert torch.equal(su_a[:n], su_b[:n]) and torch.equal(sp_a[:n + 1], sp_b[:n + 1])
+    assert torch.equal(torch.sort(pi_a.long())[0], torch.arange(B, device="cuda:0"))
+    # a pair sits in the segment of its user
+    seg_of_pos = torch.bucketize(torch.arange(B, device="cuda:0"), sp_a[1:n + 1].long(), right=True)
+    assert torch.equal(su_a[:n].long()[seg_of_pos], users.long()[pi_a.long()])
+
+
 def test_device_feeder_uses_the_grouped_path(hip_lib):
     from mvin_amd import harness
     from mvin_amd.model import MVIN
