@@ -19,5 +19,6 @@ timeout 900 scripts/pmc_counters.sh $tag > gpurun_out/pmc_counters_$tag.log 2>&1
 } > gpurun_out/kstats_$tag.log 2>&1 < /dev/null
 timeout 1500 scripts/bench_variants.sh > gpurun_out/bench_variants_$tag.log 2>&1 < /dev/null
 timeout 600 python bench.py 2> gpurun_out/bench_default_$tag.err | grep '^{' | tail -1 > gpurun_out/bench_default_$tag.json
+[ -x scripts/micro/dma_probe.bin ] || hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o scripts/micro/dma_probe.bin scripts/micro/dma_probe.hip
 timeout 120 scripts/micro/dma_probe.bin > gpurun_out/dma_probe_$tag.txt 2>&1 < /dev/null
 tail -3 gpurun_out/collect_$tag.log; tail -30 gpurun_out/bench_variants_$tag.log; cat gpurun_out/kstats_$tag.log | grep -E "==|avg|value"
