@@ -409,7 +409,6 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
     float* sL = smem + wave * 2 * Nm;    // logits -> probabilities
     float* sGm = sL + Nm;                // g_m
     const int slot0 = a.f.w ? 1 : 0;
-    const int nhop = a.f.P > 0 ? a.f.P : 1;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Ef = reinterpret_cast<const float*>(a.f.E);   // training keeps the tables in fp32
 
