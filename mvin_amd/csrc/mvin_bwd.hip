@@ -84,20 +84,17 @@ __global__ void eltwise_kernel(EltArgs a) {
 // ------------------------------------------------------------------------------------------
 // dTable[ids[r], :] += alpha * X[r, :]      (backward of tf.nn.embedding_lookup)
 // ------------------------------------------------------------------------------------------
+// One float per lane: a wave instruction adds 64 CONSECUTIVE floats (one 256-byte row at D = 64).  With a float4 chunk per
+// lane the four component atomics of a wave each touched every 16-byte-strided word of four rows -- 8 cache lines per
+// instruction, a quarter of each -- and the L2 atomic units work per line.
 __global__ void scatter_add_rows_kernel(float* __restrict__ dtable, const int32_t* __restrict__ ids, int ids64,
                                         const float* __restrict__ x, int64_t rows, int D, float alpha) {
-    const int c4 = D >> 2;
-    const int64_t n = rows * c4, stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t n = rows * D, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t r = i / c4;
-        const int c = (int)(i - r * c4);
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
         const int64_t row = ids64 ? reinterpret_cast<const int64_t*>(ids)[r] : (int64_t)ids[r];
-        const float4 v = reinterpret_cast<const float4*>(x + r * D)[c];
-        float* d = dtable + row * D + 4 * c;
-        atomicAdd(d + 0, alpha * v.x);
-        atomicAdd(d + 1, alpha * v.y);
-        atomicAdd(d + 2, alpha * v.z);
-        atomicAdd(d + 3, alpha * v.w);
+        atomicAdd(dtable + row * D + c, alpha * x[i]);
     }
 }
 
@@ -406,8 +403,14 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
     const int lpr = 1 << a.f.lpr_log2, rpw = kWave >> a.f.lpr_log2;
     const int g = lane >> a.f.lpr_log2, c = lane & (lpr - 1);
     const bool cact = (c << 2) < D;
-    float* sL = smem + wave * 2 * Nm;    // logits -> probabilities
+    const int nm2 = (2 * Nm + 3) & ~3;   // 16-byte aligned tile behind the two [Nm] arrays
+    float* sL = smem + wave * (nm2 + 3 * 256 + 3 * 64);    // logits -> probabilities
     float* sGm = sL + Nm;                // g_m
+    // row-contiguous atomics: the 4-floats-per-lane results of a step (rpw rows x 4*lpr floats = 256 words per target)
+    // go through this wave-private tile so that one atomic instruction adds 64 CONSECUTIVE floats -- the L2 atomic
+    // units work per cache line, and a float4-per-lane atomic touches a quarter of eight lines (scatter_add_rows: 4x)
+    float* sTr = sL + nm2;               // [3 targets][256]
+    int* sRowI = reinterpret_cast<int*>(sTr + 3 * 256);        // [3 targets][64] row numbers (-1: none); rpw <= 64
     const int slot0 = a.f.w ? 1 : 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Ef = reinterpret_cast<const float*>(a.f.E);   // training keeps the tables in fp32
@@ -467,47 +470,60 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                 __builtin_amdgcn_wave_barrier();
                 // scatter
                 float4 dwacc = z4;   // h-set logit-weight gradient: per-lane partial, ONE atomic set per pair
+                const int rowf = 4 * lpr;            // floats per row slot of the transpose tile (>= D)
                 for (int m0 = 0; m0 < Nm; m0 += rpw) {
                     const int m = m0 + g;
-                    if (m < Nm && cact) {
+                    const bool act = m < Nm;
+                    float4 dh = z4, dval = z4, dvv = z4;
+                    int hrow = -1, vrow = -1, rrow = -1;
+                    if (act && cact) {
                         const float p = sL[m];
                         const float dl = p * (sGm[m] - pgs);
-                        const int64_t hrow = mh[m], vrow = mv[m];
-                        const float4 h = reinterpret_cast<const float4*>(Ef + hrow * D)[c];
-                        float4 dh, dval;
+                        hrow = mh[m];
+                        vrow = mv[m];
+                        const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)hrow * D)[c];
                         if (is_set) {
                             const float4 w4 = reinterpret_cast<const float4*>(a.f.w)[c];
                             // value row == head row
                             dh = make_float4(p * dvo.x + dl * w4.x, p * dvo.y + dl * w4.y, p * dvo.z + dl * w4.z,
                                              p * dvo.w + dl * w4.w);
-                            dval = z4;
                             dwacc = f4_fma(dl, h, dwacc);
+                            vrow = -1;
                         } else {
                             const int r = mr[m];
                             const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
-                            const float4 val = reinterpret_cast<const float4*>(Ef + vrow * D)[c];
+                            const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)vrow * D)[c];
                             const float l2 = 2.f * a.l2;
                             dh = make_float4(dl * v4.x + l2 * h.x, dl * v4.y + l2 * h.y, dl * v4.z + l2 * h.z,
                                              dl * v4.w + l2 * h.w);
                             dval = make_float4(p * dvo.x + l2 * val.x, p * dvo.y + l2 * val.y, p * dvo.z + l2 * val.z,
                                                p * dvo.w + l2 * val.w);
-                            float* dV = a.dV + (b * a.f.nR + r) * (int64_t)D + 4 * c;
-                            atomicAdd(dV + 0, dl * h.x);
-                            atomicAdd(dV + 1, dl * h.y);
-                            atomicAdd(dV + 2, dl * h.z);
-                            atomicAdd(dV + 3, dl * h.w);
-                            float* dt = a.dE + vrow * D + 4 * c;
-                            atomicAdd(dt + 0, dval.x);
-                            atomicAdd(dt + 1, dval.y);
-                            atomicAdd(dt + 2, dval.z);
-                            atomicAdd(dt + 3, dval.w);
+                            dvv = make_float4(dl * h.x, dl * h.y, dl * h.z, dl * h.w);
+                            rrow = r;
                         }
-                        float* de = a.dE + hrow * D + 4 * c;
-                        atomicAdd(de + 0, dh.x);
-                        atomicAdd(de + 1, dh.y);
-                        atomicAdd(de + 2, dh.z);
-                        atomicAdd(de + 3, dh.w);
                     }
+                    // transpose through LDS: tile[target][g][4c..4c+3]
+                    *reinterpret_cast<float4*>(sTr + 0 * 256 + g * rowf + 4 * c) = dh;
+                    *reinterpret_cast<float4*>(sTr + 1 * 256 + g * rowf + 4 * c) = dval;
+                    *reinterpret_cast<float4*>(sTr + 2 * 256 + g * rowf + 4 * c) = dvv;
+                    if (c == 0) {
+                        sRowI[0 * 64 + g] = hrow;
+                        sRowI[1 * 64 + g] = vrow;
+                        sRowI[2 * 64 + g] = rrow;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int e = k * 64 + lane;
+                        const int j = e / rowf, col = e - j * rowf;
+                        if (col < D) {
+                            const int hr = sRowI[j], vr = sRowI[64 + j], rr = sRowI[128 + j];
+                            if (hr >= 0) atomicAdd(a.dE + (int64_t)hr * D + col, sTr[e]);
+                            if (vr >= 0) atomicAdd(a.dE + (int64_t)vr * D + col, sTr[256 + e]);
+                            if (rr >= 0) atomicAdd(a.dV + (b * a.f.nR + rr) * (int64_t)D + col, sTr[512 + e]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (is_set) {
                     dwacc = group_xor_sum(dwacc, lpr);
@@ -589,7 +605,7 @@ hipError_t launch_eltwise(const EltArgs& a, hipStream_t st) {
 
 hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64, const float* x, int64_t rows, int D,
                                    float alpha, hipStream_t st) {
-    scatter_add_rows_kernel<<<blocks_for(rows * (D / 4), 1024), 256, 0, st>>>(dtable, ids, ids64, x, rows, D, alpha);
+    scatter_add_rows_kernel<<<blocks_for(rows * D, 1024), 256, 0, st>>>(dtable, ids, ids64, x, rows, D, alpha);
     return hipGetLastError();
 }
 
@@ -650,7 +666,7 @@ hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const floa
 }
 
 hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)4 * 2 * a.f.Nm * sizeof(float);
+    const size_t lds = (size_t)4 * (((2 * a.f.Nm + 3) & ~3) + 3 * 256 + 3 * 64) * sizeof(float);
     key_addr_bwd_kernel<<<blocks_for(a.f.B * (a.f.P + (a.f.w ? 1 : 0)), 4), kBlock, lds, st>>>(a);
     return hipGetLastError();
 }
