@@ -345,19 +345,31 @@ __global__ __launch_bounds__(kBlock) void agg_bwd_kernel(AggBwdArgs a) {
             }
         }
         // pass 2: child gradients
-        for (int k0 = 0; k0 < K; k0 += rpw) {
-            const int k = k0 + g;
-            if (k < K && cact) {
-                const float w = pk[k] * invK;
-                const float4 o = make_float4(w * dv.x, w * dv.y, w * dv.z, w * dv.w);
-                if (a.gather) {
-                    float* d = a.dtable + (int64_t)a.adj_e[xbase + k] * D + 4 * c;
-                    atomicAdd(d + 0, o.x);
-                    atomicAdd(d + 1, o.y);
-                    atomicAdd(d + 2, o.z);
-                    atomicAdd(d + 3, o.w);
-                } else {
-                    reinterpret_cast<float4*>(a.dchild + (t * K + k) * (int64_t)D)[c] = o;
+        if (a.gather) {
+            // row-contiguous atomics (see scatter_add_rows_kernel): a lane owns ONE element of dvec, a wave
+            // instruction adds 64 consecutive floats = 64 / dpad whole rows
+            const int dpad = 4 * lpr;                      // row slot, a power of two >= D
+            if (dpad <= kWave) {
+                const int kk = lane / dpad, e = lane - kk * dpad, rp = kWave / dpad;
+                const float dve = e < D ? a.dvec[t * D + e] : 0.f;
+                for (int k0 = 0; k0 < K; k0 += rp) {
+                    const int k = k0 + kk;
+                    if (k < K && e < D) atomicAdd(a.dtable + (int64_t)a.adj_e[xbase + k] * D + e, pk[k] * invK * dve);
+                }
+            } else {
+                for (int k = 0; k < K; ++k) {
+                    const float w = pk[k] * invK;
+                    float* d = a.dtable + (int64_t)a.adj_e[xbase + k] * D;
+                    for (int e = lane; e < D; e += kWave) atomicAdd(d + e, w * a.dvec[t * D + e]);
+                }
+            }
+        } else {
+            for (int k0 = 0; k0 < K; k0 += rpw) {
+                const int k = k0 + g;
+                if (k < K && cact) {
+                    const float w = pk[k] * invK;
+                    reinterpret_cast<float4*>(a.dchild + (t * K + k) * (int64_t)D)[c] =
+                        make_float4(w * dv.x, w * dv.y, w * dv.z, w * dv.w);
                 }
             }
         }
