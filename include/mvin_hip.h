@@ -334,9 +334,13 @@ int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* re
 /* element-wise helpers: mode 0 y = alpha x + beta y | 1 sigmoid cross entropy (model.py:379): y = (sigmoid(x) -
  * z) alpha, *accum += beta * ce(x, z) | 2 relu backward y = z > 0 ? x : 0 | 3 *accum += alpha sum x^2 |
  * 4 Adam step (x param, y grad, z m, w v, alpha = lr_t) | 5 y[r,:] = beta y[r,:] + alpha z[r] x[r,:] (n = rows*D) |
- * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D) | 7 *accum += alpha sum_r z[r] sum x[r,:]^2 (n = rows*D). */
+ * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D) | 7 *accum += alpha sum_r z[r] sum x[r,:]^2 (n = rows*D) |
+ * 8 *accum += alpha sum_r sum x[ids[r],:]^2 with ids = (const int32_t*) z (n = rows*D): gathered rows, not materialised. */
 int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha,
                  float beta, float beta1, float beta2, float eps, int D, int N, void* stream);
+/* out[b] += |{i : ids[i] == b}| for b < nbins <= 4096 (the occurrence counts of the relations in a ripple-set list: the
+ * weights of the sum(r_emb^2) regulariser's gradient, model.py:383-386); out is accumulated, caller zeroes it. */
+int mvin_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, void* stream);
 
 /* All parameters in one launch: the L2 terms of model.py:387-412 and (apply_adam != 0) the
  * tf.train.AdamOptimizer update of model.py:414.  Gradients and Adam moments are flat buffers of

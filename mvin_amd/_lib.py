@@ -88,6 +88,7 @@ SIGNATURES = {
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int,
                                           C.c_void_p]),
     "mvin_key_addressing_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_count_ids": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_group_pairs_by_user": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_users_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

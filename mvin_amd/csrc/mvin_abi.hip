@@ -582,18 +582,25 @@ int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int3
 }
 
 // ---------------------------------------------------------------------------- training
+int mvin_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, void* stream) {
+    if (n < 0 || nbins < 1 || nbins > 4096) return fail(-2, "mvin_count_ids: n=%lld nbins=%d (1..4096)", (long long)n, nbins);
+    if (n == 0) return 0;
+    if (!ids || !out) return fail(-1, "mvin_count_ids: null pointer");
+    return hip_result(mvin::launch_count_ids(ids, n, nbins, out, (hipStream_t)stream), "mvin_count_ids");
+}
+
 int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha, float beta,
                  float beta1, float beta2, float eps, int D, int N, void* stream) {
-    if (mode < 0 || mode > 7) return fail(-2, "mvin_eltwise: mode=%d", mode);
+    if (mode < 0 || mode > 8) return fail(-2, "mvin_eltwise: mode=%d", mode);
     if (mode == 6 && (!y || D <= 0 || N <= 0)) return fail(-2, "mvin_eltwise: mode 6 needs y, D, N");
     if (n < 0) return fail(-2, "mvin_eltwise: n < 0");
     if (n == 0) return 0;
     if (!x) return fail(-1, "mvin_eltwise: null x");
     if ((mode == 0 || mode == 1 || mode == 2 || mode == 4 || mode == 5) && !y) return fail(-1, "mvin_eltwise: null y");
-    if ((mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 7) && !z) return fail(-1, "mvin_eltwise: null z");
+    if ((mode == 1 || mode == 2 || mode == 4 || mode == 5 || mode == 7 || mode == 8) && !z) return fail(-1, "mvin_eltwise: null z");
     if (mode == 4 && !w) return fail(-1, "mvin_eltwise: null w");
-    if ((mode == 3 || mode == 7) && !accum) return fail(-1, "mvin_eltwise: null accum");
-    if ((mode == 5 || mode == 7) && D <= 0) return fail(-2, "mvin_eltwise: D <= 0");
+    if ((mode == 3 || mode == 7 || mode == 8) && !accum) return fail(-1, "mvin_eltwise: null accum");
+    if ((mode == 5 || mode == 7 || mode == 8) && D <= 0) return fail(-2, "mvin_eltwise: D <= 0");
     mvin::EltArgs e{};
     e.mode = mode;
     e.n = n;

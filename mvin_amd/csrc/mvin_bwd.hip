@@ -68,6 +68,14 @@ __global__ void eltwise_kernel(EltArgs a) {
                 local += a.alpha * a.z[i / a.D] * xv * xv;
                 break;
             }
+            case 8: {  // sum of squares of GATHERED rows: accum += alpha * sum_r x[ids[r], :]^2, ids = (int32*) z
+                       // (the regulariser of model.py:383-385 on the ripple-set rows, without materialising them)
+                const int64_t r = i / a.D;
+                const int64_t row = reinterpret_cast<const int32_t*>(a.z)[r];
+                const float xv = a.x[row * a.D + (i - r * a.D)];
+                local += a.alpha * xv * xv;
+                break;
+            }
             case 6: {  // group row sum: y[g, j] = alpha * sum_{n < N} x[(g*N + n), j]   (n = groups * D)
                 const int64_t gidx = i / a.D;
                 const int j = (int)(i - gidx * a.D);
@@ -79,6 +87,30 @@ __global__ void eltwise_kernel(EltArgs a) {
         }
     }
     if (a.accum) block_accumulate(a.accum, local);
+}
+
+// ------------------------------------------------------------------------------------------
+// out[b] += number of i with ids[i] == b  (bins <= 4096: per-workgroup LDS histogram, one global atomic per bin and
+// workgroup; 262 k atomics straight onto 9 global addresses took 62 us)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_ids_kernel(const int32_t* __restrict__ ids, int64_t n, int nbins,
+                                                        float* __restrict__ out) {
+    __shared__ int bins[4096];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = ids[i];
+        if (b >= 0 && b < nbins) atomicAdd(&bins[b], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (bins[i]) atomicAdd(out + i, (float)bins[i]);
+}
+
+hipError_t launch_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, hipStream_t st) {
+    const int64_t nb = (n + 4095) / 4096;
+    count_ids_kernel<<<(int)(nb < 1 ? 1 : nb < 256 ? nb : 256), 256, 0, st>>>(ids, n, nbins, out);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

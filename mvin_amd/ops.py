@@ -479,6 +479,14 @@ def eltwise(mode, n, x, y=None, z=None, w=None, accum=None, alpha=1.0, beta=0.0,
                                 _stream()), "mvin_eltwise")
 
 
+def count_ids(ids, nbins):
+    """mvin_count_ids: float occurrence counts [nbins] of an int32 id list (no host sync)."""
+    _chk(ids, I32, "ids")
+    out = torch.zeros(nbins, dtype=F32, device=ids.device)
+    _lib.check(_lib.load().mvin_count_ids(_p(ids), ids.numel(), nbins, _p(out), _stream()), "mvin_count_ids")
+    return out
+
+
 def l2_adam_multi(segs, nseg, total, g, m, v, loss_accum, apply_adam, lr_t, beta1, beta2, eps):
     """mvin_l2_adam_multi over the flat gradient / Adam-moment buffers (see include/mvin_hip.h)."""
     lib = _lib.load()

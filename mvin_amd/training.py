@@ -435,15 +435,23 @@ class Trainer(object):
         # gathered-row regulariser (model.py:383-386): sum(h^2) + sum(t^2) + sum(r_emb^2) per hop
         for hop in range(P):
             for ids in (memories_h[hop], memories_t[hop]):
-                rows = self._lookup(E, ids.reshape(-1))
-                ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
+                flat = ids.reshape(-1)
                 # mvin_key_addressing_bwd adds 2*l2*rows when it ran -- it does not when ps was built but never
                 # consumed (HO_only + User_orient_kg_eh without User_orient: q has no consumer)
-                if not getattr(self, "_ka_bwd_ran", False):
-                    ops.scatter_add_rows(dP["entity_emb_matrix"], ids.reshape(-1), rows, alpha=2.0 * l2w)
-            rid = memories_r[hop].reshape(-1).long()        # occurrences per relation, without bincount's host sync
-            cnt = torch.zeros(nR, dtype=F32, device=rid.device).scatter_add_(0, rid, torch.ones(rid.shape[0], dtype=F32,
-                                                                                              device=rid.device))
+                if getattr(self, "_ka_bwd_ran", False) and flat.dtype == torch.int32 and flat.is_contiguous():
+                    ops.eltwise(8, flat.numel() * D, E.view(-1), z=flat, accum=loss_acc, alpha=l2w, D=D)   # rows stay in the table
+                else:
+                    rows = self._lookup(E, flat)
+                    ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
+                    if not getattr(self, "_ka_bwd_ran", False):
+                        ops.scatter_add_rows(dP["entity_emb_matrix"], flat, rows, alpha=2.0 * l2w)
+            # occurrences per relation, without bincount's host sync (and without 262 k atomics on nR addresses)
+            rid = memories_r[hop].reshape(-1)
+            if rid.dtype == torch.int32 and rid.is_contiguous() and nR <= 4096:
+                cnt = ops.count_ids(rid, nR)
+            else:
+                cnt = torch.zeros(nR, dtype=F32, device=rid.device).scatter_add_(
+                    0, rid.long(), torch.ones(rid.shape[0], dtype=F32, device=rid.device))
             ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
                         beta=1.0, D=D * D)
             ops.eltwise(7, nR * D * D, R.view(-1), z=cnt, accum=loss_acc, alpha=l2w, D=D * D)   # no host sync
