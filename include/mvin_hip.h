@@ -357,6 +357,11 @@ typedef struct {
 int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
                        float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
                        float eps, void* stream);
+/* Same, with the bias-corrected step size lr_t read from device memory when the kernel runs: a training step
+ * captured into a hipGraph (mvin_amd/training.py:GraphedTrainer) replays with a new lr_t without re-capture. */
+int mvin_l2_adam_multi_dev(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+                           float* v_flat, float* loss_accum, int apply_adam, const float* lr_t_device, float beta1,
+                           float beta2, float eps, void* stream);
 
 /* dtable[ids[r], :] += alpha * x[r, :]  -- backward of tf.nn.embedding_lookup (ids int32 or int64). */
 int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D,
@@ -390,6 +395,14 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
                             const int32_t* const* mem_h, const int32_t* const* mem_r, const int32_t* const* mem_t,
                             int P, int B, int Nm, int D, int nR, const float* dout, int64_t ldo, float l2,
                             float* dE, float* dV, float* dw, void* stream);
+/* Same, and the VALUE of that regulariser, which the kernel has in registers anyway:
+ * *reg_accum += l2 * sum over hops, pairs and memories of (|E[h]|^2 + |E[t]|^2)   (model.py:383-385 summed over
+ * model.py:387's hops); reg_accum may be NULL. */
+int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
+                                const int32_t* const* mem_h, const int32_t* const* mem_r,
+                                const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
+                                int64_t ldo, float l2, float* dE, float* dV, float* dw, float* reg_accum,
+                                void* stream);
 
 /* ---- inputs of the path, built on the GPU (data_loader_user_set.py) ------------------------
  * Both take the undirected KG as CSR: indptr [nE+1] int64, dst/rel [nnz] int32, every triple

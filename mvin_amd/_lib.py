@@ -108,6 +108,8 @@ SIGNATURES = {
                                   C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_l2_adam_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "mvin_l2_adam_multi_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int,
+                                         _c_f32p, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "mvin_eltwise": (C.c_int, [C.c_int, C.c_int64, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "mvin_scatter_add_rows": (C.c_int, [_c_f32p, C.c_void_p, C.c_int, _c_f32p, C.c_int64, C.c_int, C.c_float,
@@ -120,6 +122,10 @@ SIGNATURES = {
     "mvin_key_addressing_bwd": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                           C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
+    "mvin_key_addressing_bwd_reg": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                              C.c_void_p]),
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),

@@ -619,16 +619,31 @@ int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, fl
     return hip_result(mvin::launch_eltwise(e, (hipStream_t)stream), "mvin_eltwise");
 }
 
-int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
-                       float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
-                       float eps, void* stream) {
-    const char* who = "mvin_l2_adam_multi";
+static int l2_adam_multi_impl(const char* who, const mvin_param_seg* segs_device, int nseg, int64_t total,
+                              float* g_flat, float* m_flat, float* v_flat, float* loss_accum, int apply_adam,
+                              float lr_t, const float* lr_t_device, float beta1, float beta2, float eps, void* stream) {
     if (!segs_device || !g_flat) return fail(-1, "%s: null pointer", who);
     if (nseg <= 0 || nseg > 256) return fail(-2, "%s: nseg=%d (1..256)", who, nseg);
     if (total <= 0) return fail(-2, "%s: total=%lld", who, (long long)total);
     if (apply_adam && (!m_flat || !v_flat)) return fail(-1, "%s: Adam step needs the moment buffers", who);
     return hip_result(mvin::launch_l2_adam_multi(segs_device, nseg, total, g_flat, m_flat, v_flat, loss_accum,
-                                                 apply_adam, lr_t, beta1, beta2, eps, (hipStream_t)stream), who);
+                                                 apply_adam, lr_t, lr_t_device, beta1, beta2, eps,
+                                                 (hipStream_t)stream), who);
+}
+
+int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+                       float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
+                       float eps, void* stream) {
+    return l2_adam_multi_impl("mvin_l2_adam_multi", segs_device, nseg, total, g_flat, m_flat, v_flat, loss_accum,
+                              apply_adam, lr_t, nullptr, beta1, beta2, eps, stream);
+}
+
+int mvin_l2_adam_multi_dev(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+                           float* v_flat, float* loss_accum, int apply_adam, const float* lr_t_device, float beta1,
+                           float beta2, float eps, void* stream) {
+    if (!lr_t_device) return fail(-1, "mvin_l2_adam_multi_dev: null lr_t_device");
+    return l2_adam_multi_impl("mvin_l2_adam_multi_dev", segs_device, nseg, total, g_flat, m_flat, v_flat,
+                              loss_accum, apply_adam, 0.f, lr_t_device, beta1, beta2, eps, stream);
 }
 
 int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D, float alpha,
@@ -715,6 +730,15 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
                             const int32_t* const* mem_r, const int32_t* const* mem_t, int P, int B, int Nm, int D,
                             int nR, const float* dout, int64_t ldo, float l2, float* dE, float* dV, float* dw,
                             void* stream) {
+    return mvin_key_addressing_bwd_reg(entity_emb, V, w, mem_h, mem_r, mem_t, P, B, Nm, D, nR, dout, ldo, l2, dE, dV,
+                                       dw, nullptr, stream);
+}
+
+int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
+                                const int32_t* const* mem_h, const int32_t* const* mem_r,
+                                const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
+                                int64_t ldo, float l2, float* dE, float* dV, float* dw, float* reg_accum,
+                                void* stream) {
     const char* who = "mvin_key_addressing_bwd";
     if (!entity_emb || !mem_h || !dout || !dE) return fail(-1, "%s: null pointer", who);
     if (P < 0 || P > 8 || (P == 0 && !w)) return fail(-2, "%s: P=%d", who, P);
@@ -748,6 +772,7 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
     k.dV = dV;
     k.dw = dw;
     k.l2 = l2;
+    k.reg_accum = reg_accum;
     return hip_result(mvin::launch_key_addr_bwd(k, (hipStream_t)stream), who);
 }
 

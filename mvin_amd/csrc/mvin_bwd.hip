@@ -79,8 +79,17 @@ __global__ void eltwise_kernel(EltArgs a) {
             case 6: {  // group row sum: y[g, j] = alpha * sum_{n < N} x[(g*N + n), j]   (n = groups * D)
                 const int64_t gidx = i / a.D;
                 const int j = (int)(i - gidx * a.D);
+                const float* col = a.x + gidx * a.N * (int64_t)a.D + j;
                 float sgm = 0.f;
-                for (int q = 0; q < a.N; ++q) sgm += a.x[(gidx * a.N + q) * a.D + j];
+                int q = 0;
+                for (; q + 8 <= a.N; q += 8) {          // eight independent loads in flight, summed in the same order
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = col[(int64_t)(q + e) * a.D];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sgm += v[e];
+                }
+                for (; q < a.N; ++q) sgm += col[(int64_t)q * a.D];
                 a.y[i] = a.alpha * sgm;
                 break;
             }
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
     // one wave per (pair, read): the P hop reads and the h-set read of a pair are independent, and at the reference's
     // batch sizes (512 / 1024 pairs) a wave per PAIR leaves most of the chip idle behind one long dependent chain
     const int nread = a.f.P + (a.f.w ? 1 : 0);
+    float reg = 0.f;                     // this lane's share of sum(h^2) + sum(t^2) over the hop rows it reads
     for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < a.f.B * nread; u += (int64_t)gridDim.x * 4) {
         const int64_t b = u / nread;
         const int rd = (int)(u - b * nread);
@@ -544,6 +554,8 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                                                p * dvo.w + l2 * val.w);
                             dvv = make_float4(dl * h.x, dl * h.y, dl * h.z, dl * h.w);
                             rrow = r;
+                            reg = fmaf(h.x, h.x, fmaf(h.y, h.y, fmaf(h.z, h.z, fmaf(h.w, h.w, reg))));
+                            reg = fmaf(val.x, val.x, fmaf(val.y, val.y, fmaf(val.z, val.z, fmaf(val.w, val.w, reg))));
                         }
                     }
                     // transpose through LDS: tile[target][g][4c..4c+3]
@@ -583,6 +595,7 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
             }
         }
     }
+    if (a.reg_accum) block_accumulate(a.reg_accum, a.l2 * reg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -599,9 +612,11 @@ static int blocks_for(int64_t n, int per) {
 __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg* __restrict__ segs, int nseg,
                                                             int64_t total, float* __restrict__ g,
                                                             float* __restrict__ mo, float* __restrict__ vo,
-                                                            float* accum, int apply_adam, float lr_t, float b1,
+                                                            float* accum, int apply_adam, float lr_t,
+                                                            const float* __restrict__ lr_dev, float b1,
                                                             float b2, float eps) {
     __shared__ int64_t s_off[257];
+    if (lr_dev) lr_t = *lr_dev;              // step size kept on the device: a captured step replays unchanged
     for (int i = threadIdx.x; i < nseg; i += blockDim.x) s_off[i] = segs[i].off;
     if (threadIdx.x == 0) s_off[nseg] = total;
     __syncthreads();
@@ -635,15 +650,17 @@ __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg
 }
 
 hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
-                                float* accum, int apply_adam, float lr_t, float b1, float b2, float eps,
-                                hipStream_t st) {
+                                float* accum, int apply_adam, float lr_t, const float* lr_dev, float b1, float b2,
+                                float eps, hipStream_t st) {
     l2_adam_multi_kernel<<<blocks_for(total, 2048), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
-                                                                  lr_t, b1, b2, eps);
+                                                                  lr_t, lr_dev, b1, b2, eps);
     return hipGetLastError();
 }
 
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t st) {
-    eltwise_kernel<<<blocks_for(a.n, 1024), 256, 0, st>>>(a);
+    // modes whose elements are chains of dependent / strided loads (6: N rows per output, 8: id -> row) get one
+    // element per thread; the streaming modes four
+    eltwise_kernel<<<blocks_for(a.n, (a.mode == 6 || a.mode == 8) ? 256 : 1024), 256, 0, st>>>(a);
     return hipGetLastError();
 }
 

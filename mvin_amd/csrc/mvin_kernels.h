@@ -217,12 +217,13 @@ struct KeyAddrBwdArgs {
     float* dV;                // [B, nR, D] accumulated (zero-initialised by the caller)
     float* dw;                // [D] accumulated (h-set logit weights) or NULL
     float l2;                 // l2_weight of the sum(h^2)+sum(t^2) regulariser
+    float* reg_accum;         // *reg_accum += l2 (sum h^2 + sum t^2) over the hop rows (model.py:383-385) or NULL
 };
 
 hipError_t launch_eltwise(const EltArgs& a, hipStream_t st);
 hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
-                                float* accum, int apply_adam, float lr_t, float b1, float b2, float eps,
-                                hipStream_t st);
+                                float* accum, int apply_adam, float lr_t, const float* lr_dev, float b1, float b2,
+                                float eps, hipStream_t st);
 hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64, const float* x, int64_t rows, int D,
                                    float alpha, hipStream_t st);
 hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st);

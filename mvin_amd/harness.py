@@ -114,13 +114,20 @@ def train_epoch(args, model, train_data, user_triplet_set, sess=None, rng=None):
     return losses
 
 
-def train_epoch_device(feeder, train_data, batch_size, rng=None):
-    """Same epoch with device-side feeds (ripple sets gathered on the GPU)."""
+def train_epoch_device(feeder, train_data, batch_size, rng=None, graph=False):
+    """Same epoch with device-side feeds (ripple sets gathered on the GPU).  ``graph=True``: every step is one
+    hipGraph replay (training.GraphedTrainer, captured once per batch size) and the losses are read back once,
+    at the end of the epoch, instead of once per step."""
     import torch
-    from .training import Trainer
+    from .training import GraphedTrainer, Trainer
     model = feeder.model
     if model.trainer is None:
         model.trainer = Trainer(model)
+    gt = None
+    if graph:
+        gt = getattr(model, "_graphed_trainer", None)
+        if gt is None or gt.tr is not model.trainer or gt.users.shape[0] != batch_size:
+            gt = model._graphed_trainer = GraphedTrainer(model.trainer, batch_size)
     (rng or np.random).shuffle(train_data)
     dev = model.device
     data = torch.from_numpy(np.ascontiguousarray(train_data)).to(dev)
@@ -129,8 +136,13 @@ def train_epoch_device(feeder, train_data, batch_size, rng=None):
         blk = data[start:start + batch_size]
         users, items, labels = blk[:, 0].contiguous(), blk[:, 1].contiguous(), blk[:, 2].to(torch.float32)
         mh, mr, mt = feeder.memories(users)
-        losses.append(model.trainer.step(users, items, labels, mh, mr, mt))
+        if gt is not None:
+            losses.append(gt.step(users, items, labels, mh, mr, mt).clone())
+        else:
+            losses.append(model.trainer.step(users, items, labels, mh, mr, mt))
         start += batch_size
+    if gt is not None and losses:
+        losses = torch.cat(losses).cpu().tolist()
     return losses
 
 

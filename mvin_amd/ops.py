@@ -479,19 +479,27 @@ def eltwise(mode, n, x, y=None, z=None, w=None, accum=None, alpha=1.0, beta=0.0,
                                 _stream()), "mvin_eltwise")
 
 
-def count_ids(ids, nbins):
-    """mvin_count_ids: float occurrence counts [nbins] of an int32 id list (no host sync)."""
+def count_ids(ids, nbins, out=None):
+    """mvin_count_ids: float occurrence counts [nbins] of an int32 id list (no host sync); added to ``out``."""
     _chk(ids, I32, "ids")
-    out = torch.zeros(nbins, dtype=F32, device=ids.device)
+    if out is None:
+        out = torch.zeros(nbins, dtype=F32, device=ids.device)
     _lib.check(_lib.load().mvin_count_ids(_p(ids), ids.numel(), nbins, _p(out), _stream()), "mvin_count_ids")
     return out
 
 
-def l2_adam_multi(segs, nseg, total, g, m, v, loss_accum, apply_adam, lr_t, beta1, beta2, eps):
-    """mvin_l2_adam_multi over the flat gradient / Adam-moment buffers (see include/mvin_hip.h)."""
+def l2_adam_multi(segs, nseg, total, g, m, v, loss_accum, apply_adam, lr_t, beta1, beta2, eps, lr_dev=None):
+    """mvin_l2_adam_multi over the flat gradient / Adam-moment buffers (see include/mvin_hip.h);
+    ``lr_dev`` (1-element fp32 device tensor): the step size is read on the device (mvin_l2_adam_multi_dev)."""
     lib = _lib.load()
     for t, nm in ((g, "g"), (m, "m"), (v, "v"), (loss_accum, "loss_accum")):
         _chk(t, F32, nm)
+    if lr_dev is not None:
+        _chk(lr_dev, F32, "lr_dev")
+        _lib.check(lib.mvin_l2_adam_multi_dev(_p(segs), nseg, total, _p(g), _p(m), _p(v), _p(loss_accum),
+                                              1 if apply_adam else 0, _p(lr_dev), beta1, beta2, eps, _stream()),
+                   "mvin_l2_adam_multi_dev")
+        return
     _lib.check(lib.mvin_l2_adam_multi(_p(segs), nseg, total, _p(g), _p(m), _p(v), _p(loss_accum),
                                       1 if apply_adam else 0, lr_t, beta1, beta2, eps, _stream()),
                "mvin_l2_adam_multi")
@@ -543,7 +551,8 @@ def rel_score_bwd(relation_emb, urh_weights, dT, drel, durh):
                "mvin_rel_score_bwd")
 
 
-def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, l2, dE, dV, dw):
+def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, l2, dE, dV, dw, reg_accum=None):
+    """mvin_key_addressing_bwd_reg; ``reg_accum`` (1-element fp32): += l2 * (sum h^2 + sum t^2) of the hop rows."""
     lib = _lib.load()
     nh = max(1, P)
     arr_t = C.c_void_p * nh
@@ -552,5 +561,6 @@ def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, 
     pt = arr_t(*([t.data_ptr() for t in mem_t[:P]] + [None] * (nh - P)))
     B, Nm = mem_h[0].shape
     D = entity_emb.shape[1]
-    _lib.check(lib.mvin_key_addressing_bwd(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(dout), ldo,
-                                           l2, _p(dE), _p(dV), _p(dw), _stream()), "mvin_key_addressing_bwd")
+    _lib.check(lib.mvin_key_addressing_bwd_reg(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(dout),
+                                               ldo, l2, _p(dE), _p(dV), _p(dw), _p(reg_accum), _stream()),
+               "mvin_key_addressing_bwd")

@@ -164,6 +164,19 @@ class Trainer(object):
     # ------------------------------------------------------------------ one step
     def step(self, user_indices, item_indices, labels, memories_h, memories_r, memories_t, apply=True):
         """One training step on device-resident inputs.  Returns the loss (python float)."""
+        return float(self.enqueue(user_indices, item_indices, labels, memories_h, memories_r, memories_t,
+                                  apply=apply).item())
+
+    def lr_t(self, t):
+        """Bias-corrected step size of tf.train.AdamOptimizer at (1-based) step t."""
+        return self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+
+    def enqueue(self, user_indices, item_indices, labels, memories_h, memories_r, memories_t, apply=True,
+                lr_dev=None):
+        """Enqueue one training step on the current stream without any host synchronisation; returns the
+        1-element device tensor the loss is accumulated in.  ``lr_dev`` (1-element fp32 device tensor): the
+        Adam step size is read from it when the optimizer kernel runs and the step counter is left to the
+        caller -- the form GraphedTrainer captures."""
         m, a = self.m, self.m.args
         dev = m.device
         D, K, H, M, P, nR = m.dim, m.n_neighbor, m.h_hop, m.n_mix_hop, m.p_hop, m.n_relation
@@ -181,6 +194,17 @@ class Trainer(object):
 
         def zeros(*shape):
             return torch.zeros(shape, dtype=F32, device=dev)
+
+        tcache = {}
+
+        def T3(w):
+            """Per-matrix transposes of a [n, D, D] weight stack (or of one [n*D, D] block matrix seen as such):
+            ONE launch per stack and step, shared by every backward product that needs W^T."""
+            w3 = w.view(-1, D, w.shape[-1]) if w.dim() == 2 else w
+            k = (w3.data_ptr(), tuple(w3.shape))
+            if k not in tcache:
+                tcache[k] = w3.transpose(1, 2).contiguous()
+            return tcache[k]
 
         # ================================================================ forward
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
@@ -213,13 +237,13 @@ class Trainer(object):
                 self._ka_bwd_ran = True      # mvin_key_addressing_bwd adds the 2*l2*(h, t) regulariser rows
                 ops.linear_wgrad([o_cat], d, dP["user_mlp_matrix"], db=dP["user_mlp_bias"])
                 do_cat = torch.empty_like(o_cat)
-                for s in range(n_o):  # d o_s = d . Wu[sD:(s+1)D]^T
-                    ops.linear([d], self._T(m.user_mlp_matrix[s * D:(s + 1) * D]), D, out=do_cat, out_offset=s * D,
-                               ldo=n_o * D)
+                # d o_s = d . Wu[sD:(s+1)D]^T for every slot s: one z-batched launch over the transposed blocks
+                ops.linear([d], T3(m.user_mlp_matrix), D, out=do_cat, ldo=n_o * D, nz=n_o, w_zstride=D * D, out_zstride=D)
                 dV = zeros(B, nR, D) if P > 0 else None
                 dw = zeros(D) if a.PS_O_ft else None
+                # ... and, from the rows it reads anyway, their regulariser value l2*(sum h^2 + sum t^2) (model.py:383-385)
                 ops.key_addressing_bwd(E, V, w_h, memories_h, memories_r, memories_t, P, do_cat, n_o * D, nR,
-                                       float(a.l2_weight), dP["entity_emb_matrix"], dV, dw)
+                                       float(a.l2_weight), dP["entity_emb_matrix"], dV, dw, reg_accum=loss_acc)
                 if a.PS_O_ft:
                     ops.axpby(1.0, dw, 1.0, dP["h_emb_item_mlp_matrix"].view(-1)[:D])
                 if P > 0:
@@ -269,12 +293,17 @@ class Trainer(object):
                 c = [c_all[e] for e in range(L)]      # stable tensor objects: gradients are keyed by identity
 
                 def bwd_c():
+                    ds = [G.get(c[e - 1]) for e in range(1, L + 1)]
                     for e in range(1, L + 1):
-                        d = G.get(c[e - 1])
-                        if d is None:
-                            continue
-                        ops.linear_wgrad([q], d, dP["transfer_W"][e], db=dP["transfer_b"][e])
-                        G.add(q, ops.linear([d], self._T(Wt[e]), D))
+                        if ds[e - 1] is not None:
+                            ops.linear_wgrad([q], ds[e - 1], dP["transfer_W"][e], db=dP["transfer_b"][e])
+                    if all(d is not None for d in ds) and L <= 4:
+                        # dq += sum_e d_e . W_e^T: the concatenated [d_1 | ... | d_L] times the stacked transposes
+                        G.add(q, ops.linear(ds, T3(m._transfer_W)[1:].reshape(L * D, D), D))
+                    else:
+                        for e in range(1, L + 1):
+                            if ds[e - 1] is not None:
+                                G.add(q, ops.linear([ds[e - 1]], T3(m._transfer_W)[e], D))
                 tape.append(bwd_c)
                 ev0 = ops.linear([E, q], Wt[0], D, ids=[ents[0].view(-1), None], bias=bt[0], sum_sources=True).view(B, 1, D)
 
@@ -285,7 +314,7 @@ class Trainer(object):
                     d2 = d.view(B, D)
                     ops.linear_wgrad([E, q], d2, dP["transfer_W"][0], ids=[ents[0].view(-1), None], db=dP["transfer_b"][0],
                                      sum_sources=True)
-                    dx = ops.linear([d2], self._T(Wt[0]), D)
+                    dx = ops.linear([d2], T3(m._transfer_W)[0], D)
                     ops.scatter_add_rows(dP["entity_emb_matrix"], ents[0].view(-1), dx)
                     G.add(q, dx.clone())
                 tape.append(bwd_ev0)
@@ -300,7 +329,7 @@ class Trainer(object):
                             return
                         d2 = d.view(-1, D)
                         ops.linear_wgrad([E], d2, dP["transfer_W"][e], ids=[ids_e])
-                        ops.scatter_add_rows(dP["entity_emb_matrix"], ids_e, ops.linear([d2], self._T(Wt[e]), D))
+                        ops.scatter_add_rows(dP["entity_emb_matrix"], ids_e, ops.linear([d2], T3(m._transfer_W)[e], D))
                         dc = torch.empty((B, D), dtype=F32, device=dev)
                         ops.eltwise(6, B * D, d2, dc, alpha=1.0, D=D, N=K ** e)
                         G.add(c[e - 1], dc)
@@ -346,7 +375,7 @@ class Trainer(object):
                     ops.eltwise(2, T * D, d.view(-1), dm.view(-1), z=out.view(-1))       # relu'
                     i, n = key
                     ops.linear_wgrad([Z], dm, dP[f"agg_{i}_{n}_weights"], db=dP[f"agg_{i}_{n}_bias"])
-                    dZ = ops.linear([dm], self._T(agg.weights), D)                       # d(self + neighbors_agg)
+                    dZ = ops.linear([dm], T3(agg.weights)[0], D)                         # d(self + neighbors_agg)
                     G.add(self_t, dZ.view_as(self_t).clone())
                     dTk = dT.get(key)
                     pr = probs.view(T, K) if probs is not None else None
@@ -354,7 +383,7 @@ class Trainer(object):
                         if a.User_orient:
                             psum_over_k = (1.0 / K) if agg.User_orient_rela else 1.0
                             ops.linear_wgrad([S], dZ, dP["transfer_W"][L])               # dW_L += S'^T dZ
-                            dS = ops.linear([dZ], self._T(Wt[L]), D)
+                            dS = ops.linear([dZ], T3(m._transfer_W)[L], D)
                             dc = torch.empty((B, D), dtype=F32, device=dev)
                             ops.eltwise(6, B * D, dZ, dc, alpha=psum_over_k, D=D, N=N)
                             G.add(c[L - 1], dc)
@@ -402,7 +431,7 @@ class Trainer(object):
                         ops.linear_wgrad([s_.view(-1, D) for s_ in srcs], d2, dP[f"enti_transfer_matrix_{n}"],
                                          db=dP[f"enti_transfer_bias_{n}"])
                         for si, s_ in enumerate(srcs):
-                            G.add(s_, ops.linear([d2], self._T(Wm[si * D:(si + 1) * D]), D).view_as(s_))
+                            G.add(s_, ops.linear([d2], T3(Wm)[si], D).view_as(s_))
                     tape.append(bwd_comb)
                     if n == M - 1:
                         item_emb = res
@@ -433,25 +462,27 @@ class Trainer(object):
         # ================================================================ L2 terms (model.py:382-412)
         l2w = float(a.l2_weight)   # the per-parameter terms are added by mvin_l2_adam_multi below
         # gathered-row regulariser (model.py:383-386): sum(h^2) + sum(t^2) + sum(r_emb^2) per hop
+        cnt = None
         for hop in range(P):
             for ids in (memories_h[hop], memories_t[hop]):
                 flat = ids.reshape(-1)
-                # mvin_key_addressing_bwd adds 2*l2*rows when it ran -- it does not when ps was built but never
-                # consumed (HO_only + User_orient_kg_eh without User_orient: q has no consumer)
-                if getattr(self, "_ka_bwd_ran", False) and flat.dtype == torch.int32 and flat.is_contiguous():
-                    ops.eltwise(8, flat.numel() * D, E.view(-1), z=flat, accum=loss_acc, alpha=l2w, D=D)   # rows stay in the table
-                else:
-                    rows = self._lookup(E, flat)
-                    ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
-                    if not getattr(self, "_ka_bwd_ran", False):
-                        ops.scatter_add_rows(dP["entity_emb_matrix"], flat, rows, alpha=2.0 * l2w)
-            # occurrences per relation, without bincount's host sync (and without 262 k atomics on nR addresses)
+                # mvin_key_addressing_bwd adds 2*l2*rows AND the value of the term when it ran -- it does not when ps
+                # was built but never consumed (HO_only + User_orient_kg_eh without User_orient: q has no consumer)
+                if getattr(self, "_ka_bwd_ran", False):
+                    continue
+                rows = self._lookup(E, flat)
+                ops.eltwise(3, rows.numel(), rows.view(-1), accum=loss_acc, alpha=l2w)
+                ops.scatter_add_rows(dP["entity_emb_matrix"], flat, rows, alpha=2.0 * l2w)
+            # occurrences per relation, without bincount's host sync (and without 262 k atomics on nR addresses);
+            # the term is linear in the counts, so the hops share one count vector
             rid = memories_r[hop].reshape(-1)
+            if cnt is None:
+                cnt = torch.zeros(nR, dtype=F32, device=dev)
             if rid.dtype == torch.int32 and rid.is_contiguous() and nR <= 4096:
-                cnt = ops.count_ids(rid, nR)
+                ops.count_ids(rid, nR, out=cnt)
             else:
-                cnt = torch.zeros(nR, dtype=F32, device=rid.device).scatter_add_(
-                    0, rid.long(), torch.ones(rid.shape[0], dtype=F32, device=rid.device))
+                cnt.scatter_add_(0, rid.long(), torch.ones(rid.shape[0], dtype=F32, device=rid.device))
+        if cnt is not None:
             ops.eltwise(5, nR * D * D, R.view(-1), dP["relation_emb_KGE_matrix"].view(-1), z=cnt, alpha=2.0 * l2w,
                         beta=1.0, D=D * D)
             ops.eltwise(7, nR * D * D, R.view(-1), z=cnt, accum=loss_acc, alpha=l2w, D=D * D)   # no host sync
@@ -463,12 +494,77 @@ class Trainer(object):
             dist.all_reduce(self._g, group=self.group)        # one bucket: every gradient of the model
             dist.all_reduce(loss_acc, group=self.group)
         lr_t = 0.0
-        if apply:
+        if apply and lr_dev is None:
             self.t += 1
-            lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+            lr_t = self.lr_t(self.t)
         ops.l2_adam_multi(self._segs, self._nseg, self._total, self._g, self._m, self._v, loss_acc, apply,
-                          float(lr_t), self.b1, self.b2, self.eps)
+                          float(lr_t), self.b1, self.b2, self.eps, lr_dev=lr_dev if apply else None)
         if apply:
             self.m.invalidate()
         self.last_grads = dP
-        return float(loss_acc.item())
+        return loss_acc
+
+
+class GraphedTrainer(object):
+    """hipGraph replay of the training step for launch-bound batch sizes (the reference trains at 512 / 1024,
+    src/bash/mvin_*.sh; train.py:46-53 is one ``sess.run`` per batch).
+
+    A step is ~115 short launches (forward in its ``_ex`` form, loss, the backward tape, L2 + Adam) whose cost at
+    those sizes is host-side glue, not GPU work.  ``Trainer.enqueue`` is captured ONCE on static input buffers
+    (torch.cuda.CUDAGraph = hipGraph on ROCm; the ctypes launches into libmvin_hip.so are recorded on the capture
+    stream like any other kernel) and replayed per batch.  What varies between steps stays on the device: the
+    batch (static buffers), the parameters and Adam moments (updated in place by the captured optimizer launch)
+    and the bias-corrected step size, which ``mvin_l2_adam_multi_dev`` reads from a 1-element device tensor the
+    host refills before each replay.  The relation-logit tables are rebuilt inside the graph (the capture starts
+    from an invalidated model), so a replay never reads a table of older weights."""
+
+    def __init__(self, trainer, batch_size, ids_dtype=torch.int64, warmup=1):
+        if trainer.world > 1:
+            raise NotImplementedError("GraphedTrainer captures a single-rank step (the all-reduce stays eager)")
+        self.tr = trainer
+        m = trainer.m
+        dev = m.device
+        B, Nm, P = int(batch_size), m.n_memory, max(1, m.p_hop)
+        self.users = torch.zeros(B, dtype=ids_dtype, device=dev)
+        self.items = torch.zeros(B, dtype=ids_dtype, device=dev)
+        self.labels = torch.zeros(B, dtype=F32, device=dev)
+        self.mh = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        self.mr = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        self.mt = [torch.zeros((B, Nm), dtype=torch.int32, device=dev) for _ in range(P)]
+        self.lr_dev = torch.zeros(1, dtype=F32, device=dev)
+        feed = (self.users, self.items, self.labels, self.mh, self.mr, self.mt)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):            # warm-up outside capture; apply=False leaves every parameter as is
+            for _ in range(warmup):
+                trainer.enqueue(*feed, apply=False)
+        torch.cuda.current_stream().wait_stream(side)
+        m.invalidate()                           # the derived tables are to be rebuilt INSIDE the graph
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = trainer.enqueue(*feed, apply=True, lr_dev=self.lr_dev)
+        m.invalidate()                           # nothing ran during capture: no derived table is valid yet
+
+    def load(self, users, items, labels, mem_h, mem_r, mem_t):
+        """Copy a batch (device tensors) into the graph's static input buffers."""
+        self.users.copy_(users)
+        self.items.copy_(items)
+        self.labels.copy_(labels)
+        for i in range(min(len(self.mh), len(mem_h))):
+            self.mh[i].copy_(mem_h[i])
+            self.mr[i].copy_(mem_r[i])
+            self.mt[i].copy_(mem_t[i])
+
+    def replay(self):
+        """One optimizer step on whatever is in the static buffers; returns the loss as a device tensor
+        (no host synchronisation: read it with ``.item()`` when it is wanted)."""
+        tr = self.tr
+        tr.t += 1
+        self.lr_dev.fill_(float(tr.lr_t(tr.t)))
+        self.graph.replay()
+        tr.m.invalidate()                        # parameters changed: eager callers rebuild their derived tables
+        return self.loss
+
+    def step(self, users, items, labels, mem_h, mem_r, mem_t):
+        self.load(users, items, labels, mem_h, mem_r, mem_t)
+        return self.replay()

@@ -8,11 +8,12 @@ from mvin_amd import synth
 from mvin_amd.config import make_args
 from mvin_amd.model import MVIN
 from mvin_amd.params import init_params
-from mvin_amd.training import Trainer
+from mvin_amd.training import GraphedTrainer, Trainer
 ap = argparse.ArgumentParser()
 ap.add_argument("--dataset", default="last-fm_50core"); ap.add_argument("--dim", type=int, default=64)
 ap.add_argument("--hop", type=int, default=2); ap.add_argument("--fanout", type=int, default=32)
 ap.add_argument("--batch", type=int, default=512); ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (training.GraphedTrainer)")
 a = ap.parse_args()
 d = synth.DATASETS[a.dataset]
 args = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop, n_mix_hop=1, p_hop=d["p_hop"],
@@ -26,9 +27,15 @@ feed = (torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(de
         [torch.from_numpy(m).to(dev) for m in case.memories_h], [torch.from_numpy(m).to(dev) for m in case.memories_r],
         [torch.from_numpy(m).to(dev) for m in case.memories_t])
 tr = Trainer(model)
-losses = [tr.step(*feed) for _ in range(2)]
+if a.graph:
+    gt = GraphedTrainer(tr, a.batch)
+    step = lambda: gt.step(*feed).clone()          # batch copied into the static buffers every step, loss stays on the device
+else:
+    step = lambda: tr.step(*feed)
+losses = [step() for _ in range(2)]
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(a.steps): losses.append(tr.step(*feed))
+for _ in range(a.steps): losses.append(step())
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"workload": f"{a.dataset} D={a.dim} H={a.hop} K={a.fanout} B={a.batch}", "ms_per_train_step": dt * 1e3,
+losses = [float(x) for x in losses]
+print(json.dumps({"workload": f"{a.dataset} D={a.dim} H={a.hop} K={a.fanout} B={a.batch}", "mode": "hipgraph" if a.graph else "eager", "ms_per_train_step": dt * 1e3,
                   "pairs_per_s": a.batch / dt, "loss_first": losses[0], "loss_last": losses[-1]}))

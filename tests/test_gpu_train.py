@@ -95,3 +95,70 @@ def test_adam_trajectory_matches_reference(hip_lib):
     ref = mirror_fp32.forward(args, ref_p, case.adj_entity, case.adj_relation, case.users, case.items, case.memories_h,
                               case.memories_r, case.memories_t)
     np.testing.assert_allclose(s, ref.scores_normalized.numpy(), atol=2e-3)
+
+
+@pytest.mark.parametrize("shape,ablation", [("d8k3h2m1p2", "all"), ("d16k4h2m2p1", "all"), ("d64k8h2m1p2", "all"),
+                                            ("d8k3h2m1p2", "ps_only"), ("d8k3h2m1p2", "no_uor"),
+                                            ("d12k5h3m1p0", "all")])
+def test_graphed_step_equals_eager_step_and_reference(shape, ablation, hip_lib):
+    """training.GraphedTrainer: the step captured once as a hipGraph and replayed on a DIFFERENT batch every step
+    follows the eager Trainer (same kernels; float atomics reorder sums) and oracle/train_ref.py."""
+    from mvin_amd.training import GraphedTrainer, Trainer
+    args, case, params, labels, model_e = build(shape, ablation)
+    _, _, _, _, model_g = build(shape, ablation)
+    tr_e, tr_g = Trainer(model_e), Trainer(model_g)
+    gt = GraphedTrainer(tr_g, args.batch_size, ids_dtype=torch.from_numpy(case.users).dtype)
+    # capture and its apply=False warm-up must leave parameters, moments and the step counter untouched
+    assert tr_g.t == 0 and not torch.any(tr_g._m) and not torch.any(tr_g._v)
+    for k, v in model_e.parameters_dict().items():
+        np.testing.assert_array_equal(model_g.parameters_dict()[k], v, err_msg=k)
+    ref_p = {k: np.array(v, dtype=np.float32) for k, v in params.items()}
+    opt = train_ref.AdamRef(ref_p, lr=args.lr)
+    rng = np.random.default_rng(5)
+    le, lg, lr_ = [], [], []
+    for _ in range(4):
+        perm = rng.permutation(args.batch_size)
+        sub = lambda x: np.ascontiguousarray(x[perm])
+        c_u, c_i, c_l = sub(case.users), sub(case.items), sub(labels)
+        mh, mr, mt = [sub(x) for x in case.memories_h], [sub(x) for x in case.memories_r], [sub(x) for x in case.memories_t]
+        dev = model_e.device
+        feed = (torch.from_numpy(c_u).to(dev), torch.from_numpy(c_i).to(dev), torch.from_numpy(c_l).to(dev),
+                [torch.from_numpy(x).to(dev) for x in mh], [torch.from_numpy(x).to(dev) for x in mr],
+                [torch.from_numpy(x).to(dev) for x in mt])
+        le.append(tr_e.step(*feed))
+        lg.append(float(gt.step(*feed).item()))
+        rl, rg, _, _ = train_ref.loss_and_grads(args, ref_p, case.adj_entity, case.adj_relation, c_u, c_i, c_l, mh, mr, mt)
+        lr_.append(rl)
+        ref_p = opt.step(ref_p, rg)
+    assert tr_g.t == tr_e.t == 4
+    np.testing.assert_allclose(lg, le, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(lg, lr_, rtol=2e-4, atol=1e-6)
+    pe, pg = model_e.parameters_dict(), model_g.parameters_dict()
+    for k in pe:
+        # Adam divides by sqrt(v): where a gradient is ~0 the reordering of float atomics can flip a whole step of
+        # size lr, so the trajectories are compared at a few steps of slack, as the eager test does
+        np.testing.assert_allclose(pg[k], pe[k], rtol=0, atol=5e-4 * max(1.0, np.abs(pe[k]).max()), err_msg=k)
+    # scoring after the replays uses tables of the NEW weights (the graph leaves the model invalidated)
+    feed_d = {model_g.user_indices: case.users, model_g.item_indices: case.items, model_g.labels: labels}
+    feed_e = {model_e.user_indices: case.users, model_e.item_indices: case.items, model_e.labels: labels}
+    for i in range(len(case.memories_h)):
+        for f, mdl in ((feed_d, model_g), (feed_e, model_e)):
+            f[mdl.memories_h[i]], f[mdl.memories_r[i]], f[mdl.memories_t[i]] = \
+                case.memories_h[i], case.memories_r[i], case.memories_t[i]
+    np.testing.assert_allclose(model_g.get_scores(None, feed_d)[1], model_e.get_scores(None, feed_e)[1], atol=2e-3)
+
+
+def test_graphed_epoch_through_the_harness(hip_lib):
+    """harness.train_epoch_device(graph=True) == the eager epoch on the same shuffled data."""
+    from mvin_amd import harness
+    args, case, params, labels, model_e = build("d8k3h2m1p2")
+    _, _, _, _, model_g = build("d8k3h2m1p2")
+    uts = synth.ripple_sets(case.n_user, case.n_entity, case.n_relation, args.p_hop, args.n_memory, seed=3)
+    rng = np.random.default_rng(11)
+    data = np.stack([rng.integers(0, case.n_user, 40), rng.integers(0, 60, 40), rng.integers(0, 2, 40)], axis=1)
+    a = harness.train_epoch_device(harness.DeviceFeeder(model_e, uts), data.copy(), args.batch_size,
+                                   rng=np.random.default_rng(1))
+    b = harness.train_epoch_device(harness.DeviceFeeder(model_g, uts), data.copy(), args.batch_size,
+                                   rng=np.random.default_rng(1), graph=True)
+    assert len(a) == len(b) == 40 // args.batch_size
+    np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-7)
