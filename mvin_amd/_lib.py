@@ -124,8 +124,8 @@ SIGNATURES = {
                                           _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, C.c_void_p]),
     "mvin_key_addressing_bwd_reg": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                              _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
-                                              C.c_void_p]),
+                                              _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, C.c_int,
+                                              _c_f32p, C.c_void_p]),
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),

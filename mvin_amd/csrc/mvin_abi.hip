@@ -731,15 +731,17 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
                             int nR, const float* dout, int64_t ldo, float l2, float* dE, float* dV, float* dw,
                             void* stream) {
     return mvin_key_addressing_bwd_reg(entity_emb, V, w, mem_h, mem_r, mem_t, P, B, Nm, D, nR, dout, ldo, l2, dE, dV,
-                                       dw, nullptr, stream);
+                                       dw, 1, nullptr, stream);
 }
 
 int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
                                 const int32_t* const* mem_h, const int32_t* const* mem_r,
                                 const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
-                                int64_t ldo, float l2, float* dE, float* dV, float* dw, float* reg_accum,
-                                void* stream) {
+                                int64_t ldo, float l2, float* dE, float* dV, float* dw, int dw_replicas,
+                                float* reg_accum, void* stream) {
     const char* who = "mvin_key_addressing_bwd";
+    if (dw_replicas < 1 || dw_replicas > 1024 || (dw_replicas & (dw_replicas - 1)))
+        return fail(-2, "%s: dw_replicas=%d (a power of two in 1..1024)", who, dw_replicas);
     if (!entity_emb || !mem_h || !dout || !dE) return fail(-1, "%s: null pointer", who);
     if (P < 0 || P > 8 || (P == 0 && !w)) return fail(-2, "%s: P=%d", who, P);
     if (P > 0 && (!V || !mem_r || !mem_t || !dV || nR <= 0)) return fail(-1, "%s: hops need V, mem_r, mem_t, dV, nR", who);
@@ -773,6 +775,7 @@ int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const f
     k.dw = dw;
     k.l2 = l2;
     k.reg_accum = reg_accum;
+    k.dw_rep = dw_replicas;
     return hip_result(mvin::launch_key_addr_bwd(k, (hipStream_t)stream), who);
 }
 

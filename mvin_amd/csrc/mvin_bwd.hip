@@ -451,148 +451,157 @@ __global__ void rel_score_bwd_kernel(const float* __restrict__ rel, const float*
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.f.D, Nm = a.f.Nm;
     const int lpr = 1 << a.f.lpr_log2, rpw = kWave >> a.f.lpr_log2;
     const int g = lane >> a.f.lpr_log2, c = lane & (lpr - 1);
     const bool cact = (c << 2) < D;
-    const int nm2 = (2 * Nm + 3) & ~3;   // 16-byte aligned tile behind the two [Nm] arrays
-    float* sL = smem + wave * (nm2 + 3 * 256 + 3 * 64);    // logits -> probabilities
-    float* sGm = sL + Nm;                // g_m
+    const int nm2 = (2 * Nm + 3) & ~3;   // 16-byte aligned tiles behind the two [Nm] arrays
+    float* sL = smem;                    // [Nm] logits of the read          (workgroup-shared)
+    float* sGm = sL + Nm;                // [Nm] g_m
     // row-contiguous atomics: the 4-floats-per-lane results of a step (rpw rows x 4*lpr floats = 256 words per target)
-    // go through this wave-private tile so that one atomic instruction adds 64 CONSECUTIVE floats -- the L2 atomic
+    // go through a wave-private tile so that one atomic instruction adds 64 CONSECUTIVE floats -- the L2 atomic
     // units work per cache line, and a float4-per-lane atomic touches a quarter of eight lines (scatter_add_rows: 4x)
-    float* sTr = sL + nm2;               // [3 targets][256]
+    float* sTr = smem + nm2 + wave * (3 * 256 + 3 * 64);       // [3 targets][256]
     int* sRowI = reinterpret_cast<int*>(sTr + 3 * 256);        // [3 targets][64] row numbers (-1: none); rpw <= 64
+    // dV[b, r, :] of one (pair, hop) collects Nm contributions on only nR rows: summed in LDS (ds_add_f32) and flushed
+    // once -- nR row atomics per read instead of Nm
+    float* sDV = a.dv_lds ? smem + nm2 + 4 * (3 * 256 + 3 * 64) : nullptr;     // [nR][D]   (workgroup-shared)
     const int slot0 = a.f.w ? 1 : 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Ef = reinterpret_cast<const float*>(a.f.E);   // training keeps the tables in fp32
 
-    // one wave per (pair, read): the P hop reads and the h-set read of a pair are independent, and at the reference's
-    // batch sizes (512 / 1024 pairs) a wave per PAIR leaves most of the chip idle behind one long dependent chain
+    // one WORKGROUP per (pair, read), its four waves striding over the memories: the P hop reads and the h-set read of
+    // a pair are independent, and at the reference's batch sizes (512 / 1024 pairs) the kernel is one long dependent
+    // chain per task (ids -> rows -> logits -> softmax -> rows again -> atomics) with most of the chip idle: a wave per
+    // PAIR took 3x, a wave per (pair, read) 1.9x the time of this form at B = 512
     const int nread = a.f.P + (a.f.w ? 1 : 0);
+    const int mstep = 4 * rpw;
     float reg = 0.f;                     // this lane's share of sum(h^2) + sum(t^2) over the hop rows it reads
-    for (int64_t u = (int64_t)blockIdx.x * 4 + wave; u < a.f.B * nread; u += (int64_t)gridDim.x * 4) {
+    for (int64_t u = blockIdx.x; u < a.f.B * nread; u += gridDim.x) {
         const int64_t b = u / nread;
         const int rd = (int)(u - b * nread);
-        {
-            const bool is_set = rd == a.f.P;          // reads 0..P-1: hops; read P: the h-set read (rows of hop 0)
-            const int hop = is_set ? 0 : rd;
-            const int32_t* mh = a.f.mem_h[hop] + b * Nm;
-            {
-                const int32_t* mr = is_set ? nullptr : a.f.mem_r[hop] + b * Nm;
-                const int32_t* mv = is_set ? mh : a.f.mem_t[hop] + b * Nm;   // value rows
-                const float4 dvo = cact ? reinterpret_cast<const float4*>(
-                                              a.dout + b * a.f.ldo + (int64_t)(is_set ? 0 : slot0 + hop) * D)[c] : z4;
-                // logits and g_m
-                for (int m0 = 0; m0 < Nm; m0 += rpw) {
-                    const int m = m0 + g;
-                    float pl = 0.f, pg = 0.f;
-                    if (m < Nm && cact) {
-                        const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)mh[m] * D)[c];
-                        const float4 sv = is_set ? reinterpret_cast<const float4*>(a.f.w)[c]
-                                                 : reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + mr[m]) * (int64_t)D)[c];
-                        pl = fmaf(h.x, sv.x, fmaf(h.y, sv.y, fmaf(h.z, sv.z, h.w * sv.w)));
-                        const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)mv[m] * D)[c];
-                        pg = fmaf(dvo.x, val.x, fmaf(dvo.y, val.y, fmaf(dvo.z, val.z, dvo.w * val.w)));
-                    }
-                    pl = group_sum(pl, a.f.lpr_log2);
-                    pg = group_sum(pg, a.f.lpr_log2);
-                    if (m < Nm && c == 0) {
-                        sL[m] = pl;
-                        sGm[m] = pg;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                float mx = -INFINITY;
-                for (int m = lane; m < Nm; m += kWave) mx = fmaxf(mx, sL[m]);
-                mx = wave_max(mx);
-                float zs = 0.f;
-                for (int m = lane; m < Nm; m += kWave) {
-                    const float e = expf(sL[m] - mx);
-                    sL[m] = e;
-                    zs += e;
-                }
-                zs = wave_sum(zs);
-                float pgs = 0.f;
-                for (int m = lane; m < Nm; m += kWave) {
-                    const float p = sL[m] / zs;
-                    sL[m] = p;
-                    pgs += p * sGm[m];
-                }
-                pgs = wave_sum(pgs);
-                __builtin_amdgcn_wave_barrier();
-                // scatter
-                float4 dwacc = z4;   // h-set logit-weight gradient: per-lane partial, ONE atomic set per pair
-                const int rowf = 4 * lpr;            // floats per row slot of the transpose tile (>= D)
-                for (int m0 = 0; m0 < Nm; m0 += rpw) {
-                    const int m = m0 + g;
-                    const bool act = m < Nm;
-                    float4 dh = z4, dval = z4, dvv = z4;
-                    int hrow = -1, vrow = -1, rrow = -1;
-                    if (act && cact) {
-                        const float p = sL[m];
-                        const float dl = p * (sGm[m] - pgs);
-                        hrow = mh[m];
-                        vrow = mv[m];
-                        const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)hrow * D)[c];
-                        if (is_set) {
-                            const float4 w4 = reinterpret_cast<const float4*>(a.f.w)[c];
-                            // value row == head row
-                            dh = make_float4(p * dvo.x + dl * w4.x, p * dvo.y + dl * w4.y, p * dvo.z + dl * w4.z,
-                                             p * dvo.w + dl * w4.w);
-                            dwacc = f4_fma(dl, h, dwacc);
-                            vrow = -1;
-                        } else {
-                            const int r = mr[m];
-                            const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
-                            const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)vrow * D)[c];
-                            const float l2 = 2.f * a.l2;
-                            dh = make_float4(dl * v4.x + l2 * h.x, dl * v4.y + l2 * h.y, dl * v4.z + l2 * h.z,
-                                             dl * v4.w + l2 * h.w);
-                            dval = make_float4(p * dvo.x + l2 * val.x, p * dvo.y + l2 * val.y, p * dvo.z + l2 * val.z,
-                                               p * dvo.w + l2 * val.w);
-                            dvv = make_float4(dl * h.x, dl * h.y, dl * h.z, dl * h.w);
-                            rrow = r;
-                            reg = fmaf(h.x, h.x, fmaf(h.y, h.y, fmaf(h.z, h.z, fmaf(h.w, h.w, reg))));
-                            reg = fmaf(val.x, val.x, fmaf(val.y, val.y, fmaf(val.z, val.z, fmaf(val.w, val.w, reg))));
-                        }
-                    }
-                    // transpose through LDS: tile[target][g][4c..4c+3]
-                    *reinterpret_cast<float4*>(sTr + 0 * 256 + g * rowf + 4 * c) = dh;
-                    *reinterpret_cast<float4*>(sTr + 1 * 256 + g * rowf + 4 * c) = dval;
-                    *reinterpret_cast<float4*>(sTr + 2 * 256 + g * rowf + 4 * c) = dvv;
-                    if (c == 0) {
-                        sRowI[0 * 64 + g] = hrow;
-                        sRowI[1 * 64 + g] = vrow;
-                        sRowI[2 * 64 + g] = rrow;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int e = k * 64 + lane;
-                        const int j = e / rowf, col = e - j * rowf;
-                        if (col < D) {
-                            const int hr = sRowI[j], vr = sRowI[64 + j], rr = sRowI[128 + j];
-                            if (hr >= 0) atomicAdd(a.dE + (int64_t)hr * D + col, sTr[e]);
-                            if (vr >= 0) atomicAdd(a.dE + (int64_t)vr * D + col, sTr[256 + e]);
-                            if (rr >= 0) atomicAdd(a.dV + (b * a.f.nR + rr) * (int64_t)D + col, sTr[512 + e]);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (is_set) {
-                    dwacc = group_xor_sum(dwacc, lpr);
-                    if (cact && g == 0) {
-                        float* dw = a.dw + 4 * c;
-                        atomicAdd(dw + 0, dwacc.x);
-                        atomicAdd(dw + 1, dwacc.y);
-                        atomicAdd(dw + 2, dwacc.z);
-                        atomicAdd(dw + 3, dwacc.w);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
+        const bool is_set = rd == a.f.P;          // reads 0..P-1: hops; read P: the h-set read (rows of hop 0)
+        const int hop = is_set ? 0 : rd;
+        const int32_t* mh = a.f.mem_h[hop] + b * Nm;
+        const int32_t* mr = is_set ? nullptr : a.f.mem_r[hop] + b * Nm;
+        const int32_t* mv = is_set ? mh : a.f.mem_t[hop] + b * Nm;   // value rows
+        const float4 dvo = cact ? reinterpret_cast<const float4*>(
+                                      a.dout + b * a.f.ldo + (int64_t)(is_set ? 0 : slot0 + hop) * D)[c] : z4;
+        // logits and g_m
+        for (int m0 = wave * rpw; m0 < Nm; m0 += mstep) {
+            const int m = m0 + g;
+            float pl = 0.f, pg = 0.f;
+            if (m < Nm && cact) {
+                const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)mh[m] * D)[c];
+                const float4 sv = is_set ? reinterpret_cast<const float4*>(a.f.w)[c]
+                                         : reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + mr[m]) * (int64_t)D)[c];
+                pl = fmaf(h.x, sv.x, fmaf(h.y, sv.y, fmaf(h.z, sv.z, h.w * sv.w)));
+                const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)mv[m] * D)[c];
+                pg = fmaf(dvo.x, val.x, fmaf(dvo.y, val.y, fmaf(dvo.z, val.z, dvo.w * val.w)));
             }
+            pl = group_sum(pl, a.f.lpr_log2);
+            pg = group_sum(pg, a.f.lpr_log2);
+            if (m < Nm && c == 0) {
+                sL[m] = pl;
+                sGm[m] = pg;
+            }
+        }
+        if (sDV && !is_set)
+            for (int e = tid; e < a.f.nR * D; e += kBlock) sDV[e] = 0.f;
+        __syncthreads();
+        // softmax statistics over all Nm logits: every wave computes them for itself (read-only on sL / sGm)
+        float mx = -INFINITY;
+        for (int m = lane; m < Nm; m += kWave) mx = fmaxf(mx, sL[m]);
+        mx = wave_max(mx);
+        float zs = 0.f;
+        for (int m = lane; m < Nm; m += kWave) zs += expf(sL[m] - mx);
+        zs = wave_sum(zs);
+        float pgs = 0.f;
+        for (int m = lane; m < Nm; m += kWave) pgs += expf(sL[m] - mx) / zs * sGm[m];
+        pgs = wave_sum(pgs);
+        // scatter
+        float4 dwacc = z4;   // h-set logit-weight gradient: per-lane partial, ONE atomic set per wave
+        const int rowf = 4 * lpr;            // floats per row slot of the transpose tile (>= D)
+        for (int m0 = wave * rpw; m0 < Nm; m0 += mstep) {
+            const int m = m0 + g;
+            const bool act = m < Nm;
+            float4 dh = z4, dval = z4, dvv = z4;
+            int hrow = -1, vrow = -1, rrow = -1;
+            if (act && cact) {
+                const float p = expf(sL[m] - mx) / zs;
+                const float dl = p * (sGm[m] - pgs);
+                hrow = mh[m];
+                vrow = mv[m];
+                const float4 h = reinterpret_cast<const float4*>(Ef + (int64_t)hrow * D)[c];
+                if (is_set) {
+                    const float4 w4 = reinterpret_cast<const float4*>(a.f.w)[c];
+                    // value row == head row
+                    dh = make_float4(p * dvo.x + dl * w4.x, p * dvo.y + dl * w4.y, p * dvo.z + dl * w4.z,
+                                     p * dvo.w + dl * w4.w);
+                    dwacc = f4_fma(dl, h, dwacc);
+                    vrow = -1;
+                } else {
+                    const int r = mr[m];
+                    const float4 v4 = reinterpret_cast<const float4*>(a.f.V + (b * a.f.nR + r) * (int64_t)D)[c];
+                    const float4 val = reinterpret_cast<const float4*>(Ef + (int64_t)vrow * D)[c];
+                    const float l2 = 2.f * a.l2;
+                    dh = make_float4(dl * v4.x + l2 * h.x, dl * v4.y + l2 * h.y, dl * v4.z + l2 * h.z,
+                                     dl * v4.w + l2 * h.w);
+                    dval = make_float4(p * dvo.x + l2 * val.x, p * dvo.y + l2 * val.y, p * dvo.z + l2 * val.z,
+                                       p * dvo.w + l2 * val.w);
+                    dvv = make_float4(dl * h.x, dl * h.y, dl * h.z, dl * h.w);
+                    rrow = r;
+                    reg = fmaf(h.x, h.x, fmaf(h.y, h.y, fmaf(h.z, h.z, fmaf(h.w, h.w, reg))));
+                    reg = fmaf(val.x, val.x, fmaf(val.y, val.y, fmaf(val.z, val.z, fmaf(val.w, val.w, reg))));
+                }
+            }
+            // transpose through LDS: tile[target][g][4c..4c+3]
+            *reinterpret_cast<float4*>(sTr + 0 * 256 + g * rowf + 4 * c) = dh;
+            *reinterpret_cast<float4*>(sTr + 1 * 256 + g * rowf + 4 * c) = dval;
+            *reinterpret_cast<float4*>(sTr + 2 * 256 + g * rowf + 4 * c) = dvv;
+            if (c == 0) {
+                sRowI[0 * 64 + g] = hrow;
+                sRowI[1 * 64 + g] = vrow;
+                sRowI[2 * 64 + g] = rrow;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = k * 64 + lane;
+                const int j = e / rowf, col = e - j * rowf;
+                if (col < D) {
+                    const int hr = sRowI[j], vr = sRowI[64 + j], rr = sRowI[128 + j];
+                    if (hr >= 0) atomicAdd(a.dE + (int64_t)hr * D + col, sTr[e]);
+                    if (vr >= 0) atomicAdd(a.dE + (int64_t)vr * D + col, sTr[256 + e]);
+                    if (rr >= 0) {
+                        if (sDV) atomicAdd(sDV + rr * D + col, sTr[512 + e]);      // ds_add_f32
+                        else atomicAdd(a.dV + (b * a.f.nR + rr) * (int64_t)D + col, sTr[512 + e]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (is_set) {
+            dwacc = group_xor_sum(dwacc, lpr);
+            if (cact && g == 0) {
+                // dw_rep replicas of the [D] accumulator, picked by the pair: 4 B atomic instructions onto the same two
+                // cache lines serialise in the L2 atomic unit (~50 ns each: 100 us at B = 512); the caller sums the replicas
+                float* dw = a.dw + (int)((b * 4 + wave) & (a.dw_rep - 1)) * D + 4 * c;
+                atomicAdd(dw + 0, dwacc.x);
+                atomicAdd(dw + 1, dwacc.y);
+                atomicAdd(dw + 2, dwacc.z);
+                atomicAdd(dw + 3, dwacc.w);
+            }
+        }
+        __syncthreads();                 // every wave is done with sL / sGm and has added its share to sDV
+        if (sDV && !is_set) {
+            float* dvb = a.dV + b * a.f.nR * (int64_t)D;
+            for (int e = tid; e < a.f.nR * D; e += kBlock) {
+                const float v = sDV[e];
+                if (v != 0.f) atomicAdd(dvb + e, v);
+            }
+            __syncthreads();             // flushed before the next task zeroes it
         }
     }
     if (a.reg_accum) block_accumulate(a.reg_accum, a.l2 * reg);
@@ -622,28 +631,70 @@ __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float local = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        int lo = 0, hi = nseg - 1;           // last segment with off <= i
+    auto seg_of = [&](int64_t i) {           // last segment with off <= i
+        int lo = 0, hi = nseg - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (s_off[mid] <= i) lo = mid;
             else hi = mid - 1;
         }
-        const mvin_param_seg sg = segs[lo];
-        float* xp = sg.x + (i - sg.off);
-        const float x = *xp;
-        float gr = g[i];
-        if (sg.l2 != 0.f) {
-            gr = fmaf(sg.l2, x, gr);
-            local = fmaf(0.5f * sg.l2 * x, x, local);
-            g[i] = gr;
+        return lo;
+    };
+    auto one = [&](float x, float& gr, float& m, float& v, float l2) {   // -> updated x
+        if (l2 != 0.f) {
+            gr = fmaf(l2, x, gr);
+            local = fmaf(0.5f * l2 * x, x, local);
         }
         if (apply_adam) {
-            const float m = b1 * mo[i] + (1.f - b1) * gr;
-            const float v = b2 * vo[i] + (1.f - b2) * gr * gr;
-            mo[i] = m;
-            vo[i] = v;
-            *xp = x - lr_t * m / (sqrtf(v) + eps);
+            m = b1 * m + (1.f - b1) * gr;
+            v = b2 * v + (1.f - b2) * gr * gr;
+            x = x - lr_t * m / (sqrtf(v) + eps);
+        }
+        return x;
+    };
+    // four consecutive floats per thread as 16-byte accesses wherever they sit in one parameter and its storage is
+    // 16-byte aligned (every segment of the model is: D % 4 == 0); element-wise across segment boundaries and the tail
+    const int64_t nquad = (total + 3) >> 2;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        const int64_t i = q << 2;
+        const int lo = seg_of(i);
+        const mvin_param_seg sg = segs[lo];
+        float* xp = sg.x + (i - sg.off);
+        if (i + 4 <= s_off[lo + 1] && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) {
+            float4 x = *reinterpret_cast<float4*>(xp);
+            float4 gr = *reinterpret_cast<float4*>(g + i);
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), v = m;
+            if (apply_adam) {
+                m = *reinterpret_cast<float4*>(mo + i);
+                v = *reinterpret_cast<float4*>(vo + i);
+            }
+            x.x = one(x.x, gr.x, m.x, v.x, sg.l2);
+            x.y = one(x.y, gr.y, m.y, v.y, sg.l2);
+            x.z = one(x.z, gr.z, m.z, v.z, sg.l2);
+            x.w = one(x.w, gr.w, m.w, v.w, sg.l2);
+            if (sg.l2 != 0.f) *reinterpret_cast<float4*>(g + i) = gr;
+            if (apply_adam) {
+                *reinterpret_cast<float4*>(mo + i) = m;
+                *reinterpret_cast<float4*>(vo + i) = v;
+                *reinterpret_cast<float4*>(xp) = x;
+            }
+        } else {
+            for (int64_t e = i; e < i + 4 && e < total; ++e) {
+                const mvin_param_seg se = segs[seg_of(e)];
+                float* xe = se.x + (e - se.off);
+                float gr = g[e], m = 0.f, v = 0.f;
+                if (apply_adam) {
+                    m = mo[e];
+                    v = vo[e];
+                }
+                const float xn = one(*xe, gr, m, v, se.l2);
+                if (se.l2 != 0.f) g[e] = gr;
+                if (apply_adam) {
+                    mo[e] = m;
+                    vo[e] = v;
+                    *xe = xn;
+                }
+            }
         }
     }
     if (accum) block_accumulate(accum, local);
@@ -652,7 +703,7 @@ __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg
 hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
                                 float* accum, int apply_adam, float lr_t, const float* lr_dev, float b1, float b2,
                                 float eps, hipStream_t st) {
-    l2_adam_multi_kernel<<<blocks_for(total, 2048), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
+    l2_adam_multi_kernel<<<blocks_for((total + 3) / 4, 1024), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
                                                                   lr_t, lr_dev, b1, b2, eps);
     return hipGetLastError();
 }
@@ -726,9 +777,13 @@ hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const floa
     return hipGetLastError();
 }
 
-hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)4 * (((2 * a.f.Nm + 3) & ~3) + 3 * 256 + 3 * 64) * sizeof(float);
-    key_addr_bwd_kernel<<<blocks_for(a.f.B * (a.f.P + (a.f.w ? 1 : 0)), 4), kBlock, lds, st>>>(a);
+hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a0, hipStream_t st) {
+    KeyAddrBwdArgs a = a0;
+    size_t lds = ((size_t)((2 * a.f.Nm + 3) & ~3) + 4 * (3 * 256 + 3 * 64)) * sizeof(float);
+    const size_t dv = (size_t)a.f.nR * a.f.D * sizeof(float);
+    a.dv_lds = (a.f.P > 0 && a.dV && lds + dv <= 48 * 1024 && getenv("MVIN_KAB_DV_GLOBAL") == nullptr) ? 1 : 0;
+    if (a.dv_lds) lds += dv;
+    key_addr_bwd_kernel<<<blocks_for(a.f.B * (a.f.P + (a.f.w ? 1 : 0)), 1), kBlock, lds, st>>>(a);
     return hipGetLastError();
 }
 

@@ -562,5 +562,7 @@ def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, 
     B, Nm = mem_h[0].shape
     D = entity_emb.shape[1]
     _lib.check(lib.mvin_key_addressing_bwd_reg(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(dout),
-                                               ldo, l2, _p(dE), _p(dV), _p(dw), _p(reg_accum), _stream()),
+                                               ldo, l2, _p(dE), _p(dV), _p(dw),
+                                               1 if dw is None or dw.dim() == 1 else dw.shape[0], _p(reg_accum),
+                                               _stream()),
                "mvin_key_addressing_bwd")

@@ -240,12 +240,14 @@ class Trainer(object):
                 # d o_s = d . Wu[sD:(s+1)D]^T for every slot s: one z-batched launch over the transposed blocks
                 ops.linear([d], T3(m.user_mlp_matrix), D, out=do_cat, ldo=n_o * D, nz=n_o, w_zstride=D * D, out_zstride=D)
                 dV = zeros(B, nR, D) if P > 0 else None
-                dw = zeros(D) if a.PS_O_ft else None
+                dw = zeros(64, D) if a.PS_O_ft else None     # replicas: B atomics onto the same D floats serialise
                 # ... and, from the rows it reads anyway, their regulariser value l2*(sum h^2 + sum t^2) (model.py:383-385)
                 ops.key_addressing_bwd(E, V, w_h, memories_h, memories_r, memories_t, P, do_cat, n_o * D, nR,
                                        float(a.l2_weight), dP["entity_emb_matrix"], dV, dw, reg_accum=loss_acc)
                 if a.PS_O_ft:
-                    ops.axpby(1.0, dw, 1.0, dP["h_emb_item_mlp_matrix"].view(-1)[:D])
+                    dws = torch.empty(D, dtype=F32, device=dev)
+                    ops.eltwise(6, D, dw.view(-1), dws, alpha=1.0, D=D, N=dw.shape[0])
+                    ops.axpby(1.0, dws, 1.0, dP["h_emb_item_mlp_matrix"].view(-1)[:D])
                 if P > 0:
                     # V[b,r,:] = E[item_b] . R[r]  =>  dR[r] += E[item]^T dV[:,r] ; dE[item] += sum_r dV[:,r] R[r]^T
                     ops.linear_wgrad([E], dV, dP["relation_emb_KGE_matrix"], ids=[item], rows=B, nz=nR, ldy=nR * D,
