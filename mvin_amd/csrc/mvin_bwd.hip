@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void l2_adam_multi_kernel(const mvin_param_seg
 hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t total, float* g, float* mo, float* vo,
                                 float* accum, int apply_adam, float lr_t, const float* lr_dev, float b1, float b2,
                                 float eps, hipStream_t st) {
-    l2_adam_multi_kernel<<<blocks_for((total + 3) / 4, 1024), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
+    l2_adam_multi_kernel<<<blocks_for((total + 3) / 4, 4096), 256, 0, st>>>(segs, nseg, total, g, mo, vo, accum, apply_adam,
                                                                   lr_t, lr_dev, b1, b2, eps);
     return hipGetLastError();
 }
@@ -727,7 +727,7 @@ static hipError_t launch_wgrad_mfma(const WgradArgs& a, hipStream_t st) {
     constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din, ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;
     const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
     const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
-    int64_t cap = 512 / nz;
+    int64_t cap = 512 / nz;      // measured: 256 is 20 % faster at 512 pairs and 25 % slower at 4 096
     if (cap < 1) cap = 1;
     const int gx = (int)(ntiles < 1 ? 1 : ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)kTM * (ldx + ldy) * sizeof(float);
