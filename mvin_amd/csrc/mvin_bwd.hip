@@ -727,7 +727,13 @@ static hipError_t launch_wgrad_mfma(const WgradArgs& a, hipStream_t st) {
     constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din, ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;
     const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
     const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
-    int64_t cap = 512 / nz;      // measured: 256 is 20 % faster at 512 pairs and 25 % slower at 4 096
+    // workgroups per weight matrix: every workgroup ends with Din x Dout atomics onto the SAME 16 KB, so more
+    // workgroups = more same-line atomics, fewer = a longer serial tile loop.  Measured optimum ~ tiles / 8
+    // (512 tiles: 256 workgroups 11.9 us vs 14.5 at 512; 4 096 tiles: 512 -> 27 us vs 34 at 256 and 30 at 1 024;
+    // 16 384 tiles: 1 024 -> 66 us vs 89 at 512)
+    int64_t cap = ntiles / 8;
+    cap = cap < 256 ? 256 : cap > 1024 ? 1024 : cap;
+    cap /= nz;
     if (cap < 1) cap = 1;
     const int gx = (int)(ntiles < 1 ? 1 : ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)kTM * (ldx + ldy) * sizeof(float);

@@ -156,7 +156,10 @@ __global__ __launch_bounds__(kBlock) void linear_kernel(mvin_linear_args a) {
 // Phase B (tile of kTM tasks): Z = self + (S.Wc + psum*c_child[b]) / K   (or self + S/K).
 // Phase C: out = relu(Z.Wagg + bagg).
 // --------------------------------------------------------------------------------------
-template <int NR>
+// PRE: child-row loads of the first PRE steps issued ahead of the softmax (latency-bound launches of few tiles:
+// 43 -> 36 us at 512 nodes, 52 -> 43 at 16 384; the 24 extra VGPRs cost occupancy when the grid fills the chip:
+// 228 -> 311 us at 131 072 nodes, hence PRE = 0 there)
+template <int NR, int PRE>
 __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int RP = kTM / NR;
@@ -205,9 +208,23 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                 } else if (a.rel_score) {
                     r = a.rel_ids ? (int64_t)a.rel_ids[t * K + k] : t * K + k;
                 }
+                yp[k].x = y;      // the id first: the row loads below need it, not the score that is still in flight
                 const float sc = a.rel_score ? a.rel_score[r] : 0.f;
-                yp[k] = make_int2(y, __float_as_int(sc));
+                yp[k].y = __float_as_int(sc);
                 mx = fmaxf(mx, sc);
+            }
+            // the child rows do not depend on the softmax: the first kPre steps' loads are issued BEFORE the three
+            // wave reductions (ids -> {scores -> softmax | rows} instead of ids -> scores -> softmax -> rows)
+            constexpr int kPre = PRE;
+            float4 pre[PRE > 0 ? PRE : 1];
+            const float* dbase = a.gather ? nullptr : a.neigh + t * K * (int64_t)D;
+#pragma unroll
+            for (int i = 0; i < kPre; ++i) {
+                const int k = g + i * rpw;
+                pre[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && cact)
+                    pre[i] = a.gather ? load_row4(a.table, a.table_bf16, yp[k].x, D, c)
+                                      : reinterpret_cast<const float4*>(dbase + (int64_t)k * D)[c];
             }
             mx = wave_max(mx);
             float sum = 0.f;
@@ -224,9 +241,14 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
             }
             // weighted sum of the K child rows
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < kPre; ++i) {
+                const int k = g + i * rpw;
+                if (k < K) acc = f4_fma(__int_as_float(yp[k].y), pre[i], acc);
+            }
             if (a.gather) {
 #pragma unroll 8
-                for (int k = g; k < K; k += rpw) {
+                for (int k = g + kPre * rpw; k < K; k += rpw) {
                     const int2 e = yp[k];
                     if (cact) {
                         const float4 v = load_row4(a.table, a.table_bf16, e.x, D, c);
@@ -234,12 +256,11 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                     }
                 }
             } else {
-                const float* base = a.neigh + t * K * (int64_t)D;
 #pragma unroll 8
-                for (int k = g; k < K; k += rpw) {
+                for (int k = g + kPre * rpw; k < K; k += rpw) {
                     const float p = __int_as_float(yp[k].y);
                     if (cact) {
-                        const float4 v = reinterpret_cast<const float4*>(base + (int64_t)k * D)[c];
+                        const float4 v = reinterpret_cast<const float4*>(dbase + (int64_t)k * D)[c];
                         acc = f4_fma(p, v, acc);
                     }
                 }
@@ -435,11 +456,14 @@ hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * kTM * (a.D + 4) * sizeof(float) + (size_t)4 * a.K * sizeof(int2);
     const int64_t ntiles = (a.T + kTM - 1) / kTM;
     dim3 grid(grid_for(ntiles));
+    const bool pre = ntiles <= 1024;
 #define CALL(NRV)                                                         \
     {                                                                     \
-        hipError_t e = ensure_lds(gather_attn_kernel<NRV>, lds);          \
+        hipError_t e = pre ? ensure_lds(gather_attn_kernel<NRV, 8>, lds)  \
+                           : ensure_lds(gather_attn_kernel<NRV, 0>, lds); \
         if (e != hipSuccess) return e;                                    \
-        gather_attn_kernel<NRV><<<grid, kBlock, lds, st>>>(a);            \
+        if (pre) gather_attn_kernel<NRV, 8><<<grid, kBlock, lds, st>>>(a);\
+        else gather_attn_kernel<NRV, 0><<<grid, kBlock, lds, st>>>(a);    \
     }
     MVIN_DISPATCH_NR(nr, CALL)
 #undef CALL

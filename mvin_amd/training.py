@@ -546,6 +546,14 @@ class GraphedTrainer(object):
         with torch.cuda.graph(self.graph):
             self.loss = trainer.enqueue(*feed, apply=True, lr_dev=self.lr_dev)
         m.invalidate()                           # nothing ran during capture: no derived table is valid yet
+        self._captured = self._storage_key()
+
+    def _storage_key(self):
+        """Addresses the captured launches read: a graph outlives neither ``set_adjacency`` nor a parameter tensor
+        being REPLACED (in-place updates, which is what the optimizer does, are fine)."""
+        m = self.tr.m
+        return (m.adj_entity.data_ptr(), m.adj_relation.data_ptr(), m.entity_emb_matrix.data_ptr(),
+                m.user_emb_matrix.data_ptr(), m.relation_emb_KGE_matrix.data_ptr())
 
     def load(self, users, items, labels, mem_h, mem_r, mem_t):
         """Copy a batch (device tensors) into the graph's static input buffers."""
@@ -561,6 +569,9 @@ class GraphedTrainer(object):
         """One optimizer step on whatever is in the static buffers; returns the loss as a device tensor
         (no host synchronisation: read it with ``.item()`` when it is wanted)."""
         tr = self.tr
+        if self._storage_key() != self._captured:
+            raise RuntimeError("the model's adjacency or a parameter tensor was replaced since this step was captured: "
+                               "build a new GraphedTrainer")
         tr.t += 1
         self.lr_dev.fill_(float(tr.lr_t(tr.t)))
         self.graph.replay()

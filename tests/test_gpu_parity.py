@@ -46,3 +46,37 @@ def test_every_ablation(ablation, fused, hip_lib):
         args = make_args(ablation=ablation, **shape)
         case = synth.small_case(args, seed=5)
         check_case(args, case, seed=7, fused=fused)
+
+
+def test_per_level_kernel_large_grid_instance(hip_lib):
+    """mvin_gather_attn_fwd has two instances: few tiles (child-row loads issued ahead of the softmax) and more than
+    1 024 tiles (not).  B = 3 000 pairs x K = 12 children = 36 000 level-1 nodes takes the second one; slices of 500
+    pairs take the first; both against the fp32 mirror on a sample."""
+    import torch
+    from mvin_amd.model import MVIN
+    from mvin_amd.params import init_params
+    from oracle import mirror_fp32
+    from parity import assert_close
+    B = 3000
+    args = make_args(dim=12, neighbor_sample_size=12, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=4, batch_size=B)
+    case = synth.small_case(args, n_user=40, n_entity=900, n_relation=6, seed=21, zero_rows=4)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=22, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+                 device="cuda:0", fused=False)
+    dev = model.device
+
+    def run(sl):
+        return model.forward_device(torch.from_numpy(case.users[sl]).to(dev), torch.from_numpy(case.items[sl]).to(dev),
+                                    [torch.from_numpy(m[sl]).to(dev) for m in case.memories_h],
+                                    [torch.from_numpy(m[sl]).to(dev) for m in case.memories_r],
+                                    [torch.from_numpy(m[sl]).to(dev) for m in case.memories_t]).scores.cpu().numpy()
+    big = run(slice(None))
+    for s0 in (0, 2500):
+        sl = slice(s0, s0 + 500)
+        assert_close(run(sl), big[sl], f"slice {s0}: few-tile instance vs many-tile instance")
+    n = 64
+    sargs = make_args(**dict(vars(args), batch_size=n))
+    ref = mirror_fp32.forward(sargs, params, case.adj_entity, case.adj_relation, case.users[:n], case.items[:n],
+                              [m[:n] for m in case.memories_h], [m[:n] for m in case.memories_r],
+                              [m[:n] for m in case.memories_t])
+    assert_close(big[:n], ref.scores.numpy(), "many-tile instance vs fp32 mirror")

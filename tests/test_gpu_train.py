@@ -162,3 +162,8 @@ def test_graphed_epoch_through_the_harness(hip_lib):
                                    rng=np.random.default_rng(1), graph=True)
     assert len(a) == len(b) == 40 // args.batch_size
     np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-7)
+    # a captured step must not outlive the adjacency it was captured on
+    gt = model_g._graphed_trainer
+    model_g.set_adjacency(case.adj_entity.copy(), case.adj_relation.copy())
+    with pytest.raises(RuntimeError, match="GraphedTrainer"):
+        gt.replay()
