@@ -256,6 +256,43 @@ def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5):
     return out
 
 
+def training_steps(margs, case, params, dev, users, items, mems, sizes=(512, 4096), steps=20):
+    """ms per optimisation step (mvin_amd/training.py) eager and as one hipGraph replay per step."""
+    import torch
+    from mvin_amd.model import MVIN
+    from mvin_amd.training import GraphedTrainer, Trainer
+    out = []
+    for B in sizes:
+        if B > items.shape[0]:
+            continue
+        feed = (users[:B].contiguous(), items[:B].contiguous(), (torch.arange(B, device=dev) % 2).to(torch.float32),
+                [m[:B].contiguous() for m in mems[0]], [m[:B].contiguous() for m in mems[1]],
+                [m[:B].contiguous() for m in mems[2]])
+        row = {"batch": B}
+        for mode in ("eager", "hipgraph"):
+            tm = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                      params=params, device=dev)
+            tr = Trainer(tm)
+            if mode == "hipgraph":
+                gt = GraphedTrainer(tr, B, ids_dtype=users.dtype)
+                one = lambda: gt.step(*feed)                               # noqa: E731
+            else:
+                one = lambda: tr.step(*feed)                               # noqa: E731
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = one()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            row[mode] = {"ms_per_step": 1e3 * dt, "pairs_per_s": B / dt, "loss_after": float(loss)}
+            del tr, tm
+        out.append(row)
+    return {"what": "forward + loss (model.py:378-412) + backward + tf.train.AdamOptimizer rule, all HIP; hipgraph = the "
+                    "whole step replayed as one graph (training.GraphedTrainer)", "steps": steps, "rows": out}
+
+
 def main():
     a = parse()
     import torch
@@ -565,6 +602,17 @@ def main():
                 "note": "per-entity tables hoist the pair-independent part of the two deepest levels "
                         "(SURVEY 7.3-c route 2b): different algorithmic bytes per pair, reported separately"}
             del hm, ho
+        if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard and a.table_dtype == "f32":
+            # informational, after the timed region: the caller AFTER the path -- forward + loss + backward +
+            # Adam on a separate model instance with the same parameters, at the reference's batch sizes
+            try:
+                nt = min(4096, Bl)
+                tmem = [[torch.from_numpy(x).to(dev) for x in lst]
+                        for lst in synth.memories_for(case.user_triplet_set, case.users[sl][:nt])]
+                rec.setdefault("other_modes", {})["training_step"] = training_steps(margs, case, params, dev, users[:nt],
+                                                                                   items[:nt], tmem)
+            except Exception as e:                                        # never lose the scoring line to this leg
+                rec.setdefault("other_modes", {})["training_step"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not a.no_cpu_baseline:
             cb, ref, Bc = cpu_baseline(a, margs, case, params)
             rec["cpu_baseline"] = cb

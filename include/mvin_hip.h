@@ -286,7 +286,7 @@ typedef struct {
     const int64_t* users;          /*   (mvin_key_addressing_users_fwd); NULL = the per-pair arrays above */
     float* V;                      /* workspace [B, nR, D] */
     float* o_cat;                  /* workspace [B, (P + (h_set_w != NULL)) * D] */
-    int32_t* parents;              /* workspace [B] */
+    int32_t* parents;              /* unused since the depth-2 kernel reads `items` in place; kept for layout */
     float* nagg0;                  /* workspace [B, D] */
     float* nagg1;
     float* user_o;                 /* out [B, D] */

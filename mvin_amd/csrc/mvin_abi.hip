@@ -175,12 +175,14 @@ int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, i
     return mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D) ? 2 : 1;
 }
 
-int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
-                            const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
-                            const float* W2, const float* b1, const float* b2, const float* q,
-                            const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
-                            float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
-                            int table_bf16, void* stream) {
+// pid_stride 2: parent_ids points at an int64 [P] array whose low words are read (the item ids of the reference's
+// placeholder, model.py:50) -- mvin_score_l2_fwd's depth-2 pass then needs no id-conversion launch
+static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                               const int32_t* parent_ids, int pid_stride, const float* t0, const float* t1,
+                               const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
+                               const float* A0, const float* a0, int B, int parents_per_pair, int K, int D,
+                               int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
+                               float* probs_child, int table_bf16, void* stream) {
     const char* who = "mvin_gather_attn_l2_fwd";
     if (!mvin::fused_l2_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {16,32,64,128}, K power of two in [4,256])",
@@ -217,6 +219,8 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
     f.parents_per_pair = parents_per_pair;
     f.K = K;
     f.nR = nR;
+    f.pid_stride = pid_stride;
+    f.max_id = (unsigned)(n_entity - 1);
     int l = 0;
     while ((4 << l) < K) ++l;
     f.lpn_log2 = l;
@@ -225,6 +229,17 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
         f.dbg = dbg ? atoi(dbg) : 0;
     }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
+}
+
+int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                            const int32_t* parent_ids, const float* t0, const float* t1, const float* W1,
+                            const float* W2, const float* b1, const float* b2, const float* q,
+                            const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                            float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
+                            int table_bf16, void* stream) {
+    return gather_attn_l2_impl(table, adj_entity, adj_relation, parent_ids, 1, t0, t1, W1, W2, b1, b2, q, A0, a0, B,
+                               parents_per_pair, K, D, n_entity, nR, nagg0, nagg1, probs_parent, probs_child,
+                               table_bf16, stream);
 }
 
 int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
@@ -435,12 +450,11 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     u.nz = 1;
     rc = mvin_linear_fwd(&u, stream);
     if (rc) return rc;
-    rc = mvin_expand_ids(a->adj_entity, a->adj_relation, a->items, nullptr, (int)a->B, a->K, 0, a->n_entity, a->parents,
-                         nullptr, stream);
-    if (rc) return rc;
-    rc = mvin_gather_attn_l2_fwd(a->entity_emb, a->adj_entity, a->adj_relation, a->parents, a->t0, a->t1, a->W1, a->W2,
-                                 a->b1, a->b2, a->W1 ? a->user_o : nullptr, a->A0, a->a0, (int)a->B, 1, a->K, D,
-                                 a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr, a->table_bf16, stream);
+    // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
+    rc = gather_attn_l2_impl(a->entity_emb, a->adj_entity, a->adj_relation, reinterpret_cast<const int32_t*>(a->items), 2,
+                             a->t0, a->t1, a->W1, a->W2, a->b1, a->b2, a->W1 ? a->user_o : nullptr, a->A0, a->a0,
+                             (int)a->B, 1, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr,
+                             a->table_bf16, stream);
     if (rc) return rc;
     return mvin_l2_tail_fwd(a->entity_emb, a->items, nullptr, a->W0 ? a->user_o : nullptr, a->user_o, a->nagg0, a->nagg1,
                             a->W0, a->b0, a->A0, a->a0, a->A1, a->a1, a->Wmix, a->bmix, a->B, D, a->n_entity, a->item_emb,

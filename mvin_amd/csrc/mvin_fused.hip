@@ -222,9 +222,9 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
         __syncthreads();                // sT0/sT1 visible
         if (wave == 0 && p0i < a.P) {
             int xs[4], rr[4];
-            parent_load(a.parent_ids[p0i], xs, rr);
+            parent_load(fused_parent_id(a, p0i), xs, rr);
             parent_store(p0i, xs, rr, sX1b, sP0b, sP1b);
-            if (p0i + gridDim.x < a.P) x0_next = a.parent_ids[p0i + gridDim.x];
+            if (p0i + gridDim.x < a.P) x0_next = fused_parent_id(a, p0i + gridDim.x);
         }
         __syncthreads();
         if (p0i < a.P) {
@@ -245,12 +245,12 @@ __global__ __launch_bounds__(NW * 64) void gather_attn_l2_kernel(FusedL2Args a) 
             __syncthreads();  // previous parent fully consumed (sP*, sN*, sX1)
             if (wave == 0) {
                 int xs[4], rr[4];
-                parent_load(a.parent_ids[p], xs, rr);
+                parent_load(fused_parent_id(a, p), xs, rr);
                 parent_store(p, xs, rr, sX1, sP0, sP1);
             }
         } else if (wave == 0 && has_next) {
             parent_load(x0_next, nxs, nrr);                       // lands during this parent's phase A
-            x0_next = pn + gridDim.x < a.P ? a.parent_ids[pn + gridDim.x] : 0;
+            x0_next = pn + gridDim.x < a.P ? fused_parent_id(a, pn + gridDim.x) : 0;
         }
         if (tid < D) {
             sN0[tid] = 0.f;

@@ -262,10 +262,10 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         if (wave == 0) {
             int xs[G::NPL], rr[G::NPL];
             float qr[(D + 63) / 64];
-            parent_load(parent_of(0), a.parent_ids[parent_of(0)], xs, rr, qr);
+            parent_load(parent_of(0), fused_parent_id(a, parent_of(0)), xs, rr, qr);
             parent_store(xs, rr, qr, 0, true);
             if (nloc > 1) {
-                parent_load(parent_of(1), a.parent_ids[parent_of(1)], xs, rr, qr);
+                parent_load(parent_of(1), fused_parent_id(a, parent_of(1)), xs, rr, qr);
                 parent_store(xs, rr, qr, 1, true);
             }
         }
@@ -287,7 +287,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         // whatever was issued just before it (measured: ~3000 cycles per step).
         // The entity id of the parent to prepare is a wave-uniform scalar load taken one step ahead.
         auto clampi = [&](int64_t i) -> int64_t { return i < nloc ? i : nloc - 1; };
-        int x0n = a.parent_ids[parent_of(clampi(2 / G::NTILE))];
+        int x0n = fused_parent_id(a, parent_of(clampi(2 / G::NTILE)));
         int dense_iter = 0;
         for (int64_t s = 0; s <= S; ++s) {
             stamp(s, 0);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
             int nxs[G::NPL], nrr[G::NPL];
             float nq[(D + 63) / 64];
             parent_load(parent_of(i2), x0n, nxs, nrr, nq);
-            x0n = a.parent_ids[parent_of(clampi((s + 3) / G::NTILE))];
+            x0n = fused_parent_id(a, parent_of(clampi((s + 3) / G::NTILE)));
             // ---------------- dense phases of tile s-1 ----------------
             if (s >= 1) {
                 const int64_t td = s - 1;

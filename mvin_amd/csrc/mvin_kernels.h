@@ -162,8 +162,15 @@ struct FusedL2Args {
     uint64_t table_bytes;        // nE * D * 4 (buffer descriptor range)
     uint64_t adj_bytes;          // nE * K * 4: size of adj_e / adj_r (0: unknown)
     int parents_per_pair, K, nR, lpn_log2;
+    int pid_stride;              // 1: parent_ids is int32 [P]; 2: the low words of an int64 [P] array (little endian)
+    unsigned max_id;             // n_entity - 1: parent ids are clamped (a fault would kill the process)
     int dbg;                     // timing experiments only (MVIN_SPLIT_DBG): 1 = skip the MFMAs, 2 = skip the row loads
 };
+
+__device__ __forceinline__ int fused_parent_id(const FusedL2Args& a, int64_t i) {
+    const unsigned v = (unsigned)a.parent_ids[i * a.pid_stride];
+    return (int)(v < a.max_id ? v : a.max_id);
+}
 
 // ---- backward (mvin_bwd.hip) ----
 struct EltArgs {
