@@ -301,7 +301,7 @@ class EarlyStop(object):
 
 
 def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=None, topk_batch=65536, hoist=True,
-          topk_early_stop=False):
+          topk_early_stop=False, graph="auto"):
     """train.py:16-109 on the GPU path.  ``data`` = the 16-tuple of mvin_amd.data_io.load_data / the
     reference's ``load_data`` (read by position exactly as train.py:17-21 does; a 10-tuple prefix
     (..., user_triplet_set) is accepted for CTR runs).  Per epoch: shuffle, full minibatches only
@@ -314,6 +314,9 @@ def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=
     ``hoist``: evaluate through the entity-table mode (weights are frozen while an epoch is evaluated; the
     tables are dropped by every optimizer step and rebuilt by the first evaluation batch) -- 2-4x faster
     evaluation at the same tolerance; training steps always take the faithful kernels.
+    ``graph``: replay every optimisation step as one hipGraph (training.GraphedTrainer; same kernels, losses read back
+    once per epoch); "auto" = at batch sizes up to 2 048, where a step is launch- and latency-bound (the reference's
+    scripts train at 512 / 1 024).
     Returns (model, history): one dict per epoch."""
     from .model import MVIN
     n_user, n_item, n_entity, n_relation = data[0], data[1], data[2], data[3]
@@ -334,7 +337,8 @@ def train(args, data, show_topk=False, model=None, device="cuda", rng=None, log=
     history = []
     train_data = train_data.copy()
     for epoch in range(getattr(args, "n_epochs", 20)):
-        losses = train_epoch_device(feeder, train_data, args.batch_size, rng=rng)
+        losses = train_epoch_device(feeder, train_data, args.batch_size, rng=rng,
+                                    graph=(args.batch_size <= 2048) if graph == "auto" else bool(graph))
         rec = {"epoch": epoch, "loss": float(np.mean(losses)) if losses else float("nan")}
         if show_topk:
             for mode in ("eval", "test"):
