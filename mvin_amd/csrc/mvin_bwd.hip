@@ -789,6 +789,11 @@ hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a0, hipStream_t st) {
     const size_t dv = (size_t)a.f.nR * a.f.D * sizeof(float);
     a.dv_lds = (a.f.P > 0 && a.dV && lds + dv <= 48 * 1024 && getenv("MVIN_KAB_DV_GLOBAL") == nullptr) ? 1 : 0;
     if (a.dv_lds) lds += dv;
+    if (lds > 64 * 1024) {       // n_memory beyond ~6 000: raise the dynamic-LDS limit (the ABI caps Nm at 8 192 = 80 KB)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(key_addr_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     key_addr_bwd_kernel<<<blocks_for(a.f.B * (a.f.P + (a.f.w ? 1 : 0)), 1), kBlock, lds, st>>>(a);
     return hipGetLastError();
 }

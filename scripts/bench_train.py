@@ -13,12 +13,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--dataset", default="last-fm_50core"); ap.add_argument("--dim", type=int, default=64)
 ap.add_argument("--hop", type=int, default=2); ap.add_argument("--fanout", type=int, default=32)
 ap.add_argument("--batch", type=int, default=512); ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--uniform-adj", action="store_true", help="uniform random adjacency (no KG hubs) instead of the heavy-tailed one")
 ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (training.GraphedTrainer)")
 a = ap.parse_args()
 d = synth.DATASETS[a.dataset]
 args = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop, n_mix_hop=1, p_hop=d["p_hop"],
                  n_memory=d["n_memory"], batch_size=a.batch, l2_weight=1e-7, l2_agg_weight=1e-7, lr=1e-3)
-case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch)
+case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch, uniform_adj=a.uniform_adj)
 params = init_params(args, case.n_user, case.n_entity, case.n_relation)
 model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
 dev = model.device
