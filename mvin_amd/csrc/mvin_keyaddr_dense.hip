@@ -330,20 +330,29 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
             __syncthreads();
             if (t0 == p0) stamp(6);
             // softmax over the Nm memories of every (pair, hop) (:223): un-normalised weights back to sL, 1/sum to sZ
-            for (int task = wave; task < kDT * P; task += kDW) {
-                const int pi = task / P, hop = task - pi * P;
-                float* row = sL + (size_t)pi * LDL + hop * NmP;
-                float mx = -INFINITY;
-                for (int m = lane; m < Nm; m += 64) mx = fmaxf(mx, row[m]);
-                mx = wave_max_fast(mx);
-                float z = 0.f;
-                for (int m = lane; m < NmP; m += 64) {
-                    const float e = m < Nm ? expf(row[m] - mx) : 0.f;
-                    row[m] = e;
-                    z += e;
+            // FOUR rows per wave pass, a 16-lane DPP row per (pair, hop) and NmP/16 values per lane: with a whole wave
+            // per row the phase was VALU-issue-bound on two 64-wide reductions per 64 values (3.7 k cycles per tile,
+            // three rounds over the 12 waves; interleaving three rows per wave changed nothing)
+            {
+                const int rg = lane >> 4, cl = lane & 15;
+                for (int base = wave * 4; base < kDT * P; base += kDW * 4) {
+                    const int task = base + rg;
+                    const bool ok = task < kDT * P;
+                    const int tk = ok ? task : base;
+                    const int pi = tk / P, hop = tk - pi * P;
+                    float* row = sL + (size_t)pi * LDL + hop * NmP;
+                    float mx = -INFINITY;
+                    for (int m = cl; m < Nm; m += 16) mx = fmaxf(mx, row[m]);
+                    mx = group_max(mx, 4);
+                    float z = 0.f;
+                    for (int m = cl; m < NmP; m += 16) {
+                        const float e = m < Nm ? expf(row[m] - mx) : 0.f;
+                        if (ok) row[m] = e;
+                        z += e;
+                    }
+                    z = group_sum(z, 4);
+                    if (ok && cl == 0) sZ[task] = 1.f / z;      // sZ[pi * P + hop]
                 }
-                z = wave_sum_fast(z);
-                if (lane == 0) sZ[pi * P + hop] = 1.f / z;
             }
             __syncthreads();
             if (t0 == p0) stamp(7);
@@ -353,7 +362,18 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const float* ar = sL + (size_t)l16 * LDL + hop * NmP + q16;
                 const float* br = sT + (size_t)(hop * NmP + q16) * LDT + 16 * nt + l16;
-                for (int k = 0; k < NmP / 4; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], br[(size_t)4 * k * LDT], acc, 0, 0, 0);
+                // NmP is a multiple of 16: four steps per round, their eight LDS reads issued before the first MFMA (one
+                // step at a time the loop was a chain of LDS latencies: 2.7 k cycles for 16 MFMAs)
+                for (int k = 0; k < NmP / 4; k += 4) {
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        av[u] = ar[4 * (k + u)];
+                        bv[u] = br[(size_t)4 * (k + u) * LDT];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int pi = 4 * q16 + i;
