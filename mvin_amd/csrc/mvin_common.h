@@ -9,17 +9,6 @@ constexpr int kWave = 64;    // CDNA wavefront
 constexpr int kBlock = 256;  // 4 waves per workgroup
 constexpr int kTM = 32;      // node tasks (rows) per workgroup tile
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
 
 // ---- DPP cross-lane reductions (no LDS traffic) --------------------------------------------
 // A DPP "row" is 16 lanes.  quad_perm [1,0,3,2] (0xB1) = lane^1, quad_perm [2,3,0,1] (0x4E) =
@@ -74,6 +63,10 @@ __device__ __forceinline__ float rows_combine_max(float v) {
 
 __device__ __forceinline__ float wave_sum_fast(float v) { return rows_combine_sum(group_sum(v, 4)); }
 __device__ __forceinline__ float wave_max_fast(float v) { return rows_combine_max(group_max(v, 4)); }
+// the plain names are the same reductions (they used to be six __shfl_xor = ds_bpermute round trips through the LDS
+// crossbar, ~300 cycles of dependent latency per reduction in every wave-per-node / wave-per-pair kernel)
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_fast(v); }
+__device__ __forceinline__ float wave_max(float v) { return wave_max_fast(v); }
 
 // ---- entity-table rows: fp32 (16-byte lane loads) or bf16 (8-byte lane loads, widened to fp32
 // exactly: bf16 -> f32 is a 16-bit shift) ------------------------------------------------------
