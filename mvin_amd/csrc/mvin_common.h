@@ -20,14 +20,38 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// lane l <-> lane l^16 and l^32 without the LDS crossbar: v_permlane16_swap / v_permlane32_swap (gfx950) exchange the
+// odd 16-lane rows (32-lane halves) of one operand with the even ones of the other; fed the same value twice they return
+// {value of the even partner, value of the odd partner} in every lane
+__device__ __forceinline__ float xor16_sum(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const unsigned x = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+}
+
 // sum over aligned groups of 2^l2 lanes (l2 wave-uniform, 0..6); every lane gets the result
 __device__ __forceinline__ float group_sum(float v, int l2) {
     if (l2 >= 1) v += dpp_mov<0xB1>(v);
     if (l2 >= 2) v += dpp_mov<0x4E>(v);
     if (l2 >= 3) v += dpp_mov<0x141>(v);
     if (l2 >= 4) v += dpp_mov<0x140>(v);
-    if (l2 >= 5) v += __shfl_xor(v, 16, kWave);
-    if (l2 >= 6) v += __shfl_xor(v, 32, kWave);
+    if (l2 >= 5) v = xor16_sum(v);
+    if (l2 >= 6) v = xor32_sum(v);
     return v;
 }
 
@@ -36,8 +60,8 @@ __device__ __forceinline__ float group_max(float v, int l2) {
     if (l2 >= 2) v = fmaxf(v, dpp_mov<0x4E>(v));
     if (l2 >= 3) v = fmaxf(v, dpp_mov<0x141>(v));
     if (l2 >= 4) v = fmaxf(v, dpp_mov<0x140>(v));
-    if (l2 >= 5) v = fmaxf(v, __shfl_xor(v, 16, kWave));
-    if (l2 >= 6) v = fmaxf(v, __shfl_xor(v, 32, kWave));
+    if (l2 >= 5) v = xor16_max(v);
+    if (l2 >= 6) v = xor32_max(v);
     return v;
 }
 
@@ -91,12 +115,14 @@ __device__ __forceinline__ float4 f4_fma(float s, float4 v, float4 a) {
 
 // Sum a float4 over the lane groups of a wave: lanes l and l^off for off = lpr, 2*lpr, ... < 64.
 __device__ __forceinline__ float4 group_xor_sum(float4 a, int lpr) {
-    for (int o = lpr; o < kWave; o <<= 1) {
+    for (int o = lpr; o < 16; o <<= 1) {       // inside a 16-lane row: the LDS crossbar (D < 64 only)
         a.x += __shfl_xor(a.x, o, kWave);
         a.y += __shfl_xor(a.y, o, kWave);
         a.z += __shfl_xor(a.z, o, kWave);
         a.w += __shfl_xor(a.w, o, kWave);
     }
+    if (lpr <= 16) a = make_float4(xor16_sum(a.x), xor16_sum(a.y), xor16_sum(a.z), xor16_sum(a.w));
+    if (lpr <= 32) a = make_float4(xor32_sum(a.x), xor32_sum(a.y), xor32_sum(a.z), xor32_sum(a.w));
     return a;
 }
 

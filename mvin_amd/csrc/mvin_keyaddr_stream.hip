@@ -148,12 +148,16 @@ __global__ __launch_bounds__(64) void key_addr_stream_kernel(KeyAddrArgs a) {
     // reductions over the row groups of a wave (values are already equal inside a group)
     auto groups_max = [&](float v) {
 #pragma unroll
-        for (int o = LPR; o < kWave; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+        for (int o = LPR; o < 16; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+        if (LPR <= 16) v = xor16_max(v);
+        if (LPR <= 32) v = xor32_max(v);
         return v;
     };
     auto groups_sum = [&](float v) {
 #pragma unroll
-        for (int o = LPR; o < kWave; o <<= 1) v += __shfl_xor(v, o, kWave);
+        for (int o = LPR; o < 16; o <<= 1) v += __shfl_xor(v, o, kWave);
+        if (LPR <= 16) v = xor16_sum(v);
+        if (LPR <= 32) v = xor32_sum(v);
         return v;
     };
     auto store_o = [&](float* o, float4 a0, float4 a1, float inv) {
