@@ -10,7 +10,7 @@ os.environ.setdefault("MVIN_SPLIT_DBG", "4")
 from mvin_amd import _lib, ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
-D, K, B, nE = 64, int(os.environ.get("K", 32)), 65536, 106389
+D, K, B, nE = int(os.environ.get("D", 64)), int(os.environ.get("K", 32)), 65536, int(os.environ.get("NE", 106389))
 table = torch.rand((nE, D), device=dev, generator=g) - 0.5
 if "--kg" in sys.argv:      # the bench.py default workload: synthetic KG adjacency + Zipf items
     from mvin_amd import synth
