@@ -33,14 +33,23 @@ class _Grads(object):
     def __init__(self):
         self.g = {}
         self.keep = []   # keep keyed tensors alive so ids stay unique
+        self.lent = set()
 
-    def add(self, t, g):
+    def add(self, t, g, borrowed=False):
+        """``borrowed``: ``g`` stays in use (read-only) by the caller, so it must not be accumulated into; it is
+        stored as is and replaced by a fresh sum only if another contribution arrives (no copy launch otherwise)."""
         k = id(t)
         if k in self.g:
-            ops.axpby(1.0, g.view(-1), 1.0, self.g[k].view(-1))
+            if k in self.lent:
+                self.g[k] = torch.add(self.g[k], g.view_as(self.g[k]))
+                self.lent.discard(k)
+            else:
+                ops.axpby(1.0, g.view(-1), 1.0, self.g[k].view(-1))
         else:
             self.g[k] = g
             self.keep.append(t)
+            if borrowed:
+                self.lent.add(k)
 
     def get(self, t):
         return self.g.get(id(t))
@@ -189,7 +198,17 @@ class Trainer(object):
         G = _Grads()
         self._g.zero_()
         dP = self._grads                                                  # parameter gradients (views of _g)
-        loss_acc = torch.zeros(1, dtype=F32, device=dev)
+        # every small accumulator of the step out of ONE zero-filled arena (one fill launch instead of six)
+        n_agg = len(m._agg)
+        arena = torch.zeros(4 + (n_agg + 1) * ((nR + 3) & ~3) + 64 * D, dtype=F32, device=dev)
+        loss_acc = arena[0:1]
+        arena_off = [4]
+
+        def small_zeros(n):
+            o = arena_off[0]
+            arena_off[0] = o + ((n + 3) & ~3)
+            assert arena_off[0] <= arena.numel()
+            return arena[o:o + n]
         tape = []
 
         def zeros(*shape):
@@ -240,7 +259,7 @@ class Trainer(object):
                 # d o_s = d . Wu[sD:(s+1)D]^T for every slot s: one z-batched launch over the transposed blocks
                 ops.linear([d], T3(m.user_mlp_matrix), D, out=do_cat, ldo=n_o * D, nz=n_o, w_zstride=D * D, out_zstride=D)
                 dV = zeros(B, nR, D) if P > 0 else None
-                dw = zeros(64, D) if a.PS_O_ft else None     # replicas: B atomics onto the same D floats serialise
+                dw = small_zeros(64 * D).view(64, D) if a.PS_O_ft else None     # replicas: B atomics onto the same D floats serialise
                 # ... and, from the rows it reads anyway, their regulariser value l2*(sum h^2 + sum t^2) (model.py:383-385)
                 ops.key_addressing_bwd(E, V, w_h, memories_h, memories_r, memories_t, P, do_cat, n_o * D, nR,
                                        float(a.l2_weight), dP["entity_emb_matrix"], dV, dw, reg_accum=loss_acc)
@@ -318,7 +337,7 @@ class Trainer(object):
                                      sum_sources=True)
                     dx = ops.linear([d2], T3(m._transfer_W)[0], D)
                     ops.scatter_add_rows(dP["entity_emb_matrix"], ents[0].view(-1), dx)
-                    G.add(q, dx.clone())
+                    G.add(q, dx, borrowed=True)
                 tape.append(bwd_ev0)
                 ev.append(ev0)
                 for e in range(1, L):
@@ -355,7 +374,7 @@ class Trainer(object):
                 T = B * N
                 t_tab = agg.relation_scores() if agg.User_orient_rela else None
                 if agg.User_orient_rela and key not in dT:
-                    dT[key] = zeros(nR)
+                    dT[key] = small_zeros(nR)
                 self_t = cur[hop]
                 if fused:
                     Wc = Wt[L] if a.User_orient else None
@@ -378,7 +397,7 @@ class Trainer(object):
                     i, n = key
                     ops.linear_wgrad([Z], dm, dP[f"agg_{i}_{n}_weights"], db=dP[f"agg_{i}_{n}_bias"])
                     dZ = ops.linear([dm], T3(agg.weights)[0], D)                         # d(self + neighbors_agg)
-                    G.add(self_t, dZ.view_as(self_t).clone())
+                    G.add(self_t, dZ.view_as(self_t), borrowed=True)
                     dTk = dT.get(key)
                     pr = probs.view(T, K) if probs is not None else None
                     if fused:
@@ -479,7 +498,7 @@ class Trainer(object):
             # the term is linear in the counts, so the hops share one count vector
             rid = memories_r[hop].reshape(-1)
             if cnt is None:
-                cnt = torch.zeros(nR, dtype=F32, device=dev)
+                cnt = small_zeros(nR)
             if rid.dtype == torch.int32 and rid.is_contiguous() and nR <= 4096:
                 ops.count_ids(rid, nR, out=cnt)
             else:
