@@ -398,12 +398,17 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
 /* Same, and the VALUE of that regulariser, which the kernel has in registers anyway:
  * *reg_accum += l2 * sum over hops, pairs and memories of (|E[h]|^2 + |E[t]|^2)   (model.py:383-385 summed over
  * model.py:387's hops); reg_accum may be NULL.  dw is [dw_replicas, D] (a power of two; 1 = the plain form): every
- * pair adds its share to one replica and the caller sums them -- B atomic updates of the same D floats serialise. */
+ * pair adds its share to one replica and the caller sums them -- B atomic updates of the same D floats serialise.
+ * relation_kge [nR, D, D] + items [B] (int64 when items64; both or neither): the kernel also adds the item's share of
+ * V = E[item] . R_KGE[r], dE[item_b, :] += sum_r dV[b, r, :] . R_KGE[r]^T, from the dV block it holds in LDS; allowed only
+ * where mvin_key_addressing_bwd_adds_item_grad(P, Nm, D, nR) != 0 (else -3: do that product with mvin_linear_fwd). */
 int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
                                 const int32_t* const* mem_h, const int32_t* const* mem_r,
                                 const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
                                 int64_t ldo, float l2, float* dE, float* dV, float* dw, int dw_replicas,
-                                float* reg_accum, void* stream);
+                                float* reg_accum, const float* relation_kge, const void* items, int items64,
+                                void* stream);
+int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR);
 
 /* ---- inputs of the path, built on the GPU (data_loader_user_set.py) ------------------------
  * Both take the undirected KG as CSR: indptr [nE+1] int64, dst/rel [nnz] int32, every triple

@@ -125,7 +125,8 @@ SIGNATURES = {
     "mvin_key_addressing_bwd_reg": (C.c_int, [_c_f32p, _c_f32p, _c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               _c_f32p, C.c_int64, C.c_float, _c_f32p, _c_f32p, _c_f32p, C.c_int,
-                                              _c_f32p, C.c_void_p]),
+                                              _c_f32p, _c_f32p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mvin_key_addressing_bwd_adds_item_grad": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),

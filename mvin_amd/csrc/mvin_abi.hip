@@ -740,19 +740,27 @@ int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, cons
                       "mvin_rel_score_bwd");
 }
 
+int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR) {
+    // mirrors launch_key_addr_bwd: the dV block of a (pair, hop) must fit the kernel's LDS budget next to its tiles
+    if (P <= 0 || D > 64 || (D & 3)) return 0;
+    const size_t lds = ((size_t)((2 * Nm + 3) & ~3) + 4 * (3 * 256 + 3 * 64)) * sizeof(float);
+    return lds + (size_t)nR * D * sizeof(float) <= 48 * 1024 ? 1 : 0;
+}
+
 int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float* w, const int32_t* const* mem_h,
                             const int32_t* const* mem_r, const int32_t* const* mem_t, int P, int B, int Nm, int D,
                             int nR, const float* dout, int64_t ldo, float l2, float* dE, float* dV, float* dw,
                             void* stream) {
     return mvin_key_addressing_bwd_reg(entity_emb, V, w, mem_h, mem_r, mem_t, P, B, Nm, D, nR, dout, ldo, l2, dE, dV,
-                                       dw, 1, nullptr, stream);
+                                       dw, 1, nullptr, nullptr, nullptr, 0, stream);
 }
 
 int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
                                 const int32_t* const* mem_h, const int32_t* const* mem_r,
                                 const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
                                 int64_t ldo, float l2, float* dE, float* dV, float* dw, int dw_replicas,
-                                float* reg_accum, void* stream) {
+                                float* reg_accum, const float* relation_kge, const void* items, int items64,
+                                void* stream) {
     const char* who = "mvin_key_addressing_bwd";
     if (dw_replicas < 1 || dw_replicas > 1024 || (dw_replicas & (dw_replicas - 1)))
         return fail(-2, "%s: dw_replicas=%d (a power of two in 1..1024)", who, dw_replicas);
@@ -790,6 +798,13 @@ int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const f
     k.l2 = l2;
     k.reg_accum = reg_accum;
     k.dw_rep = dw_replicas;
+    if ((relation_kge == nullptr) != (items == nullptr)) return fail(-1, "%s: relation_kge and items go together", who);
+    if (relation_kge && !mvin_key_addressing_bwd_adds_item_grad(P, Nm, D, nR))
+        return fail(-3, "%s: the item gradient is not added in-kernel at this shape (query "
+                        "mvin_key_addressing_bwd_adds_item_grad)", who);
+    k.Rk = relation_kge;
+    k.items = items;
+    k.items64 = items64;
     return hip_result(mvin::launch_key_addr_bwd(k, (hipStream_t)stream), who);
 }
 

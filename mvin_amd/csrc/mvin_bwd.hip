@@ -601,6 +601,27 @@ __global__ __launch_bounds__(kBlock) void key_addr_bwd_kernel(KeyAddrBwdArgs a) 
                 const float v = sDV[e];
                 if (v != 0.f) atomicAdd(dvb + e, v);
             }
+            if (a.Rk && a.items && D <= kWave) {
+                // the item's share, from the block that is in LDS anyway: V[b, r, :] = E[item_b] . R[r]  =>
+                // dE[item_b, i] += sum_r sum_j dV[b, r, j] R[r, i, j].  Lane = component i, the four waves stride over
+                // the relations; one row-contiguous atomic per wave (it was a [B, nR*D] x [nR*D, D] product on the VALU
+                // tile kernel -- 49 us at every batch size -- plus a scatter-add launch)
+                const int64_t item = a.items64 ? reinterpret_cast<const int64_t*>(a.items)[b]
+                                               : (int64_t)reinterpret_cast<const int32_t*>(a.items)[b];
+                if (lane < D) {
+                    float acc = 0.f;
+                    for (int r = wave; r < a.f.nR; r += 4) {
+                        const float4* rr = reinterpret_cast<const float4*>(a.Rk + ((size_t)r * D + lane) * D);
+                        const float4* dv = reinterpret_cast<const float4*>(sDV + r * D);
+#pragma unroll 4
+                        for (int j = 0; j < (D >> 2); ++j) {
+                            const float4 w4 = rr[j], d4 = dv[j];
+                            acc = fmaf(w4.x, d4.x, fmaf(w4.y, d4.y, fmaf(w4.z, d4.z, fmaf(w4.w, d4.w, acc))));
+                        }
+                    }
+                    if (acc != 0.f) atomicAdd(a.dE + item * D + lane, acc);
+                }
+            }
             __syncthreads();             // flushed before the next task zeroes it
         }
     }
@@ -789,6 +810,7 @@ hipError_t launch_key_addr_bwd(const KeyAddrBwdArgs& a0, hipStream_t st) {
     const size_t dv = (size_t)a.f.nR * a.f.D * sizeof(float);
     a.dv_lds = (a.f.P > 0 && a.dV && lds + dv <= 48 * 1024 && getenv("MVIN_KAB_DV_GLOBAL") == nullptr) ? 1 : 0;
     if (a.dv_lds) lds += dv;
+    if (a.Rk && !a.dv_lds) return hipErrorInvalidValue;      // the in-kernel item gradient reads the LDS copy of dV
     if (lds > 64 * 1024) {       // n_memory beyond ~6 000: raise the dynamic-LDS limit (the ABI caps Nm at 8 192 = 80 KB)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(key_addr_bwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -224,6 +224,9 @@ struct KeyAddrBwdArgs {
     float* dV;                // [B, nR, D] accumulated (zero-initialised by the caller)
     float* dw;                // [D] accumulated (h-set logit weights) or NULL
     float l2;                 // l2_weight of the sum(h^2)+sum(t^2) regulariser
+    const float* Rk;          // R_KGE [nR, D, D] and ...
+    const void* items;        // ... the pairs' item ids [B] (int64 when items64): when both are given (and dV sits in
+    int items64;              //     LDS) the kernel adds dE[item_b] += sum_r dV[b, r, :] . R[r]^T itself (V = E[item] . R)
     int dw_rep;               // dw is [dw_rep, D] (power of two >= 1): replicas spread the same-address atomics
     int dv_lds;               // set by the launcher: dV contributions summed per (pair, hop) in LDS first
     float* reg_accum;         // *reg_accum += l2 (sum h^2 + sum t^2) over the hop rows (model.py:383-385) or NULL

@@ -551,8 +551,14 @@ def rel_score_bwd(relation_emb, urh_weights, dT, drel, durh):
                "mvin_rel_score_bwd")
 
 
-def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, l2, dE, dV, dw, reg_accum=None):
-    """mvin_key_addressing_bwd_reg; ``reg_accum`` (1-element fp32): += l2 * (sum h^2 + sum t^2) of the hop rows."""
+def key_addressing_bwd_adds_item_grad(P, Nm, D, nR):
+    return bool(_lib.load().mvin_key_addressing_bwd_adds_item_grad(P, Nm, D, nR))
+
+
+def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, l2, dE, dV, dw, reg_accum=None,
+                       relation_kge=None, items=None):
+    """mvin_key_addressing_bwd_reg; ``reg_accum`` (1-element fp32): += l2 * (sum h^2 + sum t^2) of the hop rows;
+    ``relation_kge`` + ``items``: the kernel adds dE[item] += sum_r dV[:, r] . R[r]^T itself (see the header)."""
     lib = _lib.load()
     nh = max(1, P)
     arr_t = C.c_void_p * nh
@@ -564,5 +570,6 @@ def key_addressing_bwd(entity_emb, V, w, mem_h, mem_r, mem_t, P, dout, ldo, nR, 
     _lib.check(lib.mvin_key_addressing_bwd_reg(_p(entity_emb), _p(V), _p(w), ph, pr, pt, P, B, Nm, D, nR, _p(dout),
                                                ldo, l2, _p(dE), _p(dV), _p(dw),
                                                1 if dw is None or dw.dim() == 1 else dw.shape[0], _p(reg_accum),
-                                               _stream()),
+                                               _p(relation_kge), _p(items),
+                                               1 if items is not None and items.dtype == torch.int64 else 0, _stream()),
                "mvin_key_addressing_bwd")
