@@ -76,6 +76,7 @@ class Trainer(object):
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
         self.by_entity = os.environ.get("MVIN_TRAIN_BY_ENTITY", "1") != "0"   # de-duplicated deepest-hop backward
+        self.item_grad_in_kernel_max_batch = 2048    # up to here key_addr_bwd adds dE[item] of V = E[item].R_KGE itself
         self.params = self._named_params()
         self._build_flat_state()
         self.last_grads = None
@@ -263,7 +264,8 @@ class Trainer(object):
                 # ... and, from the rows it reads anyway, their regulariser value l2*(sum h^2 + sum t^2) (model.py:383-385)
                 # ... and, where the shape allows, the item's share dE[item] += sum_r dV[:, r] . R[r]^T from the dV block in LDS
                 # (measured: -40 us per step at 512 pairs, +20 us at 4 096, where the separate product runs at full width)
-                item_in_kernel = P > 0 and B <= 2048 and ops.key_addressing_bwd_adds_item_grad(P, m.n_memory, D, nR)
+                item_in_kernel = (P > 0 and B <= self.item_grad_in_kernel_max_batch
+                                  and ops.key_addressing_bwd_adds_item_grad(P, m.n_memory, D, nR))
                 ops.key_addressing_bwd(E, V, w_h, memories_h, memories_r, memories_t, P, do_cat, n_o * D, nR,
                                        float(a.l2_weight), dP["entity_emb_matrix"], dV, dw, reg_accum=loss_acc,
                                        relation_kge=R if item_in_kernel else None, items=item if item_in_kernel else None)

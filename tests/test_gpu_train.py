@@ -68,6 +68,22 @@ def test_loss_and_every_gradient(shape, ablation, hip_lib):
     check_grads(tr.grads_by_reference_name(), ref_grads, loss, ref_loss)
 
 
+@pytest.mark.parametrize("shape", ["d8k3h2m1p2", "d64k8h2m1p2"])
+def test_item_gradient_of_the_relation_projection_both_ways(shape, hip_lib):
+    """dE[item] of V = E[item] . R_KGE[r]: added inside mvin_key_addressing_bwd_reg at small batches, by a separate
+    product + scatter-add above Trainer.item_grad_in_kernel_max_batch -- both against the oracle."""
+    from mvin_amd.training import Trainer
+    for max_batch in (0, 1 << 20):
+        args, case, params, labels, model = build(shape)
+        tr = Trainer(model)
+        tr.item_grad_in_kernel_max_batch = max_batch
+        loss = tr.step(*dev_feed(model, case, labels), apply=False)
+        ref_loss, ref_grads, _, _ = train_ref.loss_and_grads(args, params, case.adj_entity, case.adj_relation, case.users,
+                                                             case.items, labels, case.memories_h, case.memories_r,
+                                                             case.memories_t)
+        check_grads(tr.grads_by_reference_name(), ref_grads, loss, ref_loss)
+
+
 def test_adam_trajectory_matches_reference(hip_lib):
     args, case, params, labels, model = build("d8k3h2m1p2")
     feed = {model.user_indices: case.users, model.item_indices: case.items, model.labels: labels}
