@@ -29,6 +29,7 @@ struct GatherAttnArgs {
     float* z_out;             // [T, D] or NULL: self + neighbors_agg, the input of the dense layer (training)
     int64_t T;
     int N, K, D, lpr_log2;
+    int tile_rows;            // node tasks per workgroup tile: 32, or 8 when there are fewer tiles than CUs (set by the launcher)
 };
 
 struct RippleArgs {

@@ -183,12 +183,15 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
     const float invK_den = (float)K;
     const float psum = a.rel_score ? 1.f : (float)K;
 
-    const int64_t ntiles = (a.T + kTM - 1) / kTM;
+    // TR node tasks per tile (rows TR.. of the LDS tiles are unused: computed on, never stored): launches of a few
+    // hundred nodes spread over 4x the workgroups, a wave walks 2 tasks instead of 8
+    const int TR = a.tile_rows;
+    const int64_t ntiles = (a.T + TR - 1) / TR;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t t0 = tile * kTM;
+        const int64_t t0 = tile * TR;
         // ---------------- phase A ----------------
-        for (int tt = 0; tt < kTM / 4; ++tt) {
-            const int trow = wave * (kTM / 4) + tt;
+        for (int tt = 0; tt < TR / 4; ++tt) {
+            const int trow = wave * (TR / 4) + tt;
             const int64_t t = t0 + trow;
             if (t >= a.T) {
                 if (cact && g == 0)
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
                 const int row = rg + RP * i;
                 const int64_t t = t0 + row;
                 float zv = 0.f;
-                if (t < a.T) {
+                if (t < a.T && row < TR) {
                     float v = acc[i];
                     if (a.Wc && a.c_child) v = fmaf(psum, a.c_child[(t / a.N) * D + j], v);
                     zv = a.self_vec[t * D + j] + v / invK_den;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void gather_attn_kernel(GatherAttnArgs a) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int64_t t = t0 + rg + RP * i;
-                if (t < a.T) a.out[t * D + j] = fmaxf(acc[i] + bj, 0.f);
+                if (t < a.T && rg + RP * i < TR) a.out[t * D + j] = fmaxf(acc[i] + bj, 0.f);
             }
         }
         // next tile's phase A writes sS/sYP only; its phase B (after a barrier) writes sZ.
@@ -451,10 +454,12 @@ hipError_t launch_linear(const mvin_linear_args& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_gather_attn(const GatherAttnArgs& a, hipStream_t st) {
-    const int nr = nr_for(a.D);
+hipError_t launch_gather_attn(const GatherAttnArgs& a0, hipStream_t st) {
+    const int nr = nr_for(a0.D);
+    GatherAttnArgs a = a0;
     const size_t lds = (size_t)2 * kTM * (a.D + 4) * sizeof(float) + (size_t)4 * a.K * sizeof(int2);
-    const int64_t ntiles = (a.T + kTM - 1) / kTM;
+    a.tile_rows = (a.T + kTM - 1) / kTM < 256 ? 8 : kTM;
+    const int64_t ntiles = (a.T + a.tile_rows - 1) / a.tile_rows;
     dim3 grid(grid_for(ntiles));
     const bool pre = ntiles <= 1024;
 #define CALL(NRV)                                                         \
