@@ -1,5 +1,6 @@
 // rows x small dense on the matrix cores: out[z][r,:] = act(X[r,:] . W[z] + bias[z] + rowbias)
-// for Dout = D in {16, 32, 64} and Din = NE * D (NE = 1..4), the shapes of every tf.matmul
+// for Dout = D in {16, 32, 64} and Din = NE * D (NE = 1..4) -- and D = 128 with NE <= 2, two 16-column slabs per wave
+// (BASELINE config C5's projections and aggregator epilogues) --, the shapes of every tf.matmul
 // site of the path at those dims (model.py:279 projection, :312 mix-hop combiner, :234 user MLP,
 // the per-relation item projection of :214-220, aggregators.py:110).  Same contract as the VALU
 // linear_kernel (gathered / concatenated / summed sources, int32 or int64 ids, z-batched weights,
@@ -19,7 +20,8 @@ template <int D, int NE>
 __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = D / 16;
-    constexpr int MTW = (NT == 4) ? 2 : 1;
+    constexpr int MTW = (NT >= 4) ? 2 : 1;
+    constexpr int SL = (NT == 8) ? 2 : 1;      // 16-column slabs per wave (slab nt + 4 * sl)
     constexpr int DIN = NE * D;
     constexpr int KS = DIN / 4;
     constexpr int LDX = DIN + 2;
@@ -28,19 +30,22 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q16 = lane >> 4, l16 = lane & 15;
-    const int nt = (NT == 4) ? wave : (wave % NT);
-    const int mt0 = (NT == 4) ? 0 : (wave / NT);
+    const int nt = (NT >= 4) ? wave : (wave % NT);
+    const int mt0 = (NT >= 4) ? 0 : (wave / NT);
     const bool dense = mt0 < 2;
-    const int col = 16 * nt + l16;
     const int z = blockIdx.y;
     const float* W = a.W + (size_t)z * a.w_zstride;
     const float* bias = a.bias ? a.bias + (size_t)z * a.bias_zstride : nullptr;
     float* out = a.out + (size_t)z * a.out_zstride;
 
-    float bW[KS];
+    float bW[SL][KS], bj[SL];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bW[s] = dense ? W[(size_t)(4 * s + q16) * D + col] : 0.f;
-    const float bj = (dense && bias) ? bias[col] : 0.f;
+    for (int sl = 0; sl < SL; ++sl) {
+        const int col = 16 * (nt + 4 * sl) + l16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bW[sl][s] = dense ? W[(size_t)(4 * s + q16) * D + col] : 0.f;
+        bj[sl] = (dense && bias) ? bias[col] : 0.f;
+    }
 
     const int c4 = a.Dsrc >> 2;
     const int64_t ntiles = (a.rows + kTM - 1) / kTM;
@@ -71,34 +76,42 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a)
         }
         __syncthreads();
         if (dense) {
-            f32x4 acc[MTW];
+            f32x4 acc[SL][MTW];
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) acc[sl][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
 #pragma unroll
                 for (int m = 0; m < MTW; ++m) {
                     const float av = sX[(16 * (mt0 + m) + l16) * LDX + 4 * s + q16];
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bW[s], acc[m], 0, 0, 0);
+#pragma unroll
+                    for (int sl = 0; sl < SL; ++sl)
+                        acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bW[sl][s], acc[sl][m], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
+            for (int sl = 0; sl < SL; ++sl) {
+                const int col = 16 * (nt + 4 * sl) + l16;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const int row = 16 * (mt0 + m) + 4 * q16 + r4;
-                    const int64_t r = r0 + row;
-                    float part = 0.f;
-                    if (r < a.rows) {
-                        float v = acc[m][r4] + bj;
-                        if (a.rowbias) v += a.rowbias[(r / a.rows_per_group) * D + col];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        out[r * a.ldo + col] = v;
-                        if (a.score_u) part = v * a.score_u[r * D + col];
-                    }
-                    if (a.score_u) {   // uniform branch: all lanes reduce over the 16 columns of the slab
-                        part = group_sum(part, 4);
-                        if (l16 == 0) sScore[nt * kTM + row] = part;
+                for (int m = 0; m < MTW; ++m) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const int row = 16 * (mt0 + m) + 4 * q16 + r4;
+                        const int64_t r = r0 + row;
+                        float part = 0.f;
+                        if (r < a.rows) {
+                            float v = acc[sl][m][r4] + bj[sl];
+                            if (a.rowbias) v += a.rowbias[(r / a.rows_per_group) * D + col];
+                            if (a.relu) v = fmaxf(v, 0.f);
+                            out[r * a.ldo + col] = v;
+                            if (a.score_u) part = v * a.score_u[r * D + col];
+                        }
+                        if (a.score_u) {   // uniform branch: all lanes reduce over the 16 columns of the slab
+                            part = group_sum(part, 4);
+                            if (l16 == 0) sScore[(nt + 4 * sl) * kTM + row] = part;
+                        }
                     }
                 }
             }
@@ -123,11 +136,11 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a)
 bool linear_mfma_supported(const mvin_linear_args& a) {
     if (!a.W) return false;
     const int D = a.Dout;
-    if (D != 16 && D != 32 && D != 64) return false;
+    if (D != 16 && D != 32 && D != 64 && D != 128) return false;
     const int din = (a.sum_sources ? 1 : a.nsrc) * a.Dsrc;
     if (din % D) return false;
     const int ne = din / D;
-    return ne >= 1 && ne <= 4;
+    return ne >= 1 && ne <= (D == 128 ? 2 : 4);     // D = 128: 2 * Din / 4 fragment registers per lane
 }
 
 template <int D, int NE>
@@ -160,6 +173,7 @@ hipError_t launch_linear_mfma(const mvin_linear_args& a, hipStream_t st) {
     switch (a.Dout) {
         case 16: return launch_lm_ne<16>(a, ne, st);
         case 32: return launch_lm_ne<32>(a, ne, st);
+        case 128: return ne == 1 ? launch_lm<128, 1>(a, st) : launch_lm<128, 2>(a, st);
         default: return launch_lm_ne<64>(a, ne, st);
     }
 }
