@@ -97,6 +97,10 @@ def parse():
                     help="override the entity count (synthetic large-table variant, e.g. 16000000 = 4 GB at dim 64; "
                          "implies --adj uniform)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="builder-side projection on ONE GPU: score rank 0's share of the global batch as one of W ranks "
+                         "would (user-sorted split, row-shard exchange of the whole table per step); the line is marked "
+                         "`emulated_world` and its `value` is per-rank pairs/s x W -- never a measurement of W GPUs")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -327,9 +331,10 @@ def main():
         return
 
     d = synth.DATASETS[a.dataset]
-    if a.batch % world:
+    split = a.emulate_world if (a.emulate_world > 1 and world == 1) else world     # ranks the global batch is cut into
+    if a.batch % split:
         raise SystemExit("--batch must be divisible by the number of ranks")
-    Bl = a.batch // world                       # pairs this rank scores per step
+    Bl = a.batch // split                       # pairs this rank scores per step
     margs = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop,
                       n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=Bl)
     # one global synthetic batch (same seed everywhere); rank r scores pairs [r*Bl, (r+1)*Bl).
@@ -339,9 +344,27 @@ def main():
         a.adj = "uniform"
     case = synth.dataset_case(a.dataset, K=a.fanout, B=a.batch, seed=a.seed,
                               zipf=(a.items == "zipf"), uniform_adj=(a.adj == "uniform"))
+    if split > 1:
+        # Pairs are independent, so ANY partition of the batch is valid; the ranks take contiguous slices of the batch
+        # in USER order: a rank then holds all pairs of ~n_user/W users (B/n_user pairs each, as on one GPU) and key
+        # addressing keeps reading a user's ripple-set rows once per user instead of once per pair.  Slices stay
+        # exactly B/W pairs; at most W-1 users straddle a cut (both neighbours then read that user's rows).
+        order = np.argsort(case.users, kind="stable")
+        case.users, case.items = case.users[order], case.items[order]
+        case.memories_h = [m[order] for m in case.memories_h]
+        case.memories_r = [m[order] for m in case.memories_r]
+        case.memories_t = [m[order] for m in case.memories_t]
+    distinct = -(-case.n_user // split) + 1 if split > 1 else None     # users a rank expects in its slice
     sl = slice(rank * Bl, (rank + 1) * Bl)
     params = init_params(margs, case.n_user, case.n_entity, case.n_relation, seed=a.seed)
-    rowshard = a.shard == "rowshard" or (a.shard == "auto" and world > 1)
+    rowshard = a.shard == "rowshard" or (a.shard == "auto" and split > 1)
+    if a.emulate_world > 1 and world == 1:
+        a.force_collectives = True
+        if not dist.is_initialized():
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     hoist_kw = {"off": False, "cached": True, "step": "step"}[a.hoist]
     if rowshard:  # the model lives in shard space; its entity table is the sharded table's working copy
         from mvin_amd.dist import ShardedMVIN, shard_rows
@@ -383,22 +406,23 @@ def main():
     if overlap:
         runner.enable_pipeline()
     state = {"i": 0}
+    ukw = {"distinct_users": distinct} if (by_user and distinct) else {}
 
     def step():
         if scorer is not None:
             return scorer.replay()
         if not rowshard:
             if by_user:
-                return model.forward_users(users, items, uts_d)
+                return model.forward_users(users, items, uts_d, distinct_users=distinct)
             return model.forward_device(users, items, mh, mr, mt)
         if not overlap:
-            return runner.forward_device(users, items, mh, mr, mt, global_batch=a.batch)
+            return runner.forward_device(users, items, mh, mr, mt, global_batch=a.batch, **ukw)
         # every step scores one batch AND performs one row exchange (for the following batch),
         # on two streams; the same synthetic batch is re-used, the exchange is not skipped
         i = state["i"]
         if i == 0:
             runner.prefetch(0, users, items, mh, mt, global_batch=a.batch)
-        out = runner.forward_prefetched(i % 2, users, items, mh, mr, mt)
+        out = runner.forward_prefetched(i % 2, users, items, mh, mr, mt, **ukw)
         runner.prefetch((i + 1) % 2, users, items, mh, mt, global_batch=a.batch)
         state["i"] = i + 1
         return out
@@ -540,10 +564,19 @@ def main():
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
+                       "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",
+                       "key_addressing_variant": (
+                           "pairs (mvin_key_addressing_fwd: 2*P*Nm rows gathered per pair)"
+                           if (a.feed == "pairs" or scorer is not None) else
+                           "grouped (mvin_key_addressing_grouped_fwd: a user's rows staged once per user segment)"
+                           if Bl >= model.group_min_pairs_per_user * min(case.n_user, distinct or case.n_user) else
+                           "users (mvin_key_addressing_users_fwd: per pair, lists read out of user_triplet_set)"),
                        "feed": ("user_triplet_set [n_user, P, 3, n_memory] + (user, item) ids resident in HBM; the per-pair "
                                 "ripple sets of train.py:117-120 are assembled inside key addressing, which groups the "
                                 "batch's pairs by user" if a.feed == "users" and scorer is None else
                                 "per-pair ripple-set arrays [B, n_memory] + (user, item) ids resident in HBM"),
+                       "pair_split": ("contiguous slices of the batch in user order (a rank holds all pairs of ~n_user/W "
+                                      "users)" if split > 1 else "none"),
                        "parallelism": (f"pairs split over {world} rank(s); entity table row-sharded (owner = id mod {world}) "
                                        f"+ all-to-all row exchange per step ({'dense' if runner.is_dense(a.batch) else 'sparse'} regime)"
                                        f"{' overlapped with scoring (2 streams, 2 working tables)' if overlap else ''}"
@@ -552,6 +585,12 @@ def main():
                                         else "single-gpu"))},
             "roofline": roofline,
         }
+        if a.emulate_world > 1 and world == 1:
+            rec["emulated_world"] = {"world": a.emulate_world, "per_rank_pairs_per_s": Bl * a.steps / elapsed,
+                                     "note": "ONE GPU scoring rank 0's share as one of W ranks would (user-sorted split, "
+                                             "row-shard exchange of the whole table every step through RCCL at world size "
+                                             "1, two streams); `value` = per-rank rate x W is a PROJECTION of the W-GPU "
+                                             "line, not a measurement: no fabric is involved"}
         if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard:
             smh, smr, smt = (mh, mr, mt) if mh is not None else pair_feed()   # per-pair feeds: the reference's own
             rec["batch_sweep"] = batch_sweep(model, users, items, smh, smr, smt, [int(x) for x in a.sweep.split(",") if x])

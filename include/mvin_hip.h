@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 3
+#define MVIN_ABI_VERSION 4
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -197,10 +197,12 @@ int mvin_key_addressing_supported(int Nm, int D);
 /* The same reads with the feed assembly of train.py:117-120 inside the kernel: pair b uses the ripple sets of user
  * users[b] straight out of user_triplet_set `uts` [n_user, max(1,P), 3, Nm] int32 on the device (h, r, t lists per hop;
  * data_loader_user_set.py:392-441) -- no per-pair [B, Nm] arrays exist.  One of users_i64 / users_i32 is given.  For
- * batches whose users repeat, mvin_key_addressing_grouped_fwd reads a user's rows once instead. */
+ * batches whose users repeat, mvin_key_addressing_grouped_fwd reads a user's rows once instead.
+ * Device-resident ids are not validated per launch (the reference's CPU tf.gather raises InvalidArgument; here that
+ * is the host wrapper's job): a user id outside [0, n_user) is CLAMPED into the table, never read out of bounds. */
 int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
                                   const int64_t* users_i64, const int32_t* users_i32, int P, int B, int Nm, int D, int nR,
-                                  int n_entity, float* out, int64_t ldo, int table_bf16, void* stream);
+                                  int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream);
 
 /* The same reads for pairs GROUPED BY USER (the feeds of train.py:117-120 / util.py:208-230 give every pair its
  * user's ripple sets, so all pairs of one user gather the same rows).  `uts` = user_triplet_set on the device,
@@ -222,7 +224,9 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
  * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
  * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair
  * at each position (order inside a segment unspecified).  workspace: 2 * n_user int32.  Ids outside [0, n_user) are
- * dropped (the reference's TF gather would raise InvalidArgument). */
+ * CLAMPED into the table (every pair keeps a segment, so no row of `out` stays unwritten); the reference's CPU
+ * tf.gather would raise InvalidArgument -- the Python wrapper does that for host feeds and, on request, for device
+ * feeds (MVIN.validate_device_ids). */
 int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,
                              int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, void* stream);
 
@@ -295,6 +299,7 @@ typedef struct {
     float* sig;                    /* out [B] */
     int64_t B;
     int D, K, P, Nm, n_entity, n_relation, table_bf16;
+    int n_user;                    /* rows of uts (users feed); user ids are clamped to [0, n_user) */
 } mvin_score_l2_args;
 int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

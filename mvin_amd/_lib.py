@@ -49,7 +49,7 @@ class ScoreL2Args(C.Structure):
         "entity_emb", "adj_entity", "adj_relation", "relation_kge", "h_set_w", "user_mlp_W", "user_mlp_b", "t0", "t1",
         "W0", "b0", "W1", "b1", "W2", "b2", "A0", "a0", "A1", "a1", "Wmix", "bmix", "items", "mem_h", "mem_r", "mem_t",
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
-        ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16")]
+        ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -92,8 +92,8 @@ SIGNATURES = {
     "mvin_group_pairs_by_user": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_users_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
-                                                C.c_int, C.c_void_p]),
+                                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_int64, C.c_int, C.c_void_p]),
     "mvin_row_softmax_fwd": (C.c_int, [_c_f32p, C.c_int64, C.c_int, _c_f32p, C.c_void_p]),
     "mvin_gather_mix_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int64, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int, C.c_void_p]),
@@ -167,8 +167,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 3:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 3")
+    if ver != 4:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 4")
     _lib = lib
     return lib
 

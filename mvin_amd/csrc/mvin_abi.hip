@@ -306,8 +306,10 @@ int mvin_key_addressing_supported(int Nm, int D) {
 static int key_addressing_impl(const char* who, const void* entity_emb, const float* V, const float* w,
                                const int32_t* const* mem_h, const int32_t* const* mem_r, const int32_t* const* mem_t,
                                const int32_t* uts, const int64_t* users64, const int32_t* users32, int P, int B, int Nm,
-                               int D, int nR, int n_entity, float* out, int64_t ldo, int table_bf16, void* stream) {
+                               int D, int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16,
+                               void* stream) {
     if (n_entity <= 0) return fail(-2, "%s: n_entity=%d", who, n_entity);
+    if (uts && n_user <= 0) return fail(-2, "%s: n_user=%d", who, n_user);
     if (!entity_emb || !out || (!uts && !mem_h)) return fail(-1, "%s: null pointer", who);
     if (uts && !users64 && !users32) return fail(-1, "%s: user_triplet_set given without user ids", who);
     if (P < 0 || P > 8) return fail(-2, "%s: P=%d (0..8)", who, P);
@@ -324,6 +326,7 @@ static int key_addressing_impl(const char* who, const void* entity_emb, const fl
     k.uts = uts;
     k.users64 = users64;
     k.users32 = users32;
+    k.n_user = n_user;
     const int nh = P > 0 ? P : 1;
     for (int i = 0; i < nh && !uts; ++i) {
         if (!mem_h[i]) return fail(-1, "%s: null mem_h[%d]", who, i);
@@ -354,14 +357,14 @@ int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float*
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
                             float* out, int64_t ldo, int table_bf16, void* stream) {
     return key_addressing_impl("mvin_key_addressing_fwd", entity_emb, V, w, mem_h, mem_r, mem_t, nullptr, nullptr, nullptr, P,
-                               B, Nm, D, nR, n_entity, out, ldo, table_bf16, stream);
+                               B, Nm, D, nR, n_entity, 0, out, ldo, table_bf16, stream);
 }
 
 int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
                                   const int64_t* users_i64, const int32_t* users_i32, int P, int B, int Nm, int D, int nR,
-                                  int n_entity, float* out, int64_t ldo, int table_bf16, void* stream) {
+                                  int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream) {
     return key_addressing_impl("mvin_key_addressing_users_fwd", entity_emb, V, w, nullptr, nullptr, nullptr, uts, users_i64,
-                               users_i32, P, B, Nm, D, nR, n_entity, out, ldo, table_bf16, stream);
+                               users_i32, P, B, Nm, D, nR, n_entity, n_user, out, ldo, table_bf16, stream);
 }
 
 int mvin_l2_tail_supported(int D) { return mvin::l2_tail_supported(D) ? 1 : 0; }
@@ -431,7 +434,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     if (a->uts)
         rc = mvin_key_addressing_users_fwd(a->entity_emb, a->V, a->h_set_w, a->uts, a->users, nullptr, a->P, (int)a->B, a->Nm,
-                                           D, nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+                                           D, nR, a->n_entity, a->n_user, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
     else
         rc = mvin_key_addressing_fwd(a->entity_emb, a->V, a->h_set_w, a->mem_h, a->mem_r, a->mem_t, a->P, (int)a->B, a->Nm, D,
                                      nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);

@@ -9,11 +9,14 @@
 
 namespace mvin {
 
+// Device-resident ids are not validated per launch: an id outside [0, n_user) is clamped into the table (every pair keeps
+// a segment, so no output row is left unwritten), exactly as the per-pair kernels clamp it (key_addr_lists).
+__device__ __forceinline__ int64_t clamp_user(int64_t u, int n_user) { return u < 0 ? 0 : (u >= n_user ? n_user - 1 : u); }
+
 __global__ void group_count_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
                                    int32_t* __restrict__ count) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t u = u64 ? u64[i] : (int64_t)u32[i];
-        if (u >= 0 && u < n_user) atomicAdd(count + u, 1);
+        atomicAdd(count + clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user), 1);
     }
 }
 
@@ -69,15 +72,14 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t* __restr
     }
     if (tid == 0) {
         nseg[0] = carryS;
-        seg_ptr[carryS] = carryC;                             // = number of pairs with a valid user id
+        seg_ptr[carryS] = carryC;                             // = B
     }
 }
 
 __global__ void group_scatter_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
                                      int32_t* __restrict__ offs, int32_t* __restrict__ pair_index) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t u = u64 ? u64[i] : (int64_t)u32[i];
-        if (u >= 0 && u < n_user) pair_index[atomicAdd(offs + u, 1)] = (int32_t)i;
+        pair_index[atomicAdd(offs + clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user), 1)] = (int32_t)i;
     }
 }
 

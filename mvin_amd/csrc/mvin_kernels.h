@@ -74,6 +74,7 @@ struct KeyAddrArgs {
     const int32_t* uts;
     const int64_t* users64;
     const int32_t* users32;
+    int n_user;                // rows of uts: user ids are clamped to [0, n_user) (device feeds are not validated per launch)
 };
 
 // the three id lists (heads, relations, tails) of pair b at `hop`
@@ -82,7 +83,8 @@ struct KeyAddrLists {
 };
 __device__ __forceinline__ KeyAddrLists key_addr_lists(const KeyAddrArgs& a, int64_t b, int hop) {
     if (a.uts) {
-        const int64_t u = a.users64 ? a.users64[b] : (int64_t)a.users32[b];
+        int64_t u = a.users64 ? a.users64[b] : (int64_t)a.users32[b];
+        u = u < 0 ? 0 : (u >= a.n_user ? a.n_user - 1 : u);
         const int32_t* base = a.uts + ((u * (a.P > 0 ? a.P : 1) + hop) * 3) * (int64_t)a.Nm;
         return {base, base + a.Nm, base + 2 * a.Nm};
     }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGrouped
                 idh = ub[(hop * 3 + 0) * Nm + m];
                 if (hop < P) {
                     idt = ub[(hop * 3 + 2) * Nm + m];
-                    r = ub[(hop * 3 + 1) * Nm + m];
+                    r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));            // indexes LDS
                     rk = atomicAdd(&sCnt[r], 1);
                 }
             }

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
             const int hop = i / Nm, m = i - hop * Nm;
             sIdH[i] = ub[(hop * 3 + 0) * Nm + m];
             sIdT[i] = ub[(hop * 3 + 2) * Nm + m];
-            const int r = ub[(hop * 3 + 1) * Nm + m];
+            const int r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));   // indexes LDS below
             sRl[i] = r;
             if (hop < P) sMap[r] = 1;
         }

@@ -154,10 +154,13 @@ class ShardedEntityTable(object):
         self.row_scatter = row_scatter or (hip_row_scatter if on_gpu else _torch_row_scatter)
         self.dim = local_rows.shape[1]
         self.work = self.new_work_table()
+        self.refreshes = 0
         self.last_stats = {}
 
     def refresh(self):
-        """Call after the shard's rows changed in place (kept for API symmetry: nothing is staged)."""
+        """Call after the shard's rows changed in place through raw pointers (nothing is staged; tables derived
+        from the working table are rebuilt after the next exchange)."""
+        self.refreshes += 1
 
     def new_work_table(self):
         """A working table: W*n_local rows (>= nE), addressed by shard-space id."""
@@ -232,6 +235,8 @@ class ShardedMVIN(object):
         self._bufs = None
         self._uts = None
         self._check = os.environ.get("MVIN_DIST_CHECK") == "1"
+        self._exchanges = 0
+        self._buf_token = [None, None]
 
     @classmethod
     def build(cls, args, n_user, n_entity, n_relation, adj_entity, adj_relation, params, shard, rank, world,
@@ -298,10 +303,17 @@ class ShardedMVIN(object):
         return [sel[:, :, 0], sel[:, :m.p_hop, 2]]
 
     def _exchange(self, work, users, item_p, mem_h_p, mem_t_p, global_batch):
+        """Fill ``work`` and return its CONTENT TOKEN.  The row movers and collectives write the working table
+        through raw pointers, so torch's version counter does not see them: tables derived from the working table
+        (entity-table mode, MVIN._hoist_key) are keyed on this token instead.  Dense regime: the content is the
+        whole table, the same for every step until the shard changes (its version counter / refresh());
+        sparse regime: a different row set every exchange, so a fresh token every time."""
         if self._regime(item_p.shape[0], global_batch):
             self.table.fetch_all(work)
-        else:
-            self.table.fetch(self.needed(item_p, self._ripple_ids(users, mem_h_p, mem_t_p)), work)
+            return ("dense", self.table.local._version, self.table.refreshes)
+        self.table.fetch(self.needed(item_p, self._ripple_ids(users, mem_h_p, mem_t_p)), work)
+        self._exchanges += 1
+        return ("sparse", self._exchanges)
 
     def _map_feed(self, item_indices, memories_h, memories_t):
         item_p = self.ids(item_indices)
@@ -312,7 +324,7 @@ class ShardedMVIN(object):
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t, global_batch=None, **kw):
         """Exchange, then score (serialised on the current stream).  Original entity ids in."""
         item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
-        self._exchange(self.table.work, user_indices, item_p, mh_p, mt_p, global_batch)
+        self.model._table_token = self._exchange(self.table.work, user_indices, item_p, mh_p, mt_p, global_batch)
         self.model.entity_emb_matrix = self.table.work
         if memories_h is None:
             return self.model.forward_users(user_indices, item_p, self._uts, **kw)
@@ -340,7 +352,7 @@ class ShardedMVIN(object):
             else:
                 self._side.wait_event(self._free[buf])
             item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
-            self._exchange(self._bufs[buf], user_indices, item_p, mh_p, mt_p, global_batch)
+            self._buf_token[buf] = self._exchange(self._bufs[buf], user_indices, item_p, mh_p, mt_p, global_batch)
             ev = torch.cuda.Event()
             ev.record(self._side)
             self._ready[buf] = ev
@@ -350,6 +362,7 @@ class ShardedMVIN(object):
         main = torch.cuda.current_stream()
         main.wait_event(self._ready[buf])
         self.model.entity_emb_matrix = self._bufs[buf]
+        self.model._table_token = self._buf_token[buf]
         item_p, mh_p, mt_p = self._map_feed(item_indices, memories_h, memories_t)
         if memories_h is None:
             out = self.model.forward_users(user_indices, item_p, self._uts, **kw)

@@ -124,10 +124,16 @@ def train_epoch_device(feeder, train_data, batch_size, rng=None, graph=False):
     if model.trainer is None:
         model.trainer = Trainer(model)
     gt = None
-    if graph:
+    if graph and model.trainer.world == 1:     # a data-parallel step keeps its all-reduce eager (GraphedTrainer refuses)
         gt = getattr(model, "_graphed_trainer", None)
-        if gt is None or gt.tr is not model.trainer or gt.users.shape[0] != batch_size:
-            gt = model._graphed_trainer = GraphedTrainer(model.trainer, batch_size)
+        if (gt is None or gt.tr is not model.trainer or gt.users.shape[0] != batch_size
+                or gt._storage_key() != gt._captured):      # set_adjacency / a rebound parameter: capture again
+            try:
+                gt = model._graphed_trainer = GraphedTrainer(model.trainer, batch_size)
+            except RuntimeError as e:                       # capture failed: the same kernels, launched eagerly
+                import warnings
+                warnings.warn(f"hipGraph capture of the training step failed ({e}); running the epoch eagerly")
+                gt = model._graphed_trainer = None
     (rng or np.random).shuffle(train_data)
     dev = model.device
     data = torch.from_numpy(np.ascontiguousarray(train_data)).to(dev)

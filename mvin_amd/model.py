@@ -66,6 +66,7 @@ class MVIN(object):
             raise ValueError("hoist must be False, True or 'step'")
         self.hoist = hoist
         self._hoisted = None
+        self._table_token = None     # see _hoist_key
         self._parse_args(args, adj_entity, adj_relation)
         self._build_inputs()
         self._build_model(n_user, n_entity, n_relation, params, seed)
@@ -176,8 +177,15 @@ class MVIN(object):
                 self.aggregators.append(agg)
         self._profile = None
         self._native_l2_state = None
+        self._native_l2_ws = {}
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
+        # Device-resident feeds (forward_device / forward_users): ids are NOT validated per batch by default (it costs a
+        # host sync; the kernels clamp entity / user / relation ids into their tables instead of reading out of bounds).
+        # True (or MVIN_CHECK_IDS=1): every batch is checked and raises IndexError like the host-feed path and like
+        # the reference's CPU tf.gather (InvalidArgument).  A user_triplet_set is always checked once, when first seen.
+        self.validate_device_ids = os.environ.get("MVIN_CHECK_IDS", "0") == "1"
+        self._uts_ok = None
 
     def _build_train(self):
         """model.py:378-414 (loss + Adam): the backward path is a later row of the scope
@@ -361,9 +369,13 @@ class MVIN(object):
 
     def _hoist_key(self):
         a0 = self._agg[(0, 0)]
-        ts = (self.entity_emb_matrix, self._transfer_W, self._transfer_b, a0.weights, a0.bias, a0.urh_weights,
+        ts = (self._transfer_W, self._transfer_b, a0.weights, a0.bias, a0.urh_weights,
               self.relation_emb_matrix, self.adj_entity, self.adj_relation)
-        return tuple((id(t), t._version) for t in ts)
+        # the entity table: identity + torch version counter, unless its owner writes it behind torch's back
+        # (raw-pointer HIP kernels / collectives of dist.ShardedMVIN) and hands out a content token instead
+        tok = self._table_token
+        ent = (id(self.entity_emb_matrix), self.entity_emb_matrix._version) if tok is None else ("token", tok)
+        return (ent,) + tuple((id(t), t._version) for t in ts)
 
     def hoist_entity_tables(self):
         """Entity-table mode of the two deepest levels (SURVEY.md 7.3-c route 2b; an exact
@@ -552,13 +564,16 @@ class MVIN(object):
         return item_emb, scores, sig, []
 
     # ------------------------------------------------------------------ forward
-    def forward_users(self, user_indices, item_indices, user_triplet_set, want_probs=False):
+    def forward_users(self, user_indices, item_indices, user_triplet_set, want_probs=False, distinct_users=None):
         """The same pass when the caller holds ``user_triplet_set`` on the device ([n_user, max(1,P), 3, n_memory]
         int32, data_loader_user_set.py:392-441) instead of per-pair ripple-set arrays: the feed assembly of
         train.py:117-120 (memories_x[i] = user_triplet_set[user][i][x]) happens inside the key-addressing kernel,
-        which groups the batch's pairs by user and reads each user's rows once (``_key_addressing_grouped``)."""
+        which groups the batch's pairs by user and reads each user's rows once (``_key_addressing_grouped``).
+        ``distinct_users``: how many different users the caller expects in THIS batch when it knows better than
+        "any of n_user" (a rank that scores the pairs of 1/W of the users; a top-K evaluation over 250 users): the
+        static pairs-per-user rule that picks the grouped form uses it instead of n_user."""
         return self.forward_device(user_indices, item_indices, None, None, None, want_probs=want_probs,
-                                   uts=user_triplet_set)
+                                   uts=user_triplet_set, distinct_users=distinct_users)
 
     # ------------------------------------------------------------------ native whole-pass schedule
     def _native_l2_ok(self, item, memories_h, want_probs):
@@ -583,17 +598,20 @@ class MVIN(object):
         t0 = a0.relation_scores() if a0.User_orient_rela else None
         t1 = a1.relation_scores() if a1.User_orient_rela else None
         uo = a.User_orient
-        key = (self._generation, self.entity_emb_matrix.data_ptr(), t0.data_ptr() if t0 is not None else 0,
-               t1.data_ptr() if t1 is not None else 0)
+        # The block is rebuilt when a parameter tensor may have been REPLACED (generation); what legitimately changes
+        # from call to call -- the entity table (ShardedMVIN alternates two working tables), the relation-logit tables
+        # (rebuilt after every optimizer step) and the batch -- is refreshed per call, and the workspaces live outside
+        # the block, per (batch size, stream): no allocation churn on the small-batch path this call exists for, and
+        # two streams scoring the same batch size never share V / o_cat / nagg.
+        key = self._generation
+        ptr = lambda t: t.data_ptr() if t is not None else None
         st = self._native_l2_state
         if st is None or st["key"] != key:
             s = _lib.ScoreL2Args()
-            ptr = lambda t: t.data_ptr() if t is not None else None
-            s.entity_emb, s.adj_entity, s.adj_relation = ptr(self.entity_emb_matrix), ptr(self.adj_entity), ptr(self.adj_relation)
+            s.adj_entity, s.adj_relation = ptr(self.adj_entity), ptr(self.adj_relation)
             s.relation_kge = ptr(self.relation_emb_KGE_matrix)
             s.h_set_w = ptr(self.h_emb_item_mlp_matrix) if a.PS_O_ft else None
             s.user_mlp_W, s.user_mlp_b = ptr(self.user_mlp_matrix), ptr(self.user_mlp_bias)
-            s.t0, s.t1 = ptr(t0), ptr(t1)
             for e in range(3):
                 setattr(s, f"W{e}", ptr(self.transfer_matrix_list[e]) if uo else None)
                 setattr(s, f"b{e}", ptr(self.transfer_matrix_bias[e]) if uo else None)
@@ -601,30 +619,34 @@ class MVIN(object):
             s.Wmix, s.bmix = ptr(self.enti_transfer_matrix_list[0]), ptr(self.enti_transfer_bias_list[0])
             s.D, s.K, s.P, s.Nm = D, self.n_neighbor, P, self.n_memory
             s.n_entity, s.n_relation = self.n_entity, self.n_relation
-            s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
             # every tensor whose address sits in the block is kept alive with it; rebinding a parameter attribute
             # needs invalidate(), exactly as for the cached relation logits
-            keep = (t0, t1, self.entity_emb_matrix, self.adj_entity, self.adj_relation, self.relation_emb_KGE_matrix,
+            keep = (self.adj_entity, self.adj_relation, self.relation_emb_KGE_matrix,
                     self.h_emb_item_mlp_matrix, self.user_mlp_matrix, self.user_mlp_bias, list(self.transfer_matrix_list),
                     list(self.transfer_matrix_bias), a0.weights, a0.bias, a1.weights, a1.bias,
                     self.enti_transfer_matrix_list[0], self.enti_transfer_bias_list[0])
-            st = self._native_l2_state = {"key": key, "args": s, "keep": keep, "ws": {}, "arr": (C.c_void_p * P)}
+            st = self._native_l2_state = {"key": key, "args": s, "keep": keep, "arr": (C.c_void_p * P)}
         s = st["args"]
+        s.entity_emb, s.t0, s.t1 = ptr(self.entity_emb_matrix), ptr(t0), ptr(t1)
+        s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
+        st["live"] = (self.entity_emb_matrix, t0, t1)
         n_o = P + (1 if a.PS_O_ft else 0)
-        ws = st["ws"].get(B)
-        if ws is None:        # workspace reused across calls of the same batch size (the stream orders the reuse)
+        stream = torch.cuda.current_stream()
+        wkey = (B, n_o, stream.cuda_stream)
+        ws = self._native_l2_ws.get(wkey)
+        if ws is None:        # reused across calls of the same batch size ON THE SAME STREAM (which orders the reuse)
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
-            ws = st["ws"][B] = (f(B, self.n_relation, D), f(B, n_o * D), torch.empty(B, dtype=torch.int32, device=self.device),
-                                f(B, D), f(B, D))
-            if len(st["ws"]) > 4:
-                st["ws"].pop(next(iter(st["ws"])))
+            ws = self._native_l2_ws[wkey] = (f(B, self.n_relation, D), f(B, n_o * D),
+                                             torch.empty(B, dtype=torch.int32, device=self.device), f(B, D), f(B, D))
+            if len(self._native_l2_ws) > 8:
+                self._native_l2_ws.pop(next(iter(self._native_l2_ws)))
         user_o = torch.empty((B, D), dtype=torch.float32, device=self.device)
         item_emb = torch.empty((B, D), dtype=torch.float32, device=self.device)
         scores = torch.empty((B,), dtype=torch.float32, device=self.device)
         sig = torch.empty((B,), dtype=torch.float32, device=self.device)
         s.items = item.data_ptr()
         if uts is not None:       # users feed: the kernel reads the lists of users[b] out of user_triplet_set
-            s.uts, s.users = uts.data_ptr(), users.data_ptr()
+            s.uts, s.users, s.n_user = uts.data_ptr(), users.data_ptr(), uts.shape[0]
             s.mem_h = s.mem_r = s.mem_t = None
         else:
             ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
@@ -633,8 +655,7 @@ class MVIN(object):
         s.V, s.o_cat, s.parents, s.nagg0, s.nagg1 = (w.data_ptr() for w in ws)
         s.user_o, s.item_emb, s.scores, s.sig = user_o.data_ptr(), item_emb.data_ptr(), scores.data_ptr(), sig.data_ptr()
         s.B = B
-        _lib.check(_lib.load().mvin_score_l2_fwd(C.byref(s), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "mvin_score_l2_fwd")
+        _lib.check(_lib.load().mvin_score_l2_fwd(C.byref(s), C.c_void_p(stream.cuda_stream)), "mvin_score_l2_fwd")
         return SimpleNamespace(scores=scores, scores_normalized=sig, user_o=user_o, item_embeddings=item_emb,
                                importance_list=[])
 
@@ -650,7 +671,7 @@ class MVIN(object):
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,
-                       want_probs=False, uts=None):
+                       want_probs=False, uts=None, distinct_users=None):
         """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
         [B, n_memory] per hop).  Returns a namespace of device tensors.
         Shared-user form: ripple sets given as ONE [n_memory] list per hop (and ``user_indices`` a
@@ -664,13 +685,22 @@ class MVIN(object):
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
         grouped = False
         if uts is not None:
+            self._check_uts(uts)
+        if self.validate_device_ids:
+            self._check_device_ids(item32, self.n_entity, "item_indices")
+            self._check_device_ids(user32, uts.shape[0] if uts is not None else self.n_user, "user_indices")
+            for lst, lim, what in ((memories_h, self.n_entity, "memories_h"), (memories_r, self.n_relation, "memories_r"),
+                                   (memories_t, self.n_entity, "memories_t")):
+                for m_ in (lst or ()):
+                    self._check_device_ids(m_, lim, what)
+        if uts is not None:
             if user32.numel() == 1 and item32.shape[0] > 1:
                 user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
             # grouping pays when users repeat inside the batch (a user's rows are staged once per segment); with
             # about one pair per user the per-pair kernel is the faster one (measured: amazon-shaped, 32 768 pairs
             # of 70 585 users: 15.5 M vs 10.1 M pairs/s).  Static rule, no device sync: pairs per user >= 4.
             grouped = (need_ps and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
-                       and item32.shape[0] >= self.group_min_pairs_per_user * uts.shape[0]
+                       and item32.shape[0] >= self.group_min_pairs_per_user * min(uts.shape[0], int(distinct_users or uts.shape[0]))
                        and ops.key_addressing_grouped_supported(self.dim, self.p_hop, self.n_memory, self.n_relation))
             if (need_ps and not grouped and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
                     and uts.shape[1] == self.p_hop and uts.shape[3] == self.n_memory and user32.dtype == torch.int64
@@ -721,6 +751,28 @@ class MVIN(object):
                                item_embeddings=item_emb, importance_list=importance)
 
     # ------------------------------------------------------------------ feed handling
+    def _check_uts(self, uts):
+        """A device-resident user_triplet_set is validated ONCE per tensor (identity + torch version): the grouped /
+        users-feed kernels index the entity table, the relation matrices and LDS with its entries."""
+        key = (uts.data_ptr(), uts._version, tuple(uts.shape))
+        if self._uts_ok == key:
+            return
+        if uts.dim() != 4 or uts.shape[2] != 3 or uts.shape[1] != max(1, self.p_hop) or uts.shape[3] != self.n_memory:
+            raise ValueError(f"user_triplet_set must be [n_user, {max(1, self.p_hop)}, 3, {self.n_memory}], "
+                             f"got {tuple(uts.shape)}")
+        P = self.p_hop
+        bad = (uts[:, :, 0] < 0).any() | (uts[:, :, 0] >= self.n_entity).any()
+        if P > 0:
+            r, t = uts[:, :P, 1], uts[:, :P, 2]
+            bad = bad | (r < 0).any() | (r >= self.n_relation).any() | (t < 0).any() | (t >= self.n_entity).any()
+        if bool(bad.item()):
+            raise IndexError("user_triplet_set: id out of range (heads / tails in [0, n_entity), relations in [0, n_relation))")
+        self._uts_ok = key
+
+    def _check_device_ids(self, t, limit, what):
+        if t is not None and t.numel() and bool(((t < 0) | (t >= limit)).any().item()):
+            raise IndexError(f"{what}: id out of range [0, {limit})")
+
     def _to_device_ids(self, v, dtype, limit, what):
         if isinstance(v, torch.Tensor):
             t = v

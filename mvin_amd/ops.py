@@ -316,7 +316,7 @@ def key_addressing_users(entity_emb, V, w, uts, users, P, out, ldo, nR):
     B, Nm, D = users.shape[0], uts.shape[3], entity_emb.shape[1]
     u64, u32 = (_p(users), None) if users.dtype == torch.int64 else (None, _p(users))
     _lib.check(lib.mvin_key_addressing_users_fwd(_p(entity_emb), _p(V), _p(w), _p(uts), u64, u32, P, B, Nm, D, nR,
-                                                 entity_emb.shape[0], _p(out), ldo, bf, _stream()),
+                                                 entity_emb.shape[0], uts.shape[0], _p(out), ldo, bf, _stream()),
                "mvin_key_addressing_users_fwd")
     return out
 

@@ -77,6 +77,39 @@ def main():
     got2 = sh.forward_device(*feed).scores
     assert not torch.allclose(ref2, ref)
     assert torch.allclose(got2, ref2, rtol=1e-5, atol=1e-6), f"rank {rank}: stale entity tables after an exchange"
+    # sparse regime + entity-table mode over TWO different batches: the row movers write the working table through raw
+    # pointers (no torch version bump), so the derived tables must be dropped by the exchange itself
+    sl2 = slice(((rank + 1) % world) * Bl, ((rank + 1) % world + 1) * Bl)
+    feed2 = (torch.from_numpy(case.users[sl2]).to(dev), torch.from_numpy(case.items[sl2]).to(dev),
+             [torch.from_numpy(np.ascontiguousarray(m[sl2])).to(dev) for m in case.memories_h],
+             [torch.from_numpy(np.ascontiguousarray(m[sl2])).to(dev) for m in case.memories_r],
+             [torch.from_numpy(np.ascontiguousarray(m[sl2])).to(dev) for m in case.memories_t])
+    ref_b = ref_model.forward_device(*feed2).scores
+    assert not torch.equal(ref_b, ref)
+    sh = build("sparse", hoist=True)
+    for i, (fd, want) in enumerate(((feed, ref), (feed2, ref_b), (feed, ref))):
+        got = sh.forward_device(*fd).scores
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), f"rank {rank}: sparse + entity tables, batch {i}: stale tables"
+    sh.enable_pipeline()
+    seq = [(feed, ref), (feed2, ref_b), (feed2, ref_b), (feed, ref)]
+    sh.prefetch(0, seq[0][0][0], seq[0][0][1], seq[0][0][2], seq[0][0][4])
+    for i, (fd, want) in enumerate(seq):
+        out = sh.forward_prefetched(i % 2, *fd)
+        if i + 1 < len(seq):
+            nx = seq[i + 1][0]
+            sh.prefetch((i + 1) % 2, nx[0], nx[1], nx[2], nx[4])
+        assert torch.allclose(out.scores, want, rtol=1e-5, atol=1e-6), f"rank {rank}: pipelined sparse + entity tables, step {i}"
+    # dense regime + pipeline: the two working tables hold the same content, so the entity tables are built once
+    sh = build("dense", hoist=True)
+    sh.enable_pipeline()
+    sh.prefetch(0, feed[0], feed[1], feed[2], feed[4])
+    built = []
+    for i in range(3):
+        out = sh.forward_prefetched(i % 2, *feed)
+        sh.prefetch((i + 1) % 2, feed[0], feed[1], feed[2], feed[4])
+        built.append(sh.model._hoisted)
+        assert torch.allclose(out.scores, ref, rtol=1e-5, atol=1e-6)
+    assert built[0] is built[1] is built[2], "dense regime: entity tables rebuilt although the table content is unchanged"
     # data-parallel training: each rank steps on its slice, one all-reduce of the flat gradient buffer;
     # after 3 steps every rank holds the parameters of a single-process trainer fed the whole batch
     from mvin_amd.training import Trainer

@@ -60,6 +60,34 @@ def test_sharded_scores_equal_replicated(collective, regime, hip_lib, nccl_world
     assert torch.equal(got2.scores, ref.scores)
 
 
+def test_sparse_regime_entity_tables_follow_the_exchange(hip_lib, nccl_world1):
+    """the sparse exchange fills the working table through raw-pointer HIP kernels (no torch version
+    bump); entity-table mode (hoist=True) must still rebuild its derived tables for every batch's row set."""
+    from mvin_amd.dist import ShardedMVIN
+    from mvin_amd.model import MVIN
+    args = make_args(dim=32, neighbor_sample_size=8, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=16, batch_size=32)
+    case = synth.small_case(make_args(**dict(vars(args), batch_size=64)), n_user=50, n_entity=5000, n_relation=7, seed=53)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=54, random_agg_bias=True)
+    dev = torch.device("cuda:0")
+    ref_model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                     params=params, device=dev)
+    sh = ShardedMVIN.build(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                           params, torch.from_numpy(params["entity_emb_matrix"]), 0, 1, device=dev,
+                           always_collective=True, regime="sparse", hoist=True)
+
+    def feed(sl):
+        return (torch.from_numpy(case.users[sl]).to(dev), torch.from_numpy(case.items[sl]).to(dev),
+                [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_h],
+                [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_r],
+                [torch.from_numpy(np.ascontiguousarray(m[sl])).to(dev) for m in case.memories_t])
+    fa, fb = feed(slice(0, 32)), feed(slice(32, 64))
+    ra, rb = ref_model.forward_device(*fa).scores, ref_model.forward_device(*fb).scores
+    for i, (fd, want) in enumerate(((fa, ra), (fb, rb), (fa, ra))):
+        got = sh.forward_device(*fd).scores
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), f"batch {i}: stale entity tables"
+        assert sh.table.last_stats["mode"] == "sparse"
+
+
 def _run_ranks(argv, world, extra_env=None, timeout=600):
     import subprocess
     import sys

@@ -108,3 +108,70 @@ def test_device_feeder_uses_the_grouped_path(hip_lib):
     b = model.forward_device(torch.from_numpy(users).to(model.device), torch.from_numpy(items).to(model.device),
                              mh, mr, mt).scores_normalized.cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def _oob_setup(P=2, Nm=32):
+    from mvin_amd.model import MVIN
+    args = make_args(dim=64, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=64)
+    n_user, n_entity, nR = 20, 300, 6
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, 4, seed=1)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=2)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, device="cuda:0", seed=3)
+    rng = np.random.default_rng(1)
+    users, items = rng.integers(0, n_user, 96), rng.integers(0, n_entity, 96)
+    return model, uts, users, items
+
+
+@pytest.mark.parametrize("grouped", [True, False], ids=["grouped", "users_feed"])
+def test_out_of_range_device_user_ids_are_clamped_not_dropped(grouped, hip_lib):
+    """device-resident ids are not validated per batch; a user id outside [0, n_user) must neither leave
+    an output row unwritten (grouped form) nor index user_triplet_set out of bounds (per-pair form): it is clamped."""
+    model, uts, users, items = _oob_setup()
+    model.group_min_pairs_per_user = 0 if grouped else 10 ** 9
+    dev = model.device
+    uts_d = torch.from_numpy(uts).to(dev)
+    bad = users.copy()
+    bad[5], bad[17], bad[40] = 10 ** 6, -3, 20                     # way above, negative, n_user exactly
+    clamped = np.clip(bad, 0, 19)
+    got = model.forward_users(torch.from_numpy(bad).to(dev), torch.from_numpy(items).to(dev), uts_d)
+    want = model.forward_users(torch.from_numpy(clamped).to(dev), torch.from_numpy(items).to(dev), uts_d)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.scores).all()
+    assert torch.equal(got.user_o, want.user_o) and torch.equal(got.scores, want.scores)
+
+
+def test_device_id_validation_raises_like_the_host_feed(hip_lib):
+    """MVIN.validate_device_ids (MVIN_CHECK_IDS=1): IndexError on out-of-range device ids, as _to_device_ids raises for
+    host feeds and the reference's CPU tf.gather raises InvalidArgument; a user_triplet_set is always checked once."""
+    model, uts, users, items = _oob_setup()
+    dev = model.device
+    u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
+    bad_uts = uts.copy()
+    bad_uts[3, 1, 1, 7] = 6                                          # relation id == n_relation
+    with pytest.raises(IndexError):
+        model.forward_users(u_d, i_d, torch.from_numpy(bad_uts).to(dev))
+    bad_uts = uts.copy()
+    bad_uts[0, 0, 0, 0] = 300                                        # head id == n_entity
+    with pytest.raises(IndexError):
+        model.forward_users(u_d, i_d, torch.from_numpy(bad_uts).to(dev))
+    with pytest.raises(ValueError):
+        model.forward_users(u_d, i_d, torch.from_numpy(np.ascontiguousarray(uts[:, :1])).to(dev))   # wrong hop count
+    uts_d = torch.from_numpy(uts).to(dev)
+    model.forward_users(u_d, i_d, uts_d)                             # valid: passes, and is cached
+    assert model._uts_ok is not None
+    model.validate_device_ids = True
+    bu = u_d.clone()
+    bu[2] = 20
+    with pytest.raises(IndexError, match="user_indices"):
+        model.forward_users(bu, i_d, uts_d)
+    bi = i_d.clone()
+    bi[9] = -1
+    with pytest.raises(IndexError, match="item_indices"):
+        model.forward_users(u_d, bi, uts_d)
+    mh, mr, mt = synth.memories_for(uts, users)
+    mr_d = [torch.from_numpy(m).to(dev) for m in mr]
+    mr_d[1][4, 4] = 6
+    with pytest.raises(IndexError, match="memories_r"):
+        model.forward_device(u_d, i_d, [torch.from_numpy(m).to(dev) for m in mh], mr_d,
+                             [torch.from_numpy(m).to(dev) for m in mt])
+    model.forward_users(u_d, i_d, uts_d)                             # valid ids still pass
