@@ -3,7 +3,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 namespace mvin {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{}) -- for software
+// pipelines whose slot / wait-count arithmetic must be constants (a runtime loop's back-edge makes hipcc's waitcnt pass
+// drain the loads in flight)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 constexpr int kWave = 64;    // CDNA wavefront
 constexpr int kBlock = 256;  // 4 waves per workgroup

@@ -432,18 +432,23 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         const int gw = wave - NM;
         const float c2scale = has_att0 ? invK : 1.f;    // (sum_k p_k) / K
         const int g = lane / G::LPRX, c = lane % G::LPRX;
-        const bool buf32 = !BF && a.table_bytes < (1ull << 32);
+        const bool buf32 = a.table_bytes < (1ull << 32);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(a.table), 0, buf32 ? (int)a.table_bytes : 0, 0x00020000);
         const unsigned c16 = (unsigned)c * 16u;
         // addressing mode resolved OUTSIDE the loops (a per-load wave-uniform branch keeps every load in its
-        // own basic block): 0 = bf16 rows, 1 = fp32 through the buffer descriptor, 2 = fp32, 64-bit addresses
+        // own basic block): 0 = bf16 rows, 64-bit addresses; 1 = fp32 through the buffer descriptor; 2 = fp32, 64-bit
+        // addresses; 3 = bf16 rows through the buffer descriptor (one 32-bit offset per load instead of a 64-bit
+        // pointer and its shift / add chain: fewer address registers per load in flight)
         auto run = [&](auto mode_c) {
             constexpr int MODE = decltype(mode_c)::value;
             auto row4 = [&](int id) -> float4 {
                 if constexpr (MODE == 0) {
                     return bf16x4_to_f32(reinterpret_cast<const uint2*>(
                         reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c]);
+                } else if constexpr (MODE == 3) {
+                    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)id * (unsigned)(D * 2)) + (unsigned)c * 8u, 0, 0);
+                    return bf16x4_to_f32(make_uint2(raw[0], raw[1]));
                 } else if constexpr (MODE == 1) {
                     const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
                     return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
@@ -453,9 +458,15 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                 }
             };
             auto load8 = [&](int id, float4& lo, float4& hi) {
-                const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
-                lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
-                hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
+                if constexpr (MODE == 3) {
+                    const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 2)) + c16, 0, 0);
+                    lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
+                    hi = bf16x4_to_f32(make_uint2(raw[2], raw[3]));
+                } else {
+                    const uint4 raw = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(a.table) + (int64_t)id * D)[c];
+                    lo = bf16x4_to_f32(make_uint2(raw.x, raw.y));
+                    hi = bf16x4_to_f32(make_uint2(raw.z, raw.w));
+                }
             };
             auto put = [&](float* dst, float4 lo, float4 hi) {
                 float* q = dst + G::EPL * c;
@@ -481,13 +492,45 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
                         float4 sv, sv1 = acc;
                         if constexpr (G::WIDE) {
                             load8(sX1[slot * KT + tile * TM + nl], sv, sv1);
-#pragma unroll 8
-                            for (int k = 0; k < KT; ++k) {
+                            auto body = [&](int k) {
                                 const int2 e = yp[k];
                                 float4 lo, hi;
                                 load8(e.x, lo, hi);
                                 acc = f4_fma(__int_as_float(e.y), lo, acc);
                                 acc1 = f4_fma(__int_as_float(e.y), hi, acc1);
+                            };
+                            if constexpr (UNR == 48 && MODE == 3) {
+                                // two register batches of HB rows in rotation: HB .. 2*HB loads in flight per lane, no drain
+                                // between batches.  Named arrays + a runtime loop: left to the unroller hipcc serialises
+                                // load -> use beyond 8 rows, in one fully unrolled block it sinks every load to its use,
+                                // and an indexed ring of batches goes to scratch (all measured).
+                                constexpr int HB = 8;
+                                static_assert(KT % (2 * HB) == 0, "K must be a multiple of two batches");
+                                auto issue = [&](u32x4 (&r)[HB], int k0) {
+#pragma unroll
+                                    for (int i = 0; i < HB; ++i)
+                                        r[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                                            rsrc, ((unsigned)yp[k0 + i].x * (unsigned)(D * 2)) + c16, 0, 0);
+                                };
+                                auto consume = [&](const u32x4 (&r)[HB], int k0) {
+#pragma unroll
+                                    for (int i = 0; i < HB; ++i) {
+                                        const float w = __int_as_float(yp[k0 + i].y);
+                                        acc = f4_fma(w, bf16x4_to_f32(make_uint2(r[i][0], r[i][1])), acc);
+                                        acc1 = f4_fma(w, bf16x4_to_f32(make_uint2(r[i][2], r[i][3])), acc1);
+                                    }
+                                };
+                                u32x4 ra[HB], rb[HB];
+                                issue(ra, 0);
+                                for (int k0 = 0; k0 < KT; k0 += 2 * HB) {
+                                    issue(rb, k0 + HB);
+                                    consume(ra, k0);
+                                    if (k0 + 2 * HB < KT) issue(ra, k0 + 2 * HB);
+                                    consume(rb, k0 + HB);
+                                }
+                            } else {
+#pragma unroll 8
+                                for (int k = 0; k < KT; ++k) body(k);
                             }
                         } else {
                             sv = row4(sX1[slot * KT + tile * TM + nl]);     // first: lands under the K row loads
@@ -516,7 +559,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, split_minw(D, NG)) void gather_
         __syncthreads();   // parents 0 / 1 in the ring
         __syncthreads();   // id list of tile 0
         if constexpr (BF) {
-            run(std::integral_constant<int, 0>{});
+            if (buf32) run(std::integral_constant<int, 3>{});
+            else run(std::integral_constant<int, 0>{});
         } else {
             if (buf32) run(std::integral_constant<int, 1>{});
             else run(std::integral_constant<int, 2>{});
@@ -553,20 +597,32 @@ bool fused_split_applies(const FusedL2Args& a, int D) {
            a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31);
 }
 
+// rows in flight per lane in the gather loop: 16 (the unroller's batches) everywhere, except at D = 128 on a bf16 table
+// (168-VGPR budget, one workgroup per CU, so only 4 gather waves feed the texture path): two register batches of 8 in
+// rotation for K >= 64 (UNR = 48; C5, K = 128: 10.9 -> 13.3 TB/s; K = 64: 9.2 -> 10.5).  The same rotation spills in the 128-VGPR kernels (C3 / C4: 5-10x slower)
+// and three batches / batches of 16 spill at D = 128 too.  MVIN_SPLIT_UNR = 8 / 16 selects the older variants (A/B).
 template <int D, bool BF, int NG>
 static hipError_t launch_split_k(const FusedL2Args& a, hipStream_t st) {
+    static const char* u = getenv("MVIN_SPLIT_UNR");
+    const int unr = u ? atoi(u) : 0;
+    constexpr bool ROT = D == 128 && BF;
     switch (a.K) {
-        case 32: {
-            // experiment knob: rows in flight per lane in the gather loop (default 16)
-            static const char* u = getenv("MVIN_SPLIT_UNR");
-            if (u && atoi(u) == 8) return launch_split<D, 32, BF, NG, 8>(a, st);
+        case 32:
+            if (unr == 8) return launch_split<D, 32, BF, NG, 8>(a, st);
             if constexpr (D == 64 && !BF) {
                 if (a.dbg) return launch_split<D, 32, BF, NG, 16, true>(a, st);     // MVIN_SPLIT_DBG: traced build
             }
-            return launch_split<D, 32, BF, NG>(a, st);
-        }
-        case 64: return launch_split<D, 64, BF, NG>(a, st);
-        case 128: return launch_split<D, 128, BF, NG>(a, st);
+            return launch_split<D, 32, BF, NG>(a, st);      // K = 32: the rotation is slower (2.9 -> 4.5 ms, D = 128 bf16)
+        case 64:
+            if constexpr (ROT) {
+                if (unr != 16) return launch_split<D, 64, BF, NG, 48>(a, st);
+            }
+            return launch_split<D, 64, BF, NG>(a, st);
+        case 128:
+            if constexpr (ROT) {
+                if (unr != 16) return launch_split<D, 128, BF, NG, 48>(a, st);
+            }
+            return launch_split<D, 128, BF, NG>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

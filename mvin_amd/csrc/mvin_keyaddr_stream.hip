@@ -45,14 +45,6 @@ __device__ __forceinline__ void wait_dma() {
 }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
 template <int V>
 using ic = std::integral_constant<int, V>;
 
