@@ -147,7 +147,9 @@ int mvin_gather_attn_l2_supported(int D, int K);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
- * probs, adjacency and outputs below 2 GiB).  n_parents = B * parents_per_pair.  For tests and benchmarks. */
+ * probs, adjacency and outputs below 2 GiB), 3 = the wave-per-parent kernel for D = 16, K in {4, 8, 16} (the
+ * reference's shipped settings: no workgroup phases at all; no probs, table below 4 GiB).
+ * n_parents = B * parents_per_pair.  For tests and benchmarks. */
 int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);
 /* Measurement aid: the row gathers of mvin_gather_attn_l2_fwd and nothing else, written the plain way (one wave per
  * parent, 8 loads in flight per lane).  child_ids [n_parents, K] and grandchild_ids [n_parents, K*K] are levels 1 and 2

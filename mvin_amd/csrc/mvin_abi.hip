@@ -172,7 +172,9 @@ int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, i
     f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
     float probe = 0.f;
     if (want_probs) f.probs_parent = f.probs_child = &probe;     // only tested for presence
-    return mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D) ? 2 : 1;
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 2;        // the smaller (bf16) size: sufficient for either dtype here
+    if (mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D)) return 2;
+    return mvin::fused_d16_applies(f, D) ? 3 : 1;
 }
 
 // pid_stride 2: parent_ids points at an int64 [P] array whose low words are read (the item ids of the reference's

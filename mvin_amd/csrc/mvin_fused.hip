@@ -607,6 +607,8 @@ hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hi
     // D >= 32, K in {16 (D = 32), 32, 64, 128}: the role-split pipeline (gather waves + dense waves);
     // MVIN_L2_SPLIT=0 keeps the symmetric kernel below for A/B measurements
     if (fused_l2_split_in_use() && fused_split_applies(a, D)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
+    // D = 16, K <= 16 (the reference's shipped settings): one wave per parent, no workgroup phases
+    if (fused_d16_applies(a, D)) return launch_gather_attn_l2_d16(a, table_bf16, st);
     static const bool no_small = getenv("MVIN_L2_NOSMALL") != nullptr;
     const bool small = a.K <= 16 && !no_small;
     if (table_bf16) {

@@ -1,0 +1,290 @@
+// Fused two-level gather + attention kernel for D = 16 and fan-out K in {4, 8, 16} (gfx950) -- the shapes the
+// reference's own run scripts use (src/bash/mvin_*.sh: --dim 16 --neighbor_sample_size 8 --h_hop 2).
+//
+// Same arguments, arithmetic and outputs as gather_attn_l2_kernel (mvin_fused.hip; reference model.py:251-305,
+// aggregators.py:98-146).  What changes is the mapping: a parent's whole two-level tree is 1 + K + K^2 <= 273 rows of
+// 64 bytes, so ONE WAVE owns a parent end to end and nothing is shared between waves -- no workgroup barrier, no
+// tile ownership, no id lists in LDS.  The general kernel spends ~12 000 cycles per parent at these shapes (161
+// VGPRs, 8 waves per CU, a serial chain of phases built for 32-row tiles); here a wave needs < 80 registers, so 24+
+// waves per CU hide the three dependent load levels (parent adjacency -> child adjacency -> rows) behind each other.
+//
+// Lane layout (64 lanes = 4 x K x NKH, NKH = 16 / K):  lane = c + 4 * n + 4 * K * kh
+//   c  : 16-byte chunk of a 64-byte row (4 lanes per row, 16 rows per wave-instruction)
+//   n  : child of the parent (0 .. K-1)
+//   kh : which KPL = K / NKH consecutive grandchildren of child n this lane gathers (K = 8: two halves of 4;
+//        K = 16: one lane group takes all 16; K = 4: four groups of 1)
+// Every lane loads the ids it needs itself (its child id, then its KPL grandchild ids as one 4 / 16 / 64-byte read), so
+// no id ever crosses lanes; the softmax over a child's K grandchildren and the weighted row sum are in-lane over KPL
+// plus v_permlane swaps across kh; the softmax over the parent's K children is a whole-wave reduction (every child
+// is held by 64 / K lanes).  The dense part (aggregators.py:108-116 after the sum, see mvin_fused.hip) runs on
+// v_mfma_f32_16x16x4_f32 with the K children as the rows of one 16-row tile staged through a private LDS slice.
+#include <cstdlib>
+
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kD16 = 16;
+constexpr int kD16Ld = 20;                                   // LDS row stride (floats): 16-byte aligned rows
+constexpr int kD16WaveWords = 3 * 16 * kD16Ld + 32;         // sA1 | sA2 | sZ | sP0 | sP1 per wave
+constexpr int kD16Waves = 4;
+
+size_t fused_d16_lds_bytes(int nR) { return (size_t)(2 * ((nR + 3) & ~3) + kD16Waves * kD16WaveWords) * 4; }
+
+template <int K, bool BF>
+__global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(FusedL2Args a) {
+    constexpr int D = kD16, LD = kD16Ld;
+    constexpr int NKH = 16 / K;              // lane groups per child
+    constexpr int KPL = K / NKH;             // grandchildren per lane: 1 (K=4), 4 (K=8), 16 (K=16)
+    constexpr int RB = BF ? 32 : 64;         // row bytes
+    static_assert(K == 4 || K == 8 || K == 16, "K");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nRp = (a.nR + 3) & ~3;
+    float* sT0 = smem;                                   // [nRp] relation logits of aggregator (0,.) (zeros: uniform)
+    float* sT1 = sT0 + nRp;                              // [nRp] ... of aggregator (1,.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wbase = sT1 + nRp + wave * kD16WaveWords;     // this wave's private slice
+    float* sA1 = wbase;                                  // [16][LD]  E[x1] + q
+    float* sA2 = sA1 + 16 * LD;                          // [16][LD]  S' + (sum_k p_k / K) q
+    float* sZ = sA2 + 16 * LD;                           // [16][LD]
+    float* sP0 = sZ + 16 * LD;                           // [16]
+    float* sP1 = sP0 + 16;                               // [16]
+    const bool has_proj = a.W1 != nullptr;
+    const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
+    const float invK = 1.f / (float)K;
+    const float c2scale = has_att0 ? invK : 1.f;         // sum_k of the grandchild weights
+
+    for (int i = tid; i < a.nR; i += kD16Waves * 64) {
+        sT0[i] = has_att0 ? a.t0[i] : 0.f;
+        sT1[i] = has_att1 ? a.t1[i] : 0.f;
+    }
+    for (int i = lane; i < kD16WaveWords; i += 64) wbase[i] = 0.f;       // tile rows >= K stay zero (weights 0)
+    __syncthreads();                                     // the only workgroup barrier: the two shared tables
+
+    const int c = lane & 3, n = (lane >> 2) & (K - 1), kh = lane / (4 * K);
+    const int q16 = lane >> 4, l16 = lane & 15;
+    // weights as MFMA B fragments, contraction index permuted (step s, slot q16 <-> k = 4*q16 + s) so that a lane's A
+    // operands of the four steps are the four floats of one 16-byte LDS read
+    float bW1[4], bW2[4], bA0[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kk = 4 * q16 + s;
+        bW1[s] = has_proj ? a.W1[kk * D + l16] : 0.f;
+        bW2[s] = has_proj ? a.W2[kk * D + l16] : 0.f;
+        bA0[s] = a.A0[kk * D + l16];
+    }
+    const float b1v = (has_proj && a.b1) ? a.b1[l16] : 0.f;
+    const float b2v = ((has_proj && a.b2) ? a.b2[l16] : 0.f) * c2scale;
+    const float a0v = a.a0 ? a.a0[l16] : 0.f;
+
+    // 32-bit offsets through buffer descriptors (the launcher guarantees every range < 2^31 / 2^32 bytes)
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, a.adj_r ? (int)a.adj_bytes : 0,
+                                                                           0x00020000);      // none: relation ids read as 0
+    const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out0 = __builtin_amdgcn_make_buffer_rsrc(a.nagg0, 0, (int)(a.P * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out1 = __builtin_amdgcn_make_buffer_rsrc(a.nagg1, 0, (int)(a.P * D * 4), 0x00020000);
+    auto row4 = [&](int id) -> float4 {                 // chunk c of table row `id`
+        if constexpr (BF) {
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 8u, 0, 0);
+            return bf16x4_to_f32(make_uint2(r[0], r[1]));
+        } else {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 16u, 0, 0);
+            return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+    };
+    auto across_kh_max = [&](float v) {
+        if constexpr (NKH >= 4) v = xor16_max(v);
+        if constexpr (NKH >= 2) v = xor32_max(v);
+        return v;
+    };
+    auto across_kh_sum = [&](float v) {
+        if constexpr (NKH >= 4) v = xor16_sum(v);
+        if constexpr (NKH >= 2) v = xor32_sum(v);
+        return v;
+    };
+
+    const int64_t nwaves = (int64_t)gridDim.x * kD16Waves;
+    for (int64_t p = (int64_t)blockIdx.x * kD16Waves + wave; p < a.P; p += nwaves) {
+        const int x0 = fused_parent_id(a, p);
+        // ---- level L-1: this lane's child (model.py:251-252) ----
+        const unsigned o1 = ((unsigned)x0 * K + (unsigned)n) * 4u;
+        const int x1 = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o1, 0, 0);
+        const int r1 = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o1, 0, 0);
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+        {   // no projection: zero records, the load returns 0 without touching memory
+            const unsigned qo = (((unsigned)p / (unsigned)a.parents_per_pair) * D + 4u * c) * 4u;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qo, 0, 0);
+            qv = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+        // ---- level L: this lane's KPL grandchildren of child n ----
+        const unsigned o2 = ((unsigned)x1 * K + (unsigned)(kh * KPL)) * 4u;
+        int ye[KPL], re[KPL];
+        if constexpr (KPL == 1) {
+            ye[0] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o2, 0, 0);
+            re[0] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o2, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < KPL / 4; ++j) {
+                const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, o2 + 16u * j, 0, 0);
+                const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, o2 + 16u * j, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ye[4 * j + i] = (int)e4[i];
+                    re[4 * j + i] = (int)r4[i];
+                }
+            }
+        }
+        const float4 sv = row4(x1);                      // the child's own row lands under the grandchild rows
+        // ---- attention over the parent's K children: aggregator (0,.) -> p0, aggregator (1,.) -> p1 ----
+        float p0 = 1.f, p1 = 1.f;
+        {
+            const float s0 = sT0[r1], s1 = sT1[r1];
+            if (has_att0) {
+                const float e = expf(s0 - wave_max_fast(s0));
+                p0 = e / (wave_sum_fast(e) * (K / 64.f));             // every child sits in 64 / K lanes
+            }
+            if (has_att1) {
+                const float e = expf(s1 - wave_max_fast(s1));
+                p1 = e / (wave_sum_fast(e) * (K / 64.f));
+            }
+        }
+        // ---- attention over child n's K grandchildren (aggregators.py:118-146): weights p_k / K ----
+        float w[KPL];
+        {
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                w[i] = sT0[re[i]];
+                m = fmaxf(m, w[i]);
+            }
+            m = across_kh_max(m);
+            float z = 0.f;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) {
+                w[i] = has_att0 ? expf(w[i] - m) : 1.f;
+                z += w[i];
+            }
+            z = across_kh_sum(z);
+            const float rinv = has_att0 ? invK / z : invK;
+#pragma unroll
+            for (int i = 0; i < KPL; ++i) w[i] *= rinv;
+        }
+        // ---- S' = sum_k (p_k / K) E[y_k]: KPL rows in-lane (batches of 8 loads), then across the kh groups ----
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr int NB = KPL < 8 ? KPL : 8;
+#pragma unroll
+        for (int i0 = 0; i0 < KPL; i0 += NB) {
+            float4 rows[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rows[i] = row4(ye[i0 + i]);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) acc = f4_fma(w[i0 + i], rows[i], acc);
+        }
+        acc = make_float4(across_kh_sum(acc.x), across_kh_sum(acc.y), across_kh_sum(acc.z), across_kh_sum(acc.w));
+        // ---- the K children as rows of a 16-row tile: {E[x1] + q | S' + (sum p / K) q} (model.py:277) ----
+        if (kh == 0) {
+            *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv.x + qv.x, sv.y + qv.y, sv.z + qv.z, sv.w + qv.w);
+            *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = f4_fma(c2scale, qv, acc);
+            if (c == 0) {
+                sP0[n] = p0;
+                sP1[n] = p1;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // ---- phase B: self1 = (E[x1] + q) W1 + b1 ; Z = self1 + (S' + c q) W2 + c b2 ; nagg0 = sum_n p0[n] self1[n] ----
+        float s1v[4], zv[4];
+        if (has_proj) {
+            const float4 f1 = *reinterpret_cast<const float4*>(sA1 + l16 * LD + 4 * q16);
+            const float4 f2 = *reinterpret_cast<const float4*>(sA2 + l16 * LD + 4 * q16);
+            f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accS = {0.f, 0.f, 0.f, 0.f};
+            accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.x, bW1[0], accE, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2.x, bW2[0], accS, 0, 0, 0);
+            accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.y, bW1[1], accE, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2.y, bW2[1], accS, 0, 0, 0);
+            accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.z, bW1[2], accE, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2.z, bW2[2], accS, 0, 0, 0);
+            accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1.w, bW1[3], accE, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2.w, bW2[3], accS, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1v[r] = accE[r] + b1v;
+                zv[r] = s1v[r] + (accS[r] + b2v);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1v[r] = sA1[(4 * q16 + r) * LD + l16];
+                zv[r] = s1v[r] + sA2[(4 * q16 + r) * LD + l16];
+            }
+        }
+        float part0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            part0 = fmaf(sP0[4 * q16 + r], s1v[r], part0);
+            sZ[(4 * q16 + r) * LD + l16] = zv[r];
+        }
+        const float nagg0 = rows_combine_sum(part0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // ---- phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1 = sum_n p1[n] out1[n] ----
+        const float4 fz = *reinterpret_cast<const float4*>(sZ + l16 * LD + 4 * q16);
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz.x, bA0[0], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz.y, bA0[1], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz.z, bA0[2], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz.w, bA0[3], acc2, 0, 0, 0);
+        float part1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v, 0.f), part1);
+        const float nagg1 = rows_combine_sum(part1);
+        if (q16 == 0) {
+            const unsigned off = ((unsigned)p * D + (unsigned)l16) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0 * invK), out0, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1 * invK), out1, off, 0, 0);
+        }
+        // the next parent's tile writes must stay behind this parent's tile reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+bool fused_d16_supported(int D, int K) { return D == 16 && (K == 4 || K == 8 || K == 16); }
+
+// ... and for these arguments: no attention outputs requested, every buffer addressable with 32-bit byte offsets
+bool fused_d16_applies(const FusedL2Args& a, int D) {
+    static const char* e = getenv("MVIN_L2_D16");
+    if (e && e[0] == '0') return false;                  // A/B: keep gather_attn_l2_kernel
+    return fused_d16_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
+           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31);
+}
+
+template <int K, bool BF>
+static hipError_t launch_d16(const FusedL2Args& a, hipStream_t st) {
+    const size_t lds = fused_d16_lds_bytes(a.nR);
+    const int64_t wgs = (a.P + kD16Waves - 1) / kD16Waves;
+    const int64_t cap = 256 * 8;                         // persistent: up to 32 waves per CU
+    const int grid = (int)(wgs < cap ? wgs : cap);
+    gather_attn_l2_d16_kernel<K, BF><<<grid, kD16Waves * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_attn_l2_d16(const FusedL2Args& a, int table_bf16, hipStream_t st) {
+    switch (a.K) {
+        case 4: return table_bf16 ? launch_d16<4, true>(a, st) : launch_d16<4, false>(a, st);
+        case 8: return table_bf16 ? launch_d16<8, true>(a, st) : launch_d16<8, false>(a, st);
+        case 16: return table_bf16 ? launch_d16<16, true>(a, st) : launch_d16<16, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin
