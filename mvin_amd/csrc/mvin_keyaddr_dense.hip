@@ -25,7 +25,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // development aid (MVIN_KA_TRACE=1, scripts/trace_keyaddr.py): workgroup 0 stamps s_memtime at its phase boundaries
 __device__ long long g_ka_trace[64 * 16];
-constexpr int kDW = 12;      // waves per workgroup (168 VGPRs each: room for the resident R_KGE fragments)
+// waves per workgroup: 12 (168 VGPRs each: room for the resident R_KGE fragments; one workgroup per CU), or 4 at D = 16,
+// where a segment's tiles are a quarter of the work and its LDS a quarter of the space: four workgroups per CU instead of
+// one, i.e. four user segments' dependent phases in flight per CU (the kernel is latency-bound per segment)
+constexpr int ka_dense_waves(int D) { return D == 16 ? 4 : D == 32 ? 8 : 12; }
+constexpr int ka_dense_minw(int D) { return D == 32 ? 4 : 1; }       // waves per SIMD the register budget is cut for
 constexpr int kDT = 16;      // pairs per tile
 
 struct KaDenseLds {
@@ -65,7 +69,8 @@ static KaDenseLds ka_dense_layout(int D, int P, int Nm, int nR) {
 }
 
 template <int D, bool BF, bool TRACE>
-__global__ __launch_bounds__(kDW * 64) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
+__global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
+    constexpr int kDW = ka_dense_waves(D);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LPR = D / 4, RPW = 64 / LPR, NT = D / 16, KS = D / 4, LDH = D + 2, LDT = D + 16, NTHR = kDW * 64;
     constexpr int LPR_L2 = (LPR == 4) ? 2 : (LPR == 8) ? 3 : (LPR == 16) ? 4 : 5;
@@ -404,20 +409,34 @@ bool key_addr_dense_supported(int D, int P, int Nm, int nR) {
 template <int D>
 static hipError_t launch_kad(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
     const KaDenseLds L = ka_dense_layout(D, a.P, a.Nm, a.nR);
-    const int cap = 256;                                     // 16 waves: one workgroup per CU
-    const int grid = a.nseg < cap ? a.nseg : cap;
+    constexpr int kDW = ka_dense_waves(D);
     hipError_t e = hipSuccess;
+    // persistent grid: as many workgroups as the CUs hold (registers, LDS and wave slots decide: 1 per CU at D >= 32)
+    auto grid_for = [&](const void* k) {
+        static thread_local const void* last_k = nullptr;      // the query is host-side arithmetic, but not free
+        static thread_local size_t last_lds = 0;
+        static thread_local int last_per_cu = 1;
+        if (k != last_k || L.total != last_lds) {
+            int per_cu = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kDW * 64, L.total) != hipSuccess || per_cu < 1) per_cu = 1;
+            last_k = k;
+            last_lds = L.total;
+            last_per_cu = per_cu;
+        }
+        const int cap = 256 * last_per_cu;
+        return a.nseg < cap ? a.nseg : cap;
+    };
     if (table_bf16) {
         auto k = key_addr_dense_kernel<D, true, false>;
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
-        k<<<grid, kDW * 64, L.total, st>>>(a, L);
+        k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(a, L);
     } else {
         static const bool trace = getenv("MVIN_KA_TRACE") != nullptr;
         auto k = (D == 64 && trace) ? key_addr_dense_kernel<D, false, true> : key_addr_dense_kernel<D, false, false>;
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
-        k<<<grid, kDW * 64, L.total, st>>>(a, L);
+        k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(a, L);
     }
     return hipGetLastError();
 }
