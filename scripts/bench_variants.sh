@@ -25,6 +25,19 @@ run $C2 --batch 524288
 run $C4
 run $C4 --feed pairs
 run $C5 --batch 64 --steps 3 --warmup 1
+# the reference's shipped settings (src/bash/mvin_*.sh: dim 16, fan-out 8, depth 2)
+S="--dim 16 --fanout 8"
+run $S
+run $S --batch 512 --feed pairs
+run $S --dataset MovieLens-1M
+run $S --dataset MovieLens-1M --batch 1024 --feed pairs
+run $S --dataset amazon-book_20core
+MVIN_L2_D16=0 run $S                             # general fused kernel instead of the wave-per-parent one (A/B)
+# projection of the multi-GPU line on one GPU (rank 0's share, user-sorted split, exchange included)
+run --emulate-world 2
+run --emulate-world 4
+run --emulate-world 8
+MVIN_SPLIT_UNR=16 run $C5 --batch 64 --steps 3 --warmup 1     # C5 without the two-batch rotation (A/B)
 MVIN_L2_SPLIT=0 run --feed pairs                # symmetric fused kernel (round-1 design) for A/B
 MVIN_L2_SPLIT=0 run $C4 --feed pairs
 MVIN_L2_SPLIT=0 run $C5 --batch 64 --steps 3 --warmup 1
