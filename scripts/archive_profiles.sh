@@ -1,9 +1,9 @@
 #!/bin/bash
-# Build container: copy the summaries scripts/collect_all.sh <tag> left under gpurun_out/ into profiles/r2/<prefix>_*
-# (gpurun_out/ is scratch; profiles/ is what is committed and judged).
-tag=$1; p=$2
+# Build container: copy the summaries scripts/collect_all.sh <tag> left under gpurun_out/ into profiles/<round>/<prefix>_*
+# (gpurun_out/ is scratch; profiles/ is what is committed and judged).  usage: archive_profiles.sh <tag> <prefix> [round=r3]
+tag=$1; p=$2; round=${3:-r3}
 root=$(cd "$(dirname "$0")/.." && pwd); cd "$root"
-g=gpurun_out; d=profiles/r2; mkdir -p $d
+g=gpurun_out; d=profiles/$round; mkdir -p $d
 cp $g/prof_$tag/kernel_stats.csv $d/${p}_c3_B524288_kernel_stats.csv
 cp $g/prof_$tag/bench.json $d/${p}_c3_B524288_bench.json
 cp $g/prof_$tag/pmc.json $d/${p}_c3_B524288_pmc.json
@@ -13,7 +13,7 @@ cp $g/prof_$tag/pmc_hbm_leg.json $d/${p}_hbm_leg_pmc.json
 cp $g/prof_$tag/pmc.json profiles/pmc_latest.json
 cp $g/prof_$tag/pmc_hbm_leg.json profiles/pmc_hbm_leg.json
 cp $g/pmc_$tag/counters.json $d/${p}_c3_sq_tcp_tcc_counters.json
-for v in c3_pairs c2 c4 c5; do
+for v in c3_pairs c2 c4 c5 shipped shipped_b512; do
   f=$(ls $g/ks_${tag}_$v/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" $d/${p}_${v}_kernel_stats.csv
 done

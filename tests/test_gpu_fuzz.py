@@ -1,0 +1,83 @@
+"""-m gpu: seeded random sweep over the configuration space of the path (dim, fan-out, depth, mix blocks, ripple hops,
+memories, relations, batch, ablation preset, table dtype, feed form) against the fp32 mirror and the fp64 equations.
+The hand-picked shapes of the other parity tests pin every kernel instance; this one looks for interactions nobody
+thought of (a ragged batch with a depth-3 tree, a preset without attention on the D = 16 kernel, one pair per user
+in the grouped kernel, ...).  Sizes are kept where the CPU oracles finish in well under a second per case."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import synth
+from mvin_amd.config import ABLATIONS, make_args
+from mvin_amd.params import init_params
+
+from parity import assert_close, run_oracles
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 48
+
+
+def _draw(i):
+    rng = np.random.default_rng(9000 + i)
+    D = int(rng.choice([8, 12, 16, 16, 32, 32, 64, 64, 128]))
+    K = int(rng.choice([2, 3, 4, 8, 8, 16, 32, 5]))
+    H = int(rng.choice([1, 2, 2, 2, 3]))
+    M = int(rng.choice([1, 1, 1, 2]))
+    while K ** (H * M) > 4096:                      # rows per pair the oracles gather
+        if M > 1:
+            M = 1
+        elif H > 1:
+            H -= 1
+        else:
+            K = 4
+    P = int(rng.choice([1, 2, 2, 3]))
+    Nm = int(rng.choice([3, 4, 8, 16, 32, 64]))
+    nR = int(rng.choice([2, 5, 9, 12, 39]))
+    B = int(rng.choice([1, 2, 7, 16, 33, 64, 129]))
+    n_user = int(rng.choice([1, 3, 17, 200]))
+    abl = str(rng.choice(sorted(ABLATIONS)))
+    tdt = "bf16" if (rng.random() < 0.25 and D % 8 == 0) else "f32"
+    feed = str(rng.choice(["pairs", "users", "users_grouped"]))
+    fused = bool(rng.random() < 0.8)
+    return dict(D=D, K=K, H=H, M=M, P=P, Nm=Nm, nR=nR, B=B, n_user=n_user, abl=abl, tdt=tdt, feed=feed, fused=fused)
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_random_configuration(i, hip_lib):
+    from mvin_amd.model import MVIN
+    c = _draw(i)
+    args = make_args(dim=c["D"], neighbor_sample_size=c["K"], h_hop=c["H"], n_mix_hop=c["M"], p_hop=c["P"],
+                     n_memory=c["Nm"], batch_size=c["B"], ablation=c["abl"])
+    n_entity = 150 + 37 * (i % 5)
+    case = synth.small_case(args, n_user=c["n_user"], n_entity=n_entity, n_relation=c["nR"], seed=9100 + i, zero_rows=3)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=9200 + i, random_agg_bias=True)
+    oracle_params = params
+    if c["tdt"] == "bf16":
+        oracle_params = dict(params, entity_emb_matrix=torch.from_numpy(params["entity_emb_matrix"]).to(torch.bfloat16).float().numpy())
+    # the users feeds read user_triplet_set[user]: make the per-pair arrays of the oracle exactly those rows
+    uts = synth.ripple_sets(case.n_user, case.n_entity, case.n_relation, max(1, c["P"]), c["Nm"], seed=9300 + i)
+    if c["feed"] != "pairs":
+        case.memories_h, case.memories_r, case.memories_t = synth.memories_for(uts, case.users)
+    m, e = run_oracles(args, case, oracle_params)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+                 device="cuda:0", fused=c["fused"], table_dtype=c["tdt"])
+    dev = model.device
+    u_d, i_d = torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev)
+    if c["feed"] == "pairs":
+        out = model.forward_device(u_d, i_d, [torch.from_numpy(x).to(dev) for x in case.memories_h],
+                                   [torch.from_numpy(x).to(dev) for x in case.memories_r],
+                                   [torch.from_numpy(x).to(dev) for x in case.memories_t])
+    else:
+        model.group_min_pairs_per_user = 0 if c["feed"] == "users_grouped" else 10 ** 9
+        out = model.forward_users(u_d, i_d, torch.from_numpy(uts).to(dev))
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-5, atol=1e-6) if c["tdt"] == "f32" else dict(rtol=1e-5, atol=2e-6)
+    what = f"case {i} {c}"
+    got = out.scores.cpu().numpy()
+    assert_close(got, m.scores.numpy(), f"scores vs fp32 mirror, {what}", **tol)
+    assert_close(out.user_o.cpu().numpy(), m.user_o.numpy(), f"user_o, {what}", **tol)
+    assert_close(out.item_embeddings.cpu().numpy(), m.item_embeddings.numpy(), f"item_embeddings, {what}", **tol)
+    err_hip = np.abs(got - e.scores).max()
+    err_mir = np.abs(m.scores.numpy() - e.scores).max()
+    assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
