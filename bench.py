@@ -302,6 +302,59 @@ def shipped_config(a, dev, steps=10, warmup=3):
                      {"batch": Bs, "feed": "pairs", "pairs_per_s": Bs / dt_small, "us_per_step": 1e6 * dt_small}]}
 
 
+def c1_plumbing(a, dev, cpu_threads, warmup=3, iters=10):
+    """BASELINE.json configs[0] -- MovieLens-1M-shaped tables, dim 16, ONE hop, fan-out 8, the reference's own batch of
+    1 024 (mvin_movie.sh): the configuration SURVEY 8(d) makes mandatory for the CPU column.  The torch-CPU mirror of
+    the TF graph and the HIP path score the SAME 1 024 pairs (3 warm-ups + 10 timed passes, median); the scores are compared."""
+    import torch
+    from oracle import mirror_fp32
+    from mvin_amd import synth
+    from mvin_amd.config import make_args
+    from mvin_amd.model import MVIN
+    from mvin_amd.params import init_params
+    ds, B, D, K = "MovieLens-1M", 1024, 16, 8
+    d = synth.DATASETS[ds]
+    margs = make_args(dataset=ds, dim=D, neighbor_sample_size=K, h_hop=1, n_mix_hop=1, p_hop=d["p_hop"],
+                      n_memory=d["n_memory"], batch_size=B)
+    case = synth.dataset_case(ds, K=K, B=B, seed=a.seed)
+    params = init_params(margs, case.n_user, case.n_entity, case.n_relation, seed=a.seed)
+    pt = mirror_fp32.as_torch_params(params)
+    torch.set_num_threads(cpu_threads)
+    feed = (case.users, case.items, case.memories_h, case.memories_r, case.memories_t)
+    for _ in range(warmup):
+        ref = mirror_fp32.forward(margs, pt, case.adj_entity, case.adj_relation, *feed)
+    ct = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        ref = mirror_fp32.forward(margs, pt, case.adj_entity, case.adj_relation, *feed)
+        ct.append(time.perf_counter() - t0)
+    model = MVIN(margs, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device=dev)
+    dfeed = (torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+             [torch.from_numpy(m).to(dev) for m in case.memories_h], [torch.from_numpy(m).to(dev) for m in case.memories_r],
+             [torch.from_numpy(m).to(dev) for m in case.memories_t])
+    for _ in range(warmup):
+        out = model.forward_device(*dfeed)
+    torch.cuda.synchronize()
+    gt = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        out = model.forward_device(*dfeed)
+        torch.cuda.synchronize()
+        gt.append(time.perf_counter() - t0)
+    want = ref.scores.numpy()
+    err = np.abs(out.scores.cpu().numpy() - want)
+    return {"workload": f"{ds}-shaped tables (nE={case.n_entity}, nU={case.n_user}, nR={case.n_relation}), dim=16 hop=1 "
+                        f"n_mix_hop=1 fan-out=8 p_hop={d['p_hop']} n_memory={d['n_memory']}, batch 1024, per-pair feeds "
+                        "(BASELINE.json configs[0])",
+            "bytes_per_pair": algorithmic_bytes_per_pair(D, K, 1),
+            "cpu": {"pairs_per_s": B / float(np.median(ct)), "ms_per_step": 1e3 * float(np.median(ct)), "cores": cpu_threads,
+                    "kind": "port"},
+            "gpu": {"pairs_per_s": B / float(np.median(gt)), "us_per_step": 1e6 * float(np.median(gt)),
+                    "note": "one synchronised call per step (host launch latency included)"},
+            "max_abs_err": float(err.max()),
+            "within_1e-5rel_1e-6abs": bool((err <= 1e-5 * np.abs(want) + 1e-6).all())}
+
+
 def training_steps(margs, case, params, dev, users, items, mems, sizes=(512, 4096), steps=20):
     """ms per optimisation step (mvin_amd/training.py) eager and as one hipGraph replay per step."""
     import torch
@@ -706,6 +759,11 @@ def main():
             err = np.abs(got - ref.scores.numpy())
             rec["parity_vs_cpu_sample"] = {"max_abs_err": float(err.max()),
                                            "within_1e-5rel_1e-6abs": bool((err <= 1e-5 * np.abs(ref.scores.numpy()) + 1e-6).all())}
+            if not a.no_sweep:
+                try:                                                      # the CPU column at C1 is mandatory
+                    rec["cpu_baseline"]["c1"] = c1_plumbing(a, dev, cb["cores"])
+                except Exception as e:
+                    rec["cpu_baseline"]["c1"] = {"error": f"{type(e).__name__}: {e}"}
     else:
         rec = None
     if dist.is_initialized():

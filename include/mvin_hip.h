@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 4
+#define MVIN_ABI_VERSION 5
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -143,6 +143,15 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
                             int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                             float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                             int table_bf16, void* stream);
+/* The same with the parents given as int64 ids read in place (the item ids of the reference's int64 placeholder,
+ * model.py:50: at tree depth 2 the parents ARE the batch's items, so no id-conversion launch precedes the kernel). */
+int mvin_gather_attn_l2_fwd_i64(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                                const int64_t* parent_ids, const float* t0, const float* t1,
+                                const float* W1, const float* W2, const float* b1, const float* b2,
+                                const float* q, const float* A0, const float* a0,
+                                int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                                float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
+                                int table_bf16, void* stream);
 int mvin_gather_attn_l2_supported(int D, int K);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
@@ -310,6 +319,10 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
  * rows of `row_bytes` bytes (a multiple of 4: fp32 or bf16 entity rows move untouched). */
 int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream);
 int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, const void* rows, void* stream);
+/* Entity ids into the sharded table's id space (mvin_amd/dist.py: cyclic ownership, owner(x) = x mod world, rank r's rows
+ * contiguous): out[i] = (ids[i] mod world) * n_local + ids[i] div world.  ids / out: int64 when ids_are_i64, else int32
+ * (same type in and out; out may alias ids).  One launch instead of four elementwise torch kernels per step. */
+int mvin_shard_space_ids(const void* ids, int ids_are_i64, int64_t n, int world, int n_local, void* out, void* stream);
 
 /* Entity-table ("hoisted") mode building block -- an inference-side re-association of
  * model.py:295-305 / aggregators.py:118-146 at the two deepest levels (SURVEY.md 7.3-c route 2b):

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mvin_score_l2_fwd": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvin_shard_space_ids": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mvin_key_addressing_grouped_supported": (C.c_int, [C.c_int] * 4),
     "mvin_ent_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -77,6 +78,10 @@ SIGNATURES = {
                                           _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
                                           _c_f32p, C.c_int, C.c_void_p]),
+    "mvin_gather_attn_l2_fwd_i64": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, C.c_void_p, _c_f32p, _c_f32p, _c_f32p,
+                                              _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
+                                              _c_f32p, C.c_int, C.c_void_p]),
     "mvin_gather_attn_l2_supported": (C.c_int, [C.c_int, C.c_int]),
     "mvin_gather_attn_l2_variant": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "mvin_probe_gather_l2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -167,8 +172,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 4:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 4")
+    if ver != 5:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 5")
     _lib = lib
     return lib
 

@@ -244,6 +244,18 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
                                table_bf16, stream);
 }
 
+int mvin_gather_attn_l2_fwd_i64(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+                                const int64_t* parent_ids, const float* t0, const float* t1, const float* W1,
+                                const float* W2, const float* b1, const float* b2, const float* q,
+                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                                float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
+                                int table_bf16, void* stream) {
+    // little-endian low words, stride 2; ids are clamped to the table inside the kernels like every device-resident id
+    return gather_attn_l2_impl(table, adj_entity, adj_relation, reinterpret_cast<const int32_t*>(parent_ids), 2, t0, t1, W1, W2,
+                               b1, b2, q, A0, a0, B, parents_per_pair, K, D, n_entity, nR, nagg0, nagg1, probs_parent,
+                               probs_child, table_bf16, stream);
+}
+
 int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
                  const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
                  void* stream) {
@@ -478,6 +490,13 @@ int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes,
     if (n < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(-2, "%s: n=%lld row_bytes=%d", who, (long long)n, row_bytes);
     if (n > 0 && (!table || !ids || !rows)) return fail(-1, "%s: null pointer", who);
     return hip_result(mvin::launch_move_rows(table, ids, n, row_bytes, const_cast<void*>(rows), true, (hipStream_t)stream), who);
+}
+
+int mvin_shard_space_ids(const void* ids, int ids_are_i64, int64_t n, int world, int n_local, void* out, void* stream) {
+    const char* who = "mvin_shard_space_ids";
+    if (n < 0 || world <= 0 || n_local <= 0) return fail(-2, "%s: n=%lld world=%d n_local=%d", who, (long long)n, world, n_local);
+    if (n > 0 && (!ids || !out)) return fail(-1, "%s: null pointer", who);
+    return hip_result(mvin::launch_shard_space_ids(ids, ids_are_i64 != 0, n, world, n_local, out, (hipStream_t)stream), who);
 }
 
 int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,

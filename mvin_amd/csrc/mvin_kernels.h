@@ -276,6 +276,7 @@ bool key_addr_stream_supported(const KeyAddrArgs& a, int table_bf16);       // L
 hipError_t launch_key_addr_stream(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, void* rows, bool scatter,
                             hipStream_t st);
+hipError_t launch_shard_space_ids(const void* ids, bool is64, int64_t n, int world, int n_local, void* out, hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 bool l2_tail_supported(int D);

@@ -507,4 +507,25 @@ hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_
     return hipGetLastError();
 }
 
+
+// ---- entity ids -> shard space (multi-GPU layer, mvin_amd/dist.py): pi(x) = (x mod W) * n_local + x div W ----
+template <typename T>
+__global__ __launch_bounds__(kBlock) void shard_space_ids_kernel(const T* __restrict__ ids, int64_t n, int world, int n_local,
+                                                                 T* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t x = (int64_t)ids[i];
+        const int64_t q = x / world;
+        out[i] = (T)((x - q * world) * n_local + q);
+    }
+}
+
+hipError_t launch_shard_space_ids(const void* ids, bool is64, int64_t n, int world, int n_local, void* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    const int64_t nblk = (n + kBlock - 1) / kBlock;
+    const int grid = (int)(nblk < 256 * 8 ? nblk : 256 * 8);
+    if (is64) shard_space_ids_kernel<int64_t><<<grid, kBlock, 0, st>>>((const int64_t*)ids, n, world, n_local, (int64_t*)out);
+    else shard_space_ids_kernel<int32_t><<<grid, kBlock, 0, st>>>((const int32_t*)ids, n, world, n_local, (int32_t*)out);
+    return hipGetLastError();
+}
+
 }  // namespace mvin

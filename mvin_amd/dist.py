@@ -255,6 +255,12 @@ class ShardedMVIN(object):
 
     # ---- id spaces ------------------------------------------------------------------------
     def ids(self, x):
+        """Original entity ids -> shard space.  Device tensors take one HIP launch (mvin_shard_space_ids; the
+        torch spelling is four elementwise kernels per call, ~25 us of a rank's 1.2 ms step at W = 8)."""
+        if torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.int64, torch.int32) and \
+                (self.world > 1 or self.table.always_collective):
+            from . import ops
+            return ops.shard_space_ids(x, self.world, self.table.n_local)
         return to_shard_space(x, self.n_entity, self.world)
 
     def set_user_triplet_set(self, uts):

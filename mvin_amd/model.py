@@ -458,11 +458,16 @@ class MVIN(object):
         use_hoist = bool(self.hoist) and not want_probs and self.hoist_supported()
         use_l2 = use_hoist or (self.fused and H >= 2 and ops.gather_attn_l2_supported(D, K))
         top = L - 1 if use_l2 else L          # levels 0..top-1 are materialised
-        ents, rels = self.get_neighbors(item32, levels=top - 1)
         # depth-2 trees: everything above the fused kernel (level-0 projection, both hop-0 aggregators, the
         # combiner and the score) is ONE launch (mvin_l2_tail_fwd) instead of four
         use_tail = (use_l2 and not use_hoist and L == 2 and M == 1 and self.fused is not False
                     and ops.l2_tail_supported(D))
+        if use_tail and item32.dtype == torch.int64:
+            # the parents of a depth-2 tree are the items themselves: the fused kernel reads the int64 ids in place
+            # (mvin_gather_attn_l2_fwd_i64), no level-0 id list is written
+            ents, rels = [item32], []
+        else:
+            ents, rels = self.get_neighbors(item32, levels=top - 1)
         ev, c = (None, {}) if use_tail else self._project_levels(ents, q, top, need_c=() if use_l2 else (L,))
         nagg = pp = pc = None
         if use_hoist:

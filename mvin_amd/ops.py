@@ -228,12 +228,13 @@ def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False):
 
 def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0,
                    B, parents_per_pair, K, D, nR, want_probs=False):
-    """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  Returns
+    """mvin_gather_attn_l2_fwd: the two deepest levels in one pass.  ``parent_ids``: int32, or int64 read in place
+    (mvin_gather_attn_l2_fwd_i64: the batch's item ids at tree depth 2).  Returns
     (nagg0 [P,D], nagg1 [P,D], probs_parent [P,K] | None, probs_child [P*K,K] | None)."""
     lib = _lib.load()
     bf = _chk_table(table, "table")
     for t, dt, nm in ((adj_entity, I32, "adj_entity"), (adj_relation, I32, "adj_relation"),
-                      (parent_ids, I32, "parent_ids"), (t0, F32, "t0"), (t1, F32, "t1"), (W1, F32, "W1"),
+                      (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"), (t1, F32, "t1"), (W1, F32, "W1"),
                       (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"), (A0, F32, "A0"),
                       (a0, F32, "a0")):
         _chk(t, dt, nm)
@@ -243,10 +244,11 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     nagg1 = torch.empty((P, D), dtype=F32, device=dev)
     pp = torch.empty((P, K), dtype=F32, device=dev) if want_probs else None
     pc = torch.empty((P * K, K), dtype=F32, device=dev) if want_probs else None
-    _lib.check(lib.mvin_gather_attn_l2_fwd(_p(table), _p(adj_entity), _p(adj_relation), _p(parent_ids), _p(t0),
-                                           _p(t1), _p(W1), _p(W2), _p(b1), _p(b2), _p(q), _p(A0), _p(a0), B,
-                                           parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
-                                           _p(pp), _p(pc), bf, _stream()), "mvin_gather_attn_l2_fwd")
+    fn = lib.mvin_gather_attn_l2_fwd_i64 if parent_ids.dtype == torch.int64 else lib.mvin_gather_attn_l2_fwd
+    _lib.check(fn(_p(table), _p(adj_entity), _p(adj_relation), _p(parent_ids), _p(t0),
+                  _p(t1), _p(W1), _p(W2), _p(b1), _p(b2), _p(q), _p(A0), _p(a0), B,
+                  parents_per_pair, K, D, table.shape[0], nR, _p(nagg0), _p(nagg1),
+                  _p(pp), _p(pc), bf, _stream()), "mvin_gather_attn_l2_fwd")
     return nagg0, nagg1, pp, pc
 
 
@@ -365,6 +367,17 @@ def scatter_rows(table, ids, rows):
     _lib.check(_lib.load().mvin_scatter_rows(_p(table), _p(ids), ids.shape[0], table.shape[1] * table.element_size(),
                                              _p(rows), _stream()), "mvin_scatter_rows")
     return table
+
+
+def shard_space_ids(ids, world, n_local):
+    """mvin_shard_space_ids: (ids mod world) * n_local + ids div world, int64 or int32, one launch."""
+    if ids.dtype not in (torch.int64, I32) or not ids.is_cuda:
+        raise TypeError("ids: int64 or int32 device tensor")
+    ids = ids.contiguous()
+    out = torch.empty_like(ids)
+    _lib.check(_lib.load().mvin_shard_space_ids(_p(ids), int(ids.dtype == torch.int64), ids.numel(), world, n_local,
+                                                _p(out), _stream()), "mvin_shard_space_ids")
+    return out
 
 
 def key_addressing_grouped_supported(D, P, Nm, nR):

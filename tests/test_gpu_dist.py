@@ -147,3 +147,19 @@ def test_bench_two_ranks_over_rccl(hip_lib):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and "row-sharded" in rec["config"]["parallelism"]
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+@pytest.mark.parametrize("world,n_entity,n", [(8, 113487, 70001), (2, 5000, 1), (3, 17, 300), (1, 100, 64)])
+def test_shard_space_ids_kernel_is_the_definition(world, n_entity, n, dtype, hip_lib):
+    """mvin_shard_space_ids == dist.to_shard_space (pi(x) = (x mod W) * n_local + x div W), and from_shard_space undoes it."""
+    from mvin_amd import ops
+    from mvin_amd.dist import from_shard_space, n_local_rows, to_shard_space
+    rng = np.random.default_rng(world + n)
+    x = rng.integers(0, n_entity, n)
+    want = (x % world) * n_local_rows(n_entity, world) + x // world
+    got = ops.shard_space_ids(torch.from_numpy(x).to("cuda:0").to(dtype), world, n_local_rows(n_entity, world))
+    assert got.dtype == dtype
+    np.testing.assert_array_equal(got.cpu().numpy().astype(np.int64), want)
+    np.testing.assert_array_equal(to_shard_space(x, n_entity, world), want)
+    np.testing.assert_array_equal(from_shard_space(want, n_entity, world), x)

@@ -72,9 +72,12 @@ def test_grouping_is_a_permutation_with_segments(hip_lib):
 
 
 @pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
-@pytest.mark.parametrize("B,n_user", [(9, 10), (1, 5), (5000, 37), (70000, 3000), (1025, 1025), (4096, 100000)])
+@pytest.mark.parametrize("B,n_user", [(9, 10), (1, 5), (5000, 37), (70000, 3000), (1025, 1025), (4096, 100000),
+                                      (200000, 3000), (131072, 37000), (300, 37500), (300, 38500), (140000, 23553),
+                                      (32768, 1000), (32769, 1000)])
 def test_native_grouping_matches_the_sort_based_one(B, n_user, dtype, hip_lib):
-    """mvin_group_pairs_by_user (counting sort, three kernels) against the torch.sort-based grouping: same users,
+    """mvin_group_pairs_by_user (counting sort: ONE workgroup with the counters in LDS up to 32 768 pairs and 150 KB of
+    counters, three kernels beyond, their scan staged in LDS when the counters fit -- the sizes straddle every limit) against the torch.sort-based grouping: same users,
     same segment boundaries, and every segment holds the same SET of pairs (order inside a segment is free)."""
     from mvin_amd import ops
     g = torch.Generator(device="cuda:0")
