@@ -188,6 +188,11 @@ int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_i
 int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
                          const int32_t* value_ids, const float* V, const float* w, int mode,
                          int B, int Nm, int D, int nR, float* out, int64_t ldo, void* stream);
+/* The same for either table type (table_bf16 = 1: bf16 rows; arithmetic stays fp32): the general fallback
+ * for every (D, Nm) the one-pass kernels of mvin_key_addressing_fwd do not take. */
+int mvin_ripple_attn_fwd_ex(const void* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+                            const int32_t* value_ids, const float* V, const float* w, int mode,
+                            int B, int Nm, int D, int nR, float* out, int64_t ldo, int table_bf16, void* stream);
 
 /* All attention reads of MVIN._key_addressing for a batch in one pass (model.py:161-240):
  * out[b, :] = [ o_hset (if w != NULL) | o_hop0 | ... | o_hop{P-1} ], each D wide, row stride ldo.
@@ -392,6 +397,22 @@ int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float
 int mvin_linear_wgrad(const mvin_linear_args* args, const float* dY, int64_t ldy, int64_t dy_zstride,
                       const float* mask, int64_t ldm, int64_t mask_zstride, float* dW, int64_t dw_zstride,
                       float* db, int64_t db_zstride, void* stream);
+/* n (<= 64) such problems in as few launches as their shapes allow: problems whose (Din, Dout) take the same matrix-core
+ * tile kernel share a launch (8 per launch).  At the reference's batch sizes a weight gradient is microseconds of work
+ * behind ~10 us of launch and ramp, and a training step has eleven of them.  The results are those of n
+ * mvin_linear_wgrad calls (accumulation into dW / db by float atomics in both forms). */
+typedef struct {
+    mvin_linear_args lin;          /* as for mvin_linear_wgrad */
+    const float* dY;
+    int64_t ldy, dy_zstride;
+    const float* mask;             /* or NULL */
+    int64_t ldm, mask_zstride;
+    float* dW;
+    int64_t dw_zstride;
+    float* db;                     /* or NULL */
+    int64_t db_zstride;
+} mvin_wgrad_problem;
+int mvin_linear_wgrad_multi(const mvin_wgrad_problem* problems, int n, void* stream);
 
 /* backward of the neighbor mix agg[t] = (1/K) sum_k p[t,k] c[t,k], p = softmax_k(t[rel]) (aggregators.py:118-152)
  * given dvec = dL/d agg: children from the table through the adjacency (table/adj/node_ids given: dc_k is added

@@ -43,6 +43,23 @@ class LinearArgs(C.Structure):
     ]
 
 
+class WgradProblem(C.Structure):
+    """mvin_wgrad_problem (include/mvin_hip.h)."""
+    _fields_ = [
+        ("lin", LinearArgs),
+        ("dY", C.c_void_p),
+        ("ldy", C.c_int64),
+        ("dy_zstride", C.c_int64),
+        ("mask", C.c_void_p),
+        ("ldm", C.c_int64),
+        ("mask_zstride", C.c_int64),
+        ("dW", C.c_void_p),
+        ("dw_zstride", C.c_int64),
+        ("db", C.c_void_p),
+        ("db_zstride", C.c_int64),
+    ]
+
+
 class ScoreL2Args(C.Structure):
     """mvin_score_l2_args (include/mvin_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
@@ -62,6 +79,7 @@ SIGNATURES = {
     "mvin_score_l2_fwd": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "mvin_linear_wgrad_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mvin_shard_space_ids": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mvin_key_addressing_grouped_supported": (C.c_int, [C.c_int] * 4),
@@ -135,6 +153,9 @@ SIGNATURES = {
     "mvin_ripple_attn_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64,
                                        C.c_void_p]),
+    "mvin_ripple_attn_fwd_ex": (C.c_int, [C.c_void_p, _c_i32p, _c_i32p, _c_i32p, _c_f32p, _c_f32p, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, C.c_int64, C.c_int,
+                                          C.c_void_p]),
 }
 
 _lib = None

@@ -284,9 +284,9 @@ int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* re
     return hip_result(mvin::launch_gather_attn(g, (hipStream_t)stream), "mvin_agg_fwd");
 }
 
-int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
-                         const int32_t* value_ids, const float* V, const float* w, int mode, int B, int Nm,
-                         int D, int nR, float* out, int64_t ldo, void* stream) {
+int mvin_ripple_attn_fwd_ex(const void* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+                            const int32_t* value_ids, const float* V, const float* w, int mode, int B, int Nm,
+                            int D, int nR, float* out, int64_t ldo, int table_bf16, void* stream) {
     if (!entity_emb || !score_ids || !value_ids || !out) return fail(-1, "mvin_ripple_attn_fwd: null pointer");
     if (mode != 0 && mode != 1) return fail(-2, "mvin_ripple_attn_fwd: mode=%d", mode);
     if (mode == 0 && (!V || !rel_ids || nR <= 0)) return fail(-1, "mvin_ripple_attn_fwd: mode 0 needs V, rel_ids, nR");
@@ -296,6 +296,7 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
     if (ldo < D || (ldo & 3)) return fail(-2, "mvin_ripple_attn_fwd: ldo=%lld (need >= D, %%4==0)", (long long)ldo);
     mvin::RippleArgs r{};
     r.E = entity_emb;
+    r.table_bf16 = table_bf16 ? 1 : 0;
     r.score_ids = score_ids;
     r.rel_ids = rel_ids;
     r.value_ids = value_ids;
@@ -310,6 +311,12 @@ int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, cons
     r.nR = nR;
     r.lpr_log2 = mvin::lpr_log2_for(D);
     return hip_result(mvin::launch_ripple(r, (hipStream_t)stream), "mvin_ripple_attn_fwd");
+}
+
+int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+                         const int32_t* value_ids, const float* V, const float* w, int mode, int B, int Nm,
+                         int D, int nR, float* out, int64_t ldo, void* stream) {
+    return mvin_ripple_attn_fwd_ex(entity_emb, score_ids, rel_ids, value_ids, V, w, mode, B, Nm, D, nR, out, ldo, 0, stream);
 }
 
 int mvin_key_addressing_supported(int Nm, int D) {
@@ -718,6 +725,49 @@ int mvin_linear_wgrad(const mvin_linear_args* a, const float* dY, int64_t ldy, i
     w.db = db;
     w.db_zstride = db_zstride;
     return hip_result(mvin::launch_linear_wgrad(w, (hipStream_t)stream), "mvin_linear_wgrad");
+}
+
+static int wgrad_check(const char* who, const mvin_linear_args* a, const float* dY, int64_t ldy, const float* mask, int64_t ldm,
+                       const float* dW) {
+    if (!a || !dY || !dW) return fail(-1, "%s: null pointer", who);
+    if (a->nsrc < 1 || a->nsrc > MVIN_MAX_SRC) return fail(-2, "%s: nsrc=%d", who, a->nsrc);
+    if (a->Dsrc < 4 || (a->Dsrc & 3) || a->Dout < 1 || a->Dout > MVIN_MAX_DIM)
+        return fail(-2, "%s: Dsrc=%d Dout=%d", who, a->Dsrc, a->Dout);
+    if ((size_t)a->nsrc * a->Dsrc > 4096) return fail(-2, "%s: nsrc*Dsrc > 4096", who);
+    for (int s = 0; s < a->nsrc; ++s)
+        if (!a->src[s]) return fail(-1, "%s: null src[%d]", who, s);
+    if (ldy < a->Dout || (mask && ldm < a->Dout)) return fail(-2, "%s: ldy/ldm < Dout", who);
+    if (a->rows < 0) return fail(-2, "%s: rows < 0", who);
+    return 0;
+}
+
+int mvin_linear_wgrad_multi(const mvin_wgrad_problem* problems, int n, void* stream) {
+    const char* who = "mvin_linear_wgrad_multi";
+    if (n < 0 || n > 64) return fail(-2, "%s: n=%d (0..64)", who, n);
+    if (n > 0 && !problems) return fail(-1, "%s: null pointer", who);
+    mvin::WgradArgs w[64];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const mvin_wgrad_problem& p = problems[i];
+        const int rc = wgrad_check(who, &p.lin, p.dY, p.ldy, p.mask, p.ldm, p.dW);
+        if (rc) return rc;
+        if (p.lin.rows == 0) continue;
+        mvin::WgradArgs& d = w[m++];
+        d = mvin::WgradArgs{};
+        d.lin = p.lin;
+        d.dY = p.dY;
+        d.ldy = p.ldy;
+        d.dy_zstride = p.dy_zstride;
+        d.mask = p.mask;
+        d.ldm = p.ldm;
+        d.mask_zstride = p.mask_zstride;
+        d.dW = p.dW;
+        d.dw_zstride = p.dw_zstride;
+        d.db = p.db;
+        d.db_zstride = p.db_zstride;
+    }
+    if (m == 0) return 0;
+    return hip_result(mvin::launch_linear_wgrad_multi(w, m, (hipStream_t)stream), who);
 }
 
 int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_kernel(WgradArgs a) {
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
 template <int TI, int TJ>
-__global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_mfma_body(const WgradArgs& a, const int bx, const int gx, const int z) {
     constexpr int Din = TI * 16, Dout = TJ * 16, NT = TI * TJ, NTW = (NT + 3) / 4;
     constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din;      // row stride = 16 mod 32 words: the four row groups of an
     constexpr int ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;   // A / B fragment read hit disjoint banks
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) 
     float* sY = sX + kTM * ldx;       // [32][ldy]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, q16 = lane >> 4;
-    const int z = blockIdx.z;
     f32x4w acc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc[t] = f32x4w{0.f, 0.f, 0.f, 0.f};
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) 
     const float* dY = a.dY + (size_t)z * a.dy_zstride;
     const int c4 = a.lin.Dsrc >> 2;
     const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = bx; tile < ntiles; tile += gx) {
         const int64_t r0 = tile * kTM;
         for (int s = 0; s < a.lin.nsrc; ++s) {
             const float* src = a.lin.src[s];
@@ -305,6 +304,29 @@ __global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) 
         }
     }
     if (a.db && tid < Dout && accb != 0.f) atomicAdd(a.db + (size_t)z * a.db_zstride + tid, accb);
+}
+
+template <int TI, int TJ>
+__global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_kernel(WgradArgs a) {
+    wgrad_mfma_body<TI, TJ>(a, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+// Several weight-gradient problems of ONE (Din, Dout) tile shape in one launch (blockIdx.y = problem): at the reference's
+// batch sizes every such launch is a few microseconds of work behind ~10 us of launch + ramp, and a training step has
+// eleven of them (mvin_linear_wgrad_multi; mvin_amd/training.py queues them and flushes before the optimizer).
+constexpr int kWgradMulti = 8;
+struct WgradMultiArgs {
+    WgradArgs p[kWgradMulti];
+    int gx[kWgradMulti];
+    int n;
+};
+template <int TI, int TJ>
+__global__ __launch_bounds__(kBlock) void linear_wgrad_mfma_multi_kernel(WgradMultiArgs m) {
+    const int pi = blockIdx.y;
+    const WgradArgs& a = m.p[pi];
+    const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
+    if ((int)blockIdx.x >= m.gx[pi] || (int)blockIdx.z >= nz) return;
+    wgrad_mfma_body<TI, TJ>(a, blockIdx.x, m.gx[pi], blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -742,24 +764,103 @@ hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64,
     return hipGetLastError();
 }
 
+hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st);
+
+// workgroups per weight matrix: every workgroup ends with Din x Dout atomics onto the SAME 16 KB, so more
+// workgroups = more same-line atomics, fewer = a longer serial tile loop.  Measured optimum ~ tiles / 8
+// (512 tiles: 256 workgroups 11.9 us vs 14.5 at 512; 4 096 tiles: 512 -> 27 us vs 34 at 256 and 30 at 1 024;
+// 16 384 tiles: 1 024 -> 66 us vs 89 at 512)
+static int wgrad_grid_x(const WgradArgs& a) {
+    const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
+    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
+    int64_t cap = ntiles / 8;
+    cap = cap < 256 ? 256 : cap > 1024 ? 1024 : cap;
+    cap /= nz;
+    if (cap < 1) cap = 1;
+    return (int)(ntiles < 1 ? 1 : ntiles < cap ? ntiles : cap);
+}
+
 template <int TI, int TJ>
 static hipError_t launch_wgrad_mfma(const WgradArgs& a, hipStream_t st) {
     constexpr int Din = TI * 16, Dout = TJ * 16;
     constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din, ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;
     const int nz = a.lin.nz > 0 ? a.lin.nz : 1;
-    const int64_t ntiles = (a.lin.rows + kTM - 1) / kTM;
-    // workgroups per weight matrix: every workgroup ends with Din x Dout atomics onto the SAME 16 KB, so more
-    // workgroups = more same-line atomics, fewer = a longer serial tile loop.  Measured optimum ~ tiles / 8
-    // (512 tiles: 256 workgroups 11.9 us vs 14.5 at 512; 4 096 tiles: 512 -> 27 us vs 34 at 256 and 30 at 1 024;
-    // 16 384 tiles: 1 024 -> 66 us vs 89 at 512)
-    int64_t cap = ntiles / 8;
-    cap = cap < 256 ? 256 : cap > 1024 ? 1024 : cap;
-    cap /= nz;
-    if (cap < 1) cap = 1;
-    const int gx = (int)(ntiles < 1 ? 1 : ntiles < cap ? ntiles : cap);
     const size_t lds = (size_t)kTM * (ldx + ldy) * sizeof(float);
-    linear_wgrad_mfma_kernel<TI, TJ><<<dim3(gx, 1, nz), kBlock, lds, st>>>(a);
+    linear_wgrad_mfma_kernel<TI, TJ><<<dim3(wgrad_grid_x(a), 1, nz), kBlock, lds, st>>>(a);
     return hipGetLastError();
+}
+
+template <int TI, int TJ>
+static hipError_t launch_wgrad_mfma_multi(const WgradArgs* const* probs, int n, hipStream_t st) {
+    constexpr int Din = TI * 16, Dout = TJ * 16;
+    constexpr int ldx = (Din % 32 == 0) ? Din + 16 : Din, ldy = (Dout % 32 == 0) ? Dout + 16 : Dout;
+    const size_t lds = (size_t)kTM * (ldx + ldy) * sizeof(float);
+    for (int i0 = 0; i0 < n; i0 += kWgradMulti) {
+        WgradMultiArgs m{};
+        m.n = n - i0 < kWgradMulti ? n - i0 : kWgradMulti;
+        int gx = 1, gz = 1;
+        for (int i = 0; i < m.n; ++i) {
+            m.p[i] = *probs[i0 + i];
+            m.gx[i] = wgrad_grid_x(m.p[i]);
+            gx = m.gx[i] > gx ? m.gx[i] : gx;
+            const int nz = m.p[i].lin.nz > 0 ? m.p[i].lin.nz : 1;
+            gz = nz > gz ? nz : gz;
+        }
+        linear_wgrad_mfma_multi_kernel<TI, TJ><<<dim3(gx, m.n, gz), kBlock, lds, st>>>(m);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+static bool wgrad_mfma_shape(const WgradArgs& a, int& ti, int& tj) {
+    static const bool no_mfma = getenv("MVIN_WGRAD_VALU") != nullptr;
+    const int Din = a.lin.sum_sources ? a.lin.Dsrc : a.lin.nsrc * a.lin.Dsrc;
+    if (no_mfma || (a.lin.Dsrc & 3) || Din % 16 || a.lin.Dout % 16) return false;
+    ti = Din / 16;
+    tj = a.lin.Dout / 16;
+#define MVIN_WG(TIV, TJV) if (ti == TIV && tj == TJV) return true;
+    MVIN_WG(1, 1) MVIN_WG(2, 1) MVIN_WG(3, 1) MVIN_WG(4, 1)
+    MVIN_WG(2, 2) MVIN_WG(4, 2) MVIN_WG(6, 2) MVIN_WG(8, 2)
+    MVIN_WG(4, 4) MVIN_WG(8, 4) MVIN_WG(12, 4) MVIN_WG(16, 4)
+    MVIN_WG(8, 8)
+#undef MVIN_WG
+    return false;
+}
+
+// n problems: those of one MFMA tile shape go out together (up to kWgradMulti per launch), the rest one by one
+hipError_t launch_linear_wgrad_multi(const WgradArgs* probs, int n, hipStream_t st) {
+    static const bool one_by_one = getenv("MVIN_WGRAD_MULTI") != nullptr && atoi(getenv("MVIN_WGRAD_MULTI")) == 0;
+    bool done[64] = {};
+    if (n > 64) return hipErrorInvalidValue;
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        int ti = 0, tj = 0;
+        if (one_by_one || !wgrad_mfma_shape(probs[i], ti, tj)) {
+            hipError_t e = launch_linear_wgrad(probs[i], st);
+            if (e != hipSuccess) return e;
+            done[i] = true;
+            continue;
+        }
+        const WgradArgs* grp[64];
+        int ng = 0;
+        for (int j = i; j < n; ++j) {
+            int tij = 0, tjj = 0;
+            if (!done[j] && wgrad_mfma_shape(probs[j], tij, tjj) && tij == ti && tjj == tj) {
+                grp[ng++] = &probs[j];
+                done[j] = true;
+            }
+        }
+        hipError_t e = hipErrorInvalidValue;
+#define MVIN_WG(TIV, TJV) if (ti == TIV && tj == TJV) e = launch_wgrad_mfma_multi<TIV, TJV>(grp, ng, st);
+        MVIN_WG(1, 1) MVIN_WG(2, 1) MVIN_WG(3, 1) MVIN_WG(4, 1)
+        MVIN_WG(2, 2) MVIN_WG(4, 2) MVIN_WG(6, 2) MVIN_WG(8, 2)
+        MVIN_WG(4, 4) MVIN_WG(8, 4) MVIN_WG(12, 4) MVIN_WG(16, 4)
+        MVIN_WG(8, 8)
+#undef MVIN_WG
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st) {

@@ -33,7 +33,8 @@ struct GatherAttnArgs {
 };
 
 struct RippleArgs {
-    const float* E;
+    const void* E;              // [nE, D] fp32 or bf16 (table_bf16)
+    int table_bf16;
     const int32_t* score_ids;
     const int32_t* rel_ids;
     const int32_t* value_ids;
@@ -242,6 +243,7 @@ hipError_t launch_l2_adam_multi(const mvin_param_seg* segs, int nseg, int64_t to
 hipError_t launch_scatter_add_rows(float* dtable, const int32_t* ids, int ids64, const float* x, int64_t rows, int D,
                                    float alpha, hipStream_t st);
 hipError_t launch_linear_wgrad(WgradArgs a, hipStream_t st);
+hipError_t launch_linear_wgrad_multi(const WgradArgs* probs, int n, hipStream_t st);   // n <= 64
 hipError_t launch_agg_bwd(const AggBwdArgs& a, hipStream_t st);
 hipError_t launch_rel_score_bwd(const float* rel, const float* urh_w, const float* dT, int nR, int D, float* drel,
                                 float* durh, hipStream_t st);

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kBlock) void ripple_attn_kernel(RippleArgs a) {
             const bool valid = m < Nm;
             float part = 0.f;
             if (valid && cact) {
-                const float4 h = reinterpret_cast<const float4*>(a.E + (int64_t)sid[m] * D)[c];
+                const float4 h = load_row4(a.E, a.table_bf16, sid[m], D, c);
                 const float* vp = a.mode == 0 ? a.V + ((b * a.nR + a.rel_ids[b * Nm + m]) * (int64_t)D) : a.w;
                 const float4 v = reinterpret_cast<const float4*>(vp)[c];
                 part = fmaf(h.x, v.x, fmaf(h.y, v.y, fmaf(h.z, v.z, h.w * v.w)));
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kBlock) void ripple_attn_kernel(RippleArgs a) {
         for (int m = g; m < Nm; m += rpw) {
             const float p = sc[m] / sum;
             if (cact) {
-                const float4 v = reinterpret_cast<const float4*>(a.E + (int64_t)vid[m] * D)[c];
+                const float4 v = load_row4(a.E, a.table_bf16, vid[m], D, c);
                 acc = f4_fma(p, v, acc);
             }
         }

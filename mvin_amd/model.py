@@ -262,10 +262,7 @@ class MVIN(object):
             V = torch.empty((B, nR, D), dtype=torch.float32, device=self.device)
             ops.linear([self.entity_emb_matrix], self.relation_emb_KGE_matrix, D, ids=[item32], rows=B,
                        out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
-        bf16 = self.entity_emb_matrix.dtype == torch.bfloat16
-        if bf16 and not ops.key_addressing_supported(self.n_memory, D):
-            raise NotImplementedError("bf16 entity table: n_memory/dim outside mvin_key_addressing_fwd's range")
-        if (self.fused or bf16) and ops.key_addressing_supported(self.n_memory, D):
+        if self.fused and ops.key_addressing_supported(self.n_memory, D):
             ops.key_addressing(self.entity_emb_matrix, V, w_h, mem_h, mem_r, mem_t, P, o_cat, n_o * D, nR)
         else:
             slot = 0

@@ -185,18 +185,19 @@ def agg(self_vec, neigh, rel_ids, rel_score_t, Wagg, bagg, B, N, K, D, want_prob
 
 
 def ripple_attn(entity_emb, score_ids, rel_ids, value_ids, V, w, mode, out, out_offset, ldo, nR):
-    """mvin_ripple_attn_fwd: one ripple-set attention read per pair, written into
+    """mvin_ripple_attn_fwd_ex: one ripple-set attention read per pair (fp32 or bf16 table), written into
     ``out`` (a [B, ldo] buffer) at column offset ``out_offset``."""
     lib = _lib.load()
-    for t, dt, nm in ((entity_emb, F32, "entity_emb"), (score_ids, I32, "score_ids"),
+    bf = _chk_table(entity_emb, "entity_emb")
+    for t, dt, nm in ((score_ids, I32, "score_ids"),
                       (rel_ids, I32, "rel_ids"), (value_ids, I32, "value_ids"), (V, F32, "V"),
                       (w, F32, "w"), (out, F32, "out")):
         _chk(t, dt, nm)
     B, Nm = score_ids.shape
     D = entity_emb.shape[1]
-    _lib.check(lib.mvin_ripple_attn_fwd(_p(entity_emb), _p(score_ids), _p(rel_ids), _p(value_ids),
-                                        _p(V), _p(w), mode, B, Nm, D, nR, _p(out, out_offset), ldo,
-                                        _stream()), "mvin_ripple_attn_fwd")
+    _lib.check(lib.mvin_ripple_attn_fwd_ex(_p(entity_emb), _p(score_ids), _p(rel_ids), _p(value_ids),
+                                           _p(V), _p(w), mode, B, Nm, D, nR, _p(out, out_offset), ldo, bf,
+                                           _stream()), "mvin_ripple_attn_fwd")
     return out
 
 
@@ -543,6 +544,32 @@ def linear_wgrad(srcs, dY, dW, *, ids=None, db=None, mask=None, sum_sources=Fals
     ldm = ldm or Dout
     _lib.check(lib.mvin_linear_wgrad(C.byref(a), _p(dY), ldy, dy_zstride, _p(mask), ldm, mask_zstride, _p(dW),
                                      dw_zstride, _p(db), db_zstride, _stream()), "mvin_linear_wgrad")
+
+
+def wgrad_problem(srcs, dY, dW, *, ids=None, db=None, mask=None, sum_sources=False, rows=None, nz=1, ldy=None,
+                  dy_zstride=0, ldm=None, mask_zstride=0, dw_zstride=0, db_zstride=0):
+    """One entry for linear_wgrad_multi (same arguments as linear_wgrad).  Returns (struct, tensors kept alive)."""
+    pr = _lib.WgradProblem()
+    Dout = dW.shape[-1]
+    _fill_linear_args(pr.lin, srcs, ids, Dout, rows, nz, sum_sources)
+    pr.dY, pr.ldy, pr.dy_zstride = dY.data_ptr(), ldy or Dout, dy_zstride
+    pr.mask, pr.ldm, pr.mask_zstride = (mask.data_ptr() if mask is not None else None), ldm or Dout, mask_zstride
+    pr.dW, pr.dw_zstride = dW.data_ptr(), dw_zstride
+    pr.db, pr.db_zstride = (db.data_ptr() if db is not None else None), db_zstride
+    for t, nm in ((dY, "dY"), (dW, "dW"), (db, "db"), (mask, "mask")):
+        _chk(t, F32, nm)
+    return pr, (list(srcs), list(ids or ()), dY, dW, db, mask)
+
+
+def linear_wgrad_multi(problems):
+    """mvin_linear_wgrad_multi: the weight gradients of ``problems`` (wgrad_problem entries) in as few launches as
+    their shapes allow.  The tensors of every entry must stay alive (and unmodified) until this call."""
+    if not problems:
+        return
+    lib = _lib.load()
+    n = len(problems)
+    arr = (_lib.WgradProblem * n)(*[p for p, _ in problems])
+    _lib.check(lib.mvin_linear_wgrad_multi(arr, n, _stream()), "mvin_linear_wgrad_multi")
 
 
 def agg_bwd(dvec, probs, T, K, D, nR, *, table=None, adj_entity=None, adj_relation=None, node_ids=None, child=None,

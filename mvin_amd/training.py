@@ -76,6 +76,7 @@ class Trainer(object):
         self.b1, self.b2, self.eps = beta1, beta2, eps
         self.t = 0
         self.by_entity = os.environ.get("MVIN_TRAIN_BY_ENTITY", "1") != "0"   # de-duplicated deepest-hop backward
+        self.batch_wgrads = os.environ.get("MVIN_WGRAD_QUEUE", "1") != "0"     # weight gradients queued -> mvin_linear_wgrad_multi
         self.item_grad_in_kernel_max_batch = 2048    # up to here key_addr_bwd adds dE[item] of V = E[item].R_KGE itself
         self.params = self._named_params()
         self._build_flat_state()
@@ -211,6 +212,17 @@ class Trainer(object):
             assert arena_off[0] <= arena.numel()
             return arena[o:o + n]
         tape = []
+        # weight gradients are QUEUED and go out together after the tape (mvin_linear_wgrad_multi: problems of one tile
+        # shape share a launch): at the reference's batch sizes each is microseconds of work behind ~10 us of launch and
+        # ramp, and a step has eleven.  Their inputs are forward tensors and FINAL gradients (a tensor's gradient is
+        # complete when its own backward runs; buffers lent to G are never accumulated into), kept alive by the queue.
+        wq = []
+
+        def wgrad(*args_, **kw):
+            if self.batch_wgrads:
+                wq.append(ops.wgrad_problem(*args_, **kw))
+            else:
+                ops.linear_wgrad(*args_, **kw)
 
         def zeros(*shape):
             return torch.zeros(shape, dtype=F32, device=dev)
@@ -255,7 +267,7 @@ class Trainer(object):
                 if d is None:
                     return
                 self._ka_bwd_ran = True      # mvin_key_addressing_bwd adds the 2*l2*(h, t) regulariser rows
-                ops.linear_wgrad([o_cat], d, dP["user_mlp_matrix"], db=dP["user_mlp_bias"])
+                wgrad([o_cat], d, dP["user_mlp_matrix"], db=dP["user_mlp_bias"])
                 do_cat = torch.empty_like(o_cat)
                 # d o_s = d . Wu[sD:(s+1)D]^T for every slot s: one z-batched launch over the transposed blocks
                 ops.linear([d], T3(m.user_mlp_matrix), D, out=do_cat, ldo=n_o * D, nz=n_o, w_zstride=D * D, out_zstride=D)
@@ -275,7 +287,7 @@ class Trainer(object):
                     ops.axpby(1.0, dws, 1.0, dP["h_emb_item_mlp_matrix"].view(-1)[:D])
                 if P > 0:
                     # V[b,r,:] = E[item_b] . R[r]  =>  dR[r] += E[item]^T dV[:,r] ; dE[item] += sum_r dV[:,r] R[r]^T
-                    ops.linear_wgrad([E], dV, dP["relation_emb_KGE_matrix"], ids=[item], rows=B, nz=nR, ldy=nR * D,
+                    wgrad([E], dV, dP["relation_emb_KGE_matrix"], ids=[item], rows=B, nz=nR, ldy=nR * D,
                                      dy_zstride=D, dw_zstride=D * D)
                     if item_in_kernel:
                         return
@@ -325,7 +337,7 @@ class Trainer(object):
                     ds = [G.get(c[e - 1]) for e in range(1, L + 1)]
                     for e in range(1, L + 1):
                         if ds[e - 1] is not None:
-                            ops.linear_wgrad([q], ds[e - 1], dP["transfer_W"][e], db=dP["transfer_b"][e])
+                            wgrad([q], ds[e - 1], dP["transfer_W"][e], db=dP["transfer_b"][e])
                     if all(d is not None for d in ds) and L <= 4:
                         # dq += sum_e d_e . W_e^T: the concatenated [d_1 | ... | d_L] times the stacked transposes
                         G.add(q, ops.linear(ds, T3(m._transfer_W)[1:].reshape(L * D, D), D))
@@ -341,7 +353,7 @@ class Trainer(object):
                     if d is None:
                         return
                     d2 = d.view(B, D)
-                    ops.linear_wgrad([E, q], d2, dP["transfer_W"][0], ids=[ents[0].view(-1), None], db=dP["transfer_b"][0],
+                    wgrad([E, q], d2, dP["transfer_W"][0], ids=[ents[0].view(-1), None], db=dP["transfer_b"][0],
                                      sum_sources=True)
                     dx = ops.linear([d2], T3(m._transfer_W)[0], D)
                     ops.scatter_add_rows(dP["entity_emb_matrix"], ents[0].view(-1), dx)
@@ -357,7 +369,7 @@ class Trainer(object):
                         if d is None:
                             return
                         d2 = d.view(-1, D)
-                        ops.linear_wgrad([E], d2, dP["transfer_W"][e], ids=[ids_e])
+                        wgrad([E], d2, dP["transfer_W"][e], ids=[ids_e])
                         ops.scatter_add_rows(dP["entity_emb_matrix"], ids_e, ops.linear([d2], T3(m._transfer_W)[e], D))
                         dc = torch.empty((B, D), dtype=F32, device=dev)
                         ops.eltwise(6, B * D, d2, dc, alpha=1.0, D=D, N=K ** e)
@@ -403,7 +415,7 @@ class Trainer(object):
                     dm = torch.empty((T, D), dtype=F32, device=dev)
                     ops.eltwise(2, T * D, d.view(-1), dm.view(-1), z=out.view(-1))       # relu'
                     i, n = key
-                    ops.linear_wgrad([Z], dm, dP[f"agg_{i}_{n}_weights"], db=dP[f"agg_{i}_{n}_bias"])
+                    wgrad([Z], dm, dP[f"agg_{i}_{n}_weights"], db=dP[f"agg_{i}_{n}_bias"])
                     dZ = ops.linear([dm], T3(agg.weights)[0], D)                         # d(self + neighbors_agg)
                     G.add(self_t, dZ.view_as(self_t), borrowed=True)
                     dTk = dT.get(key)
@@ -411,7 +423,7 @@ class Trainer(object):
                     if fused:
                         if a.User_orient:
                             psum_over_k = (1.0 / K) if agg.User_orient_rela else 1.0
-                            ops.linear_wgrad([S], dZ, dP["transfer_W"][L])               # dW_L += S'^T dZ
+                            wgrad([S], dZ, dP["transfer_W"][L])               # dW_L += S'^T dZ
                             dS = ops.linear([dZ], T3(m._transfer_W)[L], D)
                             dc = torch.empty((B, D), dtype=F32, device=dev)
                             ops.eltwise(6, B * D, dZ, dc, alpha=psum_over_k, D=D, N=N)
@@ -457,7 +469,7 @@ class Trainer(object):
                         if d is None:
                             return
                         d2 = d.view(-1, D)
-                        ops.linear_wgrad([s_.view(-1, D) for s_ in srcs], d2, dP[f"enti_transfer_matrix_{n}"],
+                        wgrad([s_.view(-1, D) for s_ in srcs], d2, dP[f"enti_transfer_matrix_{n}"],
                                          db=dP[f"enti_transfer_bias_{n}"])
                         for si, s_ in enumerate(srcs):
                             G.add(s_, ops.linear([d2], T3(Wm)[si], D).view_as(s_))
@@ -484,6 +496,8 @@ class Trainer(object):
         # ================================================================ backward
         for fn in reversed(tape):
             fn()
+        ops.linear_wgrad_multi(wq)
+        del wq[:]
         for (i, n), g in dT.items():   # relation-logit tables -> relation_emb and urh_weights[D:2D]
             ops.rel_score_bwd(m.relation_emb_matrix, m._agg[(i, n)].urh_weights, g, dP["relation_emb_matrix"],
                               dP[f"agg_{i}_{n}_urh_weights"].view(-1))

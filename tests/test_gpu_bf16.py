@@ -21,6 +21,10 @@ SHAPES = [
     dict(dim=128, neighbor_sample_size=32, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=16, batch_size=5),   # 16-byte bf16 loads, one group per child
     dict(dim=8, neighbor_sample_size=3, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=4, batch_size=5),       # per-level kernels
     dict(dim=32, neighbor_sample_size=8, h_hop=1, n_mix_hop=2, p_hop=2, n_memory=8, batch_size=6),
+    # n_memory x dim beyond the one-pass key-addressing kernels: the per-read fallback (mvin_ripple_attn_fwd_ex) on
+    # a bf16 table -- a NotImplementedError until the 1000-case fuzz campaign of round 3 drew D=128 / Nm=64 / bf16
+    dict(dim=128, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=7),
+    dict(dim=12, neighbor_sample_size=3, h_hop=2, n_mix_hop=1, p_hop=1, n_memory=5, batch_size=4),      # bf16 rows of 24 bytes
 ]
 
 
@@ -35,7 +39,7 @@ def run(model, case):
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "perlevel"])
-@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "D{dim}K{neighbor_sample_size}H{h_hop}M{n_mix_hop}".format(**s))
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "D{dim}K{neighbor_sample_size}H{h_hop}M{n_mix_hop}Nm{n_memory}".format(**s))
 def test_bf16_table(shape, fused, hip_lib):
     from mvin_amd.model import MVIN
     args = make_args(**shape)

@@ -3,6 +3,8 @@ memories, relations, batch, ablation preset, table dtype, feed form) against the
 The hand-picked shapes of the other parity tests pin every kernel instance; this one looks for interactions nobody
 thought of (a ragged batch with a depth-3 tree, a preset without attention on the D = 16 kernel, one pair per user
 in the grouped kernel, ...).  Sizes are kept where the CPU oracles finish in well under a second per case."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,8 @@ from parity import assert_close, run_oracles
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 48
+N_CASES = int(os.environ.get("MVIN_FUZZ_CASES", "48"))      # a longer campaign: MVIN_FUZZ_CASES=1000 pytest tests/test_gpu_fuzz.py
+OFFSET = int(os.environ.get("MVIN_FUZZ_OFFSET", "0"))               # first case number (fresh draws for a campaign)
 
 
 def _draw(i):
@@ -43,7 +46,7 @@ def _draw(i):
     return dict(D=D, K=K, H=H, M=M, P=P, Nm=Nm, nR=nR, B=B, n_user=n_user, abl=abl, tdt=tdt, feed=feed, fused=fused)
 
 
-@pytest.mark.parametrize("i", range(N_CASES))
+@pytest.mark.parametrize("i", range(OFFSET, OFFSET + N_CASES))
 def test_random_configuration(i, hip_lib):
     from mvin_amd.model import MVIN
     c = _draw(i)
