@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_dist.py::test_two_ranks_one_gpu: one of WORLD ranks that time-share
+"""Worker of tests/test_gpu_dist.py::test_ranks_time_sharing_one_gpu: one of WORLD ranks that time-share
 cuda:0 and talk over gloo (RCCL refuses two ranks on one device).  Everything but the transport
 is the production path: HIP kernels, ShardedMVIN in both regimes, the two-stream pipeline."""
 import os

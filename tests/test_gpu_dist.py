@@ -98,13 +98,15 @@ def _run_ranks(argv, world, extra_env=None, timeout=600):
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_two_ranks_one_gpu(hip_lib):
-    """world_size 2 on the HIP path: two processes time-share cuda:0 (gloo moves the device rows;
-    RCCL needs one device per rank).  Both regimes + the pipeline, scores bit-equal to replicated."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_time_sharing_one_gpu(world, hip_lib):
+    """world_size 2 and 3 on the HIP path: the processes time-share cuda:0 (gloo moves the device rows;
+    RCCL needs one device per rank).  Both regimes + the pipeline, scores bit-equal to replicated; with three
+    ranks the 5 003-row table does not divide (padding rows in the last shard positions) and W is odd."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = _run_ranks([os.path.join(root, "tests", "dist_gpu_worker.py")], 2)
+    r = _run_ranks([os.path.join(root, "tests", "dist_gpu_worker.py")], world)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+    assert all(f"rank {k} ok" in r.stdout for k in range(world))
 
 
 def test_bench_two_ranks_one_gpu(hip_lib):

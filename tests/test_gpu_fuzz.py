@@ -43,7 +43,14 @@ def _draw(i):
     tdt = "bf16" if (rng.random() < 0.25 and D % 8 == 0) else "f32"
     feed = str(rng.choice(["pairs", "users", "users_grouped"]))
     fused = bool(rng.random() < 0.8)
-    return dict(D=D, K=K, H=H, M=M, P=P, Nm=Nm, nR=nR, B=B, n_user=n_user, abl=abl, tdt=tdt, feed=feed, fused=fused)
+    # a second, independent stream for the switches added later (the draws above keep their values)
+    rng2 = np.random.default_rng(50000 + i)
+    hoist = [False, False, True, "step"][int(rng2.integers(0, 4))]       # entity-table mode
+    ids32 = bool(rng2.random() < 0.3)                                   # int32 user / item ids instead of int64
+    probs = bool(rng2.random() < 0.25)                                  # attention outputs requested (model.py:319-323)
+    twice = bool(rng2.random() < 0.3)                                   # score twice on one model (cached state)
+    return dict(D=D, K=K, H=H, M=M, P=P, Nm=Nm, nR=nR, B=B, n_user=n_user, abl=abl, tdt=tdt, feed=feed, fused=fused,
+                hoist=hoist, ids32=ids32, probs=probs, twice=twice)
 
 
 @pytest.mark.parametrize("i", range(OFFSET, OFFSET + N_CASES))
@@ -64,16 +71,24 @@ def test_random_configuration(i, hip_lib):
         case.memories_h, case.memories_r, case.memories_t = synth.memories_for(uts, case.users)
     m, e = run_oracles(args, case, oracle_params)
     model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
-                 device="cuda:0", fused=c["fused"], table_dtype=c["tdt"])
+                 device="cuda:0", fused=c["fused"], table_dtype=c["tdt"], hoist=c["hoist"])
     dev = model.device
     u_d, i_d = torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev)
-    if c["feed"] == "pairs":
-        out = model.forward_device(u_d, i_d, [torch.from_numpy(x).to(dev) for x in case.memories_h],
-                                   [torch.from_numpy(x).to(dev) for x in case.memories_r],
-                                   [torch.from_numpy(x).to(dev) for x in case.memories_t])
-    else:
+    if c["ids32"]:
+        u_d, i_d = u_d.to(torch.int32), i_d.to(torch.int32)
+    mem = [[torch.from_numpy(x).to(dev) for x in lst] for lst in (case.memories_h, case.memories_r, case.memories_t)]
+    uts_d = torch.from_numpy(uts).to(dev)
+
+    def score():
+        if c["feed"] == "pairs":
+            return model.forward_device(u_d, i_d, *mem, want_probs=c["probs"])
         model.group_min_pairs_per_user = 0 if c["feed"] == "users_grouped" else 10 ** 9
-        out = model.forward_users(u_d, i_d, torch.from_numpy(uts).to(dev))
+        return model.forward_users(u_d, i_d, uts_d, want_probs=c["probs"])
+    out = score()
+    if c["twice"]:
+        first = out.scores.clone()
+        out = score()
+        assert torch.equal(first, out.scores), f"second call differs from the first, case {i} {c}"
     torch.cuda.synchronize()
     tol = dict(rtol=1e-5, atol=1e-6) if c["tdt"] == "f32" else dict(rtol=1e-5, atol=2e-6)
     what = f"case {i} {c}"
@@ -81,6 +96,14 @@ def test_random_configuration(i, hip_lib):
     assert_close(got, m.scores.numpy(), f"scores vs fp32 mirror, {what}", **tol)
     assert_close(out.user_o.cpu().numpy(), m.user_o.numpy(), f"user_o, {what}", **tol)
     assert_close(out.item_embeddings.cpu().numpy(), m.item_embeddings.numpy(), f"item_embeddings, {what}", **tol)
+    if c["probs"]:
+        # importance_list of the last mix block's first aggregator pass (model.py:294,304,319-323), per hop
+        assert len(out.importance_list) == len(m.importance_list), what
+        for hop, (pg, pm) in enumerate(zip(out.importance_list, m.importance_list)):
+            if pm is None:
+                assert pg is None, f"importance_list[{hop}] given but the mirror has none, {what}"
+            else:
+                assert_close(pg.cpu().numpy(), pm.numpy(), f"importance_list[{hop}], {what}", rtol=1e-5, atol=1e-6)
     err_hip = np.abs(got - e.scores).max()
     err_mir = np.abs(m.scores.numpy() - e.scores).max()
     assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
