@@ -196,14 +196,10 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
     const size_t lds = (size_t)n_user * sizeof(int32_t);
     const bool small = lds <= kGroupSmallMaxLds && (force < 0 ? B <= kGroupSmallMaxB : force == 1);
     if (small) {
-        if (lds > 48 * 1024) {
-            static thread_local size_t set_for = 0;
-            if (lds > set_for) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_small_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGroupSmallMaxLds);
-                if (e != hipSuccess) return e;
-                set_for = kGroupSmallMaxLds;
-            }
+        if (lds > 48 * 1024) {      // per launch: the attribute belongs to the current device's copy of the function
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_small_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGroupSmallMaxLds);
+            if (e != hipSuccess) return e;
         }
         group_small_kernel<<<1, 1024, lds, st>>>(u64, u32, B, n_user, seg_user, seg_ptr, nseg, pair_index);
         return hipGetLastError();
@@ -215,13 +211,9 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
     {
         const size_t scan_lds = (size_t)(n_user < kScanTile ? n_user : kScanTile) * sizeof(int32_t);
         if (scan_lds > 48 * 1024) {
-            static thread_local bool set = false;
-            if (!set) {
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(kScanTile * sizeof(int32_t)));
-                if (e != hipSuccess) return e;
-                set = true;
-            }
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kScanTile * sizeof(int32_t)));
+            if (e != hipSuccess) return e;
         }
         group_scan_kernel<<<1, 1024, scan_lds, st>>>(count, n_user, B, offs, seg_user, seg_ptr, nseg);
     }
