@@ -35,6 +35,9 @@ def construct_adj(csr, n_entity, K, seed=1):
     """contruct_random_adj (:375-388) -> (adj_entity, adj_relation) int32 [nE, K] on the device."""
     indptr, dst, rel = csr
     lib = _lib.load()
+    if dst.numel() == 0:      # a KG without triples: every entity keeps the all-zero row of :377-380 (found by the prep fuzz test)
+        z = torch.zeros((n_entity, K), dtype=torch.int32, device=indptr.device)
+        return z, z.clone()
     adj_e = torch.empty((n_entity, K), dtype=torch.int32, device=indptr.device)
     adj_r = torch.empty((n_entity, K), dtype=torch.int32, device=indptr.device)
     _lib.check(lib.mvin_sample_adjacency(_p(indptr), _p(dst), _p(rel), n_entity, K, seed, _p(adj_e), _p(adj_r),
@@ -64,7 +67,7 @@ def get_user_triplet_set(csr, hist, n_user, p_hop, n_memory, seed=1, n_neighbor=
     P = max(1, p_hop)
     lib = _lib.load()
     out = torch.zeros((n_user, P, 3, n_memory), dtype=torch.int32, device=indptr.device)
-    if hist_items.numel() == 0:
+    if hist_items.numel() == 0 or dst.numel() == 0:     # nobody has a positive item / the KG has no triples: no entries
         return out
     _lib.check(lib.mvin_build_ripple_sets(_p(indptr), _p(dst), _p(rel), _p(hist_ptr), _p(hist_items), n_user, P,
                                           n_memory, n_neighbor, seed, _p(out), _stream()),
