@@ -109,6 +109,20 @@ def test_ranks_time_sharing_one_gpu(world, hip_lib):
     assert all(f"rank {k} ok" in r.stdout for k in range(world))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_configuration_fuzz(world, hip_lib):
+    """Seeded random configurations (dims, fan-outs, depths, ablation presets, table sizes that do not divide, bf16
+    shards, both exchange regimes and the static rule, pipeline, the three feed forms, entity-table mode) scored through
+    ShardedMVIN by ``world`` ranks time-sharing the GPU against a replicated model: tests/dist_fuzz_worker.py.
+    MVIN_DIST_FUZZ_CASES / MVIN_DIST_FUZZ_OFFSET size a longer campaign."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = os.environ.get("MVIN_DIST_FUZZ_CASES", "10")
+    off = os.environ.get("MVIN_DIST_FUZZ_OFFSET", "0")
+    r = _run_ranks([os.path.join(root, "tests", "dist_fuzz_worker.py"), n, off], world, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-4000:]
+    assert all(f"rank {k} ok" in r.stdout for k in range(world))
+
+
 def test_bench_two_ranks_one_gpu(hip_lib):
     """bench.py's N>1 branch end to end (torchrun launch line of the driver, gloo transport)."""
     import json
