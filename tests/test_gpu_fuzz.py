@@ -107,3 +107,35 @@ def test_random_configuration(i, hip_lib):
     err_hip = np.abs(got - e.scores).max()
     err_mir = np.abs(m.scores.numpy() - e.scores).max()
     assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
+
+
+N_GRAPH = int(os.environ.get("MVIN_GRAPH_FUZZ_CASES", "8"))
+
+
+@pytest.mark.parametrize("i", range(OFFSET, OFFSET + N_GRAPH))
+def test_random_configuration_hipgraph_replay(i, hip_lib):
+    """graph.GraphedScorer on a random configuration: the pass captured once, replayed on two NEW batches, must give
+    the scores of eager launches on the same inputs bit for bit."""
+    from mvin_amd.graph import GraphedScorer
+    from mvin_amd.model import MVIN
+    c = _draw(30000 + i)
+    B = c["B"]
+    args = make_args(dim=c["D"], neighbor_sample_size=c["K"], h_hop=c["H"], n_mix_hop=c["M"], p_hop=c["P"],
+                     n_memory=c["Nm"], batch_size=B, ablation=c["abl"])
+    big = make_args(**dict(vars(args), batch_size=2 * B))
+    case = synth.small_case(big, n_user=c["n_user"], n_entity=150 + 37 * (i % 5), n_relation=c["nR"], seed=39100 + i, zero_rows=3)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=39200 + i, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+                 device="cuda:0", fused=c["fused"], table_dtype=c["tdt"], hoist=c["hoist"])
+    dev = model.device
+    scorer = GraphedScorer(model, B)
+    for s in range(2):
+        sl = slice(s * B, (s + 1) * B)
+        u = torch.from_numpy(np.ascontiguousarray(case.users[sl])).to(dev)
+        it = torch.from_numpy(np.ascontiguousarray(case.items[sl])).to(dev)
+        mem = [[torch.from_numpy(np.ascontiguousarray(x[sl])).to(dev) for x in lst]
+               for lst in (case.memories_h, case.memories_r, case.memories_t)]
+        got = scorer(u, it, *mem).scores.clone()
+        ref = model.forward_device(u, it, *mem).scores
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), f"replay {s} differs from eager, case {i} {c}"

@@ -80,3 +80,51 @@ def test_random_training_configuration(i, hip_lib):
     for name, g in got.items():
         if name not in ref:
             assert not np.any(g), f"{name} has a gradient but the reference has none, {what}"
+
+
+N_TRAJ = int(os.environ.get("MVIN_TRAJ_FUZZ_CASES", "8"))
+
+
+@pytest.mark.parametrize("i", range(OFFSET, OFFSET + N_TRAJ))
+def test_random_training_trajectory_eager_graphed_reference(i, hip_lib):
+    """Three optimisation steps on a different batch each, for a random configuration: the eager Trainer, the step
+    replayed as a hipGraph (training.GraphedTrainer) and oracle/train_ref.py (autograd + tf.train.AdamOptimizer's rule)
+    must report the same losses; eager and graphed parameters stay together."""
+    from mvin_amd.model import MVIN
+    from mvin_amd.training import GraphedTrainer, Trainer
+    c = _draw(20000 + i)
+    B = max(c["B"], 2)
+    args = make_args(ablation=c["abl"], l2_weight=1e-3, l2_agg_weight=1e-4, lr=5e-3, dim=c["D"], neighbor_sample_size=c["K"],
+                     h_hop=c["H"], n_mix_hop=c["M"], p_hop=c["P"], n_memory=c["Nm"], batch_size=B)
+    big = make_args(**dict(vars(args), batch_size=3 * B))
+    case = synth.small_case(big, n_user=c["n_user"], n_entity=90 + 13 * (i % 4), n_relation=c["nR"], seed=27100 + i, zero_rows=2)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=27200 + i, random_agg_bias=True)
+    labels = (np.random.default_rng(27300 + i).random(3 * B) < 0.5).astype(np.float32)
+    mk = lambda: MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+                      device="cuda:0")
+    model_e, model_g = mk(), mk()
+    dev = model_e.device
+    tr_e, tr_g = Trainer(model_e), Trainer(model_g)
+    gt = GraphedTrainer(tr_g, B, ids_dtype=torch.from_numpy(case.users).dtype)
+    ref_p = {k: np.array(v, dtype=np.float32) for k, v in params.items()}
+    opt = train_ref.AdamRef(ref_p, lr=args.lr)
+    le, lg, lr_ = [], [], []
+    what = f"case {i} {c}"
+    for s in range(3):
+        sl = slice(s * B, (s + 1) * B)
+        cut = lambda x: np.ascontiguousarray(x[sl])
+        c_u, c_i, c_l = cut(case.users), cut(case.items), cut(labels)
+        mh, mr, mt = [cut(x) for x in case.memories_h], [cut(x) for x in case.memories_r], [cut(x) for x in case.memories_t]
+        feed = (torch.from_numpy(c_u).to(dev), torch.from_numpy(c_i).to(dev), torch.from_numpy(c_l).to(dev),
+                [torch.from_numpy(x).to(dev) for x in mh], [torch.from_numpy(x).to(dev) for x in mr],
+                [torch.from_numpy(x).to(dev) for x in mt])
+        le.append(tr_e.step(*feed))
+        lg.append(float(gt.step(*feed).item()))
+        rl, rg, _, _ = train_ref.loss_and_grads(args, ref_p, case.adj_entity, case.adj_relation, c_u, c_i, c_l, mh, mr, mt)
+        lr_.append(rl)
+        ref_p = opt.step(ref_p, rg)
+    np.testing.assert_allclose(lg, le, rtol=5e-5, atol=1e-6, err_msg=what)
+    np.testing.assert_allclose(le, lr_, rtol=1e-3, atol=1e-5, err_msg=what)
+    pe, pg = model_e.parameters_dict(), model_g.parameters_dict()
+    for k in pe:
+        np.testing.assert_allclose(pg[k], pe[k], rtol=0, atol=5e-4 * max(1.0, np.abs(pe[k]).max()), err_msg=f"{k}, {what}")
