@@ -139,3 +139,56 @@ def test_random_configuration_hipgraph_replay(i, hip_lib):
         ref = model.forward_device(u, it, *mem).scores
         torch.cuda.synchronize()
         assert torch.equal(got, ref), f"replay {s} differs from eager, case {i} {c}"
+
+
+N_LARGE = int(os.environ.get("MVIN_LARGE_FUZZ_CASES", "6"))
+
+
+@pytest.mark.parametrize("i", range(OFFSET, OFFSET + N_LARGE))
+def test_random_large_shapes_fused_against_per_level(i, hip_lib):
+    """Shapes and batches far beyond what the CPU oracles finish (ragged batches of thousands of pairs, tables of up to
+    200 000 rows, fan-outs up to 64): the fused path (persistent grids, tile pipelines, grid-stride tails) against the
+    per-level kernels -- an independent HIP implementation that the small cases pin to the oracle."""
+    from mvin_amd.model import MVIN
+    rng = np.random.default_rng(60000 + i)
+    D = int(rng.choice([16, 32, 64, 128]))
+    K = int(rng.choice([4, 8, 16, 32, 64]))
+    H = 3 if (K <= 8 and rng.random() < 0.3) else 2
+    rows = sum(K ** e for e in range(H + 1))
+    bmax = max(1, int(1.5e9 // (K ** H * D * 4)))                     # the per-level path materialises [B, K^H, D]
+    B = int(min(bmax, rng.choice([1, 3, 63, 64, 65, 257, 1000, 4099, 20000])))
+    n_entity = int(rng.choice([300, 5000, 200000]))
+    n_user = int(rng.choice([1, 50, 3000]))
+    P = int(rng.choice([1, 2]))
+    Nm = int(rng.choice([8, 16, 64]))
+    nR = int(rng.choice([3, 9, 39]))
+    tdt = "bf16" if rng.random() < 0.3 else "f32"
+    feed = str(rng.choice(["pairs", "users", "users_grouped"]))
+    abl = str(rng.choice(["all", "all", "no_uo", "no_uor", "no_ps_o_ft", "ho_only"]))
+    what = f"case {i}: D={D} K={K} H={H} B={B} nE={n_entity} nU={n_user} P={P} Nm={Nm} nR={nR} {tdt} {feed} {abl} rows/pair={rows}"
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=61000 + i)
+    adj_e[:3] = 0                                                    # entities absent from the KG
+    adj_r[:3] = 0
+    params = init_params(args, n_user, n_entity, nR, seed=62000 + i, random_agg_bias=True)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=63000 + i)
+    users = rng.integers(0, n_user, B)
+    items = rng.integers(0, n_entity, B)
+    outs = []
+    for fused in (True, False):
+        model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0", fused=fused, table_dtype=tdt)
+        dev = model.device
+        u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
+        if feed == "pairs":
+            mem = [[torch.from_numpy(x).to(dev) for x in lst] for lst in synth.memories_for(uts, users)]
+            out = model.forward_device(u_d, i_d, *mem)
+        else:
+            model.group_min_pairs_per_user = 0 if feed == "users_grouped" else 10 ** 9
+            out = model.forward_users(u_d, i_d, torch.from_numpy(uts).to(dev))
+        torch.cuda.synchronize()
+        outs.append((out.scores.cpu().numpy(), out.user_o.cpu().numpy(), out.item_embeddings.cpu().numpy()))
+        del model, out
+        torch.cuda.empty_cache()
+    for name, a_, b_ in zip(("scores", "user_o", "item_embeddings"), outs[0], outs[1]):
+        assert np.isfinite(a_).all() and np.isfinite(b_).all(), f"{name} not finite, {what}"
+        assert_close(a_, b_, f"{name}: fused vs per-level, {what}", rtol=2e-5, atol=2e-6)
