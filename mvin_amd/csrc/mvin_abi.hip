@@ -556,6 +556,7 @@ int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relatio
     k.Nm = Nm;
     k.D = D;
     k.nR = nR;
+    k.n_entity = n_entity;
     return hip_result(mvin::launch_key_addr_grouped(k, table_bf16, (hipStream_t)stream), who);
 }
 
