@@ -30,7 +30,8 @@ constexpr int kW16Waves = 4;                 // waves per workgroup (they only s
 constexpr int kW16LdP = 68;                  // row stride (words) of the wave's 16 x 64 weight tile
 constexpr int kW16LdR = 260;                 // words per relation matrix in LDS
 constexpr int kW16Ids = 2 * 3 * 64;          // the user's ids: [hop][h | r | t][64], padded with -1
-constexpr int kW16PerWave = 16 * kW16LdP + kW16Ids + 16 + 16;     // + h-set read + original pair indices
+constexpr int kW16LdH = 20;                  // row stride (words) of a staged 16-row head tile: 16-byte reads of 16 rows hit 16 bank groups
+constexpr int kW16PerWave = 16 * kW16LdP + kW16Ids + 16 + 16 + 2 * 16 * kW16LdH;   // + h-set read + pair indices + two head tiles
 
 // exp(x) for the softmax arguments (x = logit - max <= 0, or discarded by a select): the argument reduction of the
 // library routine -- x * log2(e) split into an integer and a fraction with the product's rounding error folded back in by
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(kW16Waves * 64, 4) void key_addr_wave16_kernel(KeyA
     int* sIds = reinterpret_cast<int*>(sW + 16 * kW16LdP);       // [2][3][64]
     float* sHset = sW + 16 * kW16LdP + kW16Ids;                  // [16]
     int* sOrig = reinterpret_cast<int*>(sHset + 16);             // [16]
+    float* sHt = sHset + 32;                                     // [2][16][20]
     for (int i = tid; i < a.nR * 256; i += kW16Waves * 64) sR[(i >> 8) * kW16LdR + (i & 255)] = a.R[i];
     __syncthreads();
 
@@ -120,20 +122,43 @@ __global__ __launch_bounds__(kW16Waves * 64, 4) void key_addr_wave16_kernel(KeyA
             sIds[i] = m < Nm ? ub[hx * Nm + m] : -1;
         }
         wave_lds_sync();
+        // Head rows reach the lanes through LDS: a tile of 16 rows (memories m = 16t + j of one hop) is ONE coalesced
+        // wave-load -- lane (q, j) fetches chunk q of row j -- written to a double-buffered 16 x 20-word tile, from which
+        // every lane reads the four chunks of ITS row (the four q lanes the same address).  Loading the rows straight into
+        // the lanes that need them took four 16-byte wave-loads per tile, each fetching every row four times over: the
+        // texture addresser was busy 74 % of the kernel (rocprofv3 TA_TA_BUSY), now NT * (2 + P) wave-loads per user
+        // instead of 4 * NT * (2 + P).  The load of tile i + 1 is in flight while tile i is used.
+        int stage_i = 0;                                         // tiles staged so far (buffer = parity)
+        auto head_chunk = [&](int hop, int t) {
+            const int idh = sIds[(hop * 3 + 0) * 64 + 16 * t + j];
+            return w16_chunk<BF>(a.E, idh >= 0 ? idh : 0, q);     // padding memories read row 0 (finite; masked by position)
+        };
+        auto stage = [&](const float4& v) {
+            float* dst = sHt + (stage_i & 1) * 16 * kW16LdH;
+            wave_lds_sync();                                     // the reads of this buffer two tiles ago are done
+            *reinterpret_cast<float4*>(dst + j * kW16LdH + 4 * q) = v;
+            wave_lds_sync();
+            ++stage_i;
+            return dst + j * kW16LdH;                            // this lane's row
+        };
         if (has_set) {
             // o_hset = sum_m softmax_m(h0_m . w) h0_m (:162-197), BEFORE the fragments occupy 64 registers: this lane's rows
-            // are m = 16t + j (the four q rows hold copies); two passes over four rows, the second one from L1
+            // are m = 16t + j (the four q rows hold copies); two passes over the NT tiles of hop 0
             float lg[NT];
+            float4 cur = head_chunk(0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int idh = sIds[16 * t + j];
+                float4 nxt = cur;
+                if (t + 1 < NT) nxt = head_chunk(0, t + 1);
+                const float* hr = stage(cur);
                 float dl = 0.f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float4 hv = w16_chunk<BF>(a.E, idh >= 0 ? idh : 0, c);
+                    const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * c);
                     dl = fmaf(hv.x, a.w[4 * c], fmaf(hv.y, a.w[4 * c + 1], fmaf(hv.z, a.w[4 * c + 2], fmaf(hv.w, a.w[4 * c + 3], dl))));
                 }
                 lg[t] = (16 * t + j) < Nm ? dl : -INFINITY;
+                cur = nxt;
             }
             float mx = lg[0];
 #pragma unroll
@@ -149,17 +174,21 @@ __global__ __launch_bounds__(kW16Waves * 64, 4) void key_addr_wave16_kernel(KeyA
             float part[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) part[k] = 0.f;
+            cur = head_chunk(0, 0);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int idh = sIds[16 * t + j];
+                float4 nxt = cur;
+                if (t + 1 < NT) nxt = head_chunk(0, t + 1);
+                const float* hr = stage(cur);                    // second pass (e = 0 on padding)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {                    // second pass over four rows the L1 still holds (e = 0 on padding)
-                    const float4 hv = w16_chunk<BF>(a.E, idh >= 0 ? idh : 0, c);
+                for (int c = 0; c < 4; ++c) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * c);
                     part[4 * c] = fmaf(e[t], hv.x, part[4 * c]);
                     part[4 * c + 1] = fmaf(e[t], hv.y, part[4 * c + 1]);
                     part[4 * c + 2] = fmaf(e[t], hv.z, part[4 * c + 2]);
                     part[4 * c + 3] = fmaf(e[t], hv.w, part[4 * c + 3]);
                 }
+                cur = nxt;
             }
             const float inv = 1.f / z;
             float mine = 0.f;                                    // lane k keeps sum k (selects, no divergent branches)
@@ -171,46 +200,35 @@ __global__ __launch_bounds__(kW16Waves * 64, 4) void key_addr_wave16_kernel(KeyA
             sHset[j] = mine * inv;                               // the four q rows hold copies: same value to the same address
         }
         // ---- U and T fragments -> registers ----
-        // The 4 * P head rows of this lane (row i = hop * 4 + t: memory m = 16t + j of that hop) are double-buffered: row
-        // i + 1 is in flight while row i is multiplied.  (With one chunk loaded at a time every chunk exposed a full L2
-        // latency -- 32 of them per user: the kernel ran at 49 us per user.)
         float Bl[2][NT][4], Tf[2][4 * NT];
         {
-            float4 hc[4], hn[4];
-            int r_c, r_n = 0;
-            // padding memories (id -1 beyond Nm) read row 0: their U and T values only have to be finite, the softmax
-            // masks them out by position -- no selects here
-            auto fetch = [&](int i, float4 (&dst)[4], int& r) {
-                const int hop = i / NT, t = i % NT, m = 16 * t + j;
-                const int idh = sIds[(hop * 3 + 0) * 64 + m];
-                r = min((unsigned)sIds[(hop * 3 + 1) * 64 + m], (unsigned)(a.nR - 1));
-                if (a.NRL & 1) r = 0;                            // MVIN_W16_DBG bit 0 (measurement only): every lane reads R_KGE[0]
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dst[c] = w16_chunk<BF>(a.E, idh >= 0 ? idh : 0, c);
-            };
-            fetch(0, hc, r_c);
+            float4 cur = head_chunk(0, 0);
 #pragma unroll
             for (int i = 0; i < NT * P; ++i) {
-                if (i + 1 < NT * P) fetch(i + 1, hn, r_n);
-                const float* Rr = sR + (size_t)r_c * kW16LdR + q * 16;
+                float4 nxt = cur;
+                if (i + 1 < NT * P) nxt = head_chunk((i + 1) / NT, (i + 1) % NT);
+                const float* hr = stage(cur);
+                const int hop = i / NT, t = i % NT;
+                int r = min((unsigned)sIds[(hop * 3 + 1) * 64 + 16 * t + j], (unsigned)(a.nR - 1));
+                if (a.NRL & 1) r = 0;                            // MVIN_W16_DBG bit 0 (measurement only): every lane reads R_KGE[0]
+                const float* Rr = sR + (size_t)r * kW16LdR + q * 16;
                 f32x2 d[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};       // even / odd k apart: v_pk_fma_f32
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const f32x2 h01 = {hc[c].x, hc[c].y}, h23 = {hc[c].z, hc[c].w};
+                    const float4 hv = *reinterpret_cast<const float4*>(hr + 4 * c);
+                    const f32x2 h01 = {hv.x, hv.y}, h23 = {hv.z, hv.w};
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const float4 v = *reinterpret_cast<const float4*>(Rr + 64 * s + 4 * c);          // R[r][n = 4s + q][4c ..]
                         d[s] = __builtin_elementwise_fma(f32x2{v.x, v.y}, h01, d[s]);
                         d[s] = __builtin_elementwise_fma(f32x2{v.z, v.w}, h23, d[s]);
                     }
-                    // four LDS reads at a time: left alone hipcc issues all sixteen of a row up front (64 registers) and spills
+                    // five LDS reads at a time: left alone hipcc issues all of a row's up front (80 registers) and spills
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int s = 0; s < 4; ++s) Bl[i / NT][i % NT][s] = d[s].x + d[s].y;  // U[m = 16t + j][n = 4s + q]
-#pragma unroll
-                for (int c = 0; c < 4; ++c) hc[c] = hn[c];
-                r_c = r_n;
+                for (int s = 0; s < 4; ++s) Bl[hop][t][s] = d[s].x + d[s].y;         // U[m = 16t + j][n = 4s + q]
+                cur = nxt;
             }
         }
 #pragma unroll
@@ -292,7 +310,7 @@ static size_t w16_lds_bytes(int nR) { return ((size_t)nR * kW16LdR + (size_t)kW1
 
 bool key_addr_wave16_supported(int D, int P, int Nm, int nR) {
     static const bool off = getenv("MVIN_KA_WAVE16") != nullptr && getenv("MVIN_KA_WAVE16")[0] == '0';
-    return !off && D == 16 && (P == 1 || P == 2) && Nm >= 1 && Nm <= 64 && nR >= 1 && w16_lds_bytes(nR) <= 64 * 1024;
+    return !off && D == 16 && (P == 1 || P == 2) && Nm >= 1 && Nm <= 64 && nR >= 1 && w16_lds_bytes(nR) <= 80 * 1024;      // two workgroups per CU at least
 }
 
 // rows are addressed by 32-bit byte offsets
@@ -302,12 +320,17 @@ bool key_addr_wave16_applies(const KeyAddrGroupedArgs& a) {
 
 hipError_t launch_key_addr_wave16(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
     const size_t lds = w16_lds_bytes(a.nR);
+    hipError_t err = hipSuccess;
     auto launch = [&](auto kernel) {
-        // persistent grid: as many workgroups as the CUs hold (LDS decides: 34 KB at nR = 9 -> 4 per CU = 16 waves)
+        // persistent grid: as many workgroups as the CUs hold (LDS decides: 44 KB at nR = 9 -> 3 per CU = 12 waves; 75 KB at nR = 39 -> 2)
         static thread_local const void* last_k = nullptr;
         static thread_local size_t last_lds = 0;
         static thread_local int last_per_cu = 1;
         const void* k = reinterpret_cast<const void*>(kernel);
+        if (lds > 64 * 1024) {
+            err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (err != hipSuccess) return;
+        }
         if (k != last_k || lds != last_lds) {
             int per_cu = 1;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, kW16Waves * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -334,7 +357,7 @@ hipError_t launch_key_addr_wave16(const KeyAddrGroupedArgs& a, int table_bf16, h
     MVIN_W16B(false, false) MVIN_W16B(true, false) MVIN_W16B(false, true) MVIN_W16B(true, true)
 #undef MVIN_W16B
 #undef MVIN_W16
-    return hipGetLastError();
+    return err != hipSuccess ? err : hipGetLastError();
 }
 
 }  // namespace mvin
