@@ -35,6 +35,19 @@ constexpr int kD16Waves = 4;
 
 size_t fused_d16_lds_bytes(int nR) { return (size_t)(2 * ((nR + 3) & ~3) + kD16Waves * kD16WaveWords) * 4; }
 
+// The kernel is VALU-ISSUE-bound (~520 instructions per parent and wave, 4 cycles each, against 12 MFMAs and ~6 wave-loads;
+// a software pipeline of the id chain across a wave's parents changed nothing: 0.395 ms either way).  So the softmax
+// arithmetic is spelled lean: exp with the library's argument reduction (product error folded back in by fma) but
+// without its range selects -- the arguments are logit - max <= 0 --, and v_rcp_f32 (1 ulp) instead of the ten-instruction
+// IEEE division for the three normalisations.
+__device__ __forceinline__ float d16_exp(float x) {
+    const float t = x * 1.44269502162933349609375f;              // float(log2 e)
+    const float n = rintf(t);
+    float f = fmaf(x, 1.44269502162933349609375f, -n);
+    f = fmaf(x, 1.925963033500011e-8f, f);                       // log2 e - float(log2 e)
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 template <int K, bool BF>
 __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(FusedL2Args a) {
     constexpr int D = kD16, LD = kD16Ld;
@@ -147,12 +160,12 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
         {
             const float s0 = sT0[r1], s1 = sT1[r1];
             if (has_att0) {
-                const float e = expf(s0 - wave_max_fast(s0));
-                p0 = e / (wave_sum_fast(e) * (K / 64.f));             // every child sits in 64 / K lanes
+                const float e = d16_exp(s0 - wave_max_fast(s0));
+                p0 = e * __builtin_amdgcn_rcpf(wave_sum_fast(e) * (K / 64.f));       // every child sits in 64 / K lanes
             }
             if (has_att1) {
-                const float e = expf(s1 - wave_max_fast(s1));
-                p1 = e / (wave_sum_fast(e) * (K / 64.f));
+                const float e = d16_exp(s1 - wave_max_fast(s1));
+                p1 = e * __builtin_amdgcn_rcpf(wave_sum_fast(e) * (K / 64.f));
             }
         }
         // ---- attention over child n's K grandchildren (aggregators.py:118-146): weights p_k / K ----
@@ -168,11 +181,11 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
             float z = 0.f;
 #pragma unroll
             for (int i = 0; i < KPL; ++i) {
-                w[i] = has_att0 ? expf(w[i] - m) : 1.f;
+                w[i] = has_att0 ? d16_exp(w[i] - m) : 1.f;
                 z += w[i];
             }
             z = across_kh_sum(z);
-            const float rinv = has_att0 ? invK / z : invK;
+            const float rinv = has_att0 ? invK * __builtin_amdgcn_rcpf(z) : invK;
 #pragma unroll
             for (int i = 0; i < KPL; ++i) w[i] *= rinv;
         }
