@@ -272,7 +272,7 @@ hipError_t launch_ripple_build(const RippleBuildArgs& a, hipStream_t st);
 int key_addr_nj(int Nm, int D);
 bool key_addr_grouped_supported(int D, int P, int Nm, int nR);
 hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
-bool key_addr_wave16_supported(int D, int P, int Nm, int nR);    // wave-per-user variant for D = 16, mvin_keyaddr_wave16.hip
+bool key_addr_wave16_supported(int D, int P, int Nm, int nR);    // wave-per-user variant for D = 16 / 32, mvin_keyaddr_wave.hip
 bool key_addr_wave16_applies(const KeyAddrGroupedArgs& a);     // + table small enough for 32-bit row offsets
 hipError_t launch_key_addr_wave16(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 bool key_addr_dense_supported(int D, int P, int Nm, int nR);     // dense (all-MFMA) variant, mvin_keyaddr_dense.hip

@@ -265,7 +265,8 @@ static hipError_t launch_kag(KeyAddrGroupedArgs a, int table_bf16, hipStream_t s
 }
 
 hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st) {
-    // D = 16 (the reference's shipped dimension), one or two hops of <= 64 memories: one wave per user (MVIN_KA_WAVE16=0: A/B)
+    // D = 16 (the reference's shipped dimension) and 32, one or two hops of <= 64 memories: one wave per user
+    // (MVIN_KA_WAVE=0 / MVIN_KA_WAVE32=0: A/B)
     if (key_addr_wave16_applies(a)) return launch_key_addr_wave16(a, table_bf16, st);
     // the dense (all-MFMA) form whenever its LDS footprint fits; MVIN_KA_DENSE=0 keeps this file's kernel (A/B)
     static const char* dense_env = getenv("MVIN_KA_DENSE");

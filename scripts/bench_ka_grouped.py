@@ -24,4 +24,4 @@ e0.record()
 for _ in range(20):
     ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, (P + 1) * D, nR)
 e1.record(); torch.cuda.synchronize()
-print(f"{ds} D={D} P={P} Nm={Nm} nR={nR}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call  (MVIN_W16_DBG={os.environ.get('MVIN_W16_DBG', '0')}, MVIN_KA_WAVE16={os.environ.get('MVIN_KA_WAVE16', '1')})", flush=True)
+print(f"{ds} D={D} P={P} Nm={Nm} nR={nR}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per call  (MVIN_KA_WAVE_DBG={os.environ.get('MVIN_KA_WAVE_DBG', '0')}, MVIN_KA_WAVE={os.environ.get('MVIN_KA_WAVE', '1')}, MVIN_KA_WAVE32={os.environ.get('MVIN_KA_WAVE32', '1')})", flush=True)

@@ -13,4 +13,4 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$out/g$i" -- python "$root/scripts/bench_ka_grouped.py" 16 "$@" > "$out/g$i.log" 2>&1
 done
-cd "$root"; python scripts/pmc_kernel_means.py "$out" key_addr_wave16
+cd "$root"; python scripts/pmc_kernel_means.py "$out" key_addr_wave_kernel
