@@ -157,7 +157,8 @@ int mvin_gather_attn_l2_supported(int D, int K);
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
  * probs, adjacency and outputs below 2 GiB), 3 = the wave-per-parent kernel for D = 16, K in {4, 8, 16} (the
- * reference's shipped settings: no workgroup phases at all; no probs, table below 4 GiB).
+ * reference's shipped settings: no workgroup phases at all; no probs, table below 4 GiB), 4 = the wave-per-parent
+ * kernel for D = 32, K in {8, 16} (BASELINE config C2; same conditions; it takes these shapes ahead of the pipeline).
  * n_parents = B * parents_per_pair.  For tests and benchmarks. */
 int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);
 /* Measurement aid: the row gathers of mvin_gather_attn_l2_fwd and nothing else, written the plain way (one wave per

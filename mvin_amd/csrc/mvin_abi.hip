@@ -173,6 +173,7 @@ int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, i
     float probe = 0.f;
     if (want_probs) f.probs_parent = f.probs_child = &probe;     // only tested for presence
     f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 2;        // the smaller (bf16) size: sufficient for either dtype here
+    if (mvin::fused_d32_applies(f, D)) return 4;
     if (mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D)) return 2;
     return mvin::fused_d16_applies(f, D) ? 3 : 1;
 }

@@ -606,6 +606,9 @@ bool fused_l2_split_in_use() {
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st) {
     // D >= 32, K in {16 (D = 32), 32, 64, 128}: the role-split pipeline (gather waves + dense waves);
     // MVIN_L2_SPLIT=0 keeps the symmetric kernel below for A/B measurements
+    // D = 32, K <= 16 (BASELINE config C2): one wave per parent -- tiles of 16 x 16 rows are too small for the pipeline's
+    // per-step costs (MVIN_L2_D32=0: A/B)
+    if (fused_d32_applies(a, D)) return launch_gather_attn_l2_d32(a, table_bf16, st);
     if (fused_l2_split_in_use() && fused_split_applies(a, D)) return launch_gather_attn_l2_split(a, D, table_bf16, st);
     // D = 16, K <= 16 (the reference's shipped settings): one wave per parent, no workgroup phases
     if (fused_d16_applies(a, D)) return launch_gather_attn_l2_d16(a, table_bf16, st);

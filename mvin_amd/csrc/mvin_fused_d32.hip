@@ -1,0 +1,384 @@
+// Fused two-level gather + attention kernel for D = 32 and fan-out K in {8, 16} (gfx950) -- BASELINE config C2
+// (MovieLens-1M, dim 32, fan-out 16, depth 2).
+//
+// Same arguments, arithmetic and outputs as gather_attn_l2_kernel (mvin_fused.hip; reference model.py:251-305,
+// aggregators.py:98-146).  The role-split pipeline (mvin_fused_split.hip) walks tiles of min(K, 32) children with one
+// workgroup barrier per tile; at K = 16 a tile is 16 x 16 rows of 128 bytes = 32 KB, a quarter of a C3 tile, and the
+// per-step costs (barrier, restart of the gather waves from an empty queue) dominate: 1.375 ms per 524 288 parents = 52 %
+// of the measured gather ceiling, where the same kernel reaches 90 % at C3; a plain gather-and-sum of the same rows
+// (gather_probe_l2_kernel) is 1.4x faster than it.  Here, as in mvin_fused_d16.hip, ONE WAVE owns a parent end to end:
+// a two-level tree is 1 + K + K^2 <= 273 rows of 128 bytes, nothing is shared between waves, no workgroup barrier.
+//
+// Lane layout:  lane = c + 8 * g,  c = 16-byte chunk of a 128-byte row (8 lanes per row, 8 rows per wave-instruction),
+// g = 0..7.  A lane serves the NCH = K / 8 children n = g + 8i: it gathers chunk c of all K grandchild rows of each,
+// so the weighted row sum S'[n] stays in the lane (no cross-lane reduction).  The (child, k) id / logit work of the
+// K x K grandchildren is spread the other way -- lane (c, g) takes k = c + 8e of its children -- and the (id, weight)
+// lists go through a wave-private LDS table; the softmax over a child's K grandchildren is in-lane over e plus a DPP
+// reduction over the 8 lanes of the child; the softmax over the parent's K children is a whole-wave reduction.  The dense
+// part (aggregators.py:108-116 after the sum) runs on v_mfma_f32_16x16x4_f32 with the K children as the rows of one
+// 16-row tile staged through the wave's LDS slice, weights resident as B fragments (48 VGPRs).
+#include <cstdlib>
+
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kD32 = 32;
+constexpr int kD32Ld = 36;                                   // LDS row stride (floats): 16-byte aligned rows, 16 rows -> 16 bank groups
+constexpr int kD32Waves = 4;
+constexpr int d32_wave_words(int K) { return 3 * 16 * kD32Ld + 32 + 2 * 16 * K; }      // sA1 | sA2 | sZ | sP0 | sP1 | sY | sWt
+
+size_t fused_d32_lds_bytes(int nR, int K) { return (size_t)(2 * ((nR + 3) & ~3) + kD32Waves * d32_wave_words(K)) * 4; }
+
+// exp for softmax arguments (x = logit - max <= 0): the library's argument reduction without its range selects
+__device__ __forceinline__ float d32_exp(float x) {
+    const float t = x * 1.44269502162933349609375f;
+    const float n = rintf(t);
+    float f = fmaf(x, 1.44269502162933349609375f, -n);
+    f = fmaf(x, 1.925963033500011e-8f, f);
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+template <int K, bool BF>
+__global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(FusedL2Args a) {
+    constexpr int D = kD32, LD = kD32Ld;
+    constexpr int NCH = K / 8;               // children per lane
+    constexpr int KE = K / 8;                // grandchild slots per child whose ids / logits this lane computes
+    constexpr int RB = BF ? 64 : 128;        // row bytes
+    constexpr int WW = d32_wave_words(K);
+    static_assert(K == 8 || K == 16, "K");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nRp = (a.nR + 3) & ~3;
+    float* sT0 = smem;                                   // [nRp] relation logits of aggregator (0,.) (zeros: uniform)
+    float* sT1 = sT0 + nRp;                              // [nRp] ... of aggregator (1,.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* wbase = sT1 + nRp + wave * WW;                // this wave's private slice
+    float* sA1 = wbase;                                  // [16][LD]  E[x1] + q
+    float* sA2 = sA1 + 16 * LD;                          // [16][LD]  S' + (sum_k p_k / K) q
+    float* sZ = sA2 + 16 * LD;                           // [16][LD]
+    float* sP0 = sZ + 16 * LD;                           // [16]
+    float* sP1 = sP0 + 16;                               // [16]
+    int* sY = reinterpret_cast<int*>(sP1 + 16);          // [16][K] grandchild ids
+    float* sWt = reinterpret_cast<float*>(sY + 16 * K);  // [16][K] their weights p_k / K
+    const bool has_proj = a.W1 != nullptr;
+    const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
+    const float invK = 1.f / (float)K;
+    const float c2scale = has_att0 ? invK : 1.f;         // sum_k of the grandchild weights
+
+    for (int i = tid; i < a.nR; i += kD32Waves * 64) {
+        sT0[i] = has_att0 ? a.t0[i] : 0.f;
+        sT1[i] = has_att1 ? a.t1[i] : 0.f;
+    }
+    for (int i = lane; i < WW; i += 64) wbase[i] = 0.f;  // tile rows >= K stay zero (weights 0)
+    __syncthreads();                                     // the only workgroup barrier: the two shared tables
+
+    const int c = lane & 7, g = lane >> 3;
+    const int q16 = lane >> 4, l16 = lane & 15;
+    // weights as MFMA B fragments, contraction index permuted (step s, slot q16 <-> k = 8*q16 + s) so that a lane's A
+    // operands of the eight steps are two 16-byte LDS reads
+    float bW1[8][2], bW2[8][2], bA0[8][2];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int kk = 8 * q16 + s;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            bW1[s][cc] = has_proj ? a.W1[kk * D + 16 * cc + l16] : 0.f;
+            bW2[s][cc] = has_proj ? a.W2[kk * D + 16 * cc + l16] : 0.f;
+            bA0[s][cc] = a.A0[kk * D + 16 * cc + l16];
+        }
+    }
+    float b1v[2], b2v[2], a0v[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        b1v[cc] = (has_proj && a.b1) ? a.b1[16 * cc + l16] : 0.f;
+        b2v[cc] = ((has_proj && a.b2) ? a.b2[16 * cc + l16] : 0.f) * c2scale;
+        a0v[cc] = a.a0 ? a.a0[16 * cc + l16] : 0.f;
+    }
+
+    // 32-bit offsets through buffer descriptors (the launcher guarantees every range < 2^31 / 2^32 bytes)
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, a.adj_r ? (int)a.adj_bytes : 0,
+                                                                           0x00020000);      // none: relation ids read as 0
+    const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out0 = __builtin_amdgcn_make_buffer_rsrc(a.nagg0, 0, (int)(a.P * D * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t out1 = __builtin_amdgcn_make_buffer_rsrc(a.nagg1, 0, (int)(a.P * D * 4), 0x00020000);
+    auto row4 = [&](int id) -> float4 {                 // chunk c of table row `id`
+        if constexpr (BF) {
+            const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 8u, 0, 0);
+            return bf16x4_to_f32(make_uint2(r[0], r[1]));
+        } else {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 16u, 0, 0);
+            return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+    };
+    // reductions over the K children of the parent: a child sits in the 8 c-lanes of group g (and slot i in-lane), so the
+    // groups are combined: g ^ 1 (lanes ^ 8, inside a 16-lane DPP row), then rows ^ 16 and ^ 32
+    auto over_groups_max = [&](float v) {
+        v = fmaxf(v, dpp_mov<0x128>(v));                 // row_ror:8 = lane ^ 8 inside the row
+        return rows_combine_max(v);
+    };
+    auto over_groups_sum = [&](float v) {
+        v += dpp_mov<0x128>(v);
+        return rows_combine_sum(v);
+    };
+
+    const int64_t nwaves = (int64_t)gridDim.x * kD32Waves;
+    for (int64_t p = (int64_t)blockIdx.x * kD32Waves + wave; p < a.P; p += nwaves) {
+        const int x0 = fused_parent_id(a, p);
+        // ---- level L-1: this lane's NCH children (model.py:251-252) ----
+        int x1[NCH], r1[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const unsigned o1 = ((unsigned)x0 * K + (unsigned)(g + 8 * i)) * 4u;
+            x1[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o1, 0, 0);
+            r1[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o1, 0, 0);
+        }
+        float4 qv;
+        {   // no projection: zero records, the load returns 0 without touching memory
+            const unsigned qo = (((unsigned)p / (unsigned)a.parents_per_pair) * D + 4u * c) * 4u;
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qo, 0, 0);
+            qv = make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+        }
+        // ---- level L ids and the attention over each child's K grandchildren (aggregators.py:118-146): this lane takes
+        //      k = c + 8e of its children; (id, p_k / K) -> the wave's LDS lists ----
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int ye[KE];
+            float lg[KE];
+            float m = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < KE; ++e) {
+                const unsigned o2 = ((unsigned)x1[i] * K + (unsigned)(c + 8 * e)) * 4u;
+                ye[e] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o2, 0, 0);
+                const int re = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o2, 0, 0);
+                lg[e] = sT0[re];
+                m = fmaxf(m, lg[e]);
+            }
+            m = group_max(m, 3);                         // the 8 c-lanes of this child
+            float z = 0.f;
+#pragma unroll
+            for (int e = 0; e < KE; ++e) {
+                lg[e] = has_att0 ? d32_exp(lg[e] - m) : 1.f;
+                z += lg[e];
+            }
+            z = group_sum(z, 3);
+            const float rinv = has_att0 ? invK * __builtin_amdgcn_rcpf(z) : invK;
+            const int n = g + 8 * i;
+#pragma unroll
+            for (int e = 0; e < KE; ++e) {
+                sY[n * K + c + 8 * e] = ye[e];
+                sWt[n * K + c + 8 * e] = lg[e] * rinv;
+            }
+        }
+        // ---- the children's own rows land under the rest ----
+        float4 sv[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) sv[i] = row4(x1[i]);
+        // ---- attention over the parent's K children: aggregator (0,.) -> p0, aggregator (1,.) -> p1 ----
+        float p0[NCH], p1[NCH];
+        {
+            float s0[NCH], s1[NCH], m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                s0[i] = sT0[r1[i]];
+                s1[i] = sT1[r1[i]];
+                m0 = fmaxf(m0, s0[i]);
+                m1 = fmaxf(m1, s1[i]);
+            }
+            if (has_att0) {
+                m0 = over_groups_max(m0);
+                float z = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    p0[i] = d32_exp(s0[i] - m0);
+                    z += p0[i];
+                }
+                const float rz = __builtin_amdgcn_rcpf(over_groups_sum(z));
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) p0[i] *= rz;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) p0[i] = 1.f;
+            }
+            if (has_att1) {
+                m1 = over_groups_max(m1);
+                float z = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    p1[i] = d32_exp(s1[i] - m1);
+                    z += p1[i];
+                }
+                const float rz = __builtin_amdgcn_rcpf(over_groups_sum(z));
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) p1[i] *= rz;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) p1[i] = 1.f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // ---- S'[n] = sum_k (p_k / K) E[y_k], chunk c, in-lane: the K rows of a child in batches of 8 loads ----
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int n = g + 8 * i;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                const int4 ya = *reinterpret_cast<const int4*>(sY + n * K + k0);
+                const int4 yb = *reinterpret_cast<const int4*>(sY + n * K + k0 + 4);
+                const float4 wa = *reinterpret_cast<const float4*>(sWt + n * K + k0);
+                const float4 wb = *reinterpret_cast<const float4*>(sWt + n * K + k0 + 4);
+                float4 rows[8];
+                rows[0] = row4(ya.x);
+                rows[1] = row4(ya.y);
+                rows[2] = row4(ya.z);
+                rows[3] = row4(ya.w);
+                rows[4] = row4(yb.x);
+                rows[5] = row4(yb.y);
+                rows[6] = row4(yb.z);
+                rows[7] = row4(yb.w);
+                acc = f4_fma(wa.x, rows[0], acc);
+                acc = f4_fma(wa.y, rows[1], acc);
+                acc = f4_fma(wa.z, rows[2], acc);
+                acc = f4_fma(wa.w, rows[3], acc);
+                acc = f4_fma(wb.x, rows[4], acc);
+                acc = f4_fma(wb.y, rows[5], acc);
+                acc = f4_fma(wb.z, rows[6], acc);
+                acc = f4_fma(wb.w, rows[7], acc);
+            }
+            // ---- the K children as rows of a 16-row tile: {E[x1] + q | S' + (sum p / K) q} (model.py:277) ----
+            *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv[i].x + qv.x, sv[i].y + qv.y, sv[i].z + qv.z, sv[i].w + qv.w);
+            *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = f4_fma(c2scale, qv, acc);
+            if (c == 0) {
+                sP0[n] = p0[i];
+                sP1[n] = p1[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // ---- phase B: self1 = (E[x1] + q) W1 + b1 ; Z = self1 + (S' + c q) W2 + c b2 ; nagg0 = sum_n p0[n] self1[n] ----
+        float s1v[2][4], zv[2][4];
+        if (has_proj) {
+            float f1[8], f2[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 u1 = *reinterpret_cast<const float4*>(sA1 + l16 * LD + 8 * q16 + 4 * h);
+                const float4 u2 = *reinterpret_cast<const float4*>(sA2 + l16 * LD + 8 * q16 + 4 * h);
+                f1[4 * h] = u1.x, f1[4 * h + 1] = u1.y, f1[4 * h + 2] = u1.z, f1[4 * h + 3] = u1.w;
+                f2[4 * h] = u2.x, f2[4 * h + 1] = u2.y, f2[4 * h + 2] = u2.z, f2[4 * h + 3] = u2.w;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accS = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[s], bW1[s][cc], accE, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2[s], bW2[s][cc], accS, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1v[cc][r] = accE[r] + b1v[cc];
+                    zv[cc][r] = s1v[cc][r] + (accS[r] + b2v[cc]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1v[cc][r] = sA1[(4 * q16 + r) * LD + 16 * cc + l16];
+                    zv[cc][r] = s1v[cc][r] + sA2[(4 * q16 + r) * LD + 16 * cc + l16];
+                }
+        }
+        float nagg0[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            float part0 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                part0 = fmaf(sP0[4 * q16 + r], s1v[cc][r], part0);
+                sZ[(4 * q16 + r) * LD + 16 * cc + l16] = zv[cc][r];
+            }
+            nagg0[cc] = rows_combine_sum(part0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        // ---- phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1 = sum_n p1[n] out1[n] ----
+        float fz[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 u = *reinterpret_cast<const float4*>(sZ + l16 * LD + 8 * q16 + 4 * h);
+            fz[4 * h] = u.x, fz[4 * h + 1] = u.y, fz[4 * h + 2] = u.z, fz[4 * h + 3] = u.w;
+        }
+        float nagg1[2];
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz[s], bA0[s][cc], acc2, 0, 0, 0);
+            float part1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v[cc], 0.f), part1);
+            nagg1[cc] = rows_combine_sum(part1);
+        }
+        if (q16 == 0) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const unsigned off = ((unsigned)p * D + 16u * cc + (unsigned)l16) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0[cc] * invK), out0, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1[cc] * invK), out1, off, 0, 0);
+            }
+        }
+        // the next parent's tile / list writes must stay behind this parent's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+bool fused_d32_supported(int D, int K) { return D == 32 && (K == 8 || K == 16); }
+
+// ... and for these arguments: no attention outputs requested, every buffer addressable with 32-bit byte offsets
+bool fused_d32_applies(const FusedL2Args& a, int D) {
+    static const char* e = getenv("MVIN_L2_D32");
+    if (e && e[0] == '0') return false;                  // A/B: the role-split / symmetric kernel
+    return fused_d32_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
+           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31);
+}
+
+template <int K, bool BF>
+static hipError_t launch_d32(const FusedL2Args& a, hipStream_t st) {
+    const size_t lds = fused_d32_lds_bytes(a.nR, K);
+    const int64_t wgs = (a.P + kD32Waves - 1) / kD32Waves;
+    static thread_local int per_cu = 0;
+    if (per_cu == 0) {
+        int v = 3;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(gather_attn_l2_d32_kernel<K, BF>), kD32Waves * 64, lds) !=
+                hipSuccess || v < 1)
+            v = 3;
+        per_cu = v;
+    }
+    const int64_t cap = 256 * (int64_t)per_cu;           // persistent grid
+    const int grid = (int)(wgs < cap ? wgs : cap);
+    gather_attn_l2_d32_kernel<K, BF><<<grid, kD32Waves * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st) {
+    switch (a.K) {
+        case 8: return table_bf16 ? launch_d32<8, true>(a, st) : launch_d32<8, false>(a, st);
+        case 16: return table_bf16 ? launch_d32<16, true>(a, st) : launch_d32<16, false>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin
