@@ -108,6 +108,7 @@ struct KeyAddrGroupedArgs {
     int64_t ldo;
     int nseg, P, Nm, D, nR, NRL;
     int n_entity;              // rows of E: the wave-per-user kernel clamps item ids into the table
+    int dbg;                   // wave-per-user kernel, measurement only (MVIN_KA_WAVE_DBG)
 };
 
 struct TailArgs {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(KwCfg<D>::Waves * 64, KwCfg<D>::MinW) void key_addr
                     const float* hr = stage(cur);
                     const int hl = i / NT, t = i % NT;
                     int r = min((unsigned)sIds[((h0 + hl) * 3 + 1) * 64 + 16 * t + j], (unsigned)(a.nR - 1));
-                    if (a.NRL & 1) r = 0;                        // MVIN_KA_WAVE_DBG bit 0 (measurement only): every lane reads R_KGE[0]
+                    if (a.dbg & 1) r = 0;                        // MVIN_KA_WAVE_DBG bit 0 (measurement only): every lane reads R_KGE[0]
                     const float* Rr = sR + (size_t)r * LdR + q * D;
                     f32x2 d[KS];                                 // even / odd k apart: v_pk_fma_f32
 #pragma unroll
@@ -389,7 +389,7 @@ static hipError_t launch_kw(const KeyAddrGroupedArgs& a, int table_bf16, hipStre
         const int need = (a.nseg + NWV - 1) / NWV;
         static const int dbg = getenv("MVIN_KA_WAVE_DBG") ? atoi(getenv("MVIN_KA_WAVE_DBG")) : 0;      // measurement knobs
         KeyAddrGroupedArgs b = a;
-        b.NRL = dbg;
+        b.dbg = dbg;
         const int per_cu = (dbg & 4) ? 1 : (dbg & 2) ? 2 : last_per_cu;
         const int cap = 256 * (per_cu < last_per_cu ? per_cu : last_per_cu);
         kernel<<<need < cap ? need : cap, NWV * 64, lds, st>>>(b);
