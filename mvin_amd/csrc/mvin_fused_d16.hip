@@ -124,7 +124,16 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
     };
 
     const int64_t nwaves = (int64_t)gridDim.x * kD16Waves;
-    for (int64_t p = (int64_t)blockIdx.x * kD16Waves + wave; p < a.P; p += nwaves) {
+    // PPW parents per iteration: at K <= 8 a parent's children fill at most half of the 16-row MFMA tile, so TWO parents
+    // (rows 0.. and 8..) share one pass of the dense phases -- the kernel is VALU-issue-bound and those phases (12 MFMAs,
+    // their hazard nops, three LDS fences, the epilogues) are a quarter of a parent's instructions.
+    constexpr int PPW = K <= 8 ? 2 : 1;
+    for (int64_t pp = ((int64_t)blockIdx.x * kD16Waves + wave) * PPW; pp < a.P; pp += nwaves * PPW) {
+#pragma unroll
+      for (int h = 0; h < PPW; ++h) {
+        const bool pvalid = pp + h < a.P;                // an odd tail: parent 2 of the pair repeats parent 1 with zero weights
+        const int64_t p = pvalid ? pp + h : pp;
+        const int nrow = n + 8 * h;                      // this child's row of the tile
         const int x0 = fused_parent_id(a, p);
         // ---- level L-1: this lane's child (model.py:251-252) ----
         const unsigned o1 = ((unsigned)x0 * K + (unsigned)n) * 4u;
@@ -203,13 +212,14 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
         acc = make_float4(across_kh_sum(acc.x), across_kh_sum(acc.y), across_kh_sum(acc.z), across_kh_sum(acc.w));
         // ---- the K children as rows of a 16-row tile: {E[x1] + q | S' + (sum p / K) q} (model.py:277) ----
         if (kh == 0) {
-            *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv.x + qv.x, sv.y + qv.y, sv.z + qv.z, sv.w + qv.w);
-            *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = f4_fma(c2scale, qv, acc);
+            *reinterpret_cast<float4*>(sA1 + nrow * LD + 4 * c) = make_float4(sv.x + qv.x, sv.y + qv.y, sv.z + qv.z, sv.w + qv.w);
+            *reinterpret_cast<float4*>(sA2 + nrow * LD + 4 * c) = f4_fma(c2scale, qv, acc);
             if (c == 0) {
-                sP0[n] = p0;
-                sP1[n] = p1;
+                sP0[nrow] = pvalid ? p0 : 0.f;
+                sP1[nrow] = pvalid ? p1 : 0.f;
             }
         }
+      }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
             part0 = fmaf(sP0[4 * q16 + r], s1v[r], part0);
             sZ[(4 * q16 + r) * LD + l16] = zv[r];
         }
-        const float nagg0 = rows_combine_sum(part0);
+        // rows 0-7 (q16 in {0,1}) belong to the first parent, rows 8-15 to the second: sum the row groups per parent
+        const float nagg0 = PPW == 2 ? xor16_sum(part0) : rows_combine_sum(part0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -259,11 +270,14 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
         float part1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v, 0.f), part1);
-        const float nagg1 = rows_combine_sum(part1);
-        if (q16 == 0) {
-            const unsigned off = ((unsigned)p * D + (unsigned)l16) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0 * invK), out0, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1 * invK), out1, off, 0, 0);
+        const float nagg1 = PPW == 2 ? xor16_sum(part1) : rows_combine_sum(part1);
+        {
+            const int64_t p = pp + (PPW == 2 ? (q16 >> 1) : 0);
+            if ((PPW == 2 ? (q16 & 1) == 0 : q16 == 0) && p < a.P) {
+                const unsigned off = ((unsigned)p * D + (unsigned)l16) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0 * invK), out0, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1 * invK), out1, off, 0, 0);
+            }
         }
         // the next parent's tile writes must stay behind this parent's tile reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
