@@ -16,7 +16,7 @@
 // lists go through a wave-private LDS table; the softmax over a child's K grandchildren is in-lane over e plus a DPP
 // reduction over the 8 lanes of the child; the softmax over the parent's K children is a whole-wave reduction.  The dense
 // part (aggregators.py:108-116 after the sum) runs on v_mfma_f32_16x16x4_f32 with the K children as the rows of one
-// 16-row tile staged through the wave's LDS slice, weights resident as B fragments (48 VGPRs).
+// 16-row tile staged through the wave's LDS slice, the weights read as B operands from a workgroup-wide LDS copy.
 #include <cstdlib>
 
 #include "mvin_kernels.h"
@@ -30,9 +30,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kD32 = 32;
 constexpr int kD32Ld = 36;                                   // LDS row stride (floats): 16-byte aligned rows, 16 rows -> 16 bank groups
 constexpr int kD32Waves = 4;
-constexpr int d32_wave_words(int K) { return 3 * 16 * kD32Ld + 32 + 2 * 16 * K; }      // sA1 | sA2 | sZ | sP0 | sP1 | sY | sWt
+constexpr int d32_wave_words(int K) { return 2 * 16 * kD32Ld + 32 + 2 * 16 * K; }      // sA1 | sA2 (= sZ) | sP0 | sP1 | sY | sWt
+constexpr int kD32WeightWords = 3 * kD32 * kD32;             // W1 | W2 | A0, shared by the workgroup
 
-size_t fused_d32_lds_bytes(int nR, int K) { return (size_t)(2 * ((nR + 3) & ~3) + kD32Waves * d32_wave_words(K)) * 4; }
+size_t fused_d32_lds_bytes(int nR, int K) {
+    return (size_t)(2 * ((nR + 3) & ~3) + kD32WeightWords + kD32Waves * d32_wave_words(K)) * 4;
+}
 
 // exp for softmax arguments (x = logit - max <= 0): the library's argument reduction without its range selects
 __device__ __forceinline__ float d32_exp(float x) {
@@ -44,7 +47,7 @@ __device__ __forceinline__ float d32_exp(float x) {
 }
 
 template <int K, bool BF>
-__global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(FusedL2Args a) {
+__global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(FusedL2Args a) {
     constexpr int D = kD32, LD = kD32Ld;
     constexpr int NCH = K / 8;               // children per lane
     constexpr int KE = K / 8;                // grandchild slots per child whose ids / logits this lane computes
@@ -56,11 +59,15 @@ __global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(F
     float* sT0 = smem;                                   // [nRp] relation logits of aggregator (0,.) (zeros: uniform)
     float* sT1 = sT0 + nRp;                              // [nRp] ... of aggregator (1,.)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* wbase = sT1 + nRp + wave * WW;                // this wave's private slice
+    // W1 | W2 | A0 as the workgroup's LDS copy: the MFMA B operands are read from there (one ds_read_b32 per MFMA).  Resident
+    // in registers (48 VGPRs) they held the kernel at 3 waves per SIMD; rocprofv3 showed the SIMDs 62 % and the texture
+    // addresser 67 % busy -- neither saturated, a lack of waves to overlap them.  Now 4 waves per SIMD.
+    float* sWts = sT1 + nRp;                             // [3][D][D]
+    float* wbase = sWts + kD32WeightWords + wave * WW;   // this wave's private slice
     float* sA1 = wbase;                                  // [16][LD]  E[x1] + q
     float* sA2 = sA1 + 16 * LD;                          // [16][LD]  S' + (sum_k p_k / K) q
-    float* sZ = sA2 + 16 * LD;                           // [16][LD]
-    float* sP0 = sZ + 16 * LD;                           // [16]
+    float* sZ = sA2;                                     // [16][LD]  Z takes S' 's place: phase B has read it into registers
+    float* sP0 = sA2 + 16 * LD;                          // [16]
     float* sP1 = sP0 + 16;                               // [16]
     int* sY = reinterpret_cast<int*>(sP1 + 16);          // [16][K] grandchild ids
     float* sWt = reinterpret_cast<float*>(sY + 16 * K);  // [16][K] their weights p_k / K
@@ -73,24 +80,21 @@ __global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(F
         sT0[i] = has_att0 ? a.t0[i] : 0.f;
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
+    for (int i = tid; i < D * D; i += kD32Waves * 64) {
+        sWts[i] = has_proj ? a.W1[i] : 0.f;
+        sWts[D * D + i] = has_proj ? a.W2[i] : 0.f;
+        sWts[2 * D * D + i] = a.A0[i];
+    }
     for (int i = lane; i < WW; i += 64) wbase[i] = 0.f;  // tile rows >= K stay zero (weights 0)
-    __syncthreads();                                     // the only workgroup barrier: the two shared tables
+    __syncthreads();                                     // the only workgroup barrier: the shared tables
 
     const int c = lane & 7, g = lane >> 3;
     const int q16 = lane >> 4, l16 = lane & 15;
-    // weights as MFMA B fragments, contraction index permuted (step s, slot q16 <-> k = 8*q16 + s) so that a lane's A
-    // operands of the eight steps are two 16-byte LDS reads
-    float bW1[8][2], bW2[8][2], bA0[8][2];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int kk = 8 * q16 + s;
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            bW1[s][cc] = has_proj ? a.W1[kk * D + 16 * cc + l16] : 0.f;
-            bW2[s][cc] = has_proj ? a.W2[kk * D + 16 * cc + l16] : 0.f;
-            bA0[s][cc] = a.A0[kk * D + 16 * cc + l16];
-        }
-    }
+    // B operand of step s, column tile cc: W[(8 * q16 + s) * D + 16 * cc + l16] -- the contraction index is permuted (step s,
+    // slot q16 <-> k = 8 * q16 + s) so that a lane's A operands of the eight steps are two 16-byte LDS reads
+    const float* bW1 = sWts + (8 * q16) * D + l16;
+    const float* bW2 = bW1 + D * D;
+    const float* bA0 = bW2 + D * D;
     float b1v[2], b2v[2], a0v[2];
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -281,8 +285,8 @@ __global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(F
                 f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accS = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
-                    accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[s], bW1[s][cc], accE, 0, 0, 0);
-                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2[s], bW2[s][cc], accS, 0, 0, 0);
+                    accE = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[s], bW1[s * D + 16 * cc], accE, 0, 0, 0);
+                    accS = __builtin_amdgcn_mfma_f32_16x16x4f32(f2[s], bW2[s * D + 16 * cc], accS, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -299,6 +303,9 @@ __global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(F
                     zv[cc][r] = s1v[cc][r] + sA2[(4 * q16 + r) * LD + 16 * cc + l16];
                 }
         }
+        // Z overwrites S' in place: every lane's reads of sA2 (above) are ahead of these writes in the wave's LDS queue
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
         float nagg0[2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 3) void gather_attn_l2_d32_kernel(F
         for (int cc = 0; cc < 2; ++cc) {
             f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz[s], bA0[s][cc], acc2, 0, 0, 0);
+            for (int s = 0; s < 8; ++s) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fz[s], bA0[s * D + 16 * cc], acc2, 0, 0, 0);
             float part1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v[cc], 0.f), part1);
