@@ -17,7 +17,7 @@
 //     private to the wave (conflict-free both ways); reads o = P . T (:229) as 4 NT * D/16 MFMA steps per hop; 64-byte
 //     row pieces go out straight from the accumulators;
 //   * the h-set read (:162-197) once per user: lane groups hold the head rows of hop 0, 16-lane DPP reductions.
-// 12 waves per CU at D = 16 (8 at D = 32), each on its own user, hide each other's dependent loads.
+// 16 waves per CU at D = 16 (8 at D = 32), each on its own user, hide each other's dependent loads.
 #include <cstdlib>
 
 #include "mvin_kernels.h"
@@ -39,7 +39,11 @@ struct KwCfg {
     static constexpr int LdH = D + 4;        // row stride (words) of a staged 16-row head tile: 16-byte reads of 16 rows hit 16 bank groups
     static constexpr int Waves = D == 16 ? 4 : 8;      // waves per workgroup (they only share the LDS copy of R_KGE)
     static constexpr int MinW = D == 16 ? 4 : 2;       // waves per SIMD the register budget is cut for
-    static constexpr int PerWave = 16 * kKwLdP + kKwIds + D + 16 + 2 * 16 * LdH;   // + h-set read + pair indices + two head tiles
+    // staged head tiles: two at D = 32; ONE at D = 16, where the second one cost the fourth workgroup per CU (44 KB of LDS per
+    // workgroup -> 3 per CU; 39 KB -> 4 = 16 waves) -- the LDS queue of a wave is in order, so a single tile only needs the
+    // compiler fences it already has
+    static constexpr int NBuf = D == 16 ? 1 : 2;
+    static constexpr int PerWave = 16 * kKwLdP + kKwIds + D + 16 + NBuf * 16 * LdH;   // + h-set read + pair indices + head tiles
 };
 
 // exp(x) for the softmax arguments (x = logit - max <= 0, or discarded by a select): the argument reduction of the
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(KwCfg<D>::Waves * 64, KwCfg<D>::MinW) void key_addr
     int* sIds = reinterpret_cast<int*>(sW + 16 * kKwLdP);        // [2][3][64]
     float* sHset = sW + 16 * kKwLdP + kKwIds;                    // [D]
     int* sOrig = reinterpret_cast<int*>(sHset + D);              // [16]
-    float* sHt = sHset + D + 16;                                 // [2][16][LdH]
+    float* sHt = sHset + D + 16;                                 // [NBuf][16][LdH]
     for (int i = tid; i < a.nR * D * D; i += NWV * 64) sR[(i / (D * D)) * LdR + (i % (D * D))] = a.R[i];
     __syncthreads();
 
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(KwCfg<D>::Waves * 64, KwCfg<D>::MinW) void key_addr
                 v[cc] = kw_chunk<BF, D>(a.E, idh >= 0 ? idh : 0, q + 4 * cc);
         };
         auto stage = [&](const float4 (&v)[CPL]) {
-            float* dst = sHt + (stage_i & 1) * 16 * LdH;
+            float* dst = sHt + (stage_i & (C::NBuf - 1)) * 16 * LdH;
             wave_lds_sync();                                     // the reads of this buffer two tiles ago are done
 #pragma unroll
             for (int cc = 0; cc < CPL; ++cc) *reinterpret_cast<float4*>(dst + j * LdH + 4 * (q + 4 * cc)) = v[cc];
@@ -369,7 +373,7 @@ static hipError_t launch_kw(const KeyAddrGroupedArgs& a, int table_bf16, hipStre
     const size_t lds = kw_lds_bytes<D>(a.nR);
     hipError_t err = hipSuccess;
     auto launch = [&](auto kernel) {
-        // persistent grid: as many workgroups as the CUs hold (LDS decides: D = 16: 44 KB at nR = 9 -> 3 per CU = 12 waves,
+        // persistent grid: as many workgroups as the CUs hold (LDS decides: D = 16: 39 KB at nR = 9 -> 4 per CU = 16 waves,
         // 75 KB at nR = 39 -> 2; D = 32: one workgroup of 8 waves)
         static thread_local const void* last_k = nullptr;
         static thread_local size_t last_lds = 0;
