@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 5
+#define MVIN_ABI_VERSION 6
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -240,7 +240,7 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
 /* The batch in user order for mvin_key_addressing_grouped_fwd, built on the device (counting sort by user id, int
  * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
  * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair
- * at each position (order inside a segment unspecified).  workspace: 2 * n_user int32.  Ids outside [0, n_user) are
+ * at each position (order inside a segment unspecified).  workspace: 2 * n_user + B int32 (ABI v6: + B for the per-pair ranks).  Ids outside [0, n_user) are
  * CLAMPED into the table (every pair keeps a segment, so no row of `out` stays unwritten); the reference's CPU
  * tf.gather would raise InvalidArgument -- the Python wrapper does that for host feeds and, on request, for device
  * feeds (MVIN.validate_device_ids). */

@@ -193,8 +193,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 5:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 5")
+    if ver != 6:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 6")
     _lib = lib
     return lib
 

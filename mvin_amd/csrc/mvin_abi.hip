@@ -513,7 +513,8 @@ int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32,
     if ((!users_i64 && !users_i32) || !workspace || !seg_user || !seg_ptr || !nseg || !pair_index)
         return fail(-1, "%s: null pointer", who);
     if (B <= 0 || B > 0x7fffffff || n_user <= 0) return fail(-2, "%s: bad sizes B=%lld n_user=%d", who, (long long)B, n_user);
-    return hip_result(mvin::launch_group_pairs(users_i64, users_i32, B, n_user, workspace, workspace + n_user, seg_user, seg_ptr,
+    return hip_result(mvin::launch_group_pairs(users_i64, users_i32, B, n_user, workspace, workspace + n_user, workspace + 2 * (size_t)n_user,
+                                               seg_user, seg_ptr,
                                                nseg, pair_index, (hipStream_t)stream), who);
 }
 

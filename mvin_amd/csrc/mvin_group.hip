@@ -17,10 +17,11 @@ namespace mvin {
 // a segment, so no output row is left unwritten), exactly as the per-pair kernels clamp it (key_addr_lists).
 __device__ __forceinline__ int64_t clamp_user(int64_t u, int n_user) { return u < 0 ? 0 : (u >= n_user ? n_user - 1 : u); }
 
+// rank[i] = how many pairs of the same user were counted before pair i: the scatter pass then needs no second round of atomics
 __global__ void group_count_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
-                                   int32_t* __restrict__ count) {
+                                   int32_t* __restrict__ count, int32_t* __restrict__ rank) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
-        atomicAdd(count + clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user), 1);
+        rank[i] = atomicAdd(count + clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user), 1);
     }
 }
 
@@ -178,9 +179,10 @@ __global__ __launch_bounds__(1024) void group_small_kernel(const int64_t* __rest
 }
 
 __global__ void group_scatter_kernel(const int64_t* __restrict__ u64, const int32_t* __restrict__ u32, int64_t B, int n_user,
-                                     int32_t* __restrict__ offs, int32_t* __restrict__ pair_index) {
+                                     const int32_t* __restrict__ offs, const int32_t* __restrict__ rank,
+                                     int32_t* __restrict__ pair_index) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
-        pair_index[atomicAdd(offs + clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user), 1)] = (int32_t)i;
+        pair_index[offs[clamp_user(u64 ? u64[i] : (int64_t)u32[i], n_user)] + rank[i]] = (int32_t)i;
     }
 }
 
@@ -191,7 +193,7 @@ constexpr int64_t kGroupSmallMaxB = 32768;
 constexpr size_t kGroupSmallMaxLds = 150 * 1024;
 
 hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B, int n_user, int32_t* count, int32_t* offs,
-                              int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, hipStream_t st) {
+                              int32_t* rank, int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, hipStream_t st) {
     static const int force = getenv("MVIN_GROUP_SMALL") ? atoi(getenv("MVIN_GROUP_SMALL")) : -1;   // A/B switch: 0 / 1
     const size_t lds = (size_t)n_user * sizeof(int32_t);
     const bool small = lds <= kGroupSmallMaxLds && (force < 0 ? B <= kGroupSmallMaxB : force == 1);
@@ -207,7 +209,7 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
     hipError_t e = hipMemsetAsync(count, 0, (size_t)n_user * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
     const int blocks = (int)((B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048);
-    group_count_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, count);
+    group_count_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, count, rank);
     {
         const size_t scan_lds = (size_t)(n_user < kScanTile ? n_user : kScanTile) * sizeof(int32_t);
         if (scan_lds > 48 * 1024) {
@@ -217,7 +219,7 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
         }
         group_scan_kernel<<<1, 1024, scan_lds, st>>>(count, n_user, B, offs, seg_user, seg_ptr, nseg);
     }
-    group_scatter_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, offs, pair_index);
+    group_scatter_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, offs, rank, pair_index);
     return hipGetLastError();
 }
 

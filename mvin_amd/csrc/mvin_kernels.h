@@ -295,7 +295,7 @@ bool fused_split_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_probe_l2(const void* table, const int32_t* ids1, const int32_t* ids2, int64_t n_parents, int K,
                                   int D, int table_bf16, float* sums, hipStream_t st);   // mvin_probe.hip
 hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B, int n_user, int32_t* count, int32_t* offs,
-                              int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, hipStream_t st);   // mvin_group.hip
+                              int32_t* rank, int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, hipStream_t st);   // mvin_group.hip
 hipError_t launch_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, hipStream_t st);   // mvin_bwd.hip
 bool fused_d32_supported(int D, int K);        // wave-per-parent variant for D = 32, K in {8, 16} (mvin_fused_d32.hip)
 bool fused_d32_applies(const FusedL2Args& a, int D);

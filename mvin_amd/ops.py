@@ -393,7 +393,7 @@ def group_pairs_by_user(users, n_user=None):
     B = users.shape[0]
     if n_user is not None and users.is_cuda and users.dtype in (torch.int64, I32) and users.is_contiguous():
         dev = users.device
-        ws = torch.empty(2 * n_user, dtype=I32, device=dev)
+        ws = torch.empty(2 * n_user + B, dtype=I32, device=dev)      # counters | offsets | per-pair ranks
         seg_user = torch.empty(B, dtype=I32, device=dev)
         seg_ptr = torch.empty(B + 2, dtype=I32, device=dev)
         nseg = torch.empty(1, dtype=I32, device=dev)
