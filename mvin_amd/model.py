@@ -248,8 +248,9 @@ class MVIN(object):
         """tf.nn.embedding_lookup of [B] ids -> [B, D]."""
         return ops.linear([table], None, table.shape[-1], ids=[ids32])
 
-    def _key_addressing(self, user32, item32, mem_h, mem_r, mem_t):
-        """model.py:161-240 -> user_o [B,D]."""
+    def _key_addressing(self, user32, item32, mem_h, mem_r, mem_t, uts=None):
+        """model.py:161-240 -> user_o [B,D].  ``uts``: the ripple sets of pair b are user_triplet_set[user32[b]], indexed inside
+        the kernel (mvin_key_addressing_users_fwd) instead of per-pair arrays."""
         a, D, P = self.args, self.dim, self.p_hop
         B = item32.shape[0]
         nR = self.n_relation
@@ -262,7 +263,9 @@ class MVIN(object):
             V = torch.empty((B, nR, D), dtype=torch.float32, device=self.device)
             ops.linear([self.entity_emb_matrix], self.relation_emb_KGE_matrix, D, ids=[item32], rows=B,
                        out=V, ldo=nR * D, nz=nR, w_zstride=D * D, out_zstride=D)
-        if self.fused and ops.key_addressing_supported(self.n_memory, D):
+        if uts is not None:
+            ops.key_addressing_users(self.entity_emb_matrix, V, w_h, uts, user32, P, o_cat, n_o * D, nR)
+        elif self.fused and ops.key_addressing_supported(self.n_memory, D):
             ops.key_addressing(self.entity_emb_matrix, V, w_h, mem_h, mem_r, mem_t, P, o_cat, n_o * D, nR)
         else:
             slot = 0
@@ -709,12 +712,18 @@ class MVIN(object):
                     and user32.shape[0] == item32.shape[0] and self._native_l2_ok(item32, None, want_probs)):
                 # one native call; key addressing indexes user_triplet_set by users[b] itself
                 return self._score_l2_native(item32, None, None, None, uts=uts, users=user32)
-            if need_ps and not grouped:     # any other wiring: assemble the per-pair feeds on the device
+            users_kernel = (need_ps and not grouped and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
+                            and uts.dim() == 4 and uts.shape[1] == max(1, self.p_hop) and uts.shape[3] == self.n_memory
+                            and user32.shape[0] == item32.shape[0] and user32.dtype in (torch.int64, torch.int32)
+                            and ops.key_addressing_supported(self.n_memory, self.dim))
+            if need_ps and not grouped and not users_kernel:     # any other wiring: assemble the per-pair feeds on the device
                 sel = uts[user32.long()]
                 P_ = sel.shape[1]
                 memories_h = [sel[:, i, 0].contiguous() for i in range(P_)]
                 memories_r = [sel[:, i, 1].contiguous() for i in range(P_)]
                 memories_t = [sel[:, i, 2].contiguous() for i in range(P_)]
+        else:
+            users_kernel = False
         shared = (not grouped) and memories_h is not None and memories_h[0].dim() == 1   # one user's sets for the batch
         if not grouped and not shared and memories_h is not None and self._native_l2_ok(item32, memories_h, want_probs) \
                 and all(m_.dtype == torch.int32 and m_.is_contiguous() for lst in (memories_h, memories_r, memories_t)
@@ -731,6 +740,10 @@ class MVIN(object):
             ps = None
         elif grouped:
             ps = self._key_addressing_grouped(user32, item32, uts)
+        elif users_kernel:
+            # the Python schedule of the users feed (batches above native_l2_max_batch, sharded tables): key addressing reads the
+            # lists of users[b] out of user_triplet_set itself -- it was a torch gather + three copies per step to assemble them
+            ps = self._key_addressing(user32, item32, None, None, None, uts=uts)
         elif shared:
             ps = self._key_addressing_shared(item32, [m_.contiguous() for m_ in memories_h],
                                              [m_.contiguous() for m_ in memories_r],
