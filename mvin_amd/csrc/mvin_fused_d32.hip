@@ -133,7 +133,14 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
     };
 
     const int64_t nwaves = (int64_t)gridDim.x * kD32Waves;
-    for (int64_t p = (int64_t)blockIdx.x * kD32Waves + wave; p < a.P; p += nwaves) {
+    // at K = 8 a parent's children fill half of the 16-row MFMA tile: TWO parents (rows 0.. and 8..) share one pass of the
+    // dense phases, as in mvin_fused_d16.hip
+    constexpr int PPW = K == 8 ? 2 : 1;
+    for (int64_t pp = ((int64_t)blockIdx.x * kD32Waves + wave) * PPW; pp < a.P; pp += nwaves * PPW) {
+#pragma unroll
+      for (int h = 0; h < PPW; ++h) {
+        const bool pvalid = pp + h < a.P;                // an odd tail: the pair's second parent repeats the first with zero weights
+        const int64_t p = pvalid ? pp + h : pp;
         const int x0 = fused_parent_id(a, p);
         // ---- level L-1: this lane's NCH children (model.py:251-252) ----
         int x1[NCH], r1[NCH];
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             }
             z = group_sum(z, 3);
             const float rinv = has_att0 ? invK * __builtin_amdgcn_rcpf(z) : invK;
-            const int n = g + 8 * i;
+            const int n = g + 8 * i + 8 * h;             // row of the tile / of the lists
 #pragma unroll
             for (int e = 0; e < KE; ++e) {
                 sY[n * K + c + 8 * e] = ye[e];
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
         // ---- S'[n] = sum_k (p_k / K) E[y_k], chunk c, in-lane: the K rows of a child in batches of 8 loads ----
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int n = g + 8 * i;
+            const int n = g + 8 * i + 8 * h;             // row of the tile / of the lists
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k0 = 0; k0 < K; k0 += 8) {
@@ -262,10 +269,11 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv[i].x + qv.x, sv[i].y + qv.y, sv[i].z + qv.z, sv[i].w + qv.w);
             *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = f4_fma(c2scale, qv, acc);
             if (c == 0) {
-                sP0[n] = p0[i];
-                sP1[n] = p1[i];
+                sP0[n] = pvalid ? p0[i] : 0.f;
+                sP1[n] = pvalid ? p1[i] : 0.f;
             }
         }
+      }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 part0 = fmaf(sP0[4 * q16 + r], s1v[cc][r], part0);
                 sZ[(4 * q16 + r) * LD + 16 * cc + l16] = zv[cc][r];
             }
-            nagg0[cc] = rows_combine_sum(part0);
+            nagg0[cc] = PPW == 2 ? xor16_sum(part0) : rows_combine_sum(part0);      // rows 0-7 / 8-15: one parent each
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
@@ -336,12 +344,13 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             float part1 = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v[cc], 0.f), part1);
-            nagg1[cc] = rows_combine_sum(part1);
+            nagg1[cc] = PPW == 2 ? xor16_sum(part1) : rows_combine_sum(part1);
         }
-        if (q16 == 0) {
+        const int64_t po = pp + (PPW == 2 ? (q16 >> 1) : 0);
+        if ((PPW == 2 ? (q16 & 1) == 0 : q16 == 0) && po < a.P) {
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {
-                const unsigned off = ((unsigned)p * D + 16u * cc + (unsigned)l16) * 4u;
+                const unsigned off = ((unsigned)po * D + 16u * cc + (unsigned)l16) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0[cc] * invK), out0, off, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1[cc] * invK), out1, off, 0, 0);
             }
