@@ -127,13 +127,13 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
     // PPW parents per iteration: at K <= 8 a parent's children fill at most half of the 16-row MFMA tile, so TWO parents
     // (rows 0.. and 8..) share one pass of the dense phases -- the kernel is VALU-issue-bound and those phases (12 MFMAs,
     // their hazard nops, three LDS fences, the epilogues) are a quarter of a parent's instructions.
-    constexpr int PPW = K <= 8 ? 2 : 1;
+    constexpr int PPW = 16 / K;                          // K = 8: two parents (rows 0.., 8..); K = 4: four (rows 0, 4, 8, 12 ..)
     for (int64_t pp = ((int64_t)blockIdx.x * kD16Waves + wave) * PPW; pp < a.P; pp += nwaves * PPW) {
 #pragma unroll
       for (int h = 0; h < PPW; ++h) {
         const bool pvalid = pp + h < a.P;                // an odd tail: parent 2 of the pair repeats parent 1 with zero weights
         const int64_t p = pvalid ? pp + h : pp;
-        const int nrow = n + 8 * h;                      // this child's row of the tile
+        const int nrow = n + K * h;                      // this child's row of the tile
         const int x0 = fused_parent_id(a, p);
         // ---- level L-1: this lane's child (model.py:251-252) ----
         const unsigned o1 = ((unsigned)x0 * K + (unsigned)n) * 4u;
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
             part0 = fmaf(sP0[4 * q16 + r], s1v[r], part0);
             sZ[(4 * q16 + r) * LD + l16] = zv[r];
         }
-        // rows 0-7 (q16 in {0,1}) belong to the first parent, rows 8-15 to the second: sum the row groups per parent
-        const float nagg0 = PPW == 2 ? xor16_sum(part0) : rows_combine_sum(part0);
+        // a parent's rows: one 16-lane row group (K = 4), two (K = 8: rows 0-7 / 8-15) or all four (K = 16)
+        const float nagg0 = PPW == 4 ? part0 : PPW == 2 ? xor16_sum(part0) : rows_combine_sum(part0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -270,10 +270,10 @@ __global__ __launch_bounds__(kD16Waves * 64) void gather_attn_l2_d16_kernel(Fuse
         float part1 = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part1 = fmaf(sP1[4 * q16 + r], fmaxf(acc2[r] + a0v, 0.f), part1);
-        const float nagg1 = PPW == 2 ? xor16_sum(part1) : rows_combine_sum(part1);
+        const float nagg1 = PPW == 4 ? part1 : PPW == 2 ? xor16_sum(part1) : rows_combine_sum(part1);
         {
-            const int64_t p = pp + (PPW == 2 ? (q16 >> 1) : 0);
-            if ((PPW == 2 ? (q16 & 1) == 0 : q16 == 0) && p < a.P) {
+            const int64_t p = pp + (PPW == 4 ? q16 : PPW == 2 ? (q16 >> 1) : 0);
+            if ((PPW == 4 ? true : PPW == 2 ? (q16 & 1) == 0 : q16 == 0) && p < a.P) {
                 const unsigned off = ((unsigned)p * D + (unsigned)l16) * 4u;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg0 * invK), out0, off, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nagg1 * invK), out1, off, 0, 0);
