@@ -16,6 +16,7 @@
 //     reads  : o[pair, hop] = sum_m p[pair, m] t_m                   (:229)       MFMA, A = p, B = sT
 // Nothing of size [B, nR, D] or [B, Nm, D, D] exists; a user's 2*P*Nm rows are read once per batch.
 #include <cstdlib>
+#include <utility>
 
 #include "mvin_kernels.h"
 
@@ -30,10 +31,15 @@ __device__ long long g_ka_trace[64 * 16];
 // one, i.e. four user segments' dependent phases in flight per CU (the kernel is latency-bound per segment)
 constexpr int ka_dense_waves(int D) { return D == 16 ? 4 : D == 32 ? 8 : 12; }
 constexpr int ka_dense_minw(int D) { return D == 32 ? 4 : 1; }       // waves per SIMD the register budget is cut for
+// pairs per tile: one 16-row MFMA tile.  Two at D = 64 (a user of the C3 batch has ~22 pairs: one pass of the
+// four barrier-separated tile phases instead of two) were measured and dropped: every tile phase took exactly twice
+// as long (logits 1.55 -> 3.3 k cycles, softmax 2.6 -> 4.5, reads 2.2 -> 4.3: they are throughput-, not barrier-bound) and the
+// two accumulator sets next to the resident R_KGE fragments cost 16-22 spilled registers (U phase 11.4 -> 13.7 k cycles).
 constexpr int kDT = 16;      // pairs per tile
+constexpr int kKaDmaRows = 12;   // rows a wave lands per LDS-DMA batch (below)
 
 struct KaDenseLds {
-    size_t h, u, t, ei, l, z, hset, lg, idh, idt, rel, rank, bidx, cnt, off, tile_rel, tile_row, orig, total;
+    size_t h, u, t, ei, l, z, hset, lg, idh, idt, rel, rank, bidx, cnt, off, tile_rel, tile_row, orig, idn, total;
     int NmP, PN, maxtiles;
 };
 
@@ -64,11 +70,37 @@ static KaDenseLds ka_dense_layout(int D, int P, int Nm, int nR) {
     L.tile_rel = take(L.maxtiles);
     L.tile_row = take(L.maxtiles);
     L.orig = take(kDT + 4);
+    // LDS-DMA form (ka_dense_dma_applies): {head, tail, relation} ids of this and of the next segment
+    L.idn = take((D == 64 && P > 0 && L.PN >= 64 && L.PN <= kKaDmaRows * ka_dense_waves(64)) ? (size_t)2 * 3 * L.PN : 0);
     L.total = o * 4;
     return L;
 }
 
-template <int D, bool BF, bool TRACE>
+// LDS-DMA form (D = 64, fp32 table): a table row is 256 bytes = one global_load_lds_dword of a wave (4 bytes per lane ->
+// M0 + offset + 4 * lane), the row address is wave-uniform (SGPR pair), so a row costs one instruction and no VGPR.
+// A wave lands kKaDmaRows consecutive rows of the padded LDS array behind ONE M0 write (the 13-bit signed instruction offset
+// reaches 4095 bytes; it also moves the global address, so the pointer is pre-biased).
+template <int LDB, int J>
+__device__ __forceinline__ void ka_dma_row(const char* E, int idv, int lane4) {
+    const int id = __builtin_amdgcn_readlane(idv, J);       // < 0: past this wave's rows (padding rows land row 0: weight 0)
+    if (id >= 0) {
+        const char* p = E + ((size_t)(unsigned)id << 8) - J * LDB;
+        asm volatile("global_load_lds_dword %0, %1 offset:%2" ::"v"(lane4), "s"(p), "n"(J * LDB) : "memory");
+    }
+}
+template <int LDB, int... J>
+__device__ __forceinline__ void ka_dma_rows(const char* E, int idv, int lane4, unsigned m0, std::integer_sequence<int, J...>) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(m0) : "memory");
+    (ka_dma_row<LDB, J>(E, idv, lane4), ...);
+}
+bool ka_dense_dma_applies(int D, int table_bf16, int P, int Nm) {
+    static const bool off = getenv("MVIN_KA_DMA") && atoi(getenv("MVIN_KA_DMA")) == 0;
+    const int NmP = (Nm + 15) & ~15;
+    // few rows (amazon-book: one hop of 16 memories) would be landed by one or two of the 12 waves: measured slower (3.13 -> 3.23 ms)
+    return !off && D == 64 && !table_bf16 && P > 0 && P * NmP >= 64 && P * NmP <= kKaDmaRows * ka_dense_waves(64);
+}
+
+template <int D, bool BF, bool TRACE, bool DMA>
 __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
     constexpr int kDW = ka_dense_waves(D);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -104,14 +136,18 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     // The item row of a pair hangs on three dependent loads (pair_index -> items -> E row).  A tile's rows are
     // therefore fetched one tile AHEAD into registers (tile 0: before the segment's own id -> row chain starts),
     // and the next segment's descriptor is read while the current one is processed.
+    // (D = 64: by the LAST kDT * LPR threads and after the tile's first barrier -- the logits tiles go to the first 8 of the 12
+    // waves, so the chain's waits overlap that phase instead of standing in front of it: 1.8 k cycles per tile)
+    constexpr bool LATE = D == 64;
+    const int itid = LATE ? tid - (NTHR - kDT * LPR) : (tid < kDT * LPR ? tid : -1);
     auto item_row = [&](int t0, int p1, float4& e, int& orig) {
         e = make_float4(0.f, 0.f, 0.f, 0.f);
         orig = -1;
-        if (tid < kDT * LPR && t0 < p1) {
-            const int p = t0 + tid / LPR;
+        if (itid >= 0 && t0 < p1) {
+            const int p = t0 + itid / LPR;
             const int o = a.pair_index[p < p1 ? p : p1 - 1];
             const int64_t item = a.items64 ? a.items64[o] : (int64_t)a.items32[o];
-            e = load_row4(a.E, BF, item, D, tid % LPR);
+            e = load_row4(a.E, BF, item, D, itid % LPR);
             orig = p < p1 ? o : -1;
         }
     };
@@ -161,6 +197,63 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             if (io >= 0) sU[(size_t)io * LDH + 16 * nt + l16] = acc[i];
         }
     };
+    // ---- LDS-DMA form: ids two segments ahead in registers, one ahead in LDS; head rows one segment ahead in sH ----
+    const int rows = Ph * NmP;
+    int* sIdN = reinterpret_cast<int*>(smem + L.idn);        // [parity][head | tail | relation][rows]
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int nu2 = 0, np02 = 0, np12 = 0;                         // descriptor of the segment after the next
+    int pid_h = -1, pid_t = -1, pid_r = 0;                   // thread i < rows: ids of row i of the NEXT segment
+    auto load_ids = [&](int user, int& h, int& t, int& r) {
+        h = -1;
+        t = -1;
+        r = 0;
+        if (tid < rows) {
+            const int hop = tid / NmP, m = tid - hop * NmP;
+            if (m < Nm) {
+                const int32_t* ub = a.uts + (int64_t)user * Ph * 3 * Nm;
+                h = ub[(hop * 3 + 0) * Nm + m];
+                t = ub[(hop * 3 + 2) * Nm + m];
+                r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));
+            }
+        }
+    };
+    auto put_ids = [&](int par, int h, int t, int r) {
+        if (tid < rows) {
+            int* b = sIdN + par * 3 * rows;
+            b[tid] = h;
+            b[rows + tid] = t;
+            b[2 * rows + tid] = r;
+        }
+    };
+    // this wave's kKaDmaRows rows of sH (LDB = row stride in bytes) or sT, ids from LDS
+    auto dma_batch = [&](const int* ids, size_t word_off, auto ldb_c) {
+        constexpr int LDB = decltype(ldb_c)::value;
+        const int row0 = wave_u * kKaDmaRows;
+        const int idv = (lane < kKaDmaRows && row0 + lane < rows) ? ids[row0 + lane] : -1;
+        ka_dma_rows<LDB>(reinterpret_cast<const char*>(a.E), idv, lane * 4, lds0 + (unsigned)(word_off * 4) + (unsigned)(row0 * LDB),
+                         std::make_integer_sequence<int, kKaDmaRows>{});
+    };
+    if constexpr (DMA) {
+        for (int i = tid; i < rows * LDH; i += NTHR) sH[i] = 0.f;        // padding rows (m >= Nm) are never landed: zero for good
+        for (int i = tid; i < PN * LDT; i += NTHR) sT[i] = 0.f;
+        if ((int)blockIdx.x < nseg) {
+            load_ids(nu, pid_h, pid_t, pid_r);
+            put_ids(0, pid_h, pid_t, pid_r);
+        }
+        if ((int)(blockIdx.x + gridDim.x) < nseg) {
+            nu2 = a.seg_user[blockIdx.x + gridDim.x];
+            np02 = a.seg_ptr[blockIdx.x + gridDim.x];
+            np12 = a.seg_ptr[blockIdx.x + gridDim.x + 1];
+        }
+        __syncthreads();
+        if ((int)blockIdx.x < nseg) dma_batch(sIdN, L.h, std::integral_constant<int, LDH * 4>{});
+    }
+    // first tile of the first segment; every later tile -- also a later SEGMENT's first one -- is fetched under the tile before
+    // it (at a segment's top the three dependent loads stood in the open: 4.4 k of its 37.5 k cycles)
+    float4 e_next;
+    int orig_next;
+    if constexpr (LATE) item_row(np0, np1, e_next, orig_next);
     int iter = 0;
     auto stamp = [&](int slot) {
         if constexpr (TRACE) {
@@ -170,18 +263,45 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x, ++iter) {
         stamp(0);
         const int u = nu, p0 = np0, p1 = np1;
-        if (seg + (int)gridDim.x < nseg) {
+        const int par = iter & 1;
+        const bool has_next = seg + (int)gridDim.x < nseg;
+        int* idc = sIdN + par * 3 * rows;                    // DMA form: this segment's ids
+        const int* idt_cur = DMA ? idc + rows : sIdT;
+        if constexpr (DMA) {
+            nu = nu2;
+            np0 = np02;
+            np1 = np12;
+            if (seg + 2 * (int)gridDim.x < nseg) {
+                nu2 = a.seg_user[seg + 2 * gridDim.x];
+                np02 = a.seg_ptr[seg + 2 * gridDim.x];
+                np12 = a.seg_ptr[seg + 2 * gridDim.x + 1];
+            }
+        } else if (has_next) {
             nu = a.seg_user[seg + gridDim.x];
             np0 = a.seg_ptr[seg + gridDim.x];
             np1 = a.seg_ptr[seg + gridDim.x + 1];
         }
-        float4 e_next;
-        int orig_next;
-        item_row(p0, p1, e_next, orig_next);
+        if constexpr (!LATE) item_row(p0, p1, e_next, orig_next);
         __syncthreads();                                     // previous segment fully consumed
+        stamp(13);
         for (int i = tid; i < a.nR; i += NTHR) sCnt[i] = 0;
         for (int i = tid; i < L.maxtiles * 16; i += NTHR) sBidx[i] = -1;
+        stamp(14);
         __syncthreads();
+      if constexpr (DMA) {
+        // ---- rank of every memory inside its relation (ids are in LDS since the previous segment) ----
+        if (tid < rows) {
+            int rk = 0;
+            if (idc[rows + tid] >= 0) rk = atomicAdd(&sCnt[idc[2 * rows + tid]], 1);
+            sRank[tid] = rk;
+        }
+        // tail rows (needed by the first reads phase).  The M0 write in front of a batch waits for EVERY vector memory operation
+        // the wave has in flight -- at the segment's top that is the previous tile's stores (2.5 k cycles), here nothing; and a
+        // batch goes out BEFORE the loads issued at the same point.  This segment's head rows landed a segment ago.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dma_batch(idc + rows, L.t, std::integral_constant<int, LDT * 4>{});
+        if (has_next) load_ids(nu, pid_h, pid_t, pid_r);               // consumed after the bucket scan
+      } else {
         // ---- ids (row i = hop * NmP + m; padding rows m >= Nm stay zero), rank of every memory inside its relation ----
         const int32_t* ub = a.uts + (int64_t)u * Ph * 3 * Nm;
         for (int i = tid; i < Ph * NmP; i += NTHR) {
@@ -200,6 +320,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             sRel[i] = r;
             sRank[i] = rk;
         }
+      }
         __syncthreads();
         stamp(1);
         // ---- buckets padded to whole 16-row tiles: offsets + the tile table (wave 0) ----
@@ -229,6 +350,11 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         __syncthreads();
         const int ntile = sOrig[kDT];
         stamp(2);
+      if constexpr (DMA) {
+        // ---- bucket index table; the next segment's ids -> LDS; this segment's rows have landed ----
+        if (tid < rows && idc[rows + tid] >= 0) sBidx[sOff[idc[2 * rows + tid]] + sRank[tid]] = tid;
+        if (has_next) put_ids(par ^ 1, pid_h, pid_t, pid_r);
+      } else {
         // ---- rows -> LDS; bucket index table ----
         for (int i = wave * RPW + g; i < Ph * NmP; i += kDW * RPW) {
             const int idh = sIdH[i], idt = sIdT[i];
@@ -243,6 +369,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                 if (c == 0 && idt >= 0) sBidx[sOff[sRel[i]] + sRank[i]] = i;
             }
         }
+      }
         __syncthreads();
         stamp(3);
         // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
@@ -302,7 +429,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             // padding memories: U rows never written by a tile must read as zero
             for (int i = tid; i < PN * NT; i += (has_set ? (kDW - 1) : kDW) * 64) {
                 const int row = i / NT, nt = i - row * NT;
-                if (sIdT[row] < 0) {
+                if (idt_cur[row] < 0) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) sU[(size_t)row * LDH + 16 * nt + j] = 0.f;
                 }
@@ -312,16 +439,23 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         // ---- the user's pairs, 16 at a time ----
         for (int t0 = p0; t0 < p1; t0 += kDT) {
             __syncthreads();                                 // sU / sHset complete; previous tile consumed
-            if (tid < kDT * LPR) {
-                const int i = tid / LPR, cc = tid % LPR;
+            if (itid >= 0) {
+                const int i = itid / LPR, cc = itid % LPR;
                 float* dst = sEi + i * LDH + 4 * cc;
                 *reinterpret_cast<float2*>(dst) = make_float2(e_next.x, e_next.y);
                 *reinterpret_cast<float2*>(dst + 2) = make_float2(e_next.z, e_next.w);
                 if (cc == 0) sOrig[i] = orig_next;
             }
-            item_row(t0 + kDT, p1, e_next, orig_next);       // the next tile's rows land under this tile's work
+            if (t0 == p0) stamp(10);
+            if constexpr (DMA) {                             // sH is free from here on: the next segment's head rows
+                if (t0 == p0 && has_next) dma_batch(sIdN + (par ^ 1) * 3 * rows, L.h, std::integral_constant<int, LDH * 4>{});
+            }
+            if (t0 == p0) stamp(11);
+            const bool last = t0 + kDT >= p1;                // np0 / np1: the next segment's (no next one: a harmless re-read)
+            if constexpr (!LATE) item_row(t0 + kDT, p1, e_next, orig_next);
             __syncthreads();
             if (t0 == p0) stamp(5);
+            if constexpr (LATE) item_row(last ? np0 : t0 + kDT, last ? np1 : p1, e_next, orig_next);
             // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
             for (int mt = wave; mt < PN / 16; mt += kDW) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -358,6 +492,9 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                     z = group_sum(z, 4);
                     if (ok && cl == 0) sZ[task] = 1.f / z;      // sZ[pi * P + hop]
                 }
+            }
+            if constexpr (DMA) {
+                if (t0 == p0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the tail rows have landed
             }
             __syncthreads();
             if (t0 == p0) stamp(7);
@@ -397,6 +534,13 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                 }
             }
         }
+        if (LATE && p0 >= p1) item_row(np0, np1, e_next, orig_next);         // a segment without pairs
+        if constexpr (DMA) {
+            if (p0 >= p1 && has_next) {                      // a segment without pairs still hands sH on
+                __syncthreads();
+                dma_batch(sIdN + (par ^ 1) * 3 * rows, L.h, std::integral_constant<int, LDH * 4>{});
+            }
+        }
     }
 }
 
@@ -427,13 +571,15 @@ static hipError_t launch_kad(const KeyAddrGroupedArgs& a, int table_bf16, hipStr
         return a.nseg < cap ? a.nseg : cap;
     };
     if (table_bf16) {
-        auto k = key_addr_dense_kernel<D, true, false>;
+        auto k = key_addr_dense_kernel<D, true, false, false>;
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
         k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(a, L);
     } else {
         static const bool trace = getenv("MVIN_KA_TRACE") != nullptr;
-        auto k = (D == 64 && trace) ? key_addr_dense_kernel<D, false, true> : key_addr_dense_kernel<D, false, false>;
+        const bool dma = D == 64 && ka_dense_dma_applies(D, 0, a.P, a.Nm);
+        auto k = dma ? ((D == 64 && trace) ? key_addr_dense_kernel<D, false, D == 64, D == 64> : key_addr_dense_kernel<D, false, false, D == 64>)
+                     : ((D == 64 && trace) ? key_addr_dense_kernel<D, false, true, false> : key_addr_dense_kernel<D, false, false, false>);
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
         k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(a, L);

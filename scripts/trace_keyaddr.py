@@ -29,3 +29,7 @@ print("cycles per segment:", round(float(np.mean(np.diff(t[4:60, 0])))))
 dd = np.diff(t[4:60], axis=1)
 for i in range(8):
     print("   %-14s -> %-14s %8.0f" % (names[i], names[i + 1], dd[:, i].mean()))
+ex = full[4:60]
+print("   top -> top barrier released %6.0f ; -> DMA / clears issued %6.0f" % ((ex[:, 13] - ex[:, 0]).mean(), (ex[:, 14] - ex[:, 13]).mean()))
+print("   U done -> tile0 barrier + Ei written %6.0f ; -> head-row DMA issued %6.0f ; -> barrier %6.0f" % (
+    (ex[:, 10] - ex[:, 4]).mean(), (ex[:, 11] - ex[:, 10]).mean(), (ex[:, 5] - ex[:, 11]).mean()))

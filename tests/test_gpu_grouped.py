@@ -22,6 +22,12 @@ CASES = [
     (64, 4, 2, 2, 32, 9, 13, 200, "no_kg_eh_uo", "f32"),
     (64, 4, 2, 2, 64, 9, 21, 300, "all", "bf16"),
     (128, 4, 2, 1, 16, 39, 9, 150, "all", "bf16"),
+    # more user segments than workgroups (256): the LDS-DMA form of the dense kernel hands ids / head rows from a segment to the next
+    (64, 4, 2, 2, 40, 9, 1500, 6000, "all", "f32"),        # 5-6 segments per workgroup, padding rows (Nm = 40 -> 48)
+    (64, 4, 2, 3, 48, 9, 700, 3000, "no_ps_o_ft", "f32"),  # 144 rows = the most the DMA form takes; no h-set
+    (64, 4, 2, 2, 64, 9, 300, 1300, "all", "f32"),         # some workgroups with two segments, most with one
+    (64, 4, 2, 2, 80, 9, 600, 2500, "all", "f32"),         # 160 rows: beyond it -> register staging, same loop
+    (64, 4, 2, 2, 64, 9, 900, 3000, "all", "bf16"),        # bf16 table: register staging
 ]
 
 
