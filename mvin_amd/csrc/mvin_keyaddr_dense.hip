@@ -229,7 +229,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     // this wave's kKaDmaRows rows of sH (LDB = row stride in bytes) or sT, ids from LDS
     auto dma_batch = [&](const int* ids, size_t word_off, auto ldb_c) {
         constexpr int LDB = decltype(ldb_c)::value;
-        const int row0 = wave_u * kKaDmaRows;
+        const int row0 = ((wave_u + kDW - 1) % kDW) * kKaDmaRows;      // wave 0 (the scan wave) takes the last, usually empty, block
         const int idv = (lane < kKaDmaRows && row0 + lane < rows) ? ids[row0 + lane] : -1;
         ka_dma_rows<LDB>(reinterpret_cast<const char*>(a.E), idv, lane * 4, lds0 + (unsigned)(word_off * 4) + (unsigned)(row0 * LDB),
                          std::make_integer_sequence<int, kKaDmaRows>{});
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                 np02 = a.seg_ptr[seg + 2 * gridDim.x];
                 np12 = a.seg_ptr[seg + 2 * gridDim.x + 1];
             }
+            if (has_next) load_ids(nu, pid_h, pid_t, pid_r);           // consumed after the bucket scan
         } else if (has_next) {
             nu = a.seg_user[seg + gridDim.x];
             np0 = a.seg_ptr[seg + gridDim.x];
@@ -295,12 +296,6 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             if (idc[rows + tid] >= 0) rk = atomicAdd(&sCnt[idc[2 * rows + tid]], 1);
             sRank[tid] = rk;
         }
-        // tail rows (needed by the first reads phase).  The M0 write in front of a batch waits for EVERY vector memory operation
-        // the wave has in flight -- at the segment's top that is the previous tile's stores (2.5 k cycles), here nothing; and a
-        // batch goes out BEFORE the loads issued at the same point.  This segment's head rows landed a segment ago.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        dma_batch(idc + rows, L.t, std::integral_constant<int, LDT * 4>{});
-        if (has_next) load_ids(nu, pid_h, pid_t, pid_r);               // consumed after the bucket scan
       } else {
         // ---- ids (row i = hop * NmP + m; padding rows m >= Nm stay zero), rank of every memory inside its relation ----
         const int32_t* ub = a.uts + (int64_t)u * Ph * 3 * Nm;
@@ -346,6 +341,13 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                 base += 0;
             }
             if (lane == 0) sOrig[kDT] = ntile;
+        }
+        if constexpr (DMA) {
+            // tail rows (needed by the first reads phase), landed next to wave 0's scan.  The M0 write in front of a batch waits for
+            // EVERY vector memory operation the wave has in flight -- at the segment's top that was the previous tile's stores, 2.5 k
+            // cycles; here they and the id loads of the top are done.  This segment's head rows landed a segment ago.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_batch(idc + rows, L.t, std::integral_constant<int, LDT * 4>{});
         }
         __syncthreads();
         const int ntile = sOrig[kDT];
