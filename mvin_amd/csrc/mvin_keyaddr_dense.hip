@@ -52,10 +52,10 @@ static KaDenseLds ka_dense_layout(int D, int P, int Nm, int nR) {
     L.maxtiles = L.PN / 16 + (nrl > 0 ? nrl : 1);          // every bucket wastes less than one tile
     size_t o = 0;
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };
-    L.h = take((size_t)Ph * L.NmP * (D + 2));
-    L.u = take((size_t)L.PN * (D + 2));
+    L.h = take((size_t)Ph * L.NmP * (D + 4));
+    L.u = take((size_t)L.PN * (D + 4));
     L.t = take((size_t)L.PN * (D + 16));
-    L.ei = take((size_t)kDT * (D + 2));
+    L.ei = take((size_t)kDT * (D + 4));
     L.l = take((size_t)kDT * (L.PN + 2));
     L.z = take((size_t)kDT * (P > 0 ? P : 1));
     L.hset = take(D);
@@ -104,7 +104,7 @@ template <int D, bool BF, bool TRACE, bool DMA>
 __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_addr_dense_kernel(KeyAddrGroupedArgs a, KaDenseLds L) {
     constexpr int kDW = ka_dense_waves(D);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LPR = D / 4, RPW = 64 / LPR, NT = D / 16, KS = D / 4, LDH = D + 2, LDT = D + 16, NTHR = kDW * 64;
+    constexpr int LPR = D / 4, RPW = 64 / LPR, NT = D / 16, KS = D / 4, LDH = D + 4, LDT = D + 16, NTHR = kDW * 64;
     constexpr int LPR_L2 = (LPR == 4) ? 2 : (LPR == 8) ? 3 : (LPR == 16) ? 4 : 5;
     const int P = a.P, Nm = a.Nm, Ph = P > 0 ? P : 1, NmP = L.NmP, PN = L.PN, LDL = PN + 2;
     float* sH = smem + L.h;
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     int* sOrig = reinterpret_cast<int*>(smem + L.orig);      // [kDT] original pair index (-1: padding), [kDT] = #tiles
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // the same number, known to be wave-uniform (scalar registers)
     const int g = lane / LPR, c = lane % LPR;
     const int q16 = lane >> 4, l16 = lane & 15;
     const bool has_set = a.w != nullptr;
@@ -180,28 +181,35 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     if (resident && wave < kDW - 1) {
 #pragma unroll
         for (int sl = 0; sl < RES; ++sl) {
-            const int q = wave + (kDW - 1) * sl;
+            const int q = wave_u + (kDW - 1) * sl;
             if (q < a.nR * NT) load_bfrag(q / NT, q % NT, rb[sl]);
         }
     }
     // U tile: rows sBidx[row0 .. row0+15] of sH times the fragment -> sU
     auto u_tile = [&](int row0, int nt, const float (&bf)[KS]) {
         const int ia = sBidx[row0 + l16];
-        const float* ar = sH + (size_t)(ia >= 0 ? ia : 0) * LDH + KS * q16;
+        // rows are 16-byte aligned (LDH = D + 4): 16-byte reads of the A values, and the four output rows' indices in one read
+        const float4* ar = reinterpret_cast<const float4*>(sH + (ia >= 0 ? ia : 0) * LDH + KS * q16);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[k], bf[k], acc, 0, 0, 0);
+        for (int k = 0; k < KS; k += 4) {
+            const float4 av = ar[k >> 2];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bf[k], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bf[k + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bf[k + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bf[k + 3], acc, 0, 0, 0);
+        }
+        const int4 io4 = *reinterpret_cast<const int4*>(sBidx + row0 + 4 * q16);
+        const int io[4] = {io4.x, io4.y, io4.z, io4.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int io = sBidx[row0 + 4 * q16 + i];
-            if (io >= 0) sU[(size_t)io * LDH + 16 * nt + l16] = acc[i];
+            if (io[i] >= 0) sU[io[i] * LDH + 16 * nt + l16] = acc[i];
         }
     };
     // ---- LDS-DMA form: ids two segments ahead in registers, one ahead in LDS; head rows one segment ahead in sH ----
     const int rows = Ph * NmP;
     int* sIdN = reinterpret_cast<int*>(smem + L.idn);        // [parity][head | tail | relation][rows]
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int nu2 = 0, np02 = 0, np12 = 0;                         // descriptor of the segment after the next
     int pid_h = -1, pid_t = -1, pid_r = 0;                   // thread i < rows: ids of row i of the NEXT segment
     auto load_ids = [&](int user, int& h, int& t, int& r) {
@@ -409,14 +417,22 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             const int nw = has_set ? kDW - 1 : kDW;
             if (resident) {
                 if (wave < kDW - 1) {
+                    // wave-uniform task table first (scalar: with per-lane copies of these the kernel spilled the LDS addresses
+                    // and reloaded them from scratch in front of every slot's tiles)
+                    int tl[RES > 0 ? RES : 1], rw[RES > 0 ? RES : 1];
 #pragma unroll
                     for (int sl = 0; sl < RES; ++sl) {
-                        const int q = wave + (kDW - 1) * sl;
-                        if (q < a.nR * NT) {
-                            const int r = q / NT, nt = q % NT;
-                            const int tiles = (sCnt[r] + 15) >> 4, row0 = sOff[r];
-                            for (int j = 0; j < tiles; ++j) u_tile(row0 + 16 * j, nt, rb[sl]);
-                        }
+                        const int q = wave_u + (kDW - 1) * sl;
+                        const bool ok = q < a.nR * NT;
+                        const int r = ok ? q / NT : 0;
+                        tl[sl] = ok ? (sCnt[r] + 15) >> 4 : 0;
+                        rw[sl] = sOff[r];
+                    }
+#pragma unroll
+                    for (int sl = 0; sl < RES; ++sl) {
+                        const int nt = (wave_u + (kDW - 1) * sl) % NT;
+                        const int tiles = __builtin_amdgcn_readfirstlane(tl[sl]), row0 = __builtin_amdgcn_readfirstlane(rw[sl]);
+                        for (int j = 0; j < tiles; ++j) u_tile(row0 + 16 * j, nt, rb[sl]);
                     }
                 }
             } else {
@@ -461,10 +477,19 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
             for (int mt = wave; mt < PN / 16; mt += kDW) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const float* ar = sEi + l16 * LDH + q16;
-                const float* br = sU + (size_t)(16 * mt + l16) * LDH + q16;
+                // contraction index permuted as in u_tile (step k of slot q16 stands for KS * q16 + k on both operands): a lane's
+                // values are contiguous, four steps per 16-byte read (with one 4-byte read per step and operand the loop was a
+                // chain of eight LDS latencies: 1.55 k cycles for 16 MFMAs)
+                const float4* ar = reinterpret_cast<const float4*>(sEi + l16 * LDH + KS * q16);
+                const float4* br = reinterpret_cast<const float4*>(sU + (16 * mt + l16) * LDH + KS * q16);
 #pragma unroll
-                for (int k = 0; k < KS; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * k], br[4 * k], acc, 0, 0, 0);
+                for (int k = 0; k < KS / 4; ++k) {
+                    const float4 av = ar[k], bv = br[k];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) sL[(size_t)(4 * q16 + i) * LDL + 16 * mt + l16] = acc[i];
             }
