@@ -24,6 +24,15 @@ namespace mvin {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// exp for arguments <= 0 (logit - max): the library's argument reduction without its range selects (as d16_exp / kw_exp)
+__device__ __forceinline__ float kad_exp(float x) {
+    const float t = x * 1.44269502162933349609375f;              // float(log2 e)
+    const float n = rintf(t);
+    float f = fmaf(x, 1.44269502162933349609375f, -n);
+    f = fmaf(x, 1.925963033500011e-8f, f);                       // log2 e - float(log2 e)
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // development aid (MVIN_KA_TRACE=1, scripts/trace_keyaddr.py): workgroup 0 stamps s_memtime at its phase boundaries
 __device__ long long g_ka_trace[64 * 16];
 // waves per workgroup: 12 (168 VGPRs each: room for the resident R_KGE fragments; one workgroup per CU), or 4 at D = 16,
@@ -507,14 +516,28 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
                     const int tk = ok ? task : base;
                     const int pi = tk / P, hop = tk - pi * P;
                     float* row = sL + (size_t)pi * LDL + hop * NmP;
-                    float mx = -INFINITY;
-                    for (int m = cl; m < Nm; m += 16) mx = fmaxf(mx, row[m]);
-                    mx = group_max(mx, 4);
-                    float z = 0.f;
-                    for (int m = cl; m < NmP; m += 16) {
-                        const float e = m < Nm ? expf(row[m] - mx) : 0.f;
-                        if (ok) row[m] = e;
-                        z += e;
+                    float mx = -INFINITY, z = 0.f;
+                    if (NmP <= 64) {
+                        // at most four values per lane: read ONCE, together (the two run-time loops below were chains of LDS
+                        // latencies: 2.6 k cycles per tile for 64 values per row)
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = (cl + 16 * u < Nm) ? row[cl + 16 * u] : -INFINITY;
+                        mx = group_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), 4);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float e = (cl + 16 * u < Nm) ? kad_exp(v[u] - mx) : 0.f;
+                            if (ok && cl + 16 * u < NmP) row[cl + 16 * u] = e;
+                            z += e;
+                        }
+                    } else {
+                        for (int m = cl; m < Nm; m += 16) mx = fmaxf(mx, row[m]);
+                        mx = group_max(mx, 4);
+                        for (int m = cl; m < NmP; m += 16) {
+                            const float e = m < Nm ? kad_exp(row[m] - mx) : 0.f;
+                            if (ok) row[m] = e;
+                            z += e;
+                        }
                     }
                     z = group_sum(z, 4);
                     if (ok && cl == 0) sZ[task] = 1.f / z;      // sZ[pi * P + hop]

@@ -8,7 +8,8 @@
 // nagg0 / nagg1 are the neighbor aggregates mvin_gather_attn_l2_fwd returns per pair.
 // One workgroup of D/16 waves walks 32-row tiles; all six D x D weight blocks stay resident as B fragments of
 // v_mfma_f32_16x16x4_f32 (6 * D/4 registers per wave), the five intermediates of a tile live in LDS
-// (row stride D+2: conflict-free A-fragment reads).  D in {16, 32, 64}.
+// (row stride D+4: 16-byte aligned rows; the contraction index is permuted -- MFMA step s of slot q16 stands for
+// k = KS * q16 + s on both operands -- so a lane's A values of four steps are ONE 16-byte LDS read).  D in {16, 32, 64}.
 #include "mvin_kernels.h"
 
 namespace mvin {
@@ -17,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int D>
 __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
-    constexpr int NT = D / 16, KS = D / 4, LD = D + 2, TM = 32, NTHR = NT * 64;
+    constexpr int NT = D / 16, KS = D / 4, LD = D + 4, TM = 32, NTHR = NT * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sX = smem;                   // [TM][LD]  E[item] + q, then Z2 = out0 + nagg1
     float* sE0 = sX + TM * LD;          // ev0
@@ -33,7 +34,7 @@ __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
     float bW0[KS], bA0[KS], bA1[KS], bC0[KS], bC1[KS], bC2[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-        const size_t o = (size_t)(4 * s + q16) * D + col;
+        const size_t o = (size_t)(KS * q16 + s) * D + col;
         bW0[s] = proj ? a.W0[o] : 0.f;
         bA0[s] = a.A0[o];
         bA1[s] = a.A1[o];
@@ -49,10 +50,17 @@ __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
     // acc[m] += A(tile rows of `src`) . B fragment
     auto mma = [&](const float* src, const float (&bf)[KS], f32x4 (&acc)[2]) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
+        for (int s = 0; s < KS; s += 4) {
+            float4 av[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(src[(16 * m + l16) * LD + 4 * s + q16], bf[s], acc[m], 0, 0, 0);
+            for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const float4*>(src + (16 * m + l16) * LD + KS * q16 + s);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].x, bf[s], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].y, bf[s + 1], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].z, bf[s + 2], acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m].w, bf[s + 3], acc[m], 0, 0, 0);
+            }
         }
     };
     const int64_t ntiles = (a.B + TM - 1) / TM;
@@ -110,8 +118,7 @@ __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
             const int idx = tid + i * NTHR;
             const int row = idx / (D / 4), c = idx - row * (D / 4);
             float* dst = sX + row * LD + 4 * c;
-            *reinterpret_cast<float2*>(dst) = make_float2(cur.x[i].x, cur.x[i].y);
-            *reinterpret_cast<float2*>(dst + 2) = make_float2(cur.x[i].z, cur.x[i].w);
+            *reinterpret_cast<float4*>(dst) = cur.x[i];
         }
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x, nxt);     // in flight under this tile's phases
         __syncthreads();
@@ -194,7 +201,7 @@ bool l2_tail_supported(int D) { return D == 16 || D == 32 || D == 64; }
 template <int D>
 static hipError_t launch_tail_d(const TailArgs& a, hipStream_t st) {
     constexpr int NT = D / 16;
-    const size_t lds = (size_t)(4 * 32 * (D + 2) + NT * 32) * 4;
+    const size_t lds = (size_t)(4 * 32 * (D + 4) + NT * 32) * 4;
     const int64_t ntiles = (a.B + 31) / 32;
     const int64_t cap = 256 * (D == 64 ? 4 : 8);
     l2_tail_kernel<D><<<(int)(ntiles < cap ? ntiles : cap), NT * 64, lds, st>>>(a);
