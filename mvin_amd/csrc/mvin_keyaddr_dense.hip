@@ -285,14 +285,9 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         int* idc = sIdN + par * 3 * rows;                    // DMA form: this segment's ids
         const int* idt_cur = DMA ? idc + rows : sIdT;
         if constexpr (DMA) {
-            nu = nu2;
+            nu = nu2;                                        // read during the previous segment's U phase (below)
             np0 = np02;
             np1 = np12;
-            if (seg + 2 * (int)gridDim.x < nseg) {
-                nu2 = a.seg_user[seg + 2 * gridDim.x];
-                np02 = a.seg_ptr[seg + 2 * gridDim.x];
-                np12 = a.seg_ptr[seg + 2 * gridDim.x + 1];
-            }
             if (has_next) load_ids(nu, pid_h, pid_t, pid_r);           // consumed after the bucket scan
         } else if (has_next) {
             nu = a.seg_user[seg + gridDim.x];
@@ -391,6 +386,16 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
       }
         __syncthreads();
         stamp(3);
+        // the descriptor of the segment after the next: scalar loads, which EVERY barrier waits for (lgkmcnt) -- issued here, at the
+        // start of the longest phase, they cost nothing; at the segment's top they stood in front of its first barrier (~1 k cycles).
+        // (Register-staged form: measured slower with the move, 1.336 -> 1.374 ms; it keeps its load at the top.)
+        if constexpr (DMA) {
+            if (seg + 2 * (int)gridDim.x < nseg) {
+                nu2 = a.seg_user[seg + 2 * gridDim.x];
+                np02 = a.seg_ptr[seg + 2 * gridDim.x];
+                np12 = a.seg_ptr[seg + 2 * gridDim.x + 1];
+            }
+        }
         // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
         if (has_set && wave == kDW - 1) {
             const float4 w4 = reinterpret_cast<const float4*>(a.w)[c];
