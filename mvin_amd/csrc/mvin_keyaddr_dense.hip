@@ -161,6 +161,34 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             orig = p < p1 ? o : -1;
         }
     };
+    // The same chain in three stages, one per tile phase (D = 64, register-staged form): pair index under the tile's first barrier, item
+    // id under the logits phase (these waves have no logits tile), row under softmax + reads -- every wait falls where the wave would
+    // wait anyway: logits phase 2.5 k -> 1.6 k cycles, 1.340 -> 1.295 ms at C3, amazon-book 3.08 -> 2.97 ms.  (LDS-DMA form: measured
+    // slower, 1.233 -> 1.266 ms -- the stage-2 wait also covers the head-row batch issued in front of stage 1; it keeps the one-piece chain.)
+    constexpr bool STAGED = LATE && !DMA;
+    int st_o = 0;
+    int64_t st_item = 0;
+    bool st_act = false, st_valid = false;
+    auto chain_a = [&](int t0, int p1) {
+        st_act = itid >= 0 && t0 < p1;
+        st_valid = false;
+        if (st_act) {
+            const int p = t0 + itid / LPR;
+            st_valid = p < p1;
+            st_o = a.pair_index[st_valid ? p : p1 - 1];
+        }
+    };
+    auto chain_b = [&]() {
+        if (st_act) st_item = a.items64 ? a.items64[st_o] : (int64_t)a.items32[st_o];
+    };
+    auto chain_c = [&](float4& e, int& orig) {
+        e = make_float4(0.f, 0.f, 0.f, 0.f);
+        orig = -1;
+        if (st_act) {
+            e = load_row4(a.E, BF, st_item, D, itid % LPR);
+            orig = st_valid ? st_o : -1;
+        }
+    };
     int nu = 0, np0 = 0, np1 = 0;
     if ((int)blockIdx.x < nseg) {
         nu = a.seg_user[blockIdx.x];
@@ -274,7 +302,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     int iter = 0;
     auto stamp = [&](int slot) {
         if constexpr (TRACE) {
-            if (blockIdx.x == 0 && tid == 0 && iter >= 4 && iter < 68) g_ka_trace[(iter - 4) * 16 + slot] = __builtin_readcyclecounter();
+            if (blockIdx.x == 0 && tid == 64 * a.dbg && iter >= 4 && iter < 68) g_ka_trace[(iter - 4) * 16 + slot] = __builtin_readcyclecounter();
         }
     };
     for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x, ++iter) {
@@ -485,9 +513,11 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             if (t0 == p0) stamp(11);
             const bool last = t0 + kDT >= p1;                // np0 / np1: the next segment's (no next one: a harmless re-read)
             if constexpr (!LATE) item_row(t0 + kDT, p1, e_next, orig_next);
+            if constexpr (STAGED) chain_a(last ? np0 : t0 + kDT, last ? np1 : p1);
             __syncthreads();
             if (t0 == p0) stamp(5);
-            if constexpr (LATE) item_row(last ? np0 : t0 + kDT, last ? np1 : p1, e_next, orig_next);
+            if constexpr (LATE && !STAGED) item_row(last ? np0 : t0 + kDT, last ? np1 : p1, e_next, orig_next);
+            if constexpr (STAGED) chain_b();
             // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
             for (int mt = wave; mt < PN / 16; mt += kDW) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -509,6 +539,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             }
             __syncthreads();
             if (t0 == p0) stamp(6);
+            if constexpr (STAGED) chain_c(e_next, orig_next);
             // softmax over the Nm memories of every (pair, hop) (:223): un-normalised weights back to sL, 1/sum to sZ
             // FOUR rows per wave pass, a 16-lane DPP row per (pair, hop) and NmP/16 values per lane: with a whole wave
             // per row the phase was VALU-issue-bound on two 64-wide reductions per 64 values (3.7 k cycles per tile,
@@ -637,7 +668,13 @@ static hipError_t launch_kad(const KeyAddrGroupedArgs& a, int table_bf16, hipStr
                      : ((D == 64 && trace) ? key_addr_dense_kernel<D, false, true, false> : key_addr_dense_kernel<D, false, false, false>);
         if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
         if (e != hipSuccess) return e;
-        k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(a, L);
+        KeyAddrGroupedArgs b = a;
+        b.dbg = 0;
+        if (trace) {                                         // which wave of workgroup 0 stamps (scripts/trace_keyaddr.py)
+            const char* tw = getenv("MVIN_KA_TRACE_WAVE");
+            b.dbg = tw ? atoi(tw) % kDW : 0;
+        }
+        k<<<grid_for(reinterpret_cast<const void*>(k)), kDW * 64, L.total, st>>>(b, L);
     }
     return hipGetLastError();
 }

@@ -33,3 +33,15 @@ ex = full[4:60]
 print("   top -> top barrier released %6.0f ; -> DMA / clears issued %6.0f" % ((ex[:, 13] - ex[:, 0]).mean(), (ex[:, 14] - ex[:, 13]).mean()))
 print("   U done -> tile0 barrier + Ei written %6.0f ; -> head-row DMA issued %6.0f ; -> barrier %6.0f" % (
     (ex[:, 10] - ex[:, 4]).mean(), (ex[:, 11] - ex[:, 10]).mean(), (ex[:, 5] - ex[:, 11]).mean()))
+
+# which wave is late where: the same stamps taken by each wave of workgroup 0 in turn (MVIN_KA_TRACE_WAVE)
+print("per wave: [top -> top barrier released] [U phase start -> own U work done] [U done -> tile0 first barrier + Ei] [tile0 reads done -> next top]")
+for wv in range(12):
+    os.environ["MVIN_KA_TRACE_WAVE"] = str(wv)
+    for _ in range(2):
+        ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, 3 * D, nR)
+    torch.cuda.synchronize()
+    assert _lib.load().mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+    f = buf.reshape(64, 16).astype(np.float64)[4:60]
+    print("  wave %2d: %6.0f %6.0f %6.0f %6.0f" % (wv, (f[:, 13] - f[:, 0]).mean(), (f[:, 4] - f[:, 3]).mean(), (f[:, 10] - f[:, 4]).mean(),
+                                                (f[1:, 0] - f[:-1, 8]).mean()))
