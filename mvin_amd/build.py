@@ -17,6 +17,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libmvin_hip.so")
 STAMP_PATH = LIB_PATH + ".stamp"
+OBJ_DIR = os.path.join(PKG_DIR, "_build")
 SOURCES = ["mvin_kernels.hip", "mvin_fused.hip", "mvin_fused_split.hip", "mvin_fused_d16.hip", "mvin_fused_d32.hip", "mvin_tail.hip", "mvin_keyaddr.hip", "mvin_keyaddr_stream.hip", "mvin_keyaddr_grouped.hip", "mvin_keyaddr_dense.hip", "mvin_keyaddr_wave.hip", "mvin_hoist.hip", "mvin_probe.hip", "mvin_group.hip", "mvin_prep.hip", "mvin_linear_mfma.hip", "mvin_bwd.hip", "mvin_abi.hip"]
 HEADERS = ["mvin_common.h", "mvin_kernels.h"]
 ARCH = "gfx950"
@@ -50,19 +51,55 @@ def needs_build():
         return f.read().strip() != _digest()
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source into one shared library.  Returns the library path."""
+def _obj_digest(src):
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in [src] + _existing(HEADERS, CSRC) + [os.path.join(INCLUDE, "mvin_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:20]
+
+
+def build(force=False, verbose=False, jobs=None):
+    """Compile every HIP source (one object per source, in parallel, cached under mvin_amd/_build by the
+    hash of the source, the shared headers and the flags) and link them into one shared library.
+    Returns the library path."""
     if not force and not needs_build():
         return LIB_PATH
-    srcs = _existing(SOURCES, CSRC)
-    cmd = [_hipcc()] + FLAGS + [f"-I{INCLUDE}", f"-I{CSRC}"] + srcs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"]
+    todo, objs = [], []
+    for src in _existing(SOURCES, CSRC):
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + "." + _obj_digest(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            todo.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc] + cflags + ["-c", f"-I{INCLUDE}", f"-I{CSRC}", src, "-o", obj + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({res.returncode}) on {src}:\n{res.stdout}\n{res.stderr}")
+        if verbose and res.stderr:
+            print(res.stderr, file=sys.stderr)
+        os.replace(obj + ".tmp", obj)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, todo))
+    keep = set(objs)
+    for f in os.listdir(OBJ_DIR):        # objects of older source revisions
+        if os.path.join(OBJ_DIR, f) not in keep:
+            os.remove(os.path.join(OBJ_DIR, f))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", LIB_PATH + ".tmp"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    if verbose and res.stderr:
-        print(res.stderr, file=sys.stderr)
+        raise RuntimeError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
     with open(STAMP_PATH, "w") as f:
         f.write(_digest())
     return LIB_PATH
