@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 6
+#define MVIN_ABI_VERSION 7
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -153,6 +153,20 @@ int mvin_gather_attn_l2_fwd_i64(const void* table, const int32_t* adj_entity, co
                                 float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                                 int table_bf16, void* stream);
 int mvin_gather_attn_l2_supported(int D, int K);
+/* The same pass over an adjacency in the DUPLICATE-SLOT ENCODING of mvin_encode_adjacency (below): the reference's sampler
+ * repeats (neighbour, relation) slots whenever an entity has fewer than K edges (data_loader_user_set.py:383-384); equal
+ * slots have equal logits and equal rows, so their softmax weights are added up and every distinct row is gathered once,
+ * and the distinct children of consecutive parents are packed into full MFMA tiles (mvin_fused_packed.hip).  Same
+ * arithmetic up to the order of fp32 additions; no attention outputs (those are per slot: use the plain adjacency).
+ * parent_ids: int32 [P], or int64 [P] read in place when parent_ids_i64 != 0.  D in {32, 64, 128}, K in {16, 32, 64, 128},
+ * nR <= 4096, tables below 4 GiB (-3 otherwise). */
+int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
+                                const float* W1, const float* W2, const float* b1, const float* b2,
+                                const float* q, const float* A0, const float* a0,
+                                int B, int parents_per_pair, int K, int D, int n_entity, int nR,
+                                float* nagg0, float* nagg1, int table_bf16, void* stream);
+int mvin_gather_attn_l2_enc_supported(int D, int K);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
@@ -317,6 +331,8 @@ typedef struct {
     int64_t B;
     int D, K, P, Nm, n_entity, n_relation, table_bf16;
     int n_user;                    /* rows of uts (users feed); user ids are clamped to [0, n_user) */
+    const int32_t* enc_entity;     /* duplicate-slot encoding of the adjacency (mvin_encode_adjacency) or NULL: when given */
+    const int32_t* enc_relation;   /*   the two deepest levels take mvin_gather_attn_l2_enc_fwd */
 } mvin_score_l2_args;
 int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 
@@ -462,6 +478,15 @@ int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR);
  * K distinct edges when deg >= K, K draws with replacement when 0 < deg < K, zero row when deg == 0. */
 int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
                           uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream);
+
+/* mvin_encode_adjacency: the duplicate-slot encoding of a sampled adjacency (K <= 128, relation ids < 65536), built
+ * once per adjacency.  Row x of enc_entity / enc_relation [nE, K] holds the DISTINCT (neighbour, relation) slots of row x
+ * first -- ordered by the distinct-slot count of the neighbour's own row, descending, ties in first-occurrence order --
+ * and padding (a copy of slot 0) behind them:
+ *     enc_relation = relation | multiplicity << 16 | cnt[x] << 24     (multiplicity 0: padding; unsigned word)
+ * cnt [nE] = distinct slots per row (also written).  adj_relation may be NULL (relations read as 0). */
+int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
+                          int32_t* enc_entity, int32_t* enc_relation, void* stream);
 
 /* mvin_build_ripple_sets: get_user_triplet_set / _get_user_triplet_set (:392-441).
  * hist_ptr [nU+1] int64 / hist_items int32: each user's positive train items in interaction order.

@@ -66,7 +66,8 @@ class ScoreL2Args(C.Structure):
         "entity_emb", "adj_entity", "adj_relation", "relation_kge", "h_set_w", "user_mlp_W", "user_mlp_b", "t0", "t1",
         "W0", "b0", "W1", "b1", "W2", "b2", "A0", "a0", "A1", "a1", "Wmix", "bmix", "items", "mem_h", "mem_r", "mem_t",
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
-        ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")]
+        ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
+        ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -101,6 +102,11 @@ SIGNATURES = {
                                               C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, _c_f32p,
                                               _c_f32p, C.c_int, C.c_void_p]),
     "mvin_gather_attn_l2_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_gather_attn_l2_enc_fwd": (C.c_int, [_c_f32p, _c_i32p, _c_i32p, C.c_void_p, C.c_int, _c_f32p, _c_f32p, _c_f32p,
+                                              _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_int, C.c_void_p]),
+    "mvin_gather_attn_l2_enc_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_encode_adjacency": (C.c_int, [_c_i32p, _c_i32p, C.c_int, C.c_int, _c_i32p, _c_i32p, _c_i32p, C.c_void_p]),
     "mvin_gather_attn_l2_variant": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "mvin_probe_gather_l2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
@@ -193,8 +199,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 6:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 6")
+    if ver != 7:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 7")
     _lib = lib
     return lib
 

@@ -185,8 +185,10 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D,
                                int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
-                               float* probs_child, int table_bf16, void* stream) {
-    const char* who = "mvin_gather_attn_l2_fwd";
+                               float* probs_child, int table_bf16, void* stream, bool encoded = false) {
+    const char* who = encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
+    if (encoded && !mvin::fused_packed_supported(D, K))
+        return fail(-3, "%s: unsupported shape D=%d K=%d (D in {32,64,128}, K in {16,32,64,128})", who, D, K);
     if (!mvin::fused_l2_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {16,32,64,128}, K power of two in [4,256])",
                     who, D, K);
@@ -231,7 +233,33 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
         static const char* dbg = getenv("MVIN_SPLIT_DBG");
         f.dbg = dbg ? atoi(dbg) : 0;
     }
+    if (encoded) {
+        if (!adj_relation) return fail(-1, "%s: null enc_relation", who);
+        if (!mvin::fused_packed_applies(f, D)) return fail(-3, "%s: tables too large for 32-bit offsets", who);
+        return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
+    }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
+}
+
+int mvin_gather_attn_l2_enc_supported(int D, int K) { return mvin::fused_packed_supported(D, K) ? 1 : 0; }
+
+int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
+                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
+                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity,
+                                int nR, float* nagg0, float* nagg1, int table_bf16, void* stream) {
+    return gather_attn_l2_impl(table, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
+                               parent_ids_i64 ? 2 : 1, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K, D, n_entity,
+                               nR, nagg0, nagg1, nullptr, nullptr, table_bf16, stream, true);
+}
+
+int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
+                          int32_t* enc_entity, int32_t* enc_relation, void* stream) {
+    const char* who = "mvin_encode_adjacency";
+    if (!adj_entity || !cnt || !enc_entity || !enc_relation) return fail(-1, "%s: null pointer", who);
+    if (n_entity <= 0 || K <= 0 || K > 128) return fail(-2, "%s: n_entity=%d K=%d (K <= 128)", who, n_entity, K);
+    return hip_result(mvin::launch_encode_adjacency(adj_entity, adj_relation, n_entity, K, cnt, enc_entity, enc_relation,
+                                                    (hipStream_t)stream), who);
 }
 
 int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
@@ -476,10 +504,12 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     rc = mvin_linear_fwd(&u, stream);
     if (rc) return rc;
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
-    rc = gather_attn_l2_impl(a->entity_emb, a->adj_entity, a->adj_relation, reinterpret_cast<const int32_t*>(a->items), 2,
+    const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
+    rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
+                             reinterpret_cast<const int32_t*>(a->items), 2,
                              a->t0, a->t1, a->W1, a->W2, a->b1, a->b2, a->W1 ? a->user_o : nullptr, a->A0, a->a0,
                              (int)a->B, 1, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr,
-                             a->table_bf16, stream);
+                             a->table_bf16, stream, enc);
     if (rc) return rc;
     return mvin_l2_tail_fwd(a->entity_emb, a->items, nullptr, a->W0 ? a->user_o : nullptr, a->user_o, a->nagg0, a->nagg1,
                             a->W0, a->b0, a->A0, a->a0, a->A1, a->a1, a->Wmix, a->bmix, a->B, D, a->n_entity, a->item_emb,

@@ -164,6 +164,101 @@ __global__ __launch_bounds__(kBlock) void ripple_sets_kernel(RippleBuildArgs a) 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Duplicate-slot encoding of a sampled adjacency (consumed by mvin_fused_packed.hip).
+// contruct_random_adj draws WITH replacement when deg < K (data_loader_user_set.py:383-384), so a row repeats
+// (neighbour, relation) slots; sum_k p_k E[y_k] over the K slots = sum over the DISTINCT slots with the softmax weights of
+// equal slots added up (equal slots have equal logits: weight = multiplicity * exp(t[r] - max) / Z).  Row x becomes: distinct
+// slots first, ordered by the distinct-slot count of the neighbour's own row (descending, ties in first-occurrence order:
+// the children of a tree node that share a gather round then have lists of similar length), padding (= slot 0) last;
+//   enc_r = relation | multiplicity << 16 | cnt[x] << 24     (multiplicity 0: padding)
+// One wave per row, two passes (the order needs every row's count): MODE 0 writes cnt, MODE 1 the encoding.
+// oracle/prep_ref.py:encode_adjacency restates it; integer work, bit-exact.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void encode_adjacency_kernel(const int32_t* __restrict__ adj_e,
+                                                                  const int32_t* __restrict__ adj_r, int n_entity, int K,
+                                                                  int32_t* __restrict__ cnt, int32_t* __restrict__ enc_e,
+                                                                  int32_t* __restrict__ enc_r) {
+    __shared__ int sE[4][128], sR[4][128], sF[4][128], sPad[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 4 + wave;
+    if (x >= n_entity) return;
+    int e[2], r[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = lane + 64 * i;
+        e[i] = s < K ? adj_e[(int64_t)x * K + s] : -1;
+        r[i] = s < K ? (adj_r ? adj_r[(int64_t)x * K + s] : 0) : -1;
+        if (s < K) {
+            sE[wave][s] = e[i];
+            sR[wave][s] = r[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool first[2];
+    int mult[2];
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = lane + 64 * i;
+        first[i] = s < K;
+        mult[i] = 0;
+        for (int t = 0; t < K; ++t) {
+            const bool eq = sE[wave][t] == e[i] && sR[wave][t] == r[i];
+            mult[i] += eq ? 1 : 0;
+            if (eq && t < s) first[i] = false;
+        }
+        c += __popcll(__ballot(first[i]));
+    }
+    if constexpr (MODE == 0) {
+        if (lane == 0) cnt[x] = c;
+        return;
+    } else {
+        int key[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = lane + 64 * i;
+            const int y = e[i] < 0 ? 0 : (e[i] >= n_entity ? n_entity - 1 : e[i]);
+            key[i] = first[i] ? cnt[y] : -1;
+            if (s < K) sF[wave][s] = key[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = lane + 64 * i;
+            if (first[i]) {
+                int rank = 0;
+                for (int t = 0; t < K; ++t) {
+                    const int kt = sF[wave][t];
+                    rank += (kt > key[i] || (kt == key[i] && t < s)) ? 1 : 0;
+                }
+                enc_e[(int64_t)x * K + rank] = e[i];
+                enc_r[(int64_t)x * K + rank] = (int32_t)((unsigned)r[i] | ((unsigned)mult[i] << 16) | ((unsigned)c << 24));
+                if (rank == 0) {
+                    sPad[wave][0] = e[i];
+                    sPad[wave][1] = r[i];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int s = c + lane; s < K; s += 64) {
+            enc_e[(int64_t)x * K + s] = sPad[wave][0];
+            enc_r[(int64_t)x * K + s] = (int32_t)((unsigned)sPad[wave][1] | ((unsigned)c << 24));
+        }
+    }
+}
+
+hipError_t launch_encode_adjacency(const int32_t* adj_e, const int32_t* adj_r, int n_entity, int K, int32_t* cnt,
+                                   int32_t* enc_e, int32_t* enc_r, hipStream_t st) {
+    const int grid = (n_entity + 3) / 4;
+    encode_adjacency_kernel<0><<<grid, kBlock, 0, st>>>(adj_e, adj_r, n_entity, K, cnt, nullptr, nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    encode_adjacency_kernel<1><<<grid, kBlock, 0, st>>>(adj_e, adj_r, n_entity, K, cnt, enc_e, enc_r);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity,
                                    int K, uint64_t seed, int32_t* adj_e, int32_t* adj_r, hipStream_t st) {
     sample_adjacency_kernel<<<(n_entity + 255) / 256, 256, 0, st>>>(indptr, dst, rel, n_entity, K, seed, adj_e, adj_r);

@@ -65,6 +65,7 @@ class MVIN(object):
         if hoist not in (False, True, "step"):
             raise ValueError("hoist must be False, True or 'step'")
         self.hoist = hoist
+        self.dedup = None            # None: MVIN_L2_ENC / auto; True / False: force the encoded / the plain adjacency
         self._hoisted = None
         self._table_token = None     # see _hoist_key
         self._parse_args(args, adj_entity, adj_relation)
@@ -112,7 +113,38 @@ class MVIN(object):
             return torch.from_numpy(np.asarray(a).astype(np.int32)).to(self.device).contiguous()
         self.adj_entity, self.adj_relation = conv(adj_entity), conv(adj_relation)
         self._hoisted = None
+        self._enc = None             # duplicate-slot encoding, built on first use (encoded_adjacency)
         self._generation = getattr(self, "_generation", 0) + 1
+
+    # a sampled adjacency repeats slots whenever deg < K (data_loader_user_set.py:383-384); the packed-tile fused kernel
+    # walks the distinct slots only.  It pays when rows repeat: below this mean fraction of distinct slots per row it is
+    # taken ("auto"); MVIN_L2_ENC=0 / 1 (or MVIN.dedup = False / True) force the plain / the encoded path.
+    ENC_AUTO_MAX_DISTINCT_FRACTION = 0.75
+
+    def encoded_adjacency(self):
+        """(enc_entity, enc_relation, cnt, mean distinct fraction) of the current adjacency (mvin_encode_adjacency),
+        built once per set_adjacency; None when the shape has no packed-tile kernel."""
+        if self._enc is None:
+            K = self.n_neighbor
+            if K > 128 or int(self.n_relation) > 65535 or not ops.encode_adjacency_supported(self.dim, K):
+                self._enc = False
+            else:
+                enc_e, enc_r, cnt = ops.encode_adjacency(self.adj_entity, self.adj_relation)
+                frac = float(cnt.float().mean().item()) / K       # one host sync per adjacency
+                self._enc = (enc_e, enc_r, cnt, frac)
+        return self._enc or None
+
+    def _enc_for_l2(self, want_probs=False):
+        """The encoded adjacency when the two deepest levels should take the packed-tile kernel for this call."""
+        mode = os.environ.get("MVIN_L2_ENC", "auto") if self.dedup is None else ("1" if self.dedup else "0")
+        if mode == "0" or want_probs or self.fused is False:
+            return None
+        if self.entity_emb_matrix.numel() * self.entity_emb_matrix.element_size() >= (1 << 32):
+            return None
+        enc = self.encoded_adjacency()
+        if enc is None or (mode != "1" and enc[3] > self.ENC_AUTO_MAX_DISTINCT_FRACTION):
+            return None
+        return enc
 
     def _build_inputs(self):
         """model.py:49-64."""
@@ -484,14 +516,19 @@ class MVIN(object):
             if self._profile is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            n0, n1, pp, pc = ops.gather_attn_l2(
-                self.entity_emb_matrix, self.adj_entity, self.adj_relation, ents[L - 2].view(-1),
-                a0.relation_scores() if a0.User_orient_rela else None,
-                a1.relation_scores() if a1.User_orient_rela else None,
-                self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
-                self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
-                q if uo else None, a0.weights, a0.bias,
-                B, K ** (L - 2), K, D, self.n_relation, want_probs=want_probs and a0.User_orient_rela)
+            l2_args = (a0.relation_scores() if a0.User_orient_rela else None,
+                       a1.relation_scores() if a1.User_orient_rela else None,
+                       self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
+                       self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
+                       q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
+            enc = self._enc_for_l2(want_probs)
+            if enc is not None:
+                n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
+                pp = pc = None
+            else:
+                n0, n1, pp, pc = ops.gather_attn_l2(
+                    self.entity_emb_matrix, self.adj_entity, self.adj_relation, ents[L - 2].view(-1), *l2_args,
+                    want_probs=want_probs and a0.User_orient_rela)
             if self._profile is not None:
                 e1.record()
                 self._profile.append((e0, e1))
@@ -634,7 +671,9 @@ class MVIN(object):
         s = st["args"]
         s.entity_emb, s.t0, s.t1 = ptr(self.entity_emb_matrix), ptr(t0), ptr(t1)
         s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
-        st["live"] = (self.entity_emb_matrix, t0, t1)
+        enc = self._enc_for_l2()
+        s.enc_entity, s.enc_relation = (ptr(enc[0]), ptr(enc[1])) if enc is not None else (None, None)
+        st["live"] = (self.entity_emb_matrix, t0, t1, enc)
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
         wkey = (B, n_o, stream.cuda_stream)

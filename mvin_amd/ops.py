@@ -253,6 +253,44 @@ def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, 
     return nagg0, nagg1, pp, pc
 
 
+def encode_adjacency_supported(D, K):
+    """The packed-tile fused kernel (mvin_gather_attn_l2_enc_fwd) exists for this shape."""
+    return bool(_lib.load().mvin_gather_attn_l2_enc_supported(D, K))
+
+
+def encode_adjacency(adj_entity, adj_relation):
+    """mvin_encode_adjacency: the duplicate-slot encoding of a sampled adjacency (include/mvin_hip.h) ->
+    (enc_entity [nE,K] int32, enc_relation [nE,K] int32, cnt [nE] int32 = distinct slots per row)."""
+    _chk(adj_entity, I32, "adj_entity"), _chk(adj_relation, I32, "adj_relation")
+    nE, K = adj_entity.shape
+    enc_e, enc_r = torch.empty_like(adj_entity), torch.empty_like(adj_entity)
+    cnt = torch.empty(nE, dtype=I32, device=adj_entity.device)
+    _lib.check(_lib.load().mvin_encode_adjacency(_p(adj_entity), _p(adj_relation), nE, K, _p(cnt), _p(enc_e), _p(enc_r),
+                                                 _stream()), "mvin_encode_adjacency")
+    return enc_e, enc_r, cnt
+
+
+def gather_attn_l2_enc(table, enc_entity, enc_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0,
+                       B, parents_per_pair, K, D, nR):
+    """mvin_gather_attn_l2_enc_fwd: gather_attn_l2 over the duplicate-slot encoding (packed tiles; no attention
+    outputs).  Returns (nagg0 [P,D], nagg1 [P,D])."""
+    lib = _lib.load()
+    bf = _chk_table(table, "table")
+    for t, dt, nm in ((enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
+                      (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"),
+                      (t1, F32, "t1"), (W1, F32, "W1"), (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"),
+                      (A0, F32, "A0"), (a0, F32, "a0")):
+        _chk(t, dt, nm)
+    P = B * parents_per_pair
+    nagg0 = torch.empty((P, D), dtype=F32, device=table.device)
+    nagg1 = torch.empty((P, D), dtype=F32, device=table.device)
+    _lib.check(lib.mvin_gather_attn_l2_enc_fwd(_p(table), _p(enc_entity), _p(enc_relation), _p(parent_ids),
+                                               int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(W1), _p(W2), _p(b1),
+                                               _p(b2), _p(q), _p(A0), _p(a0), B, parents_per_pair, K, D, table.shape[0], nR,
+                                               _p(nagg0), _p(nagg1), bf, _stream()), "mvin_gather_attn_l2_enc_fwd")
+    return nagg0, nagg1
+
+
 def gather_mix(table, adj_entity, adj_relation, node_ids, rel_score_t, rowbias, nodes, nodes_per_group, K, nR,
                relu=False):
     """mvin_gather_mix_fwd: out[i] = (1/K) sum_k w_k f(table[adj_entity[x_i,k]] + rowbias[i // npg]) ->

@@ -149,13 +149,25 @@ def dataset_case(name, K, B, seed=0, zipf=True, uniform_adj=False, p_hop=None, n
                            p_hop=p_hop, n_memory=n_memory)
 
 
-def small_case(args, n_user=8, n_entity=64, n_relation=5, seed=0, zero_rows=0):
+def small_case(args, n_user=8, n_entity=64, n_relation=5, seed=0, zero_rows=0, repeats=False):
     """Tiny random case for parity tests: uniform adjacency (optionally with all-zero rows,
-    the 'entity absent from the KG' case of data_loader_user_set.py:377-380)."""
+    the 'entity absent from the KG' case of data_loader_user_set.py:377-380).
+    ``repeats``: rows as contruct_random_adj builds them for low-degree entities (:383-384) -- an entity has
+    deg edges (1 .. 2K: most have few, a fifth are hubs) and its row is K draws WITH replacement when deg < K, K distinct edges
+    otherwise; an edge may also repeat a neighbour under another relation."""
     rng = np.random.default_rng(seed)
     B, K, Nm = args.batch_size, args.neighbor_sample_size, args.n_memory
     adj_e = rng.integers(0, n_entity, (n_entity, K), dtype=np.int64)
     adj_r = rng.integers(0, n_relation, (n_entity, K), dtype=np.int64)
+    if repeats:
+        deg = np.minimum(1 + rng.geometric(0.25, n_entity), 2 * K)
+        hub = rng.random(n_entity) < 0.2
+        deg[hub] = rng.integers(max(1, K // 2), 2 * K + 1, int(hub.sum()))
+        for x in range(n_entity):
+            ne = rng.integers(0, n_entity, deg[x])
+            nr = rng.integers(0, n_relation, deg[x])
+            pick = rng.choice(deg[x], K, replace=deg[x] < K)
+            adj_e[x], adj_r[x] = ne[pick], nr[pick]
     if zero_rows:
         z = rng.choice(n_entity, zero_rows, replace=False)
         adj_e[z] = 0

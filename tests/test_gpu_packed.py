@@ -1,0 +1,156 @@
+"""-m gpu: the duplicate-slot encoding (mvin_encode_adjacency) and the packed-tile fused kernel over it
+(mvin_gather_attn_l2_enc_fwd, mvin_fused_packed.hip) against the oracles and against the plain-adjacency kernels.
+
+The reference's sampler repeats (neighbour, relation) slots whenever an entity has fewer than K edges
+(data_loader_user_set.py:383-384); the encoded path adds the softmax weights of equal slots and gathers every distinct
+row once.  Scores must agree with the fp32 mirror of the reference graph (which walks all K slots) within the path's
+tolerance, on adjacencies with repeats, all-zero rows (one distinct slot, multiplicity K) and K distinct slots."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import ops, synth
+from mvin_amd.config import make_args
+from mvin_amd.model import MVIN
+from mvin_amd.params import init_params
+from oracle import prep_ref
+
+from parity import assert_close, run_oracles
+
+pytestmark = pytest.mark.gpu
+
+DK = [(32, 16), (32, 32), (32, 64), (32, 128), (64, 16), (64, 32), (64, 64), (64, 128), (128, 16), (128, 32), (128, 64),
+      (128, 128)]
+
+
+def _shape(D, K, H=2, B=None):
+    if B is None:
+        B = max(2, min(37, 4096 // (K * K)))
+    return dict(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=2, n_memory=8, batch_size=B)
+
+
+def _run(args, case, params, dedup, table_dtype="f32", want_probs=False):
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                 params=params, device="cuda:0", table_dtype=table_dtype)
+    model.dedup = dedup
+    dev = model.device
+    out = model.forward_device(
+        torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+        [torch.from_numpy(m).to(dev) for m in case.memories_h],
+        [torch.from_numpy(m).to(dev) for m in case.memories_r],
+        [torch.from_numpy(m).to(dev) for m in case.memories_t], want_probs=want_probs)
+    torch.cuda.synchronize()
+    if dedup:
+        assert model._enc_for_l2() is not None, "the encoded path was not taken"
+    return model, out
+
+
+def _check(args, case, params, table_dtype="f32", oracle_params=None, rtol=1e-5, atol=1e-6):
+    _, out = _run(args, case, params, True, table_dtype)
+    m, e = run_oracles(args, case, oracle_params or params)
+    got = out.scores.cpu().numpy()
+    assert_close(got, m.scores.numpy(), "packed-tile scores vs fp32 mirror", rtol=rtol, atol=atol)
+    assert_close(out.item_embeddings.cpu().numpy(), m.item_embeddings.numpy(), "item_embeddings", rtol=rtol, atol=atol)
+    err_hip = np.abs(got - e.scores).max()
+    err_mir = np.abs(m.scores.numpy() - e.scores).max()
+    assert err_hip <= 4 * err_mir + 1e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}"
+    return out
+
+
+@pytest.mark.parametrize("K", [4, 16, 32, 64, 128])
+@pytest.mark.parametrize("kind", ["repeats", "uniform"])
+def test_encode_adjacency_bit_exact(K, kind, hip_lib):
+    args = make_args(**_shape(32, K, B=2))
+    case = synth.small_case(args, n_entity=300, n_relation=11, seed=K, zero_rows=5, repeats=kind == "repeats")
+    ae = torch.from_numpy(case.adj_entity.astype(np.int32)).cuda()
+    ar = torch.from_numpy(case.adj_relation.astype(np.int32)).cuda()
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    torch.cuda.synchronize()
+    ref_e, ref_r, ref_c = prep_ref.encode_adjacency(case.adj_entity, case.adj_relation)
+    assert np.array_equal(cnt.cpu().numpy(), ref_c)
+    assert np.array_equal(enc_e.cpu().numpy(), ref_e)
+    assert np.array_equal(enc_r.cpu().numpy(), ref_r)
+    # and the encoding holds the row's multiset of slots
+    dec = prep_ref.decode_adjacency(enc_e.cpu().numpy(), enc_r.cpu().numpy())
+    plain = np.stack([case.adj_entity, case.adj_relation], -1)
+    plain = np.array([sorted(map(tuple, row)) for row in plain])
+    assert np.array_equal(dec, plain)
+    if kind == "repeats" and K >= 16:
+        assert ref_c.mean() < 0.8 * K
+
+
+@pytest.mark.parametrize("table", ["f32", "bf16"])
+@pytest.mark.parametrize("kind", ["repeats", "uniform"])
+@pytest.mark.parametrize("dk", DK, ids=lambda dk: "D%dK%d" % dk)
+def test_packed_kernel_vs_oracles(dk, kind, table, hip_lib):
+    D, K = dk
+    args = make_args(**_shape(D, K))
+    case = synth.small_case(args, n_user=16, n_entity=900, n_relation=7, seed=141 + D + K, zero_rows=4,
+                            repeats=kind == "repeats")
+    case.items[0] = np.flatnonzero((case.adj_entity == 0).all(1))[0]       # a zero-row parent
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=43, random_agg_bias=True)
+    if table == "bf16":
+        rounded = dict(params, entity_emb_matrix=torch.from_numpy(params["entity_emb_matrix"]).to(torch.bfloat16).float().numpy())
+        _check(args, case, params, "bf16", oracle_params=rounded)
+    else:
+        _check(args, case, params)
+
+
+@pytest.mark.parametrize("dk", [(32, 16), (64, 32), (64, 64)], ids=lambda dk: "D%dK%d" % dk)
+def test_packed_kernel_depth3(dk, hip_lib):
+    """h_hop = 3: K parents per pair, the query row shared by the K parents of a pair."""
+    D, K = dk
+    args = make_args(**_shape(D, K, H=3, B=3))
+    case = synth.small_case(args, n_user=8, n_entity=700, n_relation=5, seed=151, zero_rows=3, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=52, random_agg_bias=True)
+    _check(args, case, params)
+
+
+@pytest.mark.parametrize("ablation", ["no_uor", "no_uo", "no_uor_and_no_kg_eh_uo", "no_uo_and_no_kg_eh_uo"])
+@pytest.mark.parametrize("dk", [(32, 16), (64, 32), (128, 32)], ids=lambda dk: "D%dK%d" % dk)
+def test_packed_kernel_without_attention_or_projection(dk, ablation, hip_lib):
+    D, K = dk
+    args = make_args(ablation=ablation, **_shape(D, K, B=11))
+    case = synth.small_case(args, n_user=8, n_entity=600, n_relation=6, seed=161, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=62, random_agg_bias=True)
+    _check(args, case, params)
+
+
+@pytest.mark.parametrize("dk", [(32, 16), (64, 32), (64, 64)], ids=lambda dk: "D%dK%d" % dk)
+@pytest.mark.parametrize("B", [1, 2, 255, 4097])
+def test_packed_kernel_matches_plain_kernels_at_ragged_sizes(dk, B, hip_lib):
+    """Parent counts around the kernel's work split (one parent, a partial last workgroup, tiles that straddle parents):
+    encoded vs plain adjacency (independent programs) to fp32 round-off; and a pair's score does not depend on where in
+    the batch it sits."""
+    D, K = dk
+    args = make_args(**_shape(D, K, B=B))
+    case = synth.small_case(args, n_user=32, n_entity=2000, n_relation=9, seed=171 + B, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=72, random_agg_bias=True)
+    _, a = _run(args, case, params, True)
+    _, b = _run(args, case, params, False)
+    assert_close(a.scores.cpu().numpy(), b.scores.cpu().numpy(), "encoded vs plain adjacency")
+    _, c = _run(args, case, params, False, want_probs=True)
+    assert_close(a.scores.cpu().numpy(), c.scores.cpu().numpy(), "encoded vs symmetric fused kernel")
+    if B > 4:
+        sl = slice(B - 3, B)
+        c2 = copy.copy(case)
+        for f in ("users", "items"):
+            setattr(c2, f, getattr(case, f)[sl])
+        for f in ("memories_h", "memories_r", "memories_t"):
+            setattr(c2, f, [m[sl] for m in getattr(case, f)])
+        a2 = _run(make_args(**_shape(D, K, B=3)), c2, params, True)[1]
+        assert_close(a2.scores.cpu().numpy(), a.scores[sl].cpu().numpy(), "batch position", rtol=1e-6, atol=1e-7)
+
+
+def test_auto_mode_takes_the_encoded_path_only_when_rows_repeat(hip_lib):
+    args = make_args(**_shape(64, 32, B=8))
+    params = None
+    for rep, expect in ((True, True), (False, False)):
+        case = synth.small_case(args, n_user=8, n_entity=500, n_relation=6, seed=5, repeats=rep)
+        params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=6)
+        model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                     params=params, device="cuda:0")
+        assert (model._enc_for_l2() is not None) == expect
+        assert model._enc_for_l2(want_probs=True) is None
