@@ -47,6 +47,8 @@ int mvin_abi_version(void) { return MVIN_ABI_VERSION; }
 int mvin_debug_read_trace(long long* host_dst, size_t n) {
     if (!host_dst) return -1;
     static const bool ka = getenv("MVIN_KA_TRACE") != nullptr;     // which kernel's stamps
+    static const bool pk = getenv("MVIN_PACK_TRACE") != nullptr;
+    if (pk) return (int)mvin::pack_read_prof(host_dst, n);
     return (int)(ka ? mvin::ka_read_trace(host_dst, n) : mvin::split_read_trace(host_dst, n));
 }
 

@@ -107,6 +107,16 @@ __device__ __forceinline__ float wave_max_fast(float v) { return rows_combine_ma
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_fast(v); }
 __device__ __forceinline__ float wave_max(float v) { return wave_max_fast(v); }
 
+// exp(x) for x <= 0 (logit - max): the library's argument reduction (product error folded back in by fma) without its
+// range selects; ~1 ulp
+__device__ __forceinline__ float lean_exp(float x) {
+    const float t = x * 1.44269502162933349609375f;              // float(log2 e)
+    const float n = rintf(t);
+    float f = fmaf(x, 1.44269502162933349609375f, -n);
+    f = fmaf(x, 1.925963033500011e-8f, f);                       // log2 e - float(log2 e)
+    return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // ---- entity-table rows: fp32 (16-byte lane loads) or bf16 (8-byte lane loads, widened to fp32
 // exactly: bf16 -> f32 is a 16-bit shift) ------------------------------------------------------
 __device__ __forceinline__ float4 bf16x4_to_f32(uint2 r) {

@@ -33,6 +33,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kPackCH = 1024;       // parents per workgroup (ids and distinct-child counts staged in LDS)
+#ifndef MVIN_PACK_MAXB
+#define MVIN_PACK_MAXB 16
+#endif
+constexpr int kPackMaxB = MVIN_PACK_MAXB;
 
 template <int N>
 __device__ __forceinline__ int dpp_row_shr(int v) {      // lane l of a 16-lane row gets lane l-N (0 below the row start)
@@ -89,7 +93,7 @@ struct PackGeom {
 
 // LDS layout (words unless noted); the same function sizes the launch
 struct PackLds {
-    size_t sA, sZ, sYP, sW0, sW1, sSeg, sSegP, sSegF, sMeta, sX1, sRc, sRq, sSt, sCarry, sCnt, sT0, sT1, sBias, sPid, sPcnt, total;
+    size_t sA, sZ, sYP, sW0, sW1, sSeg, sSegP, sSegF, sMeta, sPR, sSt, sCarry, sCnt, sT0, sT1, sBias, sPid, sPq, sPcnt, total;
 };
 __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG) {
     PackLds l{};
@@ -98,29 +102,32 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG) {
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };   // 16-byte aligned pieces
     l.sA = take(2 * 32 * (size_t)(2 * D + 2));
     l.sZ = take(32 * (size_t)(D + 2));
-    l.sYP = take(32 * (size_t)(K + 1) * 2);             // int2 per entry
-    l.sW0 = take(2 * 32);
-    l.sW1 = take(2 * 32);
-    l.sSeg = take(2 * 32);
-    l.sSegP = take(2 * 16);
-    l.sSegF = take(2 * 16);
-    l.sMeta = take(2 * 2);
-    l.sX1 = take(32);
-    l.sRc = take(32);
-    l.sRq = take(32);
-    l.sSt = take((size_t)NG * 16);
+    l.sYP = take(32 * (size_t)(K + 1) * 2 + 2);         // ids [32][K+1] + a zero entry, then weights likewise
+    l.sW0 = take(3 * 32);                               // the segment tables are a ring of three tiles
+    l.sW1 = take(3 * 32);
+    l.sSeg = take(3 * 32);
+    l.sSegP = take(3 * 16);
+    l.sSegF = take(3 * 16);
+    l.sMeta = take(3 * 2);
+    l.sPR = take((size_t)NG * 2 * 96);                  // per front wave, two tiles: rows by rank | child entity | query row
+    l.sSt = take((size_t)NG * 2 * 16);
     l.sCarry = take(NM * 2 * 16);
     l.sCnt = take(2);
     l.sT0 = take(nRp);
     l.sT1 = take(nRp);
     l.sBias = take(3 * (size_t)D);
     l.sPid = take(kPackCH);
+    l.sPq = take(kPackCH);
     l.sPcnt = take(kPackCH / 4);                        // bytes
     l.total = o * 4;
     return l;
 }
 
-template <int D, int KT, bool BF, int NG>
+// Development aid (FusedL2Args::dbg & 8, env MVIN_SPLIT_DBG=8): cycles per phase summed over every workgroup's first
+// dense and first front wave (s_memtime), read back with mvin_debug_read_trace under MVIN_PACK_TRACE (scripts/trace_packed.py)
+__device__ unsigned long long g_pack_prof[2 * 8];
+
+template <int D, int KT, bool BF, int NG, bool PROF = false>
 __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_attn_l2_packed_kernel(FusedL2Args a, int ppw) {
     using G = PackGeom<D, KT, BF, NG>;
     constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
@@ -128,23 +135,23 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     const PackLds L = pack_lds(D, KT, a.nR, NG);
     float* sA = smem + L.sA;                            // [2][TM][LDA]  {E[x1] + q | S' + (sum p / K) q}
     float* sZ = smem + L.sZ;                            // [TM][LDZ]
-    int2* sYP = reinterpret_cast<int2*>(smem + L.sYP);  // [TM][YLD]  (grandchild id, weight); rows private to a front wave
+    int* sYI = reinterpret_cast<int*>(smem + L.sYP);    // [TM][YLD]  grandchild ids; rows private to a front wave
+    float* sYW = smem + L.sYP + TM * YLD + 1;           // [TM][YLD]  their weights; entry TM * YLD of both: (entity 0, weight 0)
     float* sW0 = smem + L.sW0;                          // [2][TM]  weight of the row in its parent's nagg0 (p0 m / K)
     float* sW1 = smem + L.sW1;                          // [2][TM]  ... nagg1
     int* sSeg = reinterpret_cast<int*>(smem + L.sSeg);  // [2][TM]  segment (parent of the tile) the row belongs to
     int* sSegP = reinterpret_cast<int*>(smem + L.sSegP);   // [2][16] global parent index of the segment or -1
     int* sSegF = reinterpret_cast<int*>(smem + L.sSegF);   // [2][16] bit 0: continues from the previous tile; bit 1: continues in the next
     int* sMeta = reinterpret_cast<int*>(smem + L.sMeta);   // [2][2]  segments (0 = no more tiles), rows
-    int* sX1 = reinterpret_cast<int*>(smem + L.sX1);    // [TM] child entity of the row
-    int* sRc = reinterpret_cast<int*>(smem + L.sRc);    // [TM] length of its list (0: padding row)
-    int* sRq = reinterpret_cast<int*>(smem + L.sRq);    // [TM] query row (pair) of its parent
-    int* sSt = reinterpret_cast<int*>(smem + L.sSt);    // [NG][16] first row of every segment (front-wave scratch)
+    int* sPR = reinterpret_cast<int*>(smem + L.sPR);    // [NG][2][3][TM] by rank: row | list length << 8, child entity, query row
+    int* sSt = reinterpret_cast<int*>(smem + L.sSt);    // [NG][2][16] first row of every segment (front-wave scratch)
     float* sCarry = smem + L.sCarry;                    // [NM][2][16] partial sums of the parent that straddles a tile boundary
     int* sCnt = reinterpret_cast<int*>(smem + L.sCnt);
     float* sT0 = smem + L.sT0;
     float* sT1 = smem + L.sT1;
     float* sBias = smem + L.sBias;                      // [3][D]  a0 | b1 | b2
     int* sPid = reinterpret_cast<int*>(smem + L.sPid);  // [ppw] entity id of the workgroup's parents
+    int* sPq = reinterpret_cast<int*>(smem + L.sPq);    // [ppw] their query row (pair)
     unsigned char* sPcnt = reinterpret_cast<unsigned char*>(smem + L.sPcnt);   // [ppw] distinct children
 
     const int tid = threadIdx.x;
@@ -153,6 +160,21 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     const bool has_proj = a.W1 != nullptr;
     const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
     const float invK = 1.f / (float)KT;
+    long long prof_last = 0;
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&](int slot) {
+        if constexpr (PROF) {
+            const long long t = __builtin_readcyclecounter();
+            prof_acc[slot] += (unsigned long long)(t - prof_last);
+            prof_last = t;
+        }
+    };
+    auto prof_flush = [&](int role) {
+        if constexpr (PROF) {
+            if (lane == 0)
+                for (int i = 0; i < 8; ++i) atomicAdd(&g_pack_prof[role * 8 + i], prof_acc[i]);
+        }
+    };
     const int64_t p_base = (int64_t)blockIdx.x * ppw;
     const int n_loc = (int)((a.P - p_base) < ppw ? (a.P - p_base) : ppw);     // parents of this workgroup (contiguous)
 
@@ -165,7 +187,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         sT0[i] = has_att0 ? a.t0[i] : 0.f;
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
-    if (tid == 0) sCnt[0] = 0;
+    if (tid == 0) {
+        sCnt[0] = 0;
+        sYI[TM * YLD] = 0;
+        sYW[TM * YLD] = 0.f;
+    }
     for (int i = tid; i < D; i += G::NW * 64) {
         sBias[i] = a.a0 ? a.a0[i] : 0.f;
         sBias[D + i] = (has_proj && a.b1) ? a.b1[i] : 0.f;
@@ -175,6 +201,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         const int pid = fused_parent_id(a, p_base + i);
         const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(adjR, (unsigned)pid * (unsigned)(KT * 4), 0, 0);
         sPid[i] = pid;
+        sPq[i] = (int)((unsigned)(p_base + i) / (unsigned)a.parents_per_pair);
         const unsigned cn = w >> 24;
         sPcnt[i] = (unsigned char)(cn < 1u ? 1u : (cn > (unsigned)KT ? (unsigned)KT : cn));    // (a plain adjacency has 0 here)
     }
@@ -197,10 +224,13 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         }
         float* carry = sCarry + wave * 32;
         int dense_iter = 0;
+        if constexpr (PROF) prof_last = __builtin_readcyclecounter();
         for (int64_t s = 1;; ++s) {
             __syncthreads();                            // tile s-1 is in sA[(s-1) & 1]
-            const int buf = (int)((s - 1) & 1);
-            const int nseg = sMeta[2 * buf], rows = sMeta[2 * buf + 1];
+            tick(0);
+            const int buf = (int)((s - 1) & 1);        // sA half
+            const int mb = (int)((s - 1) % 3);         // segment tables: ring of three
+            const int nseg = sMeta[2 * mb], rows = sMeta[2 * mb + 1];
             if (nseg == 0) break;
             const float* tA = sA + buf * TM * LDA;
             const bool two = rows > 16;                 // second 16-row MFMA tile in use
@@ -208,9 +238,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             float wa0[G::RT][4], wa1[G::RT][4];
 #pragma unroll
             for (int m = 0; m < G::RT; ++m) {
-                const int4 sg = *reinterpret_cast<const int4*>(sSeg + buf * TM + 16 * m + 4 * q16);
-                const float4 w0 = *reinterpret_cast<const float4*>(sW0 + buf * TM + 16 * m + 4 * q16);
-                const float4 w1 = *reinterpret_cast<const float4*>(sW1 + buf * TM + 16 * m + 4 * q16);
+                const int4 sg = *reinterpret_cast<const int4*>(sSeg + mb * TM + 16 * m + 4 * q16);
+                const float4 w0 = *reinterpret_cast<const float4*>(sW0 + mb * TM + 16 * m + 4 * q16);
+                const float4 w1 = *reinterpret_cast<const float4*>(sW1 + mb * TM + 16 * m + 4 * q16);
                 wa0[m][0] = sg.x == l16 ? w0.x : 0.f;
                 wa0[m][1] = sg.y == l16 ? w0.y : 0.f;
                 wa0[m][2] = sg.z == l16 ? w0.z : 0.f;
@@ -229,7 +259,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 accE[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 accS[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (has_proj) {
+            bool do_mfma = true;
+            if constexpr (PROF) do_mfma = !(a.dbg & 1);  // floor without the MFMAs
+            if (has_proj && do_mfma) {
                 if (two) {
 #pragma unroll
                     for (int k = 0; k < KS; ++k) {
@@ -270,6 +302,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     }
                 }
             }
+            tick(1);
             // every dense wave's columns of Z must be in LDS before any of them starts phase C
             ++dense_iter;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -277,11 +310,13 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             while (__hip_atomic_load(sCnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < NM * dense_iter)
                 __builtin_amdgcn_s_sleep(1);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            tick(2);
             // phase C: out1 = relu(Z A0 + a0) (aggregators.py:108-116) ; nagg1[segment] += w1[row] out1[row]
             f32x4 acc2[G::RT];
 #pragma unroll
             for (int m = 0; m < G::RT; ++m) acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (two) {
+            if (!do_mfma) {
+            } else if (two) {
 #pragma unroll
                 for (int k = 0; k < KS; ++k) {
 #pragma unroll
@@ -312,8 +347,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int sg = 4 * q16 + i;
-                const int pidx = sSegP[buf * 16 + sg];
-                const int fl = sSegF[buf * 16 + sg];
+                const int pidx = sSegP[mb * 16 + sg];
+                const int fl = sSegF[mb * 16 + sg];
                 if (pidx >= 0) {
                     float v0 = accN0[i], v1 = accN1[i];
                     if (fl & 1) {
@@ -329,7 +364,10 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     }
                 }
             }
+            tick(3);
+            if constexpr (PROF) prof_acc[7] += 1;
         }
+        if (wave == 0) prof_flush(0);
     } else {
         // =====================================================================================
         // front waves: tile s -> sA[s & 1] and its segment tables
@@ -365,20 +403,19 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
             }
         };
-        // local row lr (0 .. RPW-1) of this wave -> tile row: RPWX consecutive rows form a gather round, the waves interleave
-        auto rowmap = [&](int lr) -> int { return ((lr / G::RPWX) * NG + gw) * G::RPWX + (lr % G::RPWX); };
-
-        int i_next = 0, c0 = 0;                          // first parent of the next tile, children of it already placed
-        for (int64_t s = 0;; ++s) {
-            const int buf = (int)(s & 1);
-            if (i_next >= n_loc) {                       // no more tiles
-                if (gw == 0 && lane == 0) sMeta[2 * buf] = 0;
-                __syncthreads();
-                break;
-            }
-            // ---------------- pack: which parents fill this tile (every front wave computes the same thing) ----------------
+        struct Tile {
+            int i0, c0;          // first parent (local index), children of it placed in earlier tiles
+            int nseg, rows;      // parents in the tile (0: no tile), child rows
+            int st_last;         // first row of the last parent
+            bool open;           // the last parent continues in the next tile
+            unsigned Em;         // bit (end row - 1) of every parent
+        };
+        // pack: which parents fill the tile that starts at (i0, c0) (every front wave computes the same thing);
+        // segment starts -> sSt[slot]
+        auto pack = [&](int i0, int c0, int slot) -> Tile {
+            Tile t{i0, c0, 0, 0, 0, false, 0u};
             const int j16 = lane & 15;
-            int cj = (i_next + j16 < n_loc) ? (int)sPcnt[i_next + j16] : 0;
+            int cj = (i0 + j16 < n_loc) ? (int)sPcnt[i0 + j16] : 0;
             if (j16 == 0) cj -= c0;
             int e = cj;
             e += dpp_row_shr<1>(e);
@@ -386,82 +423,135 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             e += dpp_row_shr<4>(e);
             e += dpp_row_shr<8>(e);
             const int st = e - cj;                       // first row of segment j16
-            const bool in = (i_next + j16 < n_loc) && st < TM;
-            const int nseg = __popcll(__ballot(in) & 0xFFFFull);
-            const int e_last = __builtin_amdgcn_readlane(e, nseg - 1);
-            const int st_last = __builtin_amdgcn_readlane(st, nseg - 1);
-            const int rows = e_last < TM ? e_last : TM;
-            const bool open = e_last > TM;               // the last parent continues in the next tile
-            const unsigned Em = __builtin_amdgcn_readfirstlane(row_or16(in ? (1u << ((e < TM ? e : TM) - 1)) : 0u));
-            if (lane < 16) sSt[gw * 16 + lane] = st;
-            wave_lds_sync();
-            // row r -> segment, slot of the parent's encoded adjacency row
-            auto row_seg = [&](int r, int& seg, int& slot) {
-                const unsigned below = Em & ((1u << r) - 1u);       // segment ends before r
-                seg = __popc(below);
-                const int st_r = below ? 32 - __clz((int)below) : 0;
-                slot = r - st_r + (seg == 0 ? c0 : 0);
-            };
-            // ---------------- issue: parent rows (relation words) of this wave's segments ----------------
-            int prw[G::NP2][G::SPL];
+            const bool in = (i0 + j16 < n_loc) && st < TM;
+            t.nseg = __popcll(__ballot(in) & 0xFFFFull);
+            const int last = t.nseg > 0 ? t.nseg - 1 : 0;    // (no parents left: zero rows)
+            const int e_last = __builtin_amdgcn_readlane(e, last);
+            t.st_last = __builtin_amdgcn_readlane(st, last);
+            t.rows = t.nseg == 0 ? 0 : (e_last < TM ? e_last : TM);
+            t.open = t.nseg != 0 && e_last > TM;
+            t.Em = __builtin_amdgcn_readfirstlane(row_or16(in ? (1u << ((e < TM ? e : TM) - 1)) : 0u));
+            if (lane < 16) sSt[(gw * 2 + slot) * 16 + lane] = st;
+            return t;
+        };
+        auto advance = [&](const Tile& t, int& i0, int& c0) {
+            if (t.nseg == 0) {
+                c0 = 0;
+                i0 = t.i0;
+            } else if (t.open) {
+                c0 = (t.nseg == 1 ? t.c0 : 0) + (TM - t.st_last);
+                i0 = t.i0 + t.nseg - 1;
+            } else {
+                c0 = 0;
+                i0 = t.i0 + t.nseg;
+            }
+        };
+        // row r -> segment, slot of the parent's encoded adjacency row
+        auto row_seg = [&](const Tile& t, int r, int& seg, int& slot) {
+            const unsigned below = t.Em & ((1u << r) - 1u);     // segment ends before r
+            seg = __popc(below);
+            const int st_r = below ? 32 - __clz((int)below) : 0;
+            slot = r - st_r + (seg == 0 ? t.c0 : 0);
+        };
+        // ---- which rows a front wave owns: the tile's 32 rows are ranked by the length of their lists (classes of 1 << SH
+        // entries, the granularity of a load batch; longest first), rank p goes to slot p (p < NS) or, on the way back, to slot
+        // 2 NS - 1 - p, ... (a snake over NS = 32 / NRND slots), slot i to wave i % NG, lane group i / NG.  A lane group walks
+        // the lists of its NRND rows as ONE sequence, so a long list shares its group with short ones and the waves of a
+        // tile issue about the same number of row loads. ----
+        constexpr int NRND = G::NRND, NS = TM / NRND;
+        constexpr int SH = KT >= 32 ? (KT == 32 ? 2 : KT == 64 ? 3 : 4) : 1;
+        auto rank_of = [&](int h, int grp) -> int {      // rank of the h-th row of lane group grp of this wave
+            const int slot = grp * NG + gw;
+            return (h & 1) ? (h + 1) * NS - 1 - slot : h * NS + slot;
+        };
+        struct Ids {
+            int prw[G::NP2][G::SPL];     // relation words of this wave's parent rows
+            int xw;                      // encoded child id (id | list length << 24) of tile row lane & 31
+            int rq;                      // query row of its parent
+            bool valid;
+        };
+        // issue: parent rows (relation words) of this wave's segments; the child word of EVERY tile row (each wave ranks all rows)
+        auto issue_ids = [&](const Tile& t, Ids& d) {
+            const int j16 = lane & 15;
 #pragma unroll
             for (int ps = 0; ps < G::NP2; ++ps) {
                 const int sg = gw * G::SEGW + 4 * ps + (lane >> 4);
-                const int pi = i_next + sg < n_loc ? i_next + sg : n_loc - 1;
+                const int pi = t.i0 + sg < n_loc ? t.i0 + sg : n_loc - 1;
                 const unsigned off = ((unsigned)sPid[pi] * KT + (unsigned)j16 * G::SPL) * 4u;
                 if constexpr (G::SPL == 1) {
-                    prw[ps][0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
+                    d.prw[ps][0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
                 } else if constexpr (G::SPL == 2) {
                     const auto v = __builtin_amdgcn_raw_buffer_load_b64(adjR, off, 0, 0);
-                    prw[ps][0] = (int)v[0];
-                    prw[ps][1] = (int)v[1];
+                    d.prw[ps][0] = (int)v[0];
+                    d.prw[ps][1] = (int)v[1];
                 } else {
 #pragma unroll
                     for (int h = 0; h < G::SPL / 4; ++h) {
                         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(adjR, off + 16u * h, 0, 0);
-                        prw[ps][4 * h + 0] = (int)v[0];
-                        prw[ps][4 * h + 1] = (int)v[1];
-                        prw[ps][4 * h + 2] = (int)v[2];
-                        prw[ps][4 * h + 3] = (int)v[3];
+                        d.prw[ps][4 * h + 0] = (int)v[0];
+                        d.prw[ps][4 * h + 1] = (int)v[1];
+                        d.prw[ps][4 * h + 2] = (int)v[2];
+                        d.prw[ps][4 * h + 3] = (int)v[3];
                     }
                 }
             }
-            // ---------------- issue: child ids of this wave's rows, then their adjacency chunks ----------------
-            int x1[G::NP3], rq[G::NP3];
-            bool rvalid[G::NP3];
+            const int r = lane & 31;
+            int seg, slot;
+            row_seg(t, r, seg, slot);
+            d.valid = r < t.rows;
+            int pi = d.valid ? t.i0 + seg : t.i0;
+            pi = pi < n_loc ? pi : n_loc - 1;
+            d.rq = sPq[pi];
+            d.xw = __builtin_amdgcn_raw_buffer_load_b32(adjE, ((unsigned)sPid[pi] * KT + (unsigned)(d.valid ? slot : 0)) * 4u, 0, 0);
+        };
+        // rank the rows -> sPR / sPX / sPQ [par][rank] = (row | list length << 8, child entity, query row), private to the wave
+        auto rank_rows = [&](const Ids& d, int par) {
+            const unsigned w = (unsigned)d.xw;
+            const int cnt = d.valid ? (int)(w >> 24) : 0;
+            const unsigned xid = (w & 0xFFFFFFu) < a.max_id ? (w & 0xFFFFFFu) : a.max_id;
+            const int cls = (cnt + (1 << SH) - 1) >> SH;     // 0 .. 8
+            int rank = 0, base = 0;
 #pragma unroll
-            for (int ps = 0; ps < G::NP3; ++ps) {
-                const int lr = ps * G::RPP + lane / G::LPN;
-                const int r = rowmap(lr < G::RPW ? lr : G::RPW - 1);
-                int seg, slot;
-                row_seg(r, seg, slot);
-                rvalid[ps] = r < rows;
-                const int pi = rvalid[ps] ? i_next + seg : i_next;
-                rq[ps] = (int)((p_base + pi) / a.parents_per_pair);
-                x1[ps] = __builtin_amdgcn_raw_buffer_load_b32(adjE, ((unsigned)sPid[pi] * KT + (unsigned)(rvalid[ps] ? slot : 0)) * 4u, 0, 0);
+            for (int cc = 8; cc >= 0; --cc) {
+                const unsigned m = (unsigned)(__ballot(cls == cc) & 0xFFFFFFFFull);
+                if (cls == cc) rank = base + (int)__builtin_amdgcn_mbcnt_lo(m, 0u);
+                base += __popc(m);
             }
-            int4 ye[G::NP3], re[G::NP3];
+            if (lane < 32) {
+                int* dst = sPR + (gw * 2 + par) * 96;
+                dst[rank] = lane | (cnt << 8);
+                dst[32 + rank] = (int)xid;
+                dst[64 + rank] = d.rq;
+            }
+        };
+        // issue: the adjacency chunks of this wave's child rows (local row lr = h * RPWX + group)
+        auto issue_chunks = [&](int par, int4 (&ye)[G::NP3], int4 (&re)[G::NP3]) {
+            const int* src = sPR + (gw * 2 + par) * 96;
 #pragma unroll
             for (int ps = 0; ps < G::NP3; ++ps) {
+                int lr = ps * G::RPP + lane / G::LPN;
+                lr = lr < G::RPW ? lr : G::RPW - 1;
                 const int ch = lane % G::LPN;
-                const unsigned xid = (unsigned)x1[ps] < a.max_id ? (unsigned)x1[ps] : a.max_id;
-                x1[ps] = (int)xid;
+                const unsigned xid = (unsigned)src[32 + rank_of(lr / G::RPWX, lr % G::RPWX)];
                 const unsigned off = (xid * KT + 4u * ch) * 4u;
                 const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, off, 0, 0);
                 ye[ps] = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
                 const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, off, 0, 0);
                 re[ps] = make_int4((int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3]);
             }
-            // ---------------- parents: softmax over the distinct slots -> row weights, segment tables ----------------
+        };
+        // parents: softmax over the distinct slots -> row weights and segment tables of the tile, ring slot mb
+        auto parents = [&](const Tile& t, const Ids& d, int slot, int mb) {
+            const int j16 = lane & 15;
 #pragma unroll
             for (int ps = 0; ps < G::NP2; ++ps) {
                 const int sg = gw * G::SEGW + 4 * ps + (lane >> 4);
-                const bool sv = sg < nseg;
+                const bool sv = sg < t.nseg;
                 float s0[G::SPL], s1[G::SPL], mu[G::SPL];
                 float m0 = -INFINITY, m1 = -INFINITY;
 #pragma unroll
                 for (int i = 0; i < G::SPL; ++i) {
-                    const unsigned w = (unsigned)prw[ps][i];
+                    const unsigned w = (unsigned)d.prw[ps][i];
                     const int rel = (int)(w & 0xFFFFu) < a.nR ? (int)(w & 0xFFFFu) : 0;
                     mu[i] = (float)((w >> 16) & 0xFFu);
                     s0[i] = sT0[rel];
@@ -474,48 +564,52 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 float z0 = 0.f, z1 = 0.f;
 #pragma unroll
                 for (int i = 0; i < G::SPL; ++i) {
-                    s0[i] = has_att0 ? mu[i] * expf(s0[i] - m0) : mu[i];
-                    s1[i] = has_att1 ? mu[i] * expf(s1[i] - m1) : mu[i];
+                    s0[i] = has_att0 ? mu[i] * lean_exp(s0[i] - m0) : mu[i];
+                    s1[i] = has_att1 ? mu[i] * lean_exp(s1[i] - m1) : mu[i];
                     z0 += s0[i];
                     z1 += s1[i];
                 }
                 z0 = group_sum(z0, 4);
                 z1 = group_sum(z1, 4);
                 const float r0 = has_att0 ? invK / z0 : invK, r1 = has_att1 ? invK / z1 : invK;
-                const int stg = sSt[gw * 16 + (sg & 15)];
-                const int c0s = sg == 0 ? c0 : 0;
+                const int stg = sSt[(gw * 2 + slot) * 16 + (sg & 15)];
+                const int c0s = sg == 0 ? t.c0 : 0;
 #pragma unroll
                 for (int i = 0; i < G::SPL; ++i) {
-                    const int slot = j16 * G::SPL + i;
-                    const int rowi = stg + slot - c0s;
-                    if (sv && mu[i] > 0.f && slot >= c0s && rowi < TM) {
-                        sW0[buf * TM + rowi] = s0[i] * r0;
-                        sW1[buf * TM + rowi] = s1[i] * r1;
-                        sSeg[buf * TM + rowi] = sg;
+                    const int sl = j16 * G::SPL + i;
+                    const int rowi = stg + sl - c0s;
+                    if (sv && mu[i] > 0.f && sl >= c0s && rowi < TM) {
+                        sW0[mb * TM + rowi] = s0[i] * r0;
+                        sW1[mb * TM + rowi] = s1[i] * r1;
+                        sSeg[mb * TM + rowi] = sg;
                     }
                 }
                 if (j16 == 0) {
-                    sSegP[buf * 16 + sg] = sv ? (int)(p_base + i_next + sg) : -1;      // P * D * 4 < 2^31: fits an int
-                    sSegF[buf * 16 + sg] = ((sg == 0 && c0 > 0) ? 1 : 0) | ((sg == nseg - 1 && open) ? 2 : 0);
+                    sSegP[mb * 16 + sg] = sv ? (int)(p_base + t.i0 + sg) : -1;      // P * D * 4 < 2^31: fits an int
+                    sSegF[mb * 16 + sg] = ((sg == 0 && t.c0 > 0) ? 1 : 0) | ((sg == t.nseg - 1 && t.open) ? 2 : 0);
                 }
             }
             if (gw == 0) {
-                if (lane < TM && lane >= rows) {         // padding rows of a last, partial tile
-                    sW0[buf * TM + lane] = 0.f;
-                    sW1[buf * TM + lane] = 0.f;
-                    sSeg[buf * TM + lane] = 0;
+                if (lane < TM && lane >= t.rows) {       // padding rows of a last, partial tile
+                    sW0[mb * TM + lane] = 0.f;
+                    sW1[mb * TM + lane] = 0.f;
+                    sSeg[mb * TM + lane] = 0;
                 }
                 if (lane == 0) {
-                    sMeta[2 * buf] = nseg;
-                    sMeta[2 * buf + 1] = rows;
+                    sMeta[2 * mb] = t.nseg;
+                    sMeta[2 * mb + 1] = t.rows;
                 }
             }
-            // ---------------- children: softmax over the distinct slots -> (grandchild id, weight) lists ----------------
+        };
+        // children: softmax over the distinct slots -> (grandchild id, weight) lists of this wave's rows
+        auto children = [&](int par, const int4 (&ye)[G::NP3], const int4 (&re)[G::NP3]) {
+            const int* src = sPR + (gw * 2 + par) * 96;
 #pragma unroll
             for (int ps = 0; ps < G::NP3; ++ps) {
-                const int lr = ps * G::RPP + lane / G::LPN;
-                const bool lv = lr < G::RPW;
-                const int r = rowmap(lv ? lr : G::RPW - 1);
+                const int lr0 = ps * G::RPP + lane / G::LPN;
+                const bool lv = lr0 < G::RPW;
+                const int lr = lv ? lr0 : G::RPW - 1;
+                const int r = src[rank_of(lr / G::RPWX, lr % G::RPWX)] & 31;
                 const int ch = lane % G::LPN;
                 const unsigned w4[4] = {(unsigned)re[ps].x, (unsigned)re[ps].y, (unsigned)re[ps].z, (unsigned)re[ps].w};
                 float sc[4], mu[4];
@@ -531,88 +625,212 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 float z = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    sc[i] = has_att0 ? mu[i] * expf(sc[i] - m) : mu[i];
+                    sc[i] = has_att0 ? mu[i] * lean_exp(sc[i] - m) : mu[i];
                     z += sc[i];
                 }
                 z = group_sum(z, G::LPN_L2);
                 if (lv) {
                     const float rr = has_att0 ? invK / z : invK;
-                    int2* dst = sYP + (size_t)r * YLD + 4 * ch;
-                    dst[0] = make_int2(ye[ps].x, __float_as_int(sc[0] * rr));
-                    dst[1] = make_int2(ye[ps].y, __float_as_int(sc[1] * rr));
-                    dst[2] = make_int2(ye[ps].z, __float_as_int(sc[2] * rr));
-                    dst[3] = make_int2(ye[ps].w, __float_as_int(sc[3] * rr));
-                    if (ch == 0) {
-                        sX1[r] = x1[ps];
-                        sRc[r] = rvalid[ps] ? (int)(w4[0] >> 24) : 0;
-                        sRq[r] = rq[ps];
-                    }
+                    // list slot = (wave, local row), not the tile row: a tile row changes owner from tile to tile, and another
+                    // wave may still be walking the previous tile's list of that row
+                    int* di = sYI + (gw * G::RPW + lr) * YLD + 4 * ch;
+                    float* dw = sYW + (gw * G::RPW + lr) * YLD + 4 * ch;
+                    const unsigned idm = a.max_id;
+                    di[0] = (int)(((unsigned)ye[ps].x & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].x & 0xFFFFFFu) : idm);
+                    di[1] = (int)(((unsigned)ye[ps].y & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].y & 0xFFFFFFu) : idm);
+                    di[2] = (int)(((unsigned)ye[ps].z & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].z & 0xFFFFFFu) : idm);
+                    di[3] = (int)(((unsigned)ye[ps].w & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].w & 0xFFFFFFu) : idm);
+                    dw[0] = sc[0] * rr;
+                    dw[1] = sc[1] * rr;
+                    dw[2] = sc[2] * rr;
+                    dw[3] = sc[3] * rr;
                 }
             }
-            wave_lds_sync();
-            // ---------------- gather: the distinct grandchild rows of this wave's rows ----------------
+        };
+        // gather: every lane group walks the lists of its NRND rows as one sequence -> sA[buf]
+        auto gather = [&](int par, int buf) {
+            const int* src = sPR + (gw * 2 + par) * 96;
+            int rr[NRND], xx[NRND], qq[NRND], cum[NRND];
+            int tot = 0;
 #pragma unroll
-            for (int j = 0; j < G::NRND; ++j) {
-                const int r = rowmap(j * G::RPWX + g);
-                const int2* yp = sYP + (size_t)r * YLD;
-                const int cnt = sRc[r];
-                int cmax = (int)wave_max((float)cnt);
-                cmax = __builtin_amdgcn_readfirstlane(cmax);
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
-                float4 sv, sv1 = acc;
-                rowload(sX1[r], sv, sv1);
-                // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
-                const unsigned qoff = ((unsigned)sRq[r] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
-                const u32x4 qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
-                u32x4 qb = (u32x4){0u, 0u, 0u, 0u};
-                if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
-                auto batch = [&](auto nb_c, int k0) {
-                    constexpr int NB = decltype(nb_c)::value;
-                    int2 ent[NB];
-                    float4 lo[NB], hi[NB];
+            for (int h = 0; h < NRND; ++h) {
+                const int p = rank_of(h, g);
+                const int v = src[p];
+                rr[h] = v & 31;
+                xx[h] = src[32 + p];
+                qq[h] = src[64 + p];
+                tot += v >> 8;
+                cum[h] = tot;                             // entries of rows 0 .. h
+            }
+            int cmax = (int)wave_max((float)tot);
+            cmax = __builtin_amdgcn_readfirstlane(cmax);
+            if constexpr (PROF) {
+                if (a.dbg & 2) cmax = 0;                 // floor without the row gathers
+            }
+            float4 acc[NRND], acc1[NRND];
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) ent[i] = yp[k0 + i];
+            for (int h = 0; h < NRND; ++h) acc[h] = acc1[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // entry k of the sequence: row h(k), position in its list (clamped into the list: entries past `tot` get weight 0)
+            auto entry = [&](int k, int& h, int& at) {
+                h = 0;
+                int lo = 0;
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) rowload(ent[i].x, lo[i], hi[i]);
+                for (int i = 0; i + 1 < NRND; ++i) {
+                    const bool past = k >= cum[i];
+                    h = past ? i + 1 : h;
+                    lo = past ? cum[i] : lo;
+                }
+                // list slot of the group's h-th row: (wave, local row h * RPWX + g)
+                at = k < tot ? (gw * G::RPW + h * G::RPWX + g) * YLD + (k - lo) : TM * YLD;   // past the sequence: (entity 0, weight 0)
+            };
+            auto add_row = [&](int k, float4 lo, float4 hi) {
+                // (h, at) are recomputed, not kept live across the loads in flight: the laundered k stops the compiler from
+                // reusing the values of the issue side (32 registers per batch, which it spilled)
+                asm volatile("" : "+v"(k));
+                int h, at;
+                entry(k, h, at);
+                const float w = sYW[at];
 #pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        acc = f4_fma(__int_as_float(ent[i].y), lo[i], acc);
-                        if constexpr (G::WIDE) acc1 = f4_fma(__int_as_float(ent[i].y), hi[i], acc1);
+                for (int i = 0; i < NRND; ++i) {
+                    const float wi = h == i ? w : 0.f;
+                    acc[i] = f4_fma(wi, lo, acc[i]);
+                    if constexpr (G::WIDE) acc1[i] = f4_fma(wi, hi, acc1[i]);
+                }
+            };
+            // NB list rows in flight; FIRST: behind the NRND child rows and the NRND query rows, which are finished
+            // (E[x1] + q stored, (sum p / K) q added to the sums) as soon as they land
+            auto batch = [&](auto nb_c, auto first_c, int k0) {
+                constexpr int NB = decltype(nb_c)::value;
+                constexpr bool FIRST = decltype(first_c)::value;
+                float4 sv[FIRST ? NRND : 1], sv1[FIRST ? NRND : 1];
+                u32x4 qa[FIRST ? NRND : 1], qb[FIRST ? NRND : 1];
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int h = 0; h < NRND; ++h) {
+                        rowload(xx[h], sv[h], sv1[h]);
+                        // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
+                        const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
+                        qa[h] = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
+                        if constexpr (G::WIDE) qb[h] = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
                     }
-                };
-                // whole batches of MAXB rows in flight, then the shortest batch that covers the rest (the list is padded with
-                // weight-0 entries up to K)
-                constexpr int MAXB = G::WIDE ? 8 : 16;
-                int k0 = 0;
-                for (; k0 + MAXB <= cmax; k0 += MAXB) batch(std::integral_constant<int, MAXB>{}, k0);
-                const int rem = cmax - k0;
-                if (rem > 8) batch(std::integral_constant<int, MAXB>{}, k0);
-                else if (rem > 4) batch(std::integral_constant<int, 8>{}, k0);
-                else if (rem > 0) batch(std::integral_constant<int, 4>{}, k0);
-                const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
-                const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
-                float* arow = sA + ((size_t)buf * TM + r) * LDA;
-                put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                       // E[x1] + q
-                put(arow + D, f4_fma(c2scale, q0, acc), f4_fma(c2scale, q1, acc1));       // S' + (sum p / K) q
-            }
-            // ---------------- next tile ----------------
-            if (open) {
-                c0 = (nseg == 1 ? c0 : 0) + (TM - st_last);
-                i_next += nseg - 1;
+                }
+                float4 lo[NB], hi[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    int h, at;
+                    entry(k0 + i, h, at);
+                    rowload(sYI[at], lo[i], hi[i]);
+                }
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int h = 0; h < NRND; ++h) {
+                        const float4 q0 = make_float4(__uint_as_float(qa[h][0]), __uint_as_float(qa[h][1]), __uint_as_float(qa[h][2]), __uint_as_float(qa[h][3]));
+                        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if constexpr (G::WIDE) q1 = make_float4(__uint_as_float(qb[h][0]), __uint_as_float(qb[h][1]), __uint_as_float(qb[h][2]), __uint_as_float(qb[h][3]));
+                        float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
+                        put(arow, f4_fma(1.f, q0, sv[h]), f4_fma(1.f, q1, sv1[h]));            // E[x1] + q
+                        acc[h] = f4_fma(c2scale, q0, acc[h]);                                  // S' + (sum p / K) q
+                        if constexpr (G::WIDE) acc1[h] = f4_fma(c2scale, q1, acc1[h]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) add_row(k0 + i, lo[i], hi[i]);
+            };
+            using std::integral_constant;
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            constexpr int MAXB = G::WIDE ? 8 : kPackMaxB;       // rows in flight per lane
+            constexpr int NBF = (MAXB - 2 * NRND >= 12) ? 12 : (MAXB - 2 * NRND >= 8) ? 8 : 4;   // ... in the first batch
+            int k0;
+            if (cmax > 8 && NBF >= 12) {
+                batch(integral_constant<int, NBF>{}, T_{}, 0);
+                k0 = NBF;
+            } else if (cmax > 4 && NBF >= 8) {
+                batch(integral_constant<int, (NBF >= 8 ? 8 : 4)>{}, T_{}, 0);
+                k0 = 8;
             } else {
-                c0 = 0;
-                i_next += nseg;
+                batch(integral_constant<int, 4>{}, T_{}, 0);
+                k0 = 4;
             }
+            for (; k0 + MAXB <= cmax; k0 += MAXB) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+            const int rem = cmax - k0;
+            if (rem > 8) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+            else if (rem > 4) batch(integral_constant<int, 8>{}, F_{}, k0);
+            else if (rem > 0) batch(integral_constant<int, 4>{}, F_{}, k0);
+#pragma unroll
+            for (int h = 0; h < NRND; ++h) {
+                float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
+                put(arow + D, acc[h], acc1[h]);
+            }
+        };
+
+        // ---- software pipeline over the tiles: while tile s is gathered, the adjacency chunks of tile s+1 and the parent
+        // rows / child words of tile s+2 are in flight, so no step waits for an id fetch it has just issued.  Every id load
+        // and its use is unconditional (a tile past the end packs to zero rows and loads clamped addresses), and the step
+        // starts from a provably empty load queue: with conditional issue / use pairs or loads pending over the loop edge
+        // the compiler's waitcnt pass falls back to vmcnt(0) right behind the loads it has just issued. ----
+        int i0 = 0, c0 = 0;
+        Tile tb = pack(i0, c0, 0);                       // tile s+1 (slot (s+1) & 1 of sSt)
+        Ids db;
+        int4 yeb[G::NP3], reb[G::NP3];
+        issue_ids(tb, db);
+        advance(tb, i0, c0);
+        rank_rows(db, 0);
+        wave_lds_sync();
+        issue_chunks(0, yeb, reb);
+        parents(tb, db, 0, 0);
+        children(0, yeb, reb);
+        Tile tc = pack(i0, c0, 1);                       // tile s+2
+        Ids dc;
+        issue_ids(tc, dc);
+        advance(tc, i0, c0);
+        wave_lds_sync();
+        if constexpr (PROF) prof_last = __builtin_readcyclecounter();
+        // here: tile 0's lists are in LDS; (tc, dc) = tile 1 with its ids in flight
+        bool have = true;                                // tile s exists
+        for (int64_t s = 0; have; ++s) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the ids of tile s+1 (issued a step ago)
+            const int par = (int)(s & 1), par1 = par ^ 1;
+            tb = tc;
+            db = dc;
+            rank_rows(db, par1);
+            wave_lds_sync();
+            issue_chunks(par1, yeb, reb);
+            tc = pack(i0, c0, par);                      // tile s+2 -> the sSt slot tile s used
+            issue_ids(tc, dc);
+            advance(tc, i0, c0);
+            tick(0);
+            gather(par, par);
+            tick(1);
+            wave_lds_sync();                             // the lists of tile s are consumed; sSt of tile s+2 is written
+            parents(tb, db, par1, (int)((s + 1) % 3));   // (no tile s+1: zero segments = the end mark of the dense waves)
+            tick(2);
+            children(par1, yeb, reb);
+            wave_lds_sync();
+            tick(3);
+            have = tb.nseg != 0;
             __syncthreads();
+            tick(4);
+            if constexpr (PROF) prof_acc[7] += 1;
         }
+        __syncthreads();                                 // the dense waves' last step (they read the end mark behind it)
+        if (gw == 0) prof_flush(1);
     }
 }
 
-template <int D, int KT, bool BF, int NG>
+hipError_t pack_read_prof(long long* host_dst, size_t n) {
+    const size_t have = sizeof(g_pack_prof) / sizeof(long long);
+    hipError_t e = hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pack_prof), (n < have ? n : have) * sizeof(long long));
+    if (e != hipSuccess) return e;
+    static const unsigned long long zeros[2 * 8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pack_prof), zeros, sizeof(zeros));
+}
+
+template <int D, int KT, bool BF, int NG, bool PROF = false>
 static hipError_t launch_packed(const FusedL2Args& a, hipStream_t st) {
     using G = PackGeom<D, KT, BF, NG>;
     const size_t lds = pack_lds(D, KT, a.nR, NG).total;
-    auto kern = gather_attn_l2_packed_kernel<D, KT, BF, NG>;
+    auto kern = gather_attn_l2_packed_kernel<D, KT, BF, NG, PROF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -640,6 +858,7 @@ bool fused_packed_supported(int D, int K) {
 bool fused_packed_applies(const FusedL2Args& a, int D) {
     return fused_packed_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_r && a.adj_bytes > 0 &&
            a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31) && a.table_bytes < (1ull << 32) &&
+           a.max_id < (1u << 24) &&
            (uint64_t)a.P / (uint64_t)a.parents_per_pair * D * 4 < (1ull << 31);
 }
 
@@ -647,7 +866,11 @@ template <int D, bool BF>
 static hipError_t launch_packed_k(const FusedL2Args& a, hipStream_t st) {
     switch (a.K) {
         case 16: return launch_packed<D, 16, BF, 4>(a, st);
-        case 32: return launch_packed<D, 32, BF, 4>(a, st);
+        case 32:
+            if constexpr (D == 64 && !BF) {
+                if (a.dbg & 8) return launch_packed<D, 32, BF, 4, true>(a, st);      // MVIN_SPLIT_DBG=8: profiled build
+            }
+            return launch_packed<D, 32, BF, 4>(a, st);
         case 64: return launch_packed<D, 64, BF, 4>(a, st);
         case 128: return launch_packed<D, 128, BF, 4>(a, st);
         default: return hipErrorInvalidValue;

@@ -308,6 +308,7 @@ hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf
 hipError_t split_read_trace(long long* host_dst, size_t n);
 bool fused_packed_supported(int D, int K);     // packed-tile variant over the duplicate-slot encoding (mvin_fused_packed.hip)
 bool fused_packed_applies(const FusedL2Args& a, int D);
+hipError_t pack_read_prof(long long* host_dst, size_t n);
 hipError_t launch_gather_attn_l2_packed(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 hipError_t launch_encode_adjacency(const int32_t* adj_e, const int32_t* adj_r, int n_entity, int K, int32_t* cnt,
                                    int32_t* enc_e, int32_t* enc_r, hipStream_t st);   // mvin_prep.hip

@@ -171,6 +171,8 @@ __global__ __launch_bounds__(kBlock) void ripple_sets_kernel(RippleBuildArgs a) 
 // equal slots added up (equal slots have equal logits: weight = multiplicity * exp(t[r] - max) / Z).  Row x becomes: distinct
 // slots first, ordered by the distinct-slot count of the neighbour's own row (descending, ties in first-occurrence order:
 // the children of a tree node that share a gather round then have lists of similar length), padding (= slot 0) last;
+//   enc_e = neighbour | cnt[neighbour] << 24   (n_entity <= 2^24; the length of the neighbour's own list, known one
+//                                               fetch early)
 //   enc_r = relation | multiplicity << 16 | cnt[x] << 24     (multiplicity 0: padding)
 // One wave per row, two passes (the order needs every row's count): MODE 0 writes cnt, MODE 1 the encoding.
 // oracle/prep_ref.py:encode_adjacency restates it; integer work, bit-exact.
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(kBlock) void encode_adjacency_kernel(const int32_t*
                     const int kt = sF[wave][t];
                     rank += (kt > key[i] || (kt == key[i] && t < s)) ? 1 : 0;
                 }
-                enc_e[(int64_t)x * K + rank] = e[i];
+                enc_e[(int64_t)x * K + rank] = (int32_t)((unsigned)e[i] | ((unsigned)key[i] << 24));
                 enc_r[(int64_t)x * K + rank] = (int32_t)((unsigned)r[i] | ((unsigned)mult[i] << 16) | ((unsigned)c << 24));
                 if (rank == 0) {
-                    sPad[wave][0] = e[i];
+                    sPad[wave][0] = (int32_t)((unsigned)e[i] | ((unsigned)key[i] << 24));
                     sPad[wave][1] = r[i];
                 }
             }

@@ -108,13 +108,13 @@ def encode_adjacency(adj_e, adj_r):
     (data_loader_user_set.py:383-384), so a row of adj_entity / adj_relation repeats (neighbour, relation) slots.
     Row x is rewritten as: its DISTINCT (neighbour, relation) slots first -- ordered by how many distinct slots the
     neighbour's own row has (descending; ties in first-occurrence order) --, then padding that repeats slot 0.
-      enc_e[x, i] = neighbour id
+      enc_e[x, i] = neighbour id | cnt[neighbour] << 24          (n_entity <= 2^24)
       enc_r[x, i] = relation | multiplicity << 16 | cnt[x] << 24      (multiplicity 0 = padding slot)
     Returns (enc_e, enc_r, cnt) with cnt [n_entity] = distinct slots per row.  Pure integer work: bit-exact."""
     adj_e = np.asarray(adj_e, dtype=np.int64)
     adj_r = np.asarray(adj_r, dtype=np.int64)
     nE, K = adj_e.shape
-    assert K <= 128 and adj_r.max(initial=0) < 65536
+    assert K <= 128 and adj_r.max(initial=0) < 65536 and nE <= (1 << 24)
     firsts, mults = [], []
     cnt = np.zeros(nE, dtype=np.int32)
     for x in range(nE):
@@ -127,22 +127,22 @@ def encode_adjacency(adj_e, adj_r):
                 seen[key] = [s, 1]
         firsts.append(seen)
         cnt[x] = len(seen)
-    enc_e = np.zeros((nE, K), dtype=np.int32)
+    enc_e = np.zeros((nE, K), dtype=np.int64)
     enc_r = np.zeros((nE, K), dtype=np.int64)
     for x in range(nE):
         items = sorted(firsts[x].items(), key=lambda kv: (-int(cnt[kv[0][0]]), kv[1][0]))
         c = len(items)
         for i, ((y, r), (_, m)) in enumerate(items):
-            enc_e[x, i] = y
+            enc_e[x, i] = y | (int(cnt[y]) << 24)
             enc_r[x, i] = r | (m << 16) | (c << 24)
         enc_e[x, c:] = enc_e[x, 0]
         enc_r[x, c:] = (enc_r[x, 0] & 0xFFFF) | (c << 24)
-    return enc_e, enc_r.astype(np.uint32).view(np.int32), cnt      # cnt = 128 sets the sign bit: the word is unsigned
+    return enc_e.astype(np.uint32).view(np.int32), enc_r.astype(np.uint32).view(np.int32), cnt      # cnt = 128 sets the sign bit: the word is unsigned
 
 
 def decode_adjacency(enc_e, enc_r):
     """Inverse up to slot order: the multiset of (neighbour, relation) slots of every row, as a sorted [nE, K, 2] array."""
-    enc_e = np.asarray(enc_e, dtype=np.int64)
+    enc_e = np.asarray(enc_e).astype(np.int32).view(np.uint32).astype(np.int64) & 0xFFFFFF
     enc_r = np.asarray(enc_r).astype(np.int32).view(np.uint32).astype(np.int64)
     nE, K = enc_e.shape
     out = np.zeros((nE, K, 2), dtype=np.int64)
