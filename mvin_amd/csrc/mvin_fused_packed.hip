@@ -647,120 +647,88 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 }
             }
         };
-        // gather: every lane group walks the lists of its NRND rows as one sequence -> sA[buf]
+        // gather: lane group g walks the lists of its NRND rows, one row after the other (round h: the h-th rows of the
+        // wave's lane groups, of similar length thanks to the ranking) -> sA[buf]
         auto gather = [&](int par, int buf) {
             const int* src = sPR + (gw * 2 + par) * 96;
-            int rr[NRND], xx[NRND], qq[NRND], cum[NRND];
-            int tot = 0;
+            int rr[NRND], xx[NRND], qq[NRND], cn[NRND], cmx[NRND];
 #pragma unroll
             for (int h = 0; h < NRND; ++h) {
                 const int p = rank_of(h, g);
                 const int v = src[p];
                 rr[h] = v & 31;
+                cn[h] = v >> 8;
                 xx[h] = src[32 + p];
                 qq[h] = src[64 + p];
-                tot += v >> 8;
-                cum[h] = tot;                             // entries of rows 0 .. h
             }
-            int cmax = (int)wave_max((float)tot);
-            cmax = __builtin_amdgcn_readfirstlane(cmax);
-            if constexpr (PROF) {
-                if (a.dbg & 2) cmax = 0;                 // floor without the row gathers
+#pragma unroll
+            for (int h = 0; h < NRND; ++h) {             // longest list of the round (wave-uniform)
+                cmx[h] = __builtin_amdgcn_readfirstlane((int)wave_max((float)cn[h]));
+                if constexpr (PROF) {
+                    if (a.dbg & 2) cmx[h] = 0;           // floor without the row gathers
+                }
             }
-            float4 acc[NRND], acc1[NRND];
-#pragma unroll
-            for (int h = 0; h < NRND; ++h) acc[h] = acc1[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            // entry k of the sequence: row h(k), position in its list (clamped into the list: entries past `tot` get weight 0)
-            auto entry = [&](int k, int& h, int& at) {
-                h = 0;
-                int lo = 0;
-#pragma unroll
-                for (int i = 0; i + 1 < NRND; ++i) {
-                    const bool past = k >= cum[i];
-                    h = past ? i + 1 : h;
-                    lo = past ? cum[i] : lo;
-                }
-                // list slot of the group's h-th row: (wave, local row h * RPWX + g)
-                at = k < tot ? (gw * G::RPW + h * G::RPWX + g) * YLD + (k - lo) : TM * YLD;   // past the sequence: (entity 0, weight 0)
-            };
-            auto add_row = [&](int k, float4 lo, float4 hi) {
-                // (h, at) are recomputed, not kept live across the loads in flight: the laundered k stops the compiler from
-                // reusing the values of the issue side (32 registers per batch, which it spilled)
-                asm volatile("" : "+v"(k));
-                int h, at;
-                entry(k, h, at);
-                const float w = sYW[at];
-#pragma unroll
-                for (int i = 0; i < NRND; ++i) {
-                    const float wi = h == i ? w : 0.f;
-                    acc[i] = f4_fma(wi, lo, acc[i]);
-                    if constexpr (G::WIDE) acc1[i] = f4_fma(wi, hi, acc1[i]);
-                }
-            };
-            // NB list rows in flight; FIRST: behind the NRND child rows and the NRND query rows, which are finished
-            // (E[x1] + q stored, (sum p / K) q added to the sums) as soon as they land
-            auto batch = [&](auto nb_c, auto first_c, int k0) {
-                constexpr int NB = decltype(nb_c)::value;
-                constexpr bool FIRST = decltype(first_c)::value;
-                float4 sv[FIRST ? NRND : 1], sv1[FIRST ? NRND : 1];
-                u32x4 qa[FIRST ? NRND : 1], qb[FIRST ? NRND : 1];
-                if constexpr (FIRST) {
-#pragma unroll
-                    for (int h = 0; h < NRND; ++h) {
-                        rowload(xx[h], sv[h], sv1[h]);
-                        // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
-                        const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
-                        qa[h] = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
-                        if constexpr (G::WIDE) qb[h] = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
-                    }
-                }
-                float4 lo[NB], hi[NB];
-#pragma unroll
-                for (int i = 0; i < NB; ++i) {
-                    int h, at;
-                    entry(k0 + i, h, at);
-                    rowload(sYI[at], lo[i], hi[i]);
-                }
-                if constexpr (FIRST) {
-#pragma unroll
-                    for (int h = 0; h < NRND; ++h) {
-                        const float4 q0 = make_float4(__uint_as_float(qa[h][0]), __uint_as_float(qa[h][1]), __uint_as_float(qa[h][2]), __uint_as_float(qa[h][3]));
-                        float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if constexpr (G::WIDE) q1 = make_float4(__uint_as_float(qb[h][0]), __uint_as_float(qb[h][1]), __uint_as_float(qb[h][2]), __uint_as_float(qb[h][3]));
-                        float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
-                        put(arow, f4_fma(1.f, q0, sv[h]), f4_fma(1.f, q1, sv1[h]));            // E[x1] + q
-                        acc[h] = f4_fma(c2scale, q0, acc[h]);                                  // S' + (sum p / K) q
-                        if constexpr (G::WIDE) acc1[h] = f4_fma(c2scale, q1, acc1[h]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NB; ++i) add_row(k0 + i, lo[i], hi[i]);
-            };
-            using std::integral_constant;
-            using T_ = std::true_type;
-            using F_ = std::false_type;
-            constexpr int MAXB = G::WIDE ? 8 : kPackMaxB;       // rows in flight per lane
-            constexpr int NBF = (MAXB - 2 * NRND >= 12) ? 12 : (MAXB - 2 * NRND >= 8) ? 8 : 4;   // ... in the first batch
-            int k0;
-            if (cmax > 8 && NBF >= 12) {
-                batch(integral_constant<int, NBF>{}, T_{}, 0);
-                k0 = NBF;
-            } else if (cmax > 4 && NBF >= 8) {
-                batch(integral_constant<int, (NBF >= 8 ? 8 : 4)>{}, T_{}, 0);
-                k0 = 8;
-            } else {
-                batch(integral_constant<int, 4>{}, T_{}, 0);
-                k0 = 4;
-            }
-            for (; k0 + MAXB <= cmax; k0 += MAXB) batch(integral_constant<int, MAXB>{}, F_{}, k0);
-            const int rem = cmax - k0;
-            if (rem > 8) batch(integral_constant<int, MAXB>{}, F_{}, k0);
-            else if (rem > 4) batch(integral_constant<int, 8>{}, F_{}, k0);
-            else if (rem > 0) batch(integral_constant<int, 4>{}, F_{}, k0);
 #pragma unroll
             for (int h = 0; h < NRND; ++h) {
+                const int cmax = cmx[h];
+                const int lb = (gw * G::RPW + h * G::RPWX + g) * YLD;     // this row's list
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
                 float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
-                put(arow + D, acc[h], acc1[h]);
+                // NB list rows in flight (entries past the list have weight 0: children() pads to K).  FIRST: behind the
+                // child row and the query row, which are finished (E[x1] + q stored, (sum p / K) q added to the sum) as soon
+                // as they land
+                auto batch = [&](auto nb_c, auto first_c, int k0) {
+                    constexpr int NB = decltype(nb_c)::value;
+                    constexpr bool FIRST = decltype(first_c)::value;
+                    float4 sv, sv1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    u32x4 qa = (u32x4){0u, 0u, 0u, 0u}, qb = qa;
+                    if constexpr (FIRST) {
+                        rowload(xx[h], sv, sv1);
+                        // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
+                        const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
+                        qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
+                        if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
+                    }
+                    float4 lo[NB], hi[NB];
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) rowload(sYI[lb + k0 + i], lo[i], hi[i]);
+                    if constexpr (FIRST) {
+                        const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
+                        const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
+                        put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                  // E[x1] + q
+                        acc = f4_fma(c2scale, q0, acc);                                        // S' + (sum p / K) q
+                        if constexpr (G::WIDE) acc1 = f4_fma(c2scale, q1, acc1);
+                    }
+                    // the weights are read when the rows are consumed: not live while the loads are in flight
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const float w = sYW[lb + k0 + i];
+                        acc = f4_fma(w, lo[i], acc);
+                        if constexpr (G::WIDE) acc1 = f4_fma(w, hi[i], acc1);
+                    }
+                };
+                using std::integral_constant;
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                constexpr int MAXB = G::WIDE ? 8 : kPackMaxB;        // list rows in flight per lane
+                constexpr int NBF = G::WIDE ? 4 : 12;                // ... in the first batch
+                int k0;
+                if (NBF >= 12 && cmax > 8) {
+                    batch(integral_constant<int, NBF>{}, T_{}, 0);
+                    k0 = NBF;
+                } else if (NBF >= 8 && cmax > 4) {
+                    batch(integral_constant<int, (NBF >= 8 ? 8 : 4)>{}, T_{}, 0);
+                    k0 = 8;
+                } else {
+                    batch(integral_constant<int, 4>{}, T_{}, 0);
+                    k0 = 4;
+                }
+                for (; k0 + MAXB <= cmax; k0 += MAXB) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+                const int rem = cmax - k0;
+                if (rem > 8) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+                else if (rem > 4) batch(integral_constant<int, 8>{}, F_{}, k0);
+                else if (rem > 0) batch(integral_constant<int, 4>{}, F_{}, k0);
+                put(arow + D, acc, acc1);
             }
         };
 
