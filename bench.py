@@ -149,6 +149,46 @@ def cpu_baseline(args, margs, case, params):
                       f"{best_thr} threads = fastest of a probe over thread counts on a {ncpu}-core host"}, ref, Bc
 
 
+def l2_reference_f64(table, adj_e, adj_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, K):
+    """The outputs of mvin_gather_attn_l2_fwd (include/mvin_hip.h; reference model.py:295-305 with aggregators.py:98-146)
+    for the listed parents, evaluated with plain torch indexing in float64 on the tensors' device: the checker of the
+    roofline launches (parents_per_pair = 1: q[i] belongs to parents[i]).  Returns (nagg0, nagg1) [n, D] float64."""
+    import torch
+    f = lambda t: t.double()
+    par = parents.long()
+    x1 = adj_e[par].long()                                    # [n, K]
+    y = adj_e[x1].long()                                      # [n, K, K]
+    p = torch.softmax(f(t0)[adj_r[x1].long()], dim=-1)        # [n, K, K]
+    E = table
+    c1 = f(q) @ f(W1) + f(b1)
+    c2 = f(q) @ f(W2) + f(b2)
+    self1 = f(E[x1]) @ f(W1) + c1[:, None, :]
+    S = (p[..., None] * f(E[y])).sum(2)                       # [n, K, D]
+    Z = self1 + (S @ f(W2) + p.sum(-1, keepdim=True) * c2[:, None, :]) / K
+    out1 = torch.relu(Z @ f(A0) + f(a0))
+    p0 = torch.softmax(f(t0)[adj_r[par].long()], dim=-1)
+    p1 = torch.softmax(f(t1)[adj_r[par].long()], dim=-1)
+    return (p0[..., None] * self1).sum(1) / K, (p1[..., None] * out1).sum(1) / K
+
+
+def check_l2_launch(out, table, adj_e, adj_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, K, n_check=256, seed=0):
+    """Compare nagg0 / nagg1 of ``n_check`` parents sampled across a launch with l2_reference_f64:
+    |delta| <= 1e-5 |ref| + 1e-6 (BASELINE.json north_star; fp32 path).  -> (max_abs_err, worst err / bound, ok)."""
+    import torch
+    n = parents.shape[0]
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    idx = torch.randperm(n, generator=g)[:min(n_check, n)].to(parents.device)
+    r0, r1 = l2_reference_f64(table, adj_e, adj_r, parents[idx], t0, t1, W1, W2, b1, b2, q[idx], A0, a0, K)
+    worst, max_abs = 0.0, 0.0
+    for got, ref in ((out[0][idx].double(), r0), (out[1][idx].double(), r1)):
+        err = (got - ref).abs()
+        bound = 1e-5 * ref.abs() + 1e-6
+        worst = max(worst, float((err / bound).max()))
+        max_abs = max(max_abs, float(err.max()))
+    return max_abs, worst, worst <= 1.0
+
+
 def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0):
     """The dominant kernel in its HBM-bound regime: mvin_gather_attn_l2_fwd (same template instance as
     in the timed steps: same D, K, table dtype, projection + attention on) on a ``n_rows`` x D table far
@@ -179,6 +219,8 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
         evs.append((e0, e1))
     torch.cuda.synchronize()
     finite = bool(torch.isfinite(out[0]).all() and torch.isfinite(out[1]).all())
+    # the launch the roofline is quoted on is CHECKED: 256 parents sampled across it against a float64 evaluation
+    max_abs, worst, ok = check_l2_launch(out, *args[:13], K)
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     s_ = 2 if table_dtype == "bf16" else 4
     bpp = algorithmic_bytes_per_pair(D, K, 2, s=s_)
@@ -186,7 +228,10 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     torch.cuda.empty_cache()
     return {"avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
             "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows, "table_bytes": n_rows * D * s_,
-            "launches": iters, "outputs_finite": finite}
+            "launches": iters, "outputs_finite": finite, "max_abs_err": max_abs, "worst_err_over_bound": worst,
+            "verified": bool(ok and finite),
+            "verified_how": "nagg0 / nagg1 of 256 parents sampled across the launch vs a torch float64 evaluation on the GPU, "
+                            "|delta| <= 1e-5 |ref| + 1e-6"}
 
 
 PROBE_PAIRS = 131072
@@ -588,8 +633,11 @@ def main():
         value = a.batch * a.steps / elapsed
         table_bytes = case.n_entity * a.dim * s_
         cache_resident = table_bytes <= 256 * 2 ** 20        # Infinity Cache (MI355X_MICROARCH.md)
+        enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd: duplicate-slot encoding of the adjacency)"
+                 if enc is not None
                  else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if used_l2
                  else "gather_attn_kernel (mvin_gather_attn_fwd)")
         peak = L2_PEAK_GBS if cache_resident else HBM_PEAK_GBS
@@ -609,6 +657,22 @@ def main():
                           "peak; `traffic` = bytes per launch beyond L2 from rocprofv3 PMC passes (2*FETCH_SIZE + "
                           "WRITE_SIZE, profiles/pmc_latest.json)" % (table_bytes / 1e6, L2_PEAK_GBS / 1e3))
                  if cache_resident else "launches inside the timed steps; the table is far larger than the Infinity Cache"}
+        if enc is not None and L == 2 and kern_avg_ms:
+            # what the encoded path really loads: the DISTINCT slots of the item's row and of its distinct children's rows
+            # (the algorithmic bytes above stay SURVEY 8(d)'s K + K^2 rows per pair: repeated slots are not re-read)
+            enc_e, enc_r, cnt, frac_distinct = enc
+            it = items.long()
+            ch = (enc_e[it] & 0xFFFFFF).long()
+            real = ((enc_r[it] >> 16) & 0xFF) > 0
+            rows_loaded = float((1 + cnt[it].double() + (cnt[ch].double() * real).sum(1)).mean())
+            K_ = a.fanout
+            loaded_gbs = rows_loaded * a.dim * s_ * Bl / (kern_avg_ms * 1e-3) / 1e9
+            timed.update({"rows_per_pair_faithful": 1 + K_ + K_ * K_, "rows_per_pair_loaded": rows_loaded,
+                          "row_bytes_loaded_gbs": loaded_gbs, "row_bytes_loaded_frac_of_peak": loaded_gbs / peak,
+                          "distinct_slots_per_adjacency_row": frac_distinct * K_,
+                          "dedup_note": "the reference's sampler repeats slots whenever deg < K (data_loader_user_set.py:383-384); "
+                                        "`achieved` / `frac` price the FAITHFUL bytes (every slot's row), so they can exceed the "
+                                        "peak; row_bytes_loaded_* price the rows the kernel actually fetches"})
         if used_l2 and not hoisted and L == 2 and world == 1 and not a.no_probe and kern_avg_ms:
             gp = gather_probe(model, items, a.fanout, a.dim, s_)
             rows_gbs = gp["row_bytes_per_pair"] * Bl / (kern_avg_ms * 1e-3) / 1e9     # the fused kernel, rows only
@@ -618,12 +682,7 @@ def main():
                           "the same 16-byte lane loads by a PLAIN gather-and-sum kernel (one wave per parent, 8 loads in flight, ids "
                           "from the expanded level lists one round ahead) -- a reference point, not an upper bound; "
                           "fused_kernel_frac_of_probe = the full kernel's row bytes per second (adjacency chase, softmax, "
-                          "projections, MFMA epilogues on top) over the probe's.  Idealised gather ceilings of this part "
-                          "(scripts/micro/dma_probe.hip, profiles/r2/d_gather_ceiling_dma_probe.txt; 16-byte lanes, ids preloaded): "
-                          "26 TB/s for L1-resident rows, 24 TB/s L2-resident, 8.8 TB/s for uniformly random rows of a 27 MB table "
-                          "(Infinity Cache)")
-            gp["gather_ceiling_gbs"] = {"l1_resident": 26000.0, "l2_resident": 24000.0, "infinity_cache_uniform_27mb": 8800.0,
-                                        "source": "profiles/r2/d_gather_ceiling_dma_probe.txt"}
+                          "projections, MFMA epilogues on top) over the probe's")
             timed["gather_only_probe"] = gp
         roofline = timed
         if not a.no_hbm_leg and used_l2 and not hoisted and cache_resident and L == 2:
@@ -640,6 +699,7 @@ def main():
                         "bytes_per_pair": leg["bytes_per_pair"], "pairs_per_launch": leg["pairs_per_launch"],
                         "avg_launch_ms": leg["avg_launch_ms"], "table_bytes": leg["table_bytes"],
                         "table_rows": leg["table_rows"], "launches": leg["launches"],
+                        "max_abs_err": leg["max_abs_err"], "verified": leg["verified"], "verified_how": leg["verified_how"],
                         "workload": "the timed region's kernel instance (same D, K, dtype, projection + attention on) on a "
                                     "16 M-row synthetic entity table with uniform adjacency: 16x the Infinity Cache, so "
                                     "every gathered row comes from HBM; measured after the timed region with HIP events "

@@ -159,7 +159,7 @@ int mvin_gather_attn_l2_supported(int D, int K);
  * and the distinct children of consecutive parents are packed into full MFMA tiles (mvin_fused_packed.hip).  Same
  * arithmetic up to the order of fp32 additions; no attention outputs (those are per slot: use the plain adjacency).
  * parent_ids: int32 [P], or int64 [P] read in place when parent_ids_i64 != 0.  D in {32, 64, 128}, K in {16, 32, 64, 128},
- * nR <= 4096, tables below 4 GiB (-3 otherwise). */
+ * nR <= 4096, n_entity <= 2^24, tables below 4 GiB (-3 otherwise). */
 int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, const int32_t* enc_relation,
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
                                 const float* W1, const float* W2, const float* b1, const float* b2,
@@ -483,6 +483,8 @@ int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32
  * once per adjacency.  Row x of enc_entity / enc_relation [nE, K] holds the DISTINCT (neighbour, relation) slots of row x
  * first -- ordered by the distinct-slot count of the neighbour's own row, descending, ties in first-occurrence order --
  * and padding (a copy of slot 0) behind them:
+ *     enc_entity   = neighbour | cnt[neighbour] << 24                 (n_entity <= 2^24: the length of the neighbour's
+ *                                                                       own list, known one fetch early; unsigned word)
  *     enc_relation = relation | multiplicity << 16 | cnt[x] << 24     (multiplicity 0: padding; unsigned word)
  * cnt [nE] = distinct slots per row (also written).  adj_relation may be NULL (relations read as 0). */
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,

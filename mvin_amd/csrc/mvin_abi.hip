@@ -237,7 +237,8 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
     }
     if (encoded) {
         if (!adj_relation) return fail(-1, "%s: null enc_relation", who);
-        if (!mvin::fused_packed_applies(f, D)) return fail(-3, "%s: tables too large for 32-bit offsets", who);
+        if (!mvin::fused_packed_applies(f, D))
+            return fail(-3, "%s: tables too large (n_entity <= 2^24, table < 4 GiB, adjacency and outputs < 2 GiB)", who);
         return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
     }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
@@ -259,7 +260,8 @@ int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation
                           int32_t* enc_entity, int32_t* enc_relation, void* stream) {
     const char* who = "mvin_encode_adjacency";
     if (!adj_entity || !cnt || !enc_entity || !enc_relation) return fail(-1, "%s: null pointer", who);
-    if (n_entity <= 0 || K <= 0 || K > 128) return fail(-2, "%s: n_entity=%d K=%d (K <= 128)", who, n_entity, K);
+    if (n_entity <= 0 || n_entity > (1 << 24) || K <= 0 || K > 128)
+        return fail(-2, "%s: n_entity=%d K=%d (n_entity <= 2^24, K <= 128)", who, n_entity, K);
     return hip_result(mvin::launch_encode_adjacency(adj_entity, adj_relation, n_entity, K, cnt, enc_entity, enc_relation,
                                                     (hipStream_t)stream), who);
 }

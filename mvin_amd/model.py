@@ -126,7 +126,8 @@ class MVIN(object):
         built once per set_adjacency; None when the shape has no packed-tile kernel."""
         if self._enc is None:
             K = self.n_neighbor
-            if K > 128 or int(self.n_relation) > 65535 or not ops.encode_adjacency_supported(self.dim, K):
+            if (K > 128 or int(self.n_relation) > 4096 or int(self.n_entity) > (1 << 24)
+                    or not ops.encode_adjacency_supported(self.dim, K)):
                 self._enc = False
             else:
                 enc_e, enc_r, cnt = ops.encode_adjacency(self.adj_entity, self.adj_relation)
@@ -134,11 +135,19 @@ class MVIN(object):
                 self._enc = (enc_e, enc_r, cnt, frac)
         return self._enc or None
 
-    def _enc_for_l2(self, want_probs=False):
+    ENC_AUTO_MIN_PARENTS = 2048      # below: a few tiles per workgroup, the pipeline's fill / drain dominates (B = 512: 68 vs 58 us)
+
+    def _enc_for_l2(self, want_probs=False, n_parents=None):
         """The encoded adjacency when the two deepest levels should take the packed-tile kernel for this call."""
         mode = os.environ.get("MVIN_L2_ENC", "auto") if self.dedup is None else ("1" if self.dedup else "0")
         if mode == "0" or want_probs or self.fused is False:
             return None
+        if mode != "1":
+            # measured (scripts/ab_enc.sh): the wave-per-parent kernel keeps D = 32, K <= 16 (BASELINE C2: 1.53 vs 1.88 ms)
+            if self.dim == 32 and self.n_neighbor <= 16:
+                return None
+            if n_parents is not None and n_parents < self.ENC_AUTO_MIN_PARENTS:
+                return None
         if self.entity_emb_matrix.numel() * self.entity_emb_matrix.element_size() >= (1 << 32):
             return None
         enc = self.encoded_adjacency()
@@ -521,7 +530,7 @@ class MVIN(object):
                        self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
                        self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
                        q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
-            enc = self._enc_for_l2(want_probs)
+            enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
             if enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
                 pp = pc = None
@@ -671,7 +680,7 @@ class MVIN(object):
         s = st["args"]
         s.entity_emb, s.t0, s.t1 = ptr(self.entity_emb_matrix), ptr(t0), ptr(t1)
         s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
-        enc = self._enc_for_l2()
+        enc = self._enc_for_l2(n_parents=B)
         s.enc_entity, s.enc_relation = (ptr(enc[0]), ptr(enc[1])) if enc is not None else (None, None)
         st["live"] = (self.entity_emb_matrix, t0, t1, enc)
         n_o = P + (1 if a.PS_O_ft else 0)

@@ -84,3 +84,37 @@ def test_ripple_set_rule():
                     edge_mult[(e, r, t)] = edge_mult.get((e, r, t), 0) + 1
             for k in set(trip):
                 assert trip.count(k) <= edge_mult[k]
+
+
+def test_encode_adjacency_round_trip_and_order():
+    """Duplicate-slot encoding (oracle of mvin_encode_adjacency): decoding gives back every row's multiset of
+    (neighbour, relation) slots; distinct slots come first, ordered by the neighbour's own distinct count; an all-zero
+    row (entity absent from the KG, data_loader_user_set.py:377-380) is ONE slot of multiplicity K."""
+    import numpy as np
+    from oracle import prep_ref
+    rng = np.random.default_rng(3)
+    for K in (4, 16, 32, 128):
+        nE = 80
+        e = rng.integers(0, nE, (nE, K))
+        r = rng.integers(0, 7, (nE, K))
+        low = rng.random(nE) < 0.6                      # low-degree entities: draws with replacement from few edges
+        for x in np.flatnonzero(low):
+            d = rng.integers(1, max(2, K // 3))
+            pick = rng.integers(0, d, K)
+            e[x], r[x] = e[x][pick], r[x][pick]
+        e[5], r[5] = 0, 0
+        ee, er, cnt = prep_ref.encode_adjacency(e, r)
+        dec = prep_ref.decode_adjacency(ee, er)
+        ref = np.array([sorted(map(tuple, row)) for row in np.stack([e, r], -1)])
+        assert np.array_equal(dec, ref)
+        eu = ee.view(np.uint32).astype(np.int64)
+        ru = er.view(np.uint32).astype(np.int64)
+        assert cnt[5] == 1 and ((ru[5, 0] >> 16) & 0xFF) == K and (ru[5, 1:] >> 16 & 0xFF).max() == 0
+        for x in range(nE):
+            c = cnt[x]
+            assert ((ru[x] >> 24) == c).all()
+            assert ((ru[x, :c] >> 16) & 0xFF).min() >= 1 and ((ru[x, :c] >> 16) & 0xFF).sum() == K
+            child_cnt = eu[x, :c] >> 24
+            assert np.array_equal(child_cnt, cnt[eu[x, :c] & 0xFFFFFF])
+            assert (np.diff(child_cnt) <= 0).all()       # longest lists first
+            assert (eu[x, c:] == eu[x, 0]).all()
