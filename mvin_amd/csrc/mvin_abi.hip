@@ -381,6 +381,7 @@ static int key_addressing_impl(const char* who, const void* entity_emb, const fl
     k.users64 = users64;
     k.users32 = users32;
     k.n_user = n_user;
+    k.n_entity = n_entity;
     const int nh = P > 0 ? P : 1;
     for (int i = 0; i < nh && !uts; ++i) {
         if (!mem_h[i]) return fail(-1, "%s: null mem_h[%d]", who, i);

@@ -292,7 +292,8 @@ bool fused_d16_applies(const FusedL2Args& a, int D) {
     static const char* e = getenv("MVIN_L2_D16");
     if (e && e[0] == '0') return false;                  // A/B: keep gather_attn_l2_kernel
     return fused_d16_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
-           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31);
+           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
+           fused_d16_lds_bytes(a.nR) <= 64 * 1024;          // (default dynamic-LDS limit)
 }
 
 template <int K, bool BF>

@@ -368,7 +368,8 @@ bool fused_d32_applies(const FusedL2Args& a, int D) {
     static const char* e = getenv("MVIN_L2_D32");
     if (e && e[0] == '0') return false;                  // A/B: the role-split / symmetric kernel
     return fused_d32_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
-           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31);
+           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
+           fused_d32_lds_bytes(a.nR, a.K) <= 64 * 1024;     // (default dynamic-LDS limit; larger relation tables keep the pipeline)
 }
 
 template <int K, bool BF>

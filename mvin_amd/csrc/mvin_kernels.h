@@ -76,6 +76,7 @@ struct KeyAddrArgs {
     const int64_t* users64;
     const int32_t* users32;
     int n_user;                // rows of uts: user ids are clamped to [0, n_user) (device feeds are not validated per launch)
+    int n_entity;              // rows of E: head / tail ids are clamped to [0, n_entity) (0: unknown, no clamp)
 };
 
 // the three id lists (heads, relations, tails) of pair b at `hop`

@@ -29,7 +29,9 @@ __global__ __launch_bounds__(kBlock) void key_addr_kernel(KeyAddrArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.E), 0, BUF ? (int)a.table_bytes : 0, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
+    const unsigned emax = (unsigned)(a.n_entity > 0 ? a.n_entity - 1 : 0x7fffffff);      // last row of E
     auto row4 = [&](int id) -> float4 {
+        id = (int)min((unsigned)id, emax);                   // device-resident ids are clamped into the table
         if constexpr (BUF) {
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)id * (unsigned)(D * 4) + c16, 0, 0);
             return make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),

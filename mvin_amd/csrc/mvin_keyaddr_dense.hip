@@ -140,6 +140,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
     const int g = lane / LPR, c = lane % LPR;
     const int q16 = lane >> 4, l16 = lane & 15;
     const bool has_set = a.w != nullptr;
+    const unsigned emax = (unsigned)(a.n_entity > 0 ? a.n_entity - 1 : 0x7fffffff);    // last row of E
     const int slot0 = has_set ? 1 : 0;
 
     const int nseg = a.nseg_dev ? *a.nseg_dev : a.nseg;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         if (itid >= 0 && t0 < p1) {
             const int p = t0 + itid / LPR;
             const int o = a.pair_index[p < p1 ? p : p1 - 1];
-            const int64_t item = a.items64 ? a.items64[o] : (int64_t)a.items32[o];
+            const int64_t item = (int64_t)min((uint64_t)(a.items64 ? a.items64[o] : (int64_t)a.items32[o]), (uint64_t)emax);
             e = load_row4(a.E, BF, item, D, itid % LPR);
             orig = p < p1 ? o : -1;
         }
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         }
     };
     auto chain_b = [&]() {
-        if (st_act) st_item = a.items64 ? a.items64[st_o] : (int64_t)a.items32[st_o];
+        if (st_act) st_item = (int64_t)min((uint64_t)(a.items64 ? a.items64[st_o] : (int64_t)a.items32[st_o]), (uint64_t)emax);
     };
     auto chain_c = [&](float4& e, int& orig) {
         e = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -257,8 +258,9 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             const int hop = tid / NmP, m = tid - hop * NmP;
             if (m < Nm) {
                 const int32_t* ub = a.uts + (int64_t)user * Ph * 3 * Nm;
-                h = ub[(hop * 3 + 0) * Nm + m];
-                t = ub[(hop * 3 + 2) * Nm + m];
+                // device-resident ids are not validated per launch: clamped into the table (a fault would kill the process)
+                h = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);
+                t = (int)min((unsigned)ub[(hop * 3 + 2) * Nm + m], emax);
                 r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));
             }
         }
@@ -343,9 +345,9 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             const int hop = i / NmP, m = i - hop * NmP;
             int idh = -1, idt = -1, r = 0, rk = 0;
             if (m < Nm) {
-                idh = ub[(hop * 3 + 0) * Nm + m];
+                idh = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);      // clamped into the table, like every device id
                 if (hop < P) {
-                    idt = ub[(hop * 3 + 2) * Nm + m];
+                    idt = (int)min((unsigned)ub[(hop * 3 + 2) * Nm + m], emax);
                     r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));            // indexes LDS
                     rk = atomicAdd(&sCnt[r], 1);
                 }

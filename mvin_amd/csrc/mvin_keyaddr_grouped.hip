@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
     const int g = lane / LPR, c = lane % LPR;
     const int q16 = lane >> 4, l16 = lane & 15;
     const bool has_set = a.w != nullptr;
+    const unsigned emax = (unsigned)(a.n_entity > 0 ? a.n_entity - 1 : 0x7fffffff);    // last row of E
     const int slot0 = has_set ? 1 : 0;
     auto row4 = [&](int id) -> float4 { return load_row4(a.E, BF, id, D, c); };
 
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
         const int32_t* ub = a.uts + (int64_t)u * Ph * 3 * Nm;
         for (int i = tid; i < Ph * Nm; i += kGW * 64) {
             const int hop = i / Nm, m = i - hop * Nm;
-            sIdH[i] = ub[(hop * 3 + 0) * Nm + m];
-            sIdT[i] = ub[(hop * 3 + 2) * Nm + m];
+            sIdH[i] = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);     // clamped into the table, like every device id
+            sIdT[i] = (int)min((unsigned)ub[(hop * 3 + 2) * Nm + m], emax);
             const int r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));   // indexes LDS below
             sRl[i] = r;
             if (hop < P) sMap[r] = 1;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(kGW * 64) void key_addr_grouped_kernel(KeyAddrGroup
                 const int i = tid / LPR, cc = tid % LPR;
                 const int p = t0 + i;
                 const int orig = a.pair_index[p < p1 ? p : p1 - 1];
-                const int64_t item = a.items64 ? a.items64[orig] : (int64_t)a.items32[orig];
+                const int64_t item = (int64_t)min((uint64_t)(a.items64 ? a.items64[orig] : (int64_t)a.items32[orig]), (uint64_t)emax);
                 const float4 e = load_row4(a.E, BF, item, D, cc);
                 float* dst = sEi + i * LDE + 4 * cc;
                 *reinterpret_cast<float2*>(dst) = make_float2(e.x, e.y);

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64) void key_addr_stream_kernel(KeyAddrArgs a) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds0 + 4096) : "memory");     // the ONLY M0 write of the wave
 
     const char* tab = reinterpret_cast<const char*>(a.E);
+    const unsigned emax = (unsigned)(a.n_entity > 0 ? a.n_entity - 1 : 0x7fffffff);      // last row of E
     const int* sIds = reinterpret_cast<const int*>(smem + kWinIds);
     const float* sV = reinterpret_cast<const float*>(smem + kWinV);
 
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(64) void key_addr_stream_kernel(KeyAddrArgs a) {
         for (int k = 0; k < SP; ++k) {
             int m = (ST * SP + k) * RPI + g;
             m = m < Nm ? m : Nm - 1;
-            src[k] = tab + (size_t)(unsigned)sIds[WHICH * 64 + m] * RB + c * 16;
+            src[k] = tab + (size_t)min((unsigned)sIds[WHICH * 64 + m], emax) * RB + c * 16;     // clamped into the table
         }
         dma16_at<SLOT * kWinSlot - 4096>(src[0]);
         if constexpr (SP == 2) dma16_at<SLOT * kWinSlot - 4096 + 1024>(src[1]);

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(KwCfg<D>::Waves * 64, KwCfg<D>::MinW) void key_addr
         const int32_t* ub = a.uts + (int64_t)u * P * 3 * Nm;
         for (int i = lane; i < P * 3 * 64; i += 64) {
             const int hx = i >> 6, m = i & 63;
-            sIds[i] = m < Nm ? ub[hx * Nm + m] : -1;
+            const int v = m < Nm ? ub[hx * Nm + m] : -1;          // head / tail ids clamped into the table, like every device id
+            sIds[i] = (m < Nm && hx % 3 != 1) ? (int)min((unsigned)v, max_id) : v;
         }
         wave_lds_sync();
         // Head rows reach the lanes through LDS: a tile of 16 rows (memories m = 16t + j of one hop) is ONE coalesced

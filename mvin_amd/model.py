@@ -27,6 +27,7 @@ How the forward is arranged (see DESIGN.md for the data layout and the kernel ro
     is computed once per pair, then each memory needs one D-long dot product.
 """
 import os
+import weakref
 from types import SimpleNamespace
 
 import numpy as np
@@ -817,8 +818,11 @@ class MVIN(object):
     def _check_uts(self, uts):
         """A device-resident user_triplet_set is validated ONCE per tensor (identity + torch version): the grouped /
         users-feed kernels index the entity table, the relation matrices and LDS with its entries."""
-        key = (uts.data_ptr(), uts._version, tuple(uts.shape))
-        if self._uts_ok == key:
+        # identity of the tensor OBJECT (a weak reference: a freed tensor's address is reused by the caching allocator) and its
+        # torch version counter; the kernels clamp every id they index memory with, so this check is about raising the
+        # reference's IndexError, not about memory safety
+        ok = self._uts_ok
+        if ok is not None and ok[0]() is uts and ok[1] == uts._version:
             return
         if uts.dim() != 4 or uts.shape[2] != 3 or uts.shape[1] != max(1, self.p_hop) or uts.shape[3] != self.n_memory:
             raise ValueError(f"user_triplet_set must be [n_user, {max(1, self.p_hop)}, 3, {self.n_memory}], "
@@ -830,7 +834,7 @@ class MVIN(object):
             bad = bad | (r < 0).any() | (r >= self.n_relation).any() | (t < 0).any() | (t >= self.n_entity).any()
         if bool(bad.item()):
             raise IndexError("user_triplet_set: id out of range (heads / tails in [0, n_entity), relations in [0, n_relation))")
-        self._uts_ok = key
+        self._uts_ok = (weakref.ref(uts), uts._version)
 
     def _check_device_ids(self, t, limit, what):
         if t is not None and t.numel() and bool(((t < 0) | (t >= limit)).any().item()):

@@ -605,9 +605,10 @@ def linear_wgrad_multi(problems):
     if not problems:
         return
     lib = _lib.load()
-    n = len(problems)
-    arr = (_lib.WgradProblem * n)(*[p for p, _ in problems])
-    _lib.check(lib.mvin_linear_wgrad_multi(arr, n, _stream()), "mvin_linear_wgrad_multi")
+    for lo in range(0, len(problems), 64):       # the entry point takes at most 64 problems per call (deep trees queue more)
+        chunk = problems[lo:lo + 64]
+        arr = (_lib.WgradProblem * len(chunk))(*[p for p, _ in chunk])
+        _lib.check(lib.mvin_linear_wgrad_multi(arr, len(chunk), _stream()), "mvin_linear_wgrad_multi")
 
 
 def agg_bwd(dvec, probs, T, K, D, nR, *, table=None, adj_entity=None, adj_relation=None, node_ids=None, child=None,

@@ -34,6 +34,7 @@ run $S --dataset MovieLens-1M --batch 1024 --feed pairs
 run $S --dataset amazon-book_20core
 MVIN_L2_D16=0 run $S                             # general fused kernel instead of the wave-per-parent one (A/B)
 # projection of the multi-GPU line on one GPU (rank 0's share, user-sorted split, exchange included)
+run --mix 2 --batch 65536                     # parser.py:30 default n_mix_hop = 2 (tree depth 4)
 run --emulate-world 2
 run --emulate-world 4
 run --emulate-world 8

@@ -184,3 +184,48 @@ def test_device_id_validation_raises_like_the_host_feed(hip_lib):
         model.forward_device(u_d, i_d, [torch.from_numpy(m).to(dev) for m in mh], mr_d,
                              [torch.from_numpy(m).to(dev) for m in mt])
     model.forward_users(u_d, i_d, uts_d)                             # valid ids still pass
+
+
+@pytest.mark.parametrize("shape", [(64, 2, 64, 9), (64, 3, 48, 9), (32, 2, 12, 6), (16, 2, 8, 5), (128, 1, 16, 7)],
+                         ids=lambda s: "d%dP%dNm%d" % s[:3])
+@pytest.mark.parametrize("feed", ["users", "pairs"])
+def test_out_of_range_device_ids_are_clamped(shape, feed, hip_lib):
+    """Device-resident feeds are not validated per batch (MVIN.validate_device_ids = False): every kernel that indexes
+    the entity table with a head / tail / item id clamps it into the table -- a batch with ids beyond n_entity must
+    score exactly like the batch with those ids clamped (and not fault)."""
+    from mvin_amd.model import MVIN
+    D, P, Nm, nR = shape
+    n_user, n_entity, B, K = 40, 300, 500, 4
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B)
+    rng = np.random.default_rng(D + P)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=3)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    bad = uts.copy()
+    hit = rng.random(bad.shape) < 0.05
+    hit[:, :, 1, :] = False                                 # relations stay valid (they are clamped too, tested elsewhere)
+    bad[hit] += n_entity * 7                                # far beyond the table
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    bad_items = items.copy()
+    bad_items[::17] += n_entity * 3
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0")
+    model.validate_device_ids = False
+    model._check_uts = lambda t: None                      # (the once-per-tensor range check would raise the reference's IndexError)
+    model.group_min_pairs_per_user = 0
+    dev = model.device
+
+    def run(u3, it):
+        u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(it).to(dev)
+        if feed == "users":
+            return model.forward_users(u_d, i_d, torch.from_numpy(u3).to(dev))
+        mh, mr, mt = synth.memories_for(u3, users)
+        return model.forward_device(u_d, i_d, [torch.from_numpy(m).to(dev) for m in mh],
+                                    [torch.from_numpy(m).to(dev) for m in mr], [torch.from_numpy(m).to(dev) for m in mt])
+
+    got = run(bad, bad_items)
+    torch.cuda.synchronize()
+    ref = run(np.minimum(bad, n_entity - 1), np.minimum(bad_items, n_entity - 1))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.scores).all()
+    assert torch.equal(got.scores, ref.scores)
