@@ -101,6 +101,8 @@ typedef struct {
     float* score_out;          /* [rows] or NULL */
     float* sigmoid_out;        /* [rows] or NULL */
     int src_bf16;              /* bit s set: src[s] is a bf16 table (read as bf16, widened to fp32) */
+    int64_t src_rows;          /* rows of the gathered sources (those with ids[s] != NULL): ids are clamped to
+                                  [0, src_rows) like every device-resident id; 0 = unknown, no clamp */
 } mvin_linear_args;
 int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
 

@@ -40,6 +40,7 @@ class LinearArgs(C.Structure):
         ("score_out", C.c_void_p),
         ("sigmoid_out", C.c_void_p),
         ("src_bf16", C.c_int),
+        ("src_rows", C.c_int64),
     ]
 
 

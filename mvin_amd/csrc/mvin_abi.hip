@@ -456,6 +456,7 @@ int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int
     t.sig = sig;
     t.B = B;
     t.table_bf16 = table_bf16;
+    t.n_entity = n_entity;
     return hip_result(mvin::launch_l2_tail(t, D, (hipStream_t)stream), who);
 }
 
@@ -474,6 +475,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     l.ids[0] = reinterpret_cast<const int32_t*>(a->items);
     l.ids64 = 1;
     l.src_bf16 = a->table_bf16 ? 1 : 0;
+    l.src_rows = a->n_entity;
     l.nsrc = 1;
     l.Dsrc = D;
     l.Dout = D;

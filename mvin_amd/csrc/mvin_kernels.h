@@ -133,6 +133,7 @@ struct TailArgs {
     float* sig;                // [B] or NULL
     int64_t B;
     int table_bf16;
+    int n_entity;              // rows of E: item ids are clamped to [0, n_entity)
 };
 
 struct GatherMixArgs {

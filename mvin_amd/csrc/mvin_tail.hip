@@ -82,7 +82,8 @@ __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
             const int64_t r = r0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < a.B) {
-                const int64_t it = a.items64 ? a.items64[r] : (int64_t)a.items32[r];
+                int64_t it = a.items64 ? a.items64[r] : (int64_t)a.items32[r];
+                if (a.n_entity > 0) it = (int64_t)min((uint64_t)it, (uint64_t)(a.n_entity - 1));      // clamped into the table
                 v = load_row4(a.E, a.table_bf16, it, D, c);
                 if (proj) {
                     const float4 qv = reinterpret_cast<const float4*>(a.q + r * D)[c];

@@ -136,6 +136,8 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a.relu = 1 if relu else 0
     a.ids64 = 1 if ids64 else 0
     a.src_bf16 = src_bf16
+    gathered = [srcs[s].numel() // Dsrc for s in range(nsrc) if ids[s] is not None]
+    a.src_rows = min(gathered) if gathered else 0         # ids are clamped into the (smallest) gathered table
     a.sum_sources = 1 if sum_sources else 0
     a.out = out.data_ptr() + out_offset * 4
     a.ldo = ldo
