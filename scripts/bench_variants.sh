@@ -34,7 +34,9 @@ run $S --dataset MovieLens-1M --batch 1024 --feed pairs
 run $S --dataset amazon-book_20core
 MVIN_L2_D16=0 run $S                             # general fused kernel instead of the wave-per-parent one (A/B)
 # projection of the multi-GPU line on one GPU (rank 0's share, user-sorted split, exchange included)
-run --mix 2 --batch 65536                     # parser.py:30 default n_mix_hop = 2 (tree depth 4)
+S2="--dim 16 --fanout 8 --mix 2"                     # parser.py:30 default n_mix_hop = 2 with the shipped dims: tree depth 4, 4 681 rows per pair
+run $S2 --batch 16384
+run $S2 --batch 512 --feed pairs
 run --emulate-world 2
 run --emulate-world 4
 run --emulate-world 8
