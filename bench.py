@@ -630,7 +630,10 @@ def main():
         kern_ms = [e0.elapsed_time(e1) for e0, e1 in prof]
         kern_avg_ms = float(np.mean(kern_ms)) if kern_ms else None
         achieved = (bpp * Bl / (kern_avg_ms * 1e-3) / 1e9) if kern_avg_ms else None
-        value = a.batch * a.steps / elapsed
+        emulated = a.emulate_world > 1 and world == 1
+        # under --emulate-world only rank 0's share was scored: `value` is that MEASURED rate, the W-rank projection is a
+        # separate field
+        value = (Bl if emulated else a.batch) * a.steps / elapsed
         table_bytes = case.n_entity * a.dim * s_
         cache_resident = table_bytes <= 256 * 2 ** 20        # Infinity Cache (MI355X_MICROARCH.md)
         enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
@@ -740,12 +743,32 @@ def main():
                                         else "single-gpu"))},
             "roofline": roofline,
         }
+        # what the multi-GPU line rests on, printed so that the first real SCALE run verifies itself
+        import torch.distributed as tdist
+        dinfo = {"world_size": tdist.get_world_size() if tdist.is_initialized() else 1,
+                 "backend": tdist.get_backend() if tdist.is_initialized() else None, "ranks_launched": world}
+        if rowshard:
+            from mvin_amd.dist import exchange_wire_bytes, n_local_rows
+            W_ = split
+            row_b = a.dim * s_
+            dense = runner.is_dense(a.batch)
+            wb = exchange_wire_bytes(case.n_entity, row_b, W_, Bl, a.fanout, L)
+            dinfo.update({"exchange_regime": "dense (every shard to every rank)" if dense else "sparse (fixed-capacity id buffers, no host sync)",
+                          "exchange_bytes_received_per_rank_per_step": (wb["replicate"] if dense else runner.table.last_stats.get("wire_bytes_per_rank")),
+                          "exchange_bytes_if_owner_side_partial_sums": wb["partial_sums"],
+                          "shard_rows": n_local_rows(case.n_entity, W_), "row_bytes": row_b,
+                          "collective": "all_to_all over W views of the local shard (RCCL grouped send/recv)" if dense
+                                        else "all_to_all_single (ids) + all_to_all_single (rows), static equal splits",
+                          "world_in_formula": W_})
+        rec["distributed"] = dinfo
         if a.emulate_world > 1 and world == 1:
+            rec["projected_value"] = a.batch * a.steps / elapsed
             rec["emulated_world"] = {"world": a.emulate_world, "per_rank_pairs_per_s": Bl * a.steps / elapsed,
                                      "note": "ONE GPU scoring rank 0's share as one of W ranks would (user-sorted split, "
                                              "row-shard exchange of the whole table every step through RCCL at world size "
-                                             "1, two streams); `value` = per-rank rate x W is a PROJECTION of the W-GPU "
-                                             "line, not a measurement: no fabric is involved"}
+                                             "1, two streams); `value` = the MEASURED per-rank rate, `projected_value` = x W is a "
+                                             "PROJECTION of the W-GPU line, not a measurement: no fabric is involved; the user-order "
+                                             "partition of the global batch is done on the host OUTSIDE the timed steps"}
         if world == 1 and not a.no_sweep and a.hoist == "off" and not rowshard:
             smh, smr, smt = (mh, mr, mt) if mh is not None else pair_feed()   # per-pair feeds: the reference's own
             rec["batch_sweep"] = batch_sweep(model, users, items, smh, smr, smt, [int(x) for x in a.sweep.split(",") if x])

@@ -117,6 +117,25 @@ def mark_needed(n_rows, adj_entity, items, levels, extra_ids=()):
     return need
 
 
+def mark_needed_static(n_rows, adj_entity, items, levels, extra_ids=()):
+    """mark_needed without a host sync: no ``nonzero`` (whose result size the host must read) -- every level pushes the
+    frontier through ALL adjacency rows with one index_add over n_rows * K entries (3.6 M at C3: tens of microseconds)."""
+    dev = adj_entity.device
+    K = adj_entity.shape[1]
+    flat = adj_entity.reshape(-1).long()
+    frontier = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+    frontier[items.long()] = 1
+    need = frontier.clone()
+    for _ in range(levels):
+        nxt = torch.zeros(n_rows, dtype=torch.int32, device=dev)
+        nxt.index_add_(0, flat, (frontier > 0).to(torch.int32).repeat_interleave(K))
+        frontier = nxt
+        need += nxt
+    for ids in extra_ids:
+        need[ids.reshape(-1).long()] = 1
+    return need > 0
+
+
 def hip_row_gather(table, idx_int32):
     """Owner-side row gather on the GPU (mvin_gather_rows: fp32 or bf16 rows, moved untouched)."""
     from . import ops
@@ -214,6 +233,54 @@ class ShardedEntityTable(object):
         return work
 
 
+def _fetch_static(self, need_mask, capacity, work=None):
+    """The sparse regime WITHOUT a host sync: fixed-capacity id buffers.  Every rank asks every owner for exactly
+    ``C = min(capacity, n_local)`` rows -- the needed local ids of that owner first, the rest repeating its local row 0
+    (fetched and written again with its own content: harmless) -- so both collectives have static, equal splits: no count
+    exchange, no ``nonzero`` / ``.tolist()``, two collectives instead of three, and the step can be captured in a graph.
+    ``capacity`` must bound the distinct rows a rank can need from one owner (ShardedMVIN passes the row references of
+    the rank's batch share, a static number); ``self.overflow`` (device flag, never read here) is set when it did not."""
+    work = self.work if work is None else work
+    W, nl, dev = self.world, self.n_local, self.local.device
+    C = int(min(capacity, nl))
+    m = need_mask.view(W, nl)
+    order = torch.sort(m.to(torch.uint8), dim=1, descending=True, stable=True).indices[:, :C]      # needed local ids first
+    cnt = m.sum(1)
+    valid = torch.arange(C, device=dev)[None, :] < cnt[:, None]
+    ids_local = torch.where(valid, order, torch.zeros_like(order)).to(torch.int32).contiguous()     # [W, C]
+    self.overflow = (cnt > C).any() if getattr(self, "overflow", None) is None else (self.overflow | (cnt > C).any())
+    if W == 1 and not self.always_collective:
+        self.row_scatter(work, ids_local.view(-1), self.row_gather(self.local, ids_local.view(-1)))
+    else:
+        want = torch.empty_like(ids_local)                   # row w: the local ids rank w wants from me
+        dist.all_to_all_single(want, ids_local, group=self.group)
+        out_rows = self.row_gather(self.local, want.view(-1))
+        got = torch.empty((W * C, self.dim), dtype=self.local.dtype, device=dev)
+        dist.all_to_all_single(got, out_rows, group=self.group)
+        dest = (ids_local + (torch.arange(W, device=dev, dtype=torch.int32) * nl)[:, None]).view(-1)
+        self.row_scatter(work, dest, got)
+    row = self.dim * self.local.element_size()
+    self.last_stats = {"mode": "sparse-static", "capacity_per_owner": C, "requested_dev": cnt.sum(),
+                       "wire_bytes_per_rank": (W - 1) * C * (4 + row)}
+    return work
+
+
+ShardedEntityTable.fetch_static = _fetch_static
+
+
+def exchange_wire_bytes(n_entity, row_bytes, world, local_pairs, K, depth, nodes_level=None):
+    """Bytes a rank RECEIVES per step, by exchange design (the measured argument of DESIGN.md section 5):
+      replicate   : every shard to every rank (dense regime): (W-1)/W of the table;
+      partial_sums: SURVEY 8(e)'s owner-side partial sums -- one row-sized vector per requesting node of level
+                    depth-1 and per REMOTE owner (+ nothing else: owners recompute the weights from the replicated
+                    adjacency): local_pairs * K^(depth-1) * (W-1) * row bytes.
+    Partial sums win only while a rank's level-(depth-1) nodes are fewer than n_entity / W -- i.e. for batches far
+    smaller than any BASELINE config (C3 at 65 536 pairs per rank: 2.1 M nodes vs 13 k rows per shard)."""
+    nl = n_local_rows(n_entity, world)
+    nodes = local_pairs * K ** max(depth - 1, 0) if nodes_level is None else nodes_level
+    return {"replicate": (world - 1) * nl * row_bytes, "partial_sums": nodes * (world - 1) * row_bytes}
+
+
 class ShardedMVIN(object):
     """MVIN scoring with the entity table row-sharded over the ranks of ``group``.
 
@@ -237,6 +304,8 @@ class ShardedMVIN(object):
         self._check = os.environ.get("MVIN_DIST_CHECK") == "1"
         self._exchanges = 0
         self._buf_token = [None, None]
+        # sparse regime: fixed-capacity id buffers (no host sync); MVIN_DIST_DYNAMIC=1 keeps the count-exchange form
+        self.static_sparse = os.environ.get("MVIN_DIST_DYNAMIC") != "1"
 
     @classmethod
     def build(cls, args, n_user, n_entity, n_relation, adj_entity, adj_relation, params, shard, rank, world,
@@ -317,7 +386,15 @@ class ShardedMVIN(object):
         if self._regime(item_p.shape[0], global_batch):
             self.table.fetch_all(work)
             return ("dense", self.table.local._version, self.table.refreshes)
-        self.table.fetch(self.needed(item_p, self._ripple_ids(users, mem_h_p, mem_t_p)), work)
+        m = self.model
+        need = mark_needed_static(self.table.work.shape[0], m.adj_entity, item_p, self._depth(),
+                                  self._ripple_ids(users, mem_h_p, mem_t_p))
+        if self.static_sparse:
+            # fixed-capacity buffers: no host sync anywhere in the step (capacity = the batch share's row references)
+            refs = item_p.shape[0] * (sum(m.n_neighbor ** e for e in range(self._depth() + 1)) + 2 * m.n_memory * max(1, m.p_hop))
+            self.table.fetch_static(need, refs, work)
+        else:
+            self.table.fetch(need, work)
         self._exchanges += 1
         return ("sparse", self._exchanges)
 

@@ -12,7 +12,7 @@ for W in (1, 2, 4, 8):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stdout
     d = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     rows.append({"world": W, "emulated": W > 1, "pairs_per_rank": d["config"]["pairs_per_gpu_per_step"] if W == 1 else d["config"]["pairs_per_step_total"] // W,
-                 "ms_per_step": d["ms_per_step"], "projected_value": d["value"],
+                 "ms_per_step": d["ms_per_step"], "projected_value": d.get("projected_value", d["value"]),
                  "fused_kernel_ms": d["roofline"].get("timed_region", d["roofline"]).get("avg_launch_ms")})
 t1 = rows[0]["ms_per_step"]
 for r in rows:

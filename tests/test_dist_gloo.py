@@ -12,8 +12,8 @@ import torch.multiprocessing as mp
 
 from mvin_amd import synth
 from mvin_amd.config import make_args
-from mvin_amd.dist import (ShardedEntityTable, from_shard_space, mark_needed, n_local_rows, permute_adjacency,
-                           permute_ripple_sets, shard_rows, to_shard_space)
+from mvin_amd.dist import (ShardedEntityTable, exchange_wire_bytes, from_shard_space, mark_needed, mark_needed_static,
+                           n_local_rows, permute_adjacency, permute_ripple_sets, shard_rows, to_shard_space)
 from mvin_amd.params import init_params
 
 
@@ -74,6 +74,18 @@ def _worker(rank, world, port, ret):
         need2[[1, 2, 50 + rank]] = True
         work = table.fetch(need2)
         assert torch.equal(work[need2], full_p[need2])
+        # ---- sparse regime with fixed-capacity buffers (no host sync: static splits, two collectives) ----
+        assert torch.equal(mark_needed_static(world * nl, adj_p, items_p, 2, extra_ids=mh_p + mt_p), need)
+        cap = 3 * (1 + 4 + 16 + 2 * 2 * 4)                                 # the batch share's row references: a static bound
+        w3 = table.fetch_static(need, cap, table.new_work_table())
+        assert torch.equal(w3[idx], full_p[idx]) and not bool(table.overflow)
+        touched = w3.abs().sum(1) > 0                                      # beyond the needed rows only the padding row of each owner
+        extra = set(touched.nonzero(as_tuple=True)[0].tolist()) - set(idx.tolist())
+        assert extra <= {w * nl for w in range(world)}
+        assert all(torch.equal(w3[e], full_p[e]) for e in extra)
+        assert table.last_stats["wire_bytes_per_rank"] == (world - 1) * min(cap, nl) * (4 + 4 * full.shape[1])
+        table.fetch_static(need, 2, table.new_work_table())                # too small a capacity is FLAGGED (device flag)
+        assert bool(table.overflow)
         # ---- dense regime: every rank receives every shard ----
         w2 = table.fetch_all(table.new_work_table())
         assert torch.equal(w2, full_p)
@@ -124,6 +136,16 @@ def test_cyclic_partition_and_shard_space():
     w = t.fetch(need)
     assert torch.equal(w[need], full[need]) and not w[~need].any()
     assert torch.equal(t.fetch_all(), full)
+
+
+def test_wire_bytes_argument():
+    """owner-side partial sums against replicating the shards, bytes a rank receives per step."""
+    for nE, row, B, K, L in ((106389, 256, 524288, 32, 2), (113487, 256, 32768, 64, 2), (113487, 256, 64, 128, 3)):
+        b = exchange_wire_bytes(nE, row, 8, B // 8, K, L)
+        assert b["replicate"] == 7 * n_local_rows(nE, 8) * row
+        assert b["partial_sums"] > 9 * b["replicate"]         # every BASELINE config: the tree dwarfs the table (C5: 235 vs 25 MB)
+    small = exchange_wire_bytes(113487, 256, 8, 4, 128, 2)   # 4 pairs per rank at depth 2: 512 nodes < 14 186 rows per shard
+    assert small["partial_sums"] < small["replicate"]
 
 
 def test_mark_needed_matches_bruteforce_tree():
