@@ -233,6 +233,16 @@ class ShardedEntityTable(object):
         return work
 
 
+class _LazyStats(dict):
+    """Exchange statistics whose counts stay on the device until somebody reads them (reading is the host sync)."""
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        return int(v) if torch.is_tensor(v) else v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+
 def _fetch_static(self, need_mask, capacity, work=None):
     """The sparse regime WITHOUT a host sync: fixed-capacity id buffers.  Every rank asks every owner for exactly
     ``C = min(capacity, n_local)`` rows -- the needed local ids of that owner first, the rest repeating its local row 0
@@ -260,8 +270,8 @@ def _fetch_static(self, need_mask, capacity, work=None):
         dest = (ids_local + (torch.arange(W, device=dev, dtype=torch.int32) * nl)[:, None]).view(-1)
         self.row_scatter(work, dest, got)
     row = self.dim * self.local.element_size()
-    self.last_stats = {"mode": "sparse-static", "capacity_per_owner": C, "requested_dev": cnt.sum(),
-                       "wire_bytes_per_rank": (W - 1) * C * (4 + row)}
+    self.last_stats = _LazyStats({"mode": "sparse", "static": True, "capacity_per_owner": C, "requested": cnt.sum(),
+                                  "remote": cnt.sum() - cnt[self.rank], "wire_bytes_per_rank": (W - 1) * C * (4 + row)})
     return work
 
 

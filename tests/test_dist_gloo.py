@@ -83,6 +83,7 @@ def _worker(rank, world, port, ret):
         extra = set(touched.nonzero(as_tuple=True)[0].tolist()) - set(idx.tolist())
         assert extra <= {w * nl for w in range(world)}
         assert all(torch.equal(w3[e], full_p[e]) for e in extra)
+        assert table.last_stats["mode"] == "sparse" and table.last_stats["requested"] == idx.numel()
         assert table.last_stats["wire_bytes_per_rank"] == (world - 1) * min(cap, nl) * (4 + 4 * full.shape[1])
         table.fetch_static(need, 2, table.new_work_table())                # too small a capacity is FLAGGED (device flag)
         assert bool(table.overflow)
