@@ -807,9 +807,10 @@ static hipError_t launch_packed(const FusedL2Args& a, hipStream_t st) {
     // few enough that the weight fragments and the id prologue are amortised
     static const char* env = getenv("MVIN_PACK_PPW");
     int64_t ppw = env ? atoi(env) : 0;
-    if (ppw <= 0) {
-        ppw = (a.P + 2047) / 2048;
-        if (ppw < 8) ppw = 8;
+    if (ppw <= 0) {          // measured (MVIN_PACK_PPW sweeps at 512 / 4 096 / 65 536 / 524 288 parents): ~512 workgroups, 2 .. 256 parents each
+        ppw = (a.P + 511) / 512;
+        if (ppw < 2) ppw = 2;
+        if (ppw > 256) ppw = 256;
     }
     if (ppw > kPackCH) ppw = kPackCH;
     const int64_t grid = (a.P + ppw - 1) / ppw;
