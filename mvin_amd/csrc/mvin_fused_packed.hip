@@ -102,7 +102,8 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG) {
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };   // 16-byte aligned pieces
     l.sA = take(2 * 32 * (size_t)(2 * D + 2));
     l.sZ = take(32 * (size_t)(D + 2));
-    l.sYP = take(32 * (size_t)(K + 1) * 2 + 2);         // ids [32][K+1] + a zero entry, then weights likewise
+    l.sYP = take(48 * (size_t)(K + 1) * 2);             // ids [48][K+1], then weights likewise (48: the lists of the second
+                                                        // gather round are double-buffered, see list_base)
     l.sW0 = take(3 * 32);                               // the segment tables are a ring of three tiles
     l.sW1 = take(3 * 32);
     l.sSeg = take(3 * 32);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     float* sA = smem + L.sA;                            // [2][TM][LDA]  {E[x1] + q | S' + (sum p / K) q}
     float* sZ = smem + L.sZ;                            // [TM][LDZ]
     int* sYI = reinterpret_cast<int*>(smem + L.sYP);    // [TM][YLD]  grandchild ids; rows private to a front wave
-    float* sYW = smem + L.sYP + TM * YLD + 1;           // [TM][YLD]  their weights; entry TM * YLD of both: (entity 0, weight 0)
+    float* sYW = smem + L.sYP + 48 * YLD;               // [48][YLD]  their weights
     float* sW0 = smem + L.sW0;                          // [2][TM]  weight of the row in its parent's nagg0 (p0 m / K)
     float* sW1 = smem + L.sW1;                          // [2][TM]  ... nagg1
     int* sSeg = reinterpret_cast<int*>(smem + L.sSeg);  // [2][TM]  segment (parent of the tile) the row belongs to
@@ -187,11 +188,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         sT0[i] = has_att0 ? a.t0[i] : 0.f;
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
-    if (tid == 0) {
-        sCnt[0] = 0;
-        sYI[TM * YLD] = 0;
-        sYW[TM * YLD] = 0.f;
-    }
+    if (tid == 0) sCnt[0] = 0;
     for (int i = tid; i < D; i += G::NW * 64) {
         sBias[i] = a.a0 ? a.a0[i] : 0.f;
         sBias[D + i] = (has_proj && a.b1) ? a.b1[i] : 0.f;
@@ -207,13 +204,149 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     }
     __syncthreads();
 
+    // =====================================================================================
+    // what both roles use: table rows, list slots, the row gather
+    // =====================================================================================
+    const float c2scale = has_att0 ? invK : 1.f;        // (sum_k p_k) / K
+    const int g = lane / G::LPRX, c = lane % G::LPRX;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
+    const unsigned c16 = (unsigned)c * 16u;
+    // a table row as this lane's EPL elements
+    auto rowload = [&](int id, float4& lo, float4& hi) {
+        if constexpr (G::WIDE) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 2)) + c16, 0, 0);
+            lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
+            hi = bf16x4_to_f32(make_uint2(raw[2], raw[3]));
+        } else if constexpr (BF) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)id * (unsigned)(D * 2)) + (unsigned)c * 8u, 0, 0);
+            lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
+        } else {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+            lo = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
+        }
+    };
+    auto put = [&](float* dst, float4 lo, float4 hi) {
+        float* q = dst + G::EPL * c;
+        *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
+        *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
+        if constexpr (G::WIDE) {
+            *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
+            *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
+        }
+    };
+    // ---- which rows a front wave owns: the tile's 32 rows are ranked by the length of their lists (classes of 1 << SH
+    // entries, the granularity of a load batch; longest first), rank p goes to slot p (p < NS) or, on the way back, to slot
+    // 2 NS - 1 - p, ... (a snake over NS = 32 / NRND slots), slot i to wave i % NG, lane group i / NG: round h of a wave
+    // gathers the h-th rows of its lane groups, of similar length, and the waves of a tile issue about the same number of
+    // row loads.  HELP (two rounds per wave: D = 64, or D = 128 on a bf16 table): the SECOND round -- the short lists -- is
+    // gathered by dense wave gw, in the time it would otherwise wait for the front (the front is the critical path: 19 k
+    // cycles per tile against 8 k of MFMA phases); its lists are double-buffered by tile parity, because the front wave
+    // rewrites them for the next tile while the dense wave may still walk them. ----
+    constexpr int NRND = G::NRND, NS = TM / NRND;
+    constexpr bool HELP = NRND == 2;
+    constexpr int SH = KT >= 32 ? (KT == 32 ? 2 : KT == 64 ? 3 : 4) : 1;
+    auto rank_of = [&](int gwx, int h, int grp) -> int {    // rank of the h-th row of lane group grp of front wave gwx
+        const int slot = grp * NG + gwx;
+        return (h & 1) ? (h + 1) * NS - 1 - slot : h * NS + slot;
+    };
+    auto list_base = [&](int gwx, int h, int grp, int par) -> int {     // first entry of that row's (id, weight) list
+        if constexpr (HELP) return (h == 0 ? gwx * G::RPWX + grp : (1 + par) * NG * G::RPWX + gwx * G::RPWX + grp) * YLD;
+        else return (gwx * G::RPW + h * G::RPWX + grp) * YLD;
+    };
+    // gather rounds [h0, h1) of front wave gwx's rows of the tile with parity `par` -> sA[buf]; MAXB list rows in flight
+    auto gather_rounds = [&](int gwx, int par, int buf, int h0, int h1, auto maxb_c) {
+        constexpr int MAXB = decltype(maxb_c)::value;
+        const int* src = sPR + (gwx * 2 + par) * 96;
+        int rr[NRND], xx[NRND], qq[NRND], cn[NRND], cmx[NRND];
+#pragma unroll
+        for (int h = 0; h < NRND; ++h) {
+            const int p = rank_of(gwx, h, g);
+            const int v = src[p];
+            rr[h] = v & 31;
+            cn[h] = v >> 8;
+            xx[h] = src[32 + p];
+            qq[h] = src[64 + p];
+        }
+#pragma unroll
+        for (int h = 0; h < NRND; ++h) {                 // longest list of the round (wave-uniform)
+            cmx[h] = __builtin_amdgcn_readfirstlane((int)wave_max((float)cn[h]));
+            if constexpr (PROF) {
+                if (a.dbg & 2) cmx[h] = 0;               // floor without the row gathers
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NRND; ++h) {
+            if (h < h0 || h >= h1) continue;
+            const int cmax = cmx[h];
+            const int lb = list_base(gwx, h, g, par);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
+            float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
+            // NB list rows in flight (entries past the list have weight 0: children() pads to K).  FIRST: behind the
+            // child row and the query row, which are finished (E[x1] + q stored, (sum p / K) q added to the sum) as soon
+            // as they land
+            auto batch = [&](auto nb_c, auto first_c, int k0) {
+                constexpr int NB = decltype(nb_c)::value;
+                constexpr bool FIRST = decltype(first_c)::value;
+                float4 sv, sv1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                u32x4 qa = (u32x4){0u, 0u, 0u, 0u}, qb = qa;
+                if constexpr (FIRST) {
+                    rowload(xx[h], sv, sv1);
+                    // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
+                    const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
+                    qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
+                    if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
+                }
+                float4 lo[NB], hi[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) rowload(sYI[lb + k0 + i], lo[i], hi[i]);
+                if constexpr (FIRST) {
+                    const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
+                    const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
+                    put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                  // E[x1] + q
+                    acc = f4_fma(c2scale, q0, acc);                                        // S' + (sum p / K) q
+                    if constexpr (G::WIDE) acc1 = f4_fma(c2scale, q1, acc1);
+                }
+                // the weights are read when the rows are consumed: not live while the loads are in flight
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+                    const float w = sYW[lb + k0 + i];
+                    acc = f4_fma(w, lo[i], acc);
+                    if constexpr (G::WIDE) acc1 = f4_fma(w, hi[i], acc1);
+                }
+            };
+            using std::integral_constant;
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            constexpr int NBF = MAXB >= 16 ? 12 : 4;             // list rows in the first batch (2 more loads ride in it)
+            int k0;
+            if (NBF >= 12 && cmax > 8) {
+                batch(integral_constant<int, NBF>{}, T_{}, 0);
+                k0 = NBF;
+            } else if (NBF >= 12 && cmax > 4) {
+                batch(integral_constant<int, (NBF >= 12 ? 8 : 4)>{}, T_{}, 0);
+                k0 = 8;
+            } else {
+                batch(integral_constant<int, 4>{}, T_{}, 0);
+                k0 = 4;
+            }
+            for (; k0 + MAXB <= cmax; k0 += MAXB) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+            const int rem = cmax - k0;
+            if (rem > 8) batch(integral_constant<int, MAXB>{}, F_{}, k0);
+            else if (rem > 4) batch(integral_constant<int, 8>{}, F_{}, k0);
+            else if (rem > 0) batch(integral_constant<int, 4>{}, F_{}, k0);
+            put(arow + D, acc, acc1);
+        }
+    };
+
     if (is_dense) {
         // =====================================================================================
         // dense waves: MFMA phases of tile s-1
         // =====================================================================================
         const int q16 = lane >> 4, l16 = lane & 15;
         const int col = 16 * wave + l16;
-        const float c2scale = has_att0 ? invK : 1.f;    // (sum_k p_k) / K
         float bW1[KS], bW2[KS], bA0[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -224,6 +357,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         }
         float* carry = sCarry + wave * 32;
         int dense_iter = 0;
+        constexpr int DMAXB = 8;                         // list rows in flight in the helping gather (the weights stay resident)
+        __syncthreads();                                 // the front's prologue: lists and rank tables of tile 0
+        if constexpr (HELP) {
+            if (wave < NG) gather_rounds(wave, 0, 0, 1, 2, std::integral_constant<int, DMAXB>{});
+        }
         if constexpr (PROF) prof_last = __builtin_readcyclecounter();
         for (int64_t s = 1;; ++s) {
             __syncthreads();                            // tile s-1 is in sA[(s-1) & 1]
@@ -365,6 +503,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 }
             }
             tick(3);
+            if constexpr (HELP) {                        // the second gather round of tile s (if there is one)
+                if (wave < NG && sMeta[2 * (int)(s % 3)] != 0)
+                    gather_rounds(wave, (int)(s & 1), (int)(s & 1), 1, 2, std::integral_constant<int, DMAXB>{});
+            }
+            tick(4);
             if constexpr (PROF) prof_acc[7] += 1;
         }
         if (wave == 0) prof_flush(0);
@@ -373,36 +516,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         // front waves: tile s -> sA[s & 1] and its segment tables
         // =====================================================================================
         const int gw = wave - NM;
-        const float c2scale = has_att0 ? invK : 1.f;
-        const int g = lane / G::LPRX, c = lane % G::LPRX;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
-        const unsigned c16 = (unsigned)c * 16u;
-        // a table row as this lane's EPL elements
-        auto rowload = [&](int id, float4& lo, float4& hi) {
-            if constexpr (G::WIDE) {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 2)) + c16, 0, 0);
-                lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
-                hi = bf16x4_to_f32(make_uint2(raw[2], raw[3]));
-            } else if constexpr (BF) {
-                const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)id * (unsigned)(D * 2)) + (unsigned)c * 8u, 0, 0);
-                lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
-            } else {
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
-                lo = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
-            }
-        };
-        auto put = [&](float* dst, float4 lo, float4 hi) {
-            float* q = dst + G::EPL * c;
-            *reinterpret_cast<float2*>(q) = make_float2(lo.x, lo.y);
-            *reinterpret_cast<float2*>(q + 2) = make_float2(lo.z, lo.w);
-            if constexpr (G::WIDE) {
-                *reinterpret_cast<float2*>(q + 4) = make_float2(hi.x, hi.y);
-                *reinterpret_cast<float2*>(q + 6) = make_float2(hi.z, hi.w);
-            }
-        };
         struct Tile {
             int i0, c0;          // first parent (local index), children of it placed in earlier tiles
             int nseg, rows;      // parents in the tile (0: no tile), child rows
@@ -452,17 +565,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             seg = __popc(below);
             const int st_r = below ? 32 - __clz((int)below) : 0;
             slot = r - st_r + (seg == 0 ? t.c0 : 0);
-        };
-        // ---- which rows a front wave owns: the tile's 32 rows are ranked by the length of their lists (classes of 1 << SH
-        // entries, the granularity of a load batch; longest first), rank p goes to slot p (p < NS) or, on the way back, to slot
-        // 2 NS - 1 - p, ... (a snake over NS = 32 / NRND slots), slot i to wave i % NG, lane group i / NG.  A lane group walks
-        // the lists of its NRND rows as ONE sequence, so a long list shares its group with short ones and the waves of a
-        // tile issue about the same number of row loads. ----
-        constexpr int NRND = G::NRND, NS = TM / NRND;
-        constexpr int SH = KT >= 32 ? (KT == 32 ? 2 : KT == 64 ? 3 : 4) : 1;
-        auto rank_of = [&](int h, int grp) -> int {      // rank of the h-th row of lane group grp of this wave
-            const int slot = grp * NG + gw;
-            return (h & 1) ? (h + 1) * NS - 1 - slot : h * NS + slot;
         };
         struct Ids {
             int prw[G::NP2][G::SPL];     // relation words of this wave's parent rows
@@ -532,7 +634,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 int lr = ps * G::RPP + lane / G::LPN;
                 lr = lr < G::RPW ? lr : G::RPW - 1;
                 const int ch = lane % G::LPN;
-                const unsigned xid = (unsigned)src[32 + rank_of(lr / G::RPWX, lr % G::RPWX)];
+                const unsigned xid = (unsigned)src[32 + rank_of(gw, lr / G::RPWX, lr % G::RPWX)];
                 const unsigned off = (xid * KT + 4u * ch) * 4u;
                 const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, off, 0, 0);
                 ye[ps] = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
@@ -609,7 +711,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 const int lr0 = ps * G::RPP + lane / G::LPN;
                 const bool lv = lr0 < G::RPW;
                 const int lr = lv ? lr0 : G::RPW - 1;
-                const int r = src[rank_of(lr / G::RPWX, lr % G::RPWX)] & 31;
                 const int ch = lane % G::LPN;
                 const unsigned w4[4] = {(unsigned)re[ps].x, (unsigned)re[ps].y, (unsigned)re[ps].z, (unsigned)re[ps].w};
                 float sc[4], mu[4];
@@ -633,8 +734,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     const float rr = has_att0 ? invK / z : invK;
                     // list slot = (wave, local row), not the tile row: a tile row changes owner from tile to tile, and another
                     // wave may still be walking the previous tile's list of that row
-                    int* di = sYI + (gw * G::RPW + lr) * YLD + 4 * ch;
-                    float* dw = sYW + (gw * G::RPW + lr) * YLD + 4 * ch;
+                    const int lb = list_base(gw, lr / G::RPWX, lr % G::RPWX, par) + 4 * ch;
+                    int* di = sYI + lb;
+                    float* dw = sYW + lb;
                     const unsigned idm = a.max_id;
                     di[0] = (int)(((unsigned)ye[ps].x & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].x & 0xFFFFFFu) : idm);
                     di[1] = (int)(((unsigned)ye[ps].y & 0xFFFFFFu) < idm ? ((unsigned)ye[ps].y & 0xFFFFFFu) : idm);
@@ -647,91 +749,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 }
             }
         };
-        // gather: lane group g walks the lists of its NRND rows, one row after the other (round h: the h-th rows of the
-        // wave's lane groups, of similar length thanks to the ranking) -> sA[buf]
-        auto gather = [&](int par, int buf) {
-            const int* src = sPR + (gw * 2 + par) * 96;
-            int rr[NRND], xx[NRND], qq[NRND], cn[NRND], cmx[NRND];
-#pragma unroll
-            for (int h = 0; h < NRND; ++h) {
-                const int p = rank_of(h, g);
-                const int v = src[p];
-                rr[h] = v & 31;
-                cn[h] = v >> 8;
-                xx[h] = src[32 + p];
-                qq[h] = src[64 + p];
-            }
-#pragma unroll
-            for (int h = 0; h < NRND; ++h) {             // longest list of the round (wave-uniform)
-                cmx[h] = __builtin_amdgcn_readfirstlane((int)wave_max((float)cn[h]));
-                if constexpr (PROF) {
-                    if (a.dbg & 2) cmx[h] = 0;           // floor without the row gathers
-                }
-            }
-#pragma unroll
-            for (int h = 0; h < NRND; ++h) {
-                const int cmax = cmx[h];
-                const int lb = (gw * G::RPW + h * G::RPWX + g) * YLD;     // this row's list
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc;
-                float* arow = sA + ((size_t)buf * TM + rr[h]) * LDA;
-                // NB list rows in flight (entries past the list have weight 0: children() pads to K).  FIRST: behind the
-                // child row and the query row, which are finished (E[x1] + q stored, (sum p / K) q added to the sum) as soon
-                // as they land
-                auto batch = [&](auto nb_c, auto first_c, int k0) {
-                    constexpr int NB = decltype(nb_c)::value;
-                    constexpr bool FIRST = decltype(first_c)::value;
-                    float4 sv, sv1 = make_float4(0.f, 0.f, 0.f, 0.f);
-                    u32x4 qa = (u32x4){0u, 0u, 0u, 0u}, qb = qa;
-                    if constexpr (FIRST) {
-                        rowload(xx[h], sv, sv1);
-                        // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
-                        const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
-                        qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
-                        if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
-                    }
-                    float4 lo[NB], hi[NB];
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) rowload(sYI[lb + k0 + i], lo[i], hi[i]);
-                    if constexpr (FIRST) {
-                        const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
-                        const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
-                        put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                  // E[x1] + q
-                        acc = f4_fma(c2scale, q0, acc);                                        // S' + (sum p / K) q
-                        if constexpr (G::WIDE) acc1 = f4_fma(c2scale, q1, acc1);
-                    }
-                    // the weights are read when the rows are consumed: not live while the loads are in flight
-#pragma unroll
-                    for (int i = 0; i < NB; ++i) {
-                        const float w = sYW[lb + k0 + i];
-                        acc = f4_fma(w, lo[i], acc);
-                        if constexpr (G::WIDE) acc1 = f4_fma(w, hi[i], acc1);
-                    }
-                };
-                using std::integral_constant;
-                using T_ = std::true_type;
-                using F_ = std::false_type;
-                constexpr int MAXB = G::WIDE ? 8 : kPackMaxB;        // list rows in flight per lane
-                constexpr int NBF = G::WIDE ? 4 : 12;                // ... in the first batch
-                int k0;
-                if (NBF >= 12 && cmax > 8) {
-                    batch(integral_constant<int, NBF>{}, T_{}, 0);
-                    k0 = NBF;
-                } else if (NBF >= 8 && cmax > 4) {
-                    batch(integral_constant<int, (NBF >= 8 ? 8 : 4)>{}, T_{}, 0);
-                    k0 = 8;
-                } else {
-                    batch(integral_constant<int, 4>{}, T_{}, 0);
-                    k0 = 4;
-                }
-                for (; k0 + MAXB <= cmax; k0 += MAXB) batch(integral_constant<int, MAXB>{}, F_{}, k0);
-                const int rem = cmax - k0;
-                if (rem > 8) batch(integral_constant<int, MAXB>{}, F_{}, k0);
-                else if (rem > 4) batch(integral_constant<int, 8>{}, F_{}, k0);
-                else if (rem > 0) batch(integral_constant<int, 4>{}, F_{}, k0);
-                put(arow + D, acc, acc1);
-            }
-        };
-
         // ---- software pipeline over the tiles: while tile s is gathered, the adjacency chunks of tile s+1 and the parent
         // rows / child words of tile s+2 are in flight, so no step waits for an id fetch it has just issued.  Every id load
         // and its use is unconditional (a tile past the end packs to zero rows and loads clamped addresses), and the step
@@ -753,6 +770,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         issue_ids(tc, dc);
         advance(tc, i0, c0);
         wave_lds_sync();
+        __syncthreads();                                 // tile 0's lists and rank tables are visible to the helping dense waves
         if constexpr (PROF) prof_last = __builtin_readcyclecounter();
         // here: tile 0's lists are in LDS; (tc, dc) = tile 1 with its ids in flight
         bool have = true;                                // tile s exists
@@ -768,7 +786,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             issue_ids(tc, dc);
             advance(tc, i0, c0);
             tick(0);
-            gather(par, par);
+            gather_rounds(gw, par, par, 0, HELP ? 1 : NRND, std::integral_constant<int, G::WIDE ? 8 : kPackMaxB>{});
             tick(1);
             wave_lds_sync();                             // the lists of tile s are consumed; sSt of tile s+2 is written
             parents(tb, db, par1, (int)((s + 1) % 3));   // (no tile s+1: zero segments = the end mark of the dense waves)
