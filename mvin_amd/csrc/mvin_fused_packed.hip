@@ -786,7 +786,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             issue_ids(tc, dc);
             advance(tc, i0, c0);
             tick(0);
-            gather_rounds(gw, par, par, 0, HELP ? 1 : NRND, std::integral_constant<int, G::WIDE ? 8 : kPackMaxB>{});
+            gather_rounds(gw, par, par, 0, HELP ? 1 : NRND, std::integral_constant<int, (G::WIDE || KT >= 128) ? 8 : kPackMaxB>{});     // (K = 128: the id pipeline holds 40 registers)
             tick(1);
             wave_lds_sync();                             // the lists of tile s are consumed; sSt of tile s+2 is written
             parents(tb, db, par1, (int)((s + 1) % 3));   // (no tile s+1: zero segments = the end mark of the dense waves)
