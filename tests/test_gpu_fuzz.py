@@ -168,6 +168,16 @@ def test_random_large_shapes_fused_against_per_level(i, hip_lib):
     what = f"case {i}: D={D} K={K} H={H} B={B} nE={n_entity} nU={n_user} P={P} Nm={Nm} nR={nR} {tdt} {feed} {abl} rows/pair={rows}"
     args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
     adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=61000 + i)
+    repeats = bool(rng.random() < 0.6)        # rows as contruct_random_adj builds them for low-degree entities (:383-384)
+    if repeats:
+        pool_e, pool_r = rng.integers(0, n_entity, (n_entity, 8)), rng.integers(0, nR, (n_entity, 8))
+        deg = rng.integers(1, 9, n_entity)
+        pick = (rng.random((n_entity, K)) * deg[:, None]).astype(np.int64)
+        low = rng.random(n_entity) < 0.7                              # the rest keep K independent draws (hubs)
+        adj_e[low] = np.take_along_axis(pool_e, pick, 1)[low]
+        adj_r[low] = np.take_along_axis(pool_r, pick, 1)[low]
+    force_enc = bool(rng.random() < 0.5)      # the packed-tile kernel also below its auto thresholds
+    what += f" repeats={repeats} force_enc={force_enc}"
     adj_e[:3] = 0                                                    # entities absent from the KG
     adj_r[:3] = 0
     params = init_params(args, n_user, n_entity, nR, seed=62000 + i, random_agg_bias=True)
@@ -177,6 +187,8 @@ def test_random_large_shapes_fused_against_per_level(i, hip_lib):
     outs = []
     for fused in (True, False):
         model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0", fused=fused, table_dtype=tdt)
+        if force_enc and fused:
+            model.dedup = True
         dev = model.device
         u_d, i_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev)
         if feed == "pairs":
