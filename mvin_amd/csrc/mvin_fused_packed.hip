@@ -111,7 +111,7 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG) {
     l.sSegF = take(3 * 16);
     l.sMeta = take(3 * 2);
     l.sPR = take((size_t)NG * 2 * 96);                  // per front wave, two tiles: rows by rank | child entity | query row
-    l.sSt = take((size_t)NG * 2 * 16);
+    l.sSt = take((size_t)(NG + NM) * 2 * 16);           // per wave (front and dense), two tiles
     l.sCarry = take(NM * 2 * 16);
     l.sCnt = take(2);
     l.sT0 = take(nRp);
@@ -156,7 +156,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     unsigned char* sPcnt = reinterpret_cast<unsigned char*>(smem + L.sPcnt);   // [ppw] distinct children
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    int lane = tid & 63;                                // (not const: the dense loop re-defines it, see there)
+    const int wave = tid >> 6;
     const bool is_dense = wave < NM;
     const bool has_proj = a.W1 != nullptr;
     const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
@@ -208,12 +209,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     // what both roles use: table rows, list slots, the row gather
     // =====================================================================================
     const float c2scale = has_att0 ? invK : 1.f;        // (sum_k p_k) / K
-    const int g = lane / G::LPRX, c = lane % G::LPRX;
+    int g = lane / G::LPRX, c = lane % G::LPRX;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
-    const unsigned c16 = (unsigned)c * 16u;
+    unsigned c16 = (unsigned)c * 16u;
     // a table row as this lane's EPL elements
     auto rowload = [&](int id, float4& lo, float4& hi) {
         if constexpr (G::WIDE) {
@@ -341,12 +342,152 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         }
     };
 
+    // DPAR: the parent softmax (segment tables of the next tile) runs on the dense waves, in their slack, not on the front
+    constexpr bool DPAR = HELP && NM >= NG;
+    struct Tile {
+        int i0, c0;          // first parent (local index), children of it placed in earlier tiles
+        int nseg, rows;      // parents in the tile (0: no tile), child rows
+        int st_last;         // first row of the last parent
+        bool open;           // the last parent continues in the next tile
+        unsigned Em;         // bit (end row - 1) of every parent
+    };
+    // pack: which parents fill the tile that starts at (i0, c0) (every wave that needs it computes the same thing);
+    // segment starts -> sSt[slot]
+    auto pack = [&](int i0, int c0, int slot) -> Tile {
+        Tile t{i0, c0, 0, 0, 0, false, 0u};
+        const int j16 = lane & 15;
+        int cj = (i0 + j16 < n_loc) ? (int)sPcnt[i0 + j16] : 0;
+        if (j16 == 0) cj -= c0;
+        int e = cj;
+        e += dpp_row_shr<1>(e);
+        e += dpp_row_shr<2>(e);
+        e += dpp_row_shr<4>(e);
+        e += dpp_row_shr<8>(e);
+        const int st = e - cj;                       // first row of segment j16
+        const bool in = (i0 + j16 < n_loc) && st < TM;
+        t.nseg = __popcll(__ballot(in) & 0xFFFFull);
+        const int last = t.nseg > 0 ? t.nseg - 1 : 0;    // (no parents left: zero rows)
+        const int e_last = __builtin_amdgcn_readlane(e, last);
+        t.st_last = __builtin_amdgcn_readlane(st, last);
+        t.rows = t.nseg == 0 ? 0 : (e_last < TM ? e_last : TM);
+        t.open = t.nseg != 0 && e_last > TM;
+        t.Em = __builtin_amdgcn_readfirstlane(row_or16(in ? (1u << ((e < TM ? e : TM) - 1)) : 0u));
+        if (lane < 16) sSt[(wave * 2 + slot) * 16 + lane] = st;
+        return t;
+    };
+    auto advance = [&](const Tile& t, int& i0, int& c0) {
+        if (t.nseg == 0) {
+            c0 = 0;
+            i0 = t.i0;
+        } else if (t.open) {
+            c0 = (t.nseg == 1 ? t.c0 : 0) + (TM - t.st_last);
+            i0 = t.i0 + t.nseg - 1;
+        } else {
+            c0 = 0;
+            i0 = t.i0 + t.nseg;
+        }
+    };
+    // row r -> segment, slot of the parent's encoded adjacency row
+    auto row_seg = [&](const Tile& t, int r, int& seg, int& slot) {
+        const unsigned below = t.Em & ((1u << r) - 1u);     // segment ends before r
+        seg = __popc(below);
+        const int st_r = below ? 32 - __clz((int)below) : 0;
+        slot = r - st_r + (seg == 0 ? t.c0 : 0);
+    };
+    // issue: the parent rows (relation words) of the segments of quarter wv
+    auto issue_prw = [&](const Tile& t, int (&prw)[G::NP2][G::SPL], int wv) {
+    const int j16 = lane & 15;
+#pragma unroll
+    for (int ps = 0; ps < G::NP2; ++ps) {
+        const int sg = wv * G::SEGW + 4 * ps + (lane >> 4);
+        const int pi = t.i0 + sg < n_loc ? t.i0 + sg : n_loc - 1;
+        const unsigned off = ((unsigned)sPid[pi] * KT + (unsigned)j16 * G::SPL) * 4u;
+        if constexpr (G::SPL == 1) {
+            prw[ps][0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
+        } else if constexpr (G::SPL == 2) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(adjR, off, 0, 0);
+            prw[ps][0] = (int)v[0];
+            prw[ps][1] = (int)v[1];
+        } else {
+#pragma unroll
+            for (int h = 0; h < G::SPL / 4; ++h) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(adjR, off + 16u * h, 0, 0);
+                prw[ps][4 * h + 0] = (int)v[0];
+                prw[ps][4 * h + 1] = (int)v[1];
+                prw[ps][4 * h + 2] = (int)v[2];
+                prw[ps][4 * h + 3] = (int)v[3];
+            }
+        }
+    }
+    };
+    // parents: softmax over the distinct slots -> row weights and segment tables of the tile, ring slot mb
+    auto parents = [&](const Tile& t, const int (&prw)[G::NP2][G::SPL], int slot, int mb, int wv) {
+        const int j16 = lane & 15;
+#pragma unroll
+        for (int ps = 0; ps < G::NP2; ++ps) {
+            const int sg = wv * G::SEGW + 4 * ps + (lane >> 4);
+            const bool sv = sg < t.nseg;
+            float s0[G::SPL], s1[G::SPL], mu[G::SPL];
+            float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < G::SPL; ++i) {
+                const unsigned w = (unsigned)prw[ps][i];
+                const int rel = (int)(w & 0xFFFFu) < a.nR ? (int)(w & 0xFFFFu) : 0;
+                mu[i] = (float)((w >> 16) & 0xFFu);
+                s0[i] = sT0[rel];
+                s1[i] = sT1[rel];
+                m0 = fmaxf(m0, mu[i] > 0.f ? s0[i] : -INFINITY);
+                m1 = fmaxf(m1, mu[i] > 0.f ? s1[i] : -INFINITY);
+            }
+            m0 = group_max(m0, 4);
+            m1 = group_max(m1, 4);
+            float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::SPL; ++i) {
+                s0[i] = has_att0 ? mu[i] * lean_exp(s0[i] - m0) : mu[i];
+                s1[i] = has_att1 ? mu[i] * lean_exp(s1[i] - m1) : mu[i];
+                z0 += s0[i];
+                z1 += s1[i];
+            }
+            z0 = group_sum(z0, 4);
+            z1 = group_sum(z1, 4);
+            const float r0 = has_att0 ? invK / z0 : invK, r1 = has_att1 ? invK / z1 : invK;
+            const int stg = sSt[(wave * 2 + slot) * 16 + (sg & 15)];
+            const int c0s = sg == 0 ? t.c0 : 0;
+#pragma unroll
+            for (int i = 0; i < G::SPL; ++i) {
+                const int sl = j16 * G::SPL + i;
+                const int rowi = stg + sl - c0s;
+                if (sv && mu[i] > 0.f && sl >= c0s && rowi < TM) {
+                    sW0[mb * TM + rowi] = s0[i] * r0;
+                    sW1[mb * TM + rowi] = s1[i] * r1;
+                    sSeg[mb * TM + rowi] = sg;
+                }
+            }
+            if (j16 == 0) {
+                sSegP[mb * 16 + sg] = sv ? (int)(p_base + t.i0 + sg) : -1;      // P * D * 4 < 2^31: fits an int
+                sSegF[mb * 16 + sg] = ((sg == 0 && t.c0 > 0) ? 1 : 0) | ((sg == t.nseg - 1 && t.open) ? 2 : 0);
+            }
+        }
+        if (wv == 0) {
+            if (lane < TM && lane >= t.rows) {       // padding rows of a last, partial tile
+                sW0[mb * TM + lane] = 0.f;
+                sW1[mb * TM + lane] = 0.f;
+                sSeg[mb * TM + lane] = 0;
+            }
+            if (lane == 0) {
+                sMeta[2 * mb] = t.nseg;
+                sMeta[2 * mb + 1] = t.rows;
+            }
+        }
+    };
+
     if (is_dense) {
         // =====================================================================================
         // dense waves: MFMA phases of tile s-1
         // =====================================================================================
-        const int q16 = lane >> 4, l16 = lane & 15;
-        const int col = 16 * wave + l16;
+        int q16 = lane >> 4, l16 = lane & 15;
+        int col = 16 * wave + l16;
         float bW1[KS], bW2[KS], bA0[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -358,13 +499,44 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         float* carry = sCarry + wave * 32;
         int dense_iter = 0;
         constexpr int DMAXB = 8;                         // list rows in flight in the helping gather (the weights stay resident)
+        // DPAR: dense wave w < NG walks the tiles itself (same packing as the front), one tile ahead of the front's gather, and
+        // writes the segment tables of quarter w.  Parent rows are issued AFTER the MFMA phases and consumed behind the helping
+        // gather: nothing of it is live across the phases (their accumulators + the resident weights fill the budget)
+        int di0 = 0, dc0 = 0;
+        const bool dpar = DPAR && wave < NG;
+        auto dense_parents = [&](int slot, int mb, auto&& between) {
+            Tile dt = pack(di0, dc0, slot);
+            int dprw[G::NP2][G::SPL];
+            issue_prw(dt, dprw, wave);
+            advance(dt, di0, dc0);
+            between();
+            wave_lds_sync();
+            parents(dt, dprw, slot, mb, wave);
+        };
+        if (dpar) dense_parents(0, 0, [] {});            // tile 0 -> ring slot 0
         __syncthreads();                                 // the front's prologue: lists and rank tables of tile 0
-        if constexpr (HELP) {
-            if (wave < NG) gather_rounds(wave, 0, 0, 1, 2, std::integral_constant<int, DMAXB>{});
+        {
+            auto help = [&] {
+                if constexpr (HELP) {
+                    if (wave < NG) gather_rounds(wave, 0, 0, 1, 2, std::integral_constant<int, DMAXB>{});
+                }
+            };
+            if (dpar) dense_parents(1, 1, help);         // tile 1 -> ring slot 1 (zero segments: the end mark)
+            else help();
         }
         if constexpr (PROF) prof_last = __builtin_readcyclecounter();
         for (int64_t s = 1;; ++s) {
             __syncthreads();                            // tile s-1 is in sA[(s-1) & 1]
+            // Everything derived from the lane id is RE-derived per tile from an opaque copy: left loop-invariant, hipcc keeps
+            // the address constants of the MFMA phases, of the helping gather and of the parent softmax live together across
+            // the whole loop and spills 20 of them (each reload a vmcnt(0) in front of phase B); recomputing costs ~20 VALU
+            asm volatile("" : "+v"(lane));
+            q16 = lane >> 4;
+            l16 = lane & 15;
+            col = 16 * wave + l16;
+            g = lane / G::LPRX;
+            c = lane % G::LPRX;
+            c16 = (unsigned)c * 16u;
             tick(0);
             const int buf = (int)((s - 1) & 1);        // sA half
             const int mb = (int)((s - 1) % 3);         // segment tables: ring of three
@@ -503,9 +675,15 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 }
             }
             tick(3);
-            if constexpr (HELP) {                        // the second gather round of tile s (if there is one)
-                if (wave < NG && sMeta[2 * (int)(s % 3)] != 0)
-                    gather_rounds(wave, (int)(s & 1), (int)(s & 1), 1, 2, std::integral_constant<int, DMAXB>{});
+            {
+                auto help = [&] {                        // the second gather round of tile s (if there is one)
+                    if constexpr (HELP) {
+                        if (wave < NG && sMeta[2 * (int)(s % 3)] != 0)
+                            gather_rounds(wave, (int)(s & 1), (int)(s & 1), 1, 2, std::integral_constant<int, DMAXB>{});
+                    }
+                };
+                if (dpar) dense_parents((int)((s + 1) & 1), (int)((s + 1) % 3), help);     // + the segment tables of tile s+1
+                else help();
             }
             tick(4);
             if constexpr (PROF) prof_acc[7] += 1;
@@ -516,56 +694,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         // front waves: tile s -> sA[s & 1] and its segment tables
         // =====================================================================================
         const int gw = wave - NM;
-        struct Tile {
-            int i0, c0;          // first parent (local index), children of it placed in earlier tiles
-            int nseg, rows;      // parents in the tile (0: no tile), child rows
-            int st_last;         // first row of the last parent
-            bool open;           // the last parent continues in the next tile
-            unsigned Em;         // bit (end row - 1) of every parent
-        };
-        // pack: which parents fill the tile that starts at (i0, c0) (every front wave computes the same thing);
-        // segment starts -> sSt[slot]
-        auto pack = [&](int i0, int c0, int slot) -> Tile {
-            Tile t{i0, c0, 0, 0, 0, false, 0u};
-            const int j16 = lane & 15;
-            int cj = (i0 + j16 < n_loc) ? (int)sPcnt[i0 + j16] : 0;
-            if (j16 == 0) cj -= c0;
-            int e = cj;
-            e += dpp_row_shr<1>(e);
-            e += dpp_row_shr<2>(e);
-            e += dpp_row_shr<4>(e);
-            e += dpp_row_shr<8>(e);
-            const int st = e - cj;                       // first row of segment j16
-            const bool in = (i0 + j16 < n_loc) && st < TM;
-            t.nseg = __popcll(__ballot(in) & 0xFFFFull);
-            const int last = t.nseg > 0 ? t.nseg - 1 : 0;    // (no parents left: zero rows)
-            const int e_last = __builtin_amdgcn_readlane(e, last);
-            t.st_last = __builtin_amdgcn_readlane(st, last);
-            t.rows = t.nseg == 0 ? 0 : (e_last < TM ? e_last : TM);
-            t.open = t.nseg != 0 && e_last > TM;
-            t.Em = __builtin_amdgcn_readfirstlane(row_or16(in ? (1u << ((e < TM ? e : TM) - 1)) : 0u));
-            if (lane < 16) sSt[(gw * 2 + slot) * 16 + lane] = st;
-            return t;
-        };
-        auto advance = [&](const Tile& t, int& i0, int& c0) {
-            if (t.nseg == 0) {
-                c0 = 0;
-                i0 = t.i0;
-            } else if (t.open) {
-                c0 = (t.nseg == 1 ? t.c0 : 0) + (TM - t.st_last);
-                i0 = t.i0 + t.nseg - 1;
-            } else {
-                c0 = 0;
-                i0 = t.i0 + t.nseg;
-            }
-        };
-        // row r -> segment, slot of the parent's encoded adjacency row
-        auto row_seg = [&](const Tile& t, int r, int& seg, int& slot) {
-            const unsigned below = t.Em & ((1u << r) - 1u);     // segment ends before r
-            seg = __popc(below);
-            const int st_r = below ? 32 - __clz((int)below) : 0;
-            slot = r - st_r + (seg == 0 ? t.c0 : 0);
-        };
         struct Ids {
             int prw[G::NP2][G::SPL];     // relation words of this wave's parent rows
             int xw;                      // encoded child id (id | list length << 24) of tile row lane & 31
@@ -574,29 +702,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         };
         // issue: parent rows (relation words) of this wave's segments; the child word of EVERY tile row (each wave ranks all rows)
         auto issue_ids = [&](const Tile& t, Ids& d) {
-            const int j16 = lane & 15;
-#pragma unroll
-            for (int ps = 0; ps < G::NP2; ++ps) {
-                const int sg = gw * G::SEGW + 4 * ps + (lane >> 4);
-                const int pi = t.i0 + sg < n_loc ? t.i0 + sg : n_loc - 1;
-                const unsigned off = ((unsigned)sPid[pi] * KT + (unsigned)j16 * G::SPL) * 4u;
-                if constexpr (G::SPL == 1) {
-                    d.prw[ps][0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, off, 0, 0);
-                } else if constexpr (G::SPL == 2) {
-                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(adjR, off, 0, 0);
-                    d.prw[ps][0] = (int)v[0];
-                    d.prw[ps][1] = (int)v[1];
-                } else {
-#pragma unroll
-                    for (int h = 0; h < G::SPL / 4; ++h) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(adjR, off + 16u * h, 0, 0);
-                        d.prw[ps][4 * h + 0] = (int)v[0];
-                        d.prw[ps][4 * h + 1] = (int)v[1];
-                        d.prw[ps][4 * h + 2] = (int)v[2];
-                        d.prw[ps][4 * h + 3] = (int)v[3];
-                    }
-                }
-            }
+            if constexpr (!DPAR) issue_prw(t, d.prw, gw);
             const int r = lane & 31;
             int seg, slot;
             row_seg(t, r, seg, slot);
@@ -640,67 +746,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 ye[ps] = make_int4((int)e4[0], (int)e4[1], (int)e4[2], (int)e4[3]);
                 const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, off, 0, 0);
                 re[ps] = make_int4((int)r4[0], (int)r4[1], (int)r4[2], (int)r4[3]);
-            }
-        };
-        // parents: softmax over the distinct slots -> row weights and segment tables of the tile, ring slot mb
-        auto parents = [&](const Tile& t, const Ids& d, int slot, int mb) {
-            const int j16 = lane & 15;
-#pragma unroll
-            for (int ps = 0; ps < G::NP2; ++ps) {
-                const int sg = gw * G::SEGW + 4 * ps + (lane >> 4);
-                const bool sv = sg < t.nseg;
-                float s0[G::SPL], s1[G::SPL], mu[G::SPL];
-                float m0 = -INFINITY, m1 = -INFINITY;
-#pragma unroll
-                for (int i = 0; i < G::SPL; ++i) {
-                    const unsigned w = (unsigned)d.prw[ps][i];
-                    const int rel = (int)(w & 0xFFFFu) < a.nR ? (int)(w & 0xFFFFu) : 0;
-                    mu[i] = (float)((w >> 16) & 0xFFu);
-                    s0[i] = sT0[rel];
-                    s1[i] = sT1[rel];
-                    m0 = fmaxf(m0, mu[i] > 0.f ? s0[i] : -INFINITY);
-                    m1 = fmaxf(m1, mu[i] > 0.f ? s1[i] : -INFINITY);
-                }
-                m0 = group_max(m0, 4);
-                m1 = group_max(m1, 4);
-                float z0 = 0.f, z1 = 0.f;
-#pragma unroll
-                for (int i = 0; i < G::SPL; ++i) {
-                    s0[i] = has_att0 ? mu[i] * lean_exp(s0[i] - m0) : mu[i];
-                    s1[i] = has_att1 ? mu[i] * lean_exp(s1[i] - m1) : mu[i];
-                    z0 += s0[i];
-                    z1 += s1[i];
-                }
-                z0 = group_sum(z0, 4);
-                z1 = group_sum(z1, 4);
-                const float r0 = has_att0 ? invK / z0 : invK, r1 = has_att1 ? invK / z1 : invK;
-                const int stg = sSt[(gw * 2 + slot) * 16 + (sg & 15)];
-                const int c0s = sg == 0 ? t.c0 : 0;
-#pragma unroll
-                for (int i = 0; i < G::SPL; ++i) {
-                    const int sl = j16 * G::SPL + i;
-                    const int rowi = stg + sl - c0s;
-                    if (sv && mu[i] > 0.f && sl >= c0s && rowi < TM) {
-                        sW0[mb * TM + rowi] = s0[i] * r0;
-                        sW1[mb * TM + rowi] = s1[i] * r1;
-                        sSeg[mb * TM + rowi] = sg;
-                    }
-                }
-                if (j16 == 0) {
-                    sSegP[mb * 16 + sg] = sv ? (int)(p_base + t.i0 + sg) : -1;      // P * D * 4 < 2^31: fits an int
-                    sSegF[mb * 16 + sg] = ((sg == 0 && t.c0 > 0) ? 1 : 0) | ((sg == t.nseg - 1 && t.open) ? 2 : 0);
-                }
-            }
-            if (gw == 0) {
-                if (lane < TM && lane >= t.rows) {       // padding rows of a last, partial tile
-                    sW0[mb * TM + lane] = 0.f;
-                    sW1[mb * TM + lane] = 0.f;
-                    sSeg[mb * TM + lane] = 0;
-                }
-                if (lane == 0) {
-                    sMeta[2 * mb] = t.nseg;
-                    sMeta[2 * mb + 1] = t.rows;
-                }
             }
         };
         // children: softmax over the distinct slots -> (grandchild id, weight) lists of this wave's rows
@@ -763,7 +808,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         rank_rows(db, 0);
         wave_lds_sync();
         issue_chunks(0, yeb, reb);
-        parents(tb, db, 0, 0);
+        if constexpr (!DPAR) parents(tb, db.prw, 0, 0, gw);
         children(0, yeb, reb);
         Tile tc = pack(i0, c0, 1);                       // tile s+2
         Ids dc;
@@ -789,7 +834,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             gather_rounds(gw, par, par, 0, HELP ? 1 : NRND, std::integral_constant<int, (G::WIDE || KT >= 128) ? 8 : kPackMaxB>{});     // (K = 128: the id pipeline holds 40 registers)
             tick(1);
             wave_lds_sync();                             // the lists of tile s are consumed; sSt of tile s+2 is written
-            parents(tb, db, par1, (int)((s + 1) % 3));   // (no tile s+1: zero segments = the end mark of the dense waves)
+            if constexpr (!DPAR) parents(tb, db.prw, par1, (int)((s + 1) % 3), gw);   // (no tile s+1: zero segments = the end mark)
             tick(2);
             children(par1, yeb, reb);
             wave_lds_sync();
