@@ -176,7 +176,8 @@ int mvin_gather_attn_l2_enc_supported(int D, int K);
  * reference's shipped settings: no workgroup phases at all; no probs, table below 4 GiB), 4 = the wave-per-parent
  * kernel for D = 32, K in {8, 16} (BASELINE config C2; same conditions; it takes these shapes ahead of the pipeline).
  * n_parents = B * parents_per_pair.  For tests and benchmarks. */
-int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);
+int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);     /* fp32 table */
+int mvin_gather_attn_l2_variant_ex(int D, int K, int64_t n_parents, int n_entity, int want_probs, int table_bf16);
 /* Measurement aid: the row gathers of mvin_gather_attn_l2_fwd and nothing else, written the plain way (one wave per
  * parent, 8 loads in flight per lane).  child_ids [n_parents, K] and grandchild_ids [n_parents, K*K] are levels 1 and 2
  * of mvin_expand_ids for the parents; every listed row is read once (the same 16-byte lane loads, ids fetched one round

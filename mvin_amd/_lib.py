@@ -109,6 +109,7 @@ SIGNATURES = {
     "mvin_gather_attn_l2_enc_supported": (C.c_int, [C.c_int, C.c_int]),
     "mvin_encode_adjacency": (C.c_int, [_c_i32p, _c_i32p, C.c_int, C.c_int, _c_i32p, _c_i32p, _c_i32p, C.c_void_p]),
     "mvin_gather_attn_l2_variant": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "mvin_gather_attn_l2_variant_ex": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "mvin_probe_gather_l2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_void_p]),
     "mvin_agg_fwd": (C.c_int, [_c_f32p, _c_f32p, _c_i32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,

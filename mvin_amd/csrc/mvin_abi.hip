@@ -167,6 +167,10 @@ int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int3
 }
 
 int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs) {
+    return mvin_gather_attn_l2_variant_ex(D, K, n_parents, n_entity, want_probs, 0);
+}
+
+int mvin_gather_attn_l2_variant_ex(int D, int K, int64_t n_parents, int n_entity, int want_probs, int table_bf16) {
     if (!mvin::fused_l2_supported(D, K)) return 0;
     mvin::FusedL2Args f{};
     f.K = K;
@@ -174,7 +178,7 @@ int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, i
     f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
     float probe = 0.f;
     if (want_probs) f.probs_parent = f.probs_child = &probe;     // only tested for presence
-    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 2;        // the smaller (bf16) size: sufficient for either dtype here
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * (table_bf16 ? 2 : 4);
     if (mvin::fused_d32_applies(f, D)) return 4;
     if (mvin::fused_l2_split_in_use() && mvin::fused_split_applies(f, D)) return 2;
     return mvin::fused_d16_applies(f, D) ? 3 : 1;

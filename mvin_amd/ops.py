@@ -224,9 +224,9 @@ def probe_gather_l2(table, child_ids, grandchild_ids, K, sums=None):
     return sums
 
 
-def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False):
-    """0 = unsupported, 1 = symmetric fused kernel, 2 = role-split pipeline (include/mvin_hip.h)."""
-    return int(_lib.load().mvin_gather_attn_l2_variant(D, K, n_parents, n_entity, int(bool(want_probs))))
+def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False, table_bf16=False):
+    """0 = unsupported, 1 = symmetric fused kernel, 2 = role-split pipeline, 3 / 4 = wave-per-parent kernels (include/mvin_hip.h)."""
+    return int(_lib.load().mvin_gather_attn_l2_variant_ex(D, K, n_parents, n_entity, int(bool(want_probs)), int(bool(table_bf16))))
 
 
 def gather_attn_l2(table, adj_entity, adj_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0,
