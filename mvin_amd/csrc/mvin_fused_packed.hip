@@ -32,7 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPackCH = 1024;       // parents per workgroup (ids and distinct-child counts staged in LDS)
+constexpr int kPackCH = 256;        // most parents per workgroup (ids, query rows and distinct-child counts staged in LDS)
 #ifndef MVIN_PACK_MAXB
 #define MVIN_PACK_MAXB 16
 #endif
@@ -95,14 +95,20 @@ struct PackGeom {
 struct PackLds {
     size_t sA, sZ, sYP, sW0, sW1, sSeg, sSegP, sSegF, sMeta, sPR, sSt, sCarry, sCnt, sT0, sT1, sBias, sPid, sPq, sPcnt, total;
 };
-__host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG) {
+// the dense waves gather the second round of a tile (see HELP in the kernel): its lists are double-buffered
+__host__ __device__ constexpr bool pack_help(int D, int K, bool bf, int NG) {
+    const int epl = (bf && D == 128) ? 8 : 4, rpwx = 64 / (D / epl), nrnd = (32 / NG) / rpwx;
+    return nrnd == 2 && !(bf && D == 128) && K <= 32;
+}
+__host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool bf) {
     PackLds l{};
     const size_t NM = D / 16, nRp = (nR + 1) & ~1;
     size_t o = 0;
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };   // 16-byte aligned pieces
     l.sA = take(2 * 32 * (size_t)(2 * D + 2));
     l.sZ = take(32 * (size_t)(D + 2));
-    l.sYP = take(48 * (size_t)(K + 1) * 2);             // ids [48][K+1], then weights likewise (48: the lists of the second
+    const size_t lrows = pack_help(D, K, bf, NG) ? 48 : 32;
+    l.sYP = take(lrows * (size_t)(K + 1) * 2);          // ids [lrows][K+1], then weights likewise (48: the lists of the second
                                                         // gather round are double-buffered, see list_base)
     l.sW0 = take(3 * 32);                               // the segment tables are a ring of three tiles
     l.sW1 = take(3 * 32);
@@ -133,11 +139,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     using G = PackGeom<D, KT, BF, NG>;
     constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const PackLds L = pack_lds(D, KT, a.nR, NG);
+    const PackLds L = pack_lds(D, KT, a.nR, NG, BF);
     float* sA = smem + L.sA;                            // [2][TM][LDA]  {E[x1] + q | S' + (sum p / K) q}
     float* sZ = smem + L.sZ;                            // [TM][LDZ]
     int* sYI = reinterpret_cast<int*>(smem + L.sYP);    // [TM][YLD]  grandchild ids; rows private to a front wave
-    float* sYW = smem + L.sYP + 48 * YLD;               // [48][YLD]  their weights
+    float* sYW = smem + L.sYP + (pack_help(D, KT, BF, NG) ? 48 : 32) * YLD;     // their weights
     float* sW0 = smem + L.sW0;                          // [2][TM]  weight of the row in its parent's nagg0 (p0 m / K)
     float* sW1 = smem + L.sW1;                          // [2][TM]  ... nagg1
     int* sSeg = reinterpret_cast<int*>(smem + L.sSeg);  // [2][TM]  segment (parent of the tile) the row belongs to
@@ -247,7 +253,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     // cycles per tile against 8 k of MFMA phases); its lists are double-buffered by tile parity, because the front wave
     // rewrites them for the next tile while the dense wave may still walk them. ----
     constexpr int NRND = G::NRND, NS = TM / NRND;
-    constexpr bool HELP = NRND == 2;
+    constexpr bool HELP = pack_help(D, KT, BF, NG);      // (NRND == 2, not the 8-per-lane bf16 form, K <= 32: measured C4 (K = 64)
+                                                          //  1.10 -> 1.15 ms, C5 (bf16, K = 128) 1.72 -> 2.53 ms with it)
+    static_assert(!HELP || NRND == 2, "HELP needs two gather rounds");
     constexpr int SH = KT >= 32 ? (KT == 32 ? 2 : KT == 64 ? 3 : 4) : 1;
     auto rank_of = [&](int gwx, int h, int grp) -> int {    // rank of the h-th row of lane group grp of front wave gwx
         const int slot = grp * NG + gwx;
@@ -860,7 +868,7 @@ hipError_t pack_read_prof(long long* host_dst, size_t n) {
 template <int D, int KT, bool BF, int NG, bool PROF = false>
 static hipError_t launch_packed(const FusedL2Args& a, hipStream_t st) {
     using G = PackGeom<D, KT, BF, NG>;
-    const size_t lds = pack_lds(D, KT, a.nR, NG).total;
+    const size_t lds = pack_lds(D, KT, a.nR, NG, BF).total;
     auto kern = gather_attn_l2_packed_kernel<D, KT, BF, NG, PROF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
