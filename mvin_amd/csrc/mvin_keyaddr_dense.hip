@@ -434,33 +434,37 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         }
         // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
         if (has_set && wave == kDW - 1) {
+            // ONE pass over the head rows of hop 0 (online softmax per lane group, the RPW groups merged at the end): the
+            // three-pass form (logits -> LDS, softmax, weighted sum) made this wave the last of the phase by ~1.8 k cycles
             const float4 w4 = reinterpret_cast<const float4*>(a.w)[c];
-            for (int m0 = 0; m0 < NmP; m0 += RPW) {
-                const int m = m0 + g;
-                const float* hr = sH + (size_t)m * LDH + 4 * c;
-                float d = fmaf(hr[0], w4.x, fmaf(hr[1], w4.y, fmaf(hr[2], w4.z, hr[3] * w4.w)));
-                d = group_sum(d, LPR_L2);
-                if (c == 0) sLg[m] = m < Nm ? d : -INFINITY;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            float mx = -INFINITY;
-            for (int m = lane; m < NmP; m += 64) mx = fmaxf(mx, sLg[m]);
-            mx = wave_max_fast(mx);
-            float z = 0.f;
-            for (int m = lane; m < NmP; m += 64) {
-                const float e = m < Nm ? expf(sLg[m] - mx) : 0.f;
-                sLg[m] = e;
-                z += e;
-            }
-            z = wave_sum_fast(z);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            float mx = -INFINITY, z = 0.f;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int m0 = 0; m0 < NmP; m0 += RPW) {
                 const int m = m0 + g;
-                const float* hr = sH + (size_t)m * LDH + 4 * c;
-                acc = f4_fma(sLg[m], make_float4(hr[0], hr[1], hr[2], hr[3]), acc);
+                const float4 h4 = *reinterpret_cast<const float4*>(sH + (size_t)m * LDH + 4 * c);
+                float d = fmaf(h4.x, w4.x, fmaf(h4.y, w4.y, fmaf(h4.z, w4.z, h4.w * w4.w)));
+                d = group_sum(d, LPR_L2);
+                if (m < Nm) {                            // (the padding rows m >= Nm take no part)
+                    const float nm = fmaxf(mx, d);
+                    const float sc = mx == -INFINITY ? 0.f : kad_exp(mx - nm), e = kad_exp(d - nm);   // (kad_exp has no range selects)
+                    z = fmaf(z, sc, e);
+                    acc = make_float4(fmaf(acc.x, sc, e * h4.x), fmaf(acc.y, sc, e * h4.y), fmaf(acc.z, sc, e * h4.z),
+                                      fmaf(acc.w, sc, e * h4.w));
+                    mx = nm;
+                }
             }
+            // merge the lane groups (lanes l, l ^ LPR, l ^ 2 LPR, ...: the same column chunk c of different row groups)
+            float M = mx;
+            if (LPR <= 16) M = xor16_max(M);
+            if (LPR <= 32) M = xor32_max(M);
+            if (LPR < 16) {
+                for (int o = LPR; o < 16; o <<= 1) M = fmaxf(M, __shfl_xor(M, o, kWave));
+            }
+            const float f = mx == -INFINITY ? 0.f : kad_exp(mx - M);      // a group that saw no row: factor 0
+            z *= f;
+            acc = make_float4(acc.x * f, acc.y * f, acc.z * f, acc.w * f);
             acc = group_xor_sum(acc, LPR);
+            z = group_xor_sum(make_float4(z, 0.f, 0.f, 0.f), LPR).x;
             const float inv = 1.f / z;
             if (g == 0) *reinterpret_cast<float4*>(sHset + 4 * c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
         } else if (P > 0) {
