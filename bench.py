@@ -578,9 +578,9 @@ def main():
     # The dominant kernel is timed with HIP events around its launches inside the timed steps (model._profile).  At
     # small batches the pass is ONE native call (mvin_score_l2_fwd, no event hooks inside): there the timed steps run
     # un-instrumented and the kernel time comes from the same K steps repeated with the hooks on, after the clock stops.
-    one_call = (scorer is None and not rowshard and Bl <= model.native_l2_max_batch
-                and not (by_user and Bl >= model.group_min_pairs_per_user * case.n_user)     # grouped: Python schedule
-                and model._native_l2_ok(items, None if by_user else mh, False))
+    grouped_now = by_user and Bl >= model.group_min_pairs_per_user * min(case.n_user, distinct or case.n_user)
+    one_call = (scorer is None and (Bl <= model.native_l2_max_batch or grouped_now)
+                and model._native_l2_ok(items, None if by_user else mh, False, cap=not grouped_now))
     model._profile = None if one_call else []
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -649,7 +649,7 @@ def main():
                  "bytes_per_pair": bpp, "pairs_per_launch": Bl, "avg_launch_ms": kern_avg_ms,
                  "table_bytes": table_bytes, "traffic": traffic,
                  "kernel_timing": ("HIP events around the kernel's launches in a repeat of the same steps after the timed "
-                                   "region (the timed steps are one native call each, mvin_score_l2_fwd: no hooks inside)"
+                                   "region (the timed steps are ONE native call each, mvin_score_l2_fwd: no hooks inside)"
                                    if one_call else "HIP events around the kernel's launches inside the timed steps"),
                  "hbm_frac_from_traffic": (traffic / (kern_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                  if (traffic and kern_avg_ms) else None,

@@ -290,7 +290,8 @@ int mvin_l2_tail_supported(int D);
  * user_o, wide_deep, n_mix_hop = 1, h_hop = 2) enqueued by ONE native call: at the reference's own batch sizes
  * (512 / 1024, src/bash/mvin_*.sh) the pass is a handful of short kernels and the host-side cost of issuing them
  * one foreign call at a time dominates.  Sequence (each step is the entry point of the same name):
- *   mvin_linear_fwd (V = E[item] . R_KGE[r]) -> mvin_key_addressing_fwd (or _users_fwd) -> mvin_linear_fwd (user MLP, :232-236)
+ *   mvin_linear_fwd (V = E[item] . R_KGE[r]) -> mvin_key_addressing_fwd (or _users_fwd; or, with group_ws, mvin_group_pairs_by_user ->
+ *   mvin_key_addressing_grouped_fwd in place of both) -> mvin_linear_fwd (user MLP, :232-236)
  *   -> mvin_expand_ids (level 0) -> mvin_gather_attn_l2_fwd -> mvin_l2_tail_fwd.
  * All pointers are device pointers except mem_h / mem_r / mem_t (host arrays of max(1,P) device pointers).
  * Workspace and outputs are caller-owned.  Returns the first failing step's code. */
@@ -336,6 +337,9 @@ typedef struct {
     int n_user;                    /* rows of uts (users feed); user ids are clamped to [0, n_user) */
     const int32_t* enc_entity;     /* duplicate-slot encoding of the adjacency (mvin_encode_adjacency) or NULL: when given */
     const int32_t* enc_relation;   /*   the two deepest levels take mvin_gather_attn_l2_enc_fwd */
+    int32_t* group_ws;             /* users feed only, or NULL: workspace of 2 * n_user + 4 * B + 3 int32 -> key addressing in its
+                                      GROUPED form (mvin_group_pairs_by_user + mvin_key_addressing_grouped_fwd instead of the V
+                                      projection + mvin_key_addressing_users_fwd; V may then be NULL) */
 } mvin_score_l2_args;
 int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

@@ -68,7 +68,7 @@ class ScoreL2Args(C.Structure):
         "W0", "b0", "W1", "b1", "W2", "b2", "A0", "a0", "A1", "a1", "Wmix", "bmix", "items", "mem_h", "mem_r", "mem_t",
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
-        ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p)]
+        ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.

@@ -468,9 +468,11 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     const char* who = "mvin_score_l2_fwd";
     if (!a) return fail(-1, "%s: null args", who);
     if (a->P < 1 || a->P > 8) return fail(-2, "%s: P=%d (1..8)", who, a->P);
-    if (!a->V || !a->o_cat || !a->parents || !a->nagg0 || !a->nagg1 || !a->user_o || !a->scores || !a->items)
+    const bool grouped = a->uts && a->group_ws;
+    if ((!a->V && !grouped) || !a->o_cat || !a->parents || !a->nagg0 || !a->nagg1 || !a->user_o || !a->scores || !a->items)
         return fail(-1, "%s: null workspace / output / items", who);
     if (a->uts && !a->users) return fail(-1, "%s: user_triplet_set given without user ids", who);
+    if (a->group_ws && !a->uts) return fail(-1, "%s: group_ws is for the users feed (uts + users)", who);
     const int D = a->D, nR = a->n_relation;
     const int n_o = a->P + (a->h_set_w ? 1 : 0);
     // V[b, r, :] = E[item_b] . R_KGE[r]   (model.py:214-220 re-associated: (R h).v == h.(v R))
@@ -491,9 +493,25 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     l.nz = nR;
     l.w_zstride = (int64_t)D * D;
     l.out_zstride = D;
-    int rc = mvin_linear_fwd(&l, stream);
-    if (rc) return rc;
-    if (a->uts)
+    int rc = 0;
+    if (grouped) {
+        // the batch in user order (device-side counting sort, no host sync), then a user's rows staged once per segment
+        int32_t* ws = a->group_ws;
+        int32_t* seg_user = ws + 2 * (size_t)a->n_user + (size_t)a->B;
+        int32_t* seg_ptr = seg_user + a->B;
+        int32_t* nseg = seg_ptr + a->B + 2;
+        int32_t* pair_index = nseg + 1;
+        rc = mvin_group_pairs_by_user(a->users, nullptr, a->B, a->n_user, ws, seg_user, seg_ptr, nseg, pair_index, stream);
+        if (rc) return rc;
+        rc = mvin_key_addressing_grouped_fwd(a->entity_emb, a->relation_kge, a->h_set_w, a->uts, seg_user, seg_ptr, nseg, pair_index,
+                                             a->items, nullptr, (int)a->B, (int)a->B, a->P, a->Nm, D, nR, a->n_entity, a->n_user,
+                                             a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+    } else {
+        rc = mvin_linear_fwd(&l, stream);
+        if (rc) return rc;
+    }
+    if (grouped) {
+    } else if (a->uts)
         rc = mvin_key_addressing_users_fwd(a->entity_emb, a->V, a->h_set_w, a->uts, a->users, nullptr, a->P, (int)a->B, a->Nm,
                                            D, nR, a->n_entity, a->n_user, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
     else

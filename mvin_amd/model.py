@@ -628,7 +628,7 @@ class MVIN(object):
                                    uts=user_triplet_set, distinct_users=distinct_users)
 
     # ------------------------------------------------------------------ native whole-pass schedule
-    def _native_l2_ok(self, item, memories_h, want_probs):
+    def _native_l2_ok(self, item, memories_h, want_probs, cap=True):
         """The pass can be enqueued by ONE native call (mvin_score_l2_fwd): default wiring, depth-2 trees.
         ``memories_h`` None = the users feed (user_triplet_set + user ids)."""
         a = self.args
@@ -638,9 +638,9 @@ class MVIN(object):
                 and item.dtype == torch.int64 and (memories_h is None or memories_h[0].dim() == 2)
                 and ops.l2_tail_supported(self.dim) and ops.gather_attn_l2_supported(self.dim, self.n_neighbor)
                 and ops.key_addressing_supported(self.n_memory, self.dim)
-                and item.shape[0] <= self.native_l2_max_batch)
+                and (not cap or item.shape[0] <= self.native_l2_max_batch))
 
-    def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None):
+    def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):
         """model.py:125-159 through mvin_score_l2_fwd.  The argument block (every weight pointer) is built once and
         kept until a parameter tensor is replaced; per call only the batch pointers change."""
         from . import _lib
@@ -686,12 +686,14 @@ class MVIN(object):
         st["live"] = (self.entity_emb_matrix, t0, t1, enc)
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
-        wkey = (B, n_o, stream.cuda_stream)
+        wkey = (B, n_o, stream.cuda_stream, bool(grouped), uts.shape[0] if grouped else 0)
         ws = self._native_l2_ws.get(wkey)
         if ws is None:        # reused across calls of the same batch size ON THE SAME STREAM (which orders the reuse)
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
-            ws = self._native_l2_ws[wkey] = (f(B, self.n_relation, D), f(B, n_o * D),
-                                             torch.empty(B, dtype=torch.int32, device=self.device), f(B, D), f(B, D))
+            # grouped key addressing needs no [B, nR, D] item projection; its sort workspace instead
+            gws = torch.empty(2 * uts.shape[0] + 4 * B + 3, dtype=torch.int32, device=self.device) if grouped else None
+            ws = self._native_l2_ws[wkey] = (None if grouped else f(B, self.n_relation, D), f(B, n_o * D),
+                                             torch.empty(B, dtype=torch.int32, device=self.device), f(B, D), f(B, D), gws)
             if len(self._native_l2_ws) > 8:
                 self._native_l2_ws.pop(next(iter(self._native_l2_ws)))
         user_o = torch.empty((B, D), dtype=torch.float32, device=self.device)
@@ -706,7 +708,7 @@ class MVIN(object):
             ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
             s.uts = s.users = None
             s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
-        s.V, s.o_cat, s.parents, s.nagg0, s.nagg1 = (w.data_ptr() for w in ws)
+        s.V, s.o_cat, s.parents, s.nagg0, s.nagg1, s.group_ws = (w.data_ptr() if w is not None else None for w in ws)
         s.user_o, s.item_emb, s.scores, s.sig = user_o.data_ptr(), item_emb.data_ptr(), scores.data_ptr(), sig.data_ptr()
         s.B = B
         _lib.check(_lib.load().mvin_score_l2_fwd(C.byref(s), C.c_void_p(stream.cuda_stream)), "mvin_score_l2_fwd")
@@ -756,11 +758,12 @@ class MVIN(object):
             grouped = (need_ps and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
                        and item32.shape[0] >= self.group_min_pairs_per_user * min(uts.shape[0], int(distinct_users or uts.shape[0]))
                        and ops.key_addressing_grouped_supported(self.dim, self.p_hop, self.n_memory, self.n_relation))
-            if (need_ps and not grouped and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
+            if (need_ps and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
                     and uts.shape[1] == self.p_hop and uts.shape[3] == self.n_memory and user32.dtype == torch.int64
-                    and user32.shape[0] == item32.shape[0] and self._native_l2_ok(item32, None, want_probs)):
-                # one native call; key addressing indexes user_triplet_set by users[b] itself
-                return self._score_l2_native(item32, None, None, None, uts=uts, users=user32)
+                    and user32.shape[0] == item32.shape[0] and self._native_l2_ok(item32, None, want_probs, cap=not grouped)):
+                # one native call; key addressing indexes user_triplet_set by users[b] itself, or -- grouped -- sorts the
+                # batch by user on the device first (any batch size: the host issues ONE call per step instead of seven)
+                return self._score_l2_native(item32, None, None, None, uts=uts, users=user32, grouped=grouped)
             users_kernel = (need_ps and not grouped and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
                             and uts.dim() == 4 and uts.shape[1] == max(1, self.p_hop) and uts.shape[3] == self.n_memory
                             and user32.shape[0] == item32.shape[0] and user32.dtype in (torch.int64, torch.int32)
