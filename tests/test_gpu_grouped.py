@@ -229,3 +229,37 @@ def test_out_of_range_device_ids_are_clamped(shape, feed, hip_lib):
     torch.cuda.synchronize()
     assert torch.isfinite(got.scores).all()
     assert torch.equal(got.scores, ref.scores)
+
+
+@pytest.mark.parametrize("B", [300, 5000, 70000])
+def test_grouped_native_call_equals_python_schedule(B, hip_lib):
+    """The grouped users feed enqueued by ONE native call (mvin_score_l2_fwd with group_ws: device-side sort + grouped key
+    addressing + user MLP + fused kernel + tail) against the same launches issued one by one from Python: same kernels,
+    same order -> identical scores; batch sizes below and above the per-pair native path's cap."""
+    from mvin_amd.model import MVIN
+    D, K, P, Nm, nR, n_user, n_entity = 64, 32, 2, 64, 9, 60, 3000
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B)
+    rng = np.random.default_rng(B)
+    case = synth.small_case(make_args(**dict(vars(args), batch_size=4)), n_user=n_user, n_entity=n_entity, n_relation=nR,
+                            seed=3, repeats=True)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
+    model.group_min_pairs_per_user = 0
+    dev = model.device
+    u_d, i_d, uts_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev), torch.from_numpy(uts).to(dev)
+    calls = []
+    orig = model._score_l2_native
+    model._score_l2_native = lambda *a_, **k_: (calls.append(k_.get("grouped")), orig(*a_, **k_))[1]
+    native = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert calls == [True], "the grouped batch did not take the native call"
+    model._profile = []                                     # event hooks requested: the Python schedule
+    python = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    model._profile = None
+    assert calls == [True]
+    assert torch.equal(native.scores, python.scores) and torch.equal(native.user_o, python.user_o)
+    assert torch.equal(native.item_embeddings, python.item_embeddings)
