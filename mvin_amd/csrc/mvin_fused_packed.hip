@@ -15,12 +15,18 @@
 //   * the per-parent sums  nagg0 = (1/K) sum_n p0[n] self1[n],  nagg1 = (1/K) sum_n p1[n] out1[n]  become one more
 //     MFMA per accumulator register: A = [segment x row] weights (0 outside the parent's rows), B = the accumulators
 //     themselves (contraction index = row, in the order the accumulator layout holds them);
-//   * roles: NG "front" waves own 32 / NG rows each END TO END -- pack the tile, softmax over the parents' slots, child
-//     ids, child adjacency chunks -> (grandchild id, weight) lists, row gathers bounded by the longest list of the
-//     wave-round -- with no barrier among them (every LDS list is private to the wave that gathers from it); D / 16 "dense"
-//     waves run the MFMA phases of the previous tile.  One workgroup barrier per tile.
+//   * roles: NG = 4 "front" waves + D / 16 "dense" waves per workgroup, ONE workgroup barrier per tile, two workgroups per CU.
+//     A front wave owns 32 / NG rows of a tile end to end -- child ids, child adjacency chunks -> softmax over the distinct
+//     slots -> (grandchild id, weight) lists in LDS that only it (and its helper, below) reads -> row gathers bounded by the
+//     longest list of the round -- software-pipelined over tiles: the child words of tile s+2 and the adjacency chunks of
+//     tile s+1 are in flight while tile s is gathered.  Which rows a wave owns is decided per tile: the 32 rows are ranked by
+//     list length and dealt to waves / lane groups in a snake.  The dense waves run the MFMA phases of tile s-1 and then,
+//     where it pays (D = 64, K <= 32), use the time they would wait for the front: they gather the SECOND round (the short
+//     lists) of tile s and compute the parent softmax -> segment tables of tile s+1.
+//   * what hipcc needs for this shape of kernel is in the comments at wave_lds_sync(), at the dense loop's lane laundering and
+//     in HISTORY.md (round 4): spilled registers and conditional id loads each cost a vmcnt(0) behind freshly issued loads.
 //
-// Supported: D in {32, 64, 128}; K in {16, 32, 64, 128}; fp32 or bf16 table smaller than 4 GiB.
+// Supported: D in {32, 64, 128}; K in {16, 32, 64, 128}; fp32 or bf16 table smaller than 4 GiB, at most 2^24 entities.
 #include <cstdlib>
 #include <type_traits>
 
