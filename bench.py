@@ -189,11 +189,12 @@ def check_l2_launch(out, table, adj_e, adj_r, parents, t0, t1, W1, W2, b1, b2, q
     return max_abs, worst, worst <= 1.0
 
 
-def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0):
-    """The dominant kernel in its HBM-bound regime: mvin_gather_attn_l2_fwd (same template instance as
-    in the timed steps: same D, K, table dtype, projection + attention on) on a ``n_rows`` x D table far
-    larger than the Infinity Cache, uniform adjacency, ``pairs`` parents per launch.  Each launch is
-    bracketed by HIP events on the stream it is launched on (torch's current stream)."""
+def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0, encoded=False):
+    """The dominant kernel in its HBM-bound regime: the SAME kernel as in the timed steps (same D, K, table dtype,
+    projection + attention on) -- mvin_gather_attn_l2_fwd (role-split kernel), or with ``encoded`` mvin_gather_attn_l2_enc_fwd
+    (packed-tile kernel over the duplicate-slot encoding of the same adjacency) -- on a ``n_rows`` x D table far larger than the
+    Infinity Cache, uniform adjacency (no repeated slots: every one of the K + K^2 rows per pair is loaded), ``pairs`` parents
+    per launch.  Each launch is bracketed by HIP events on the stream it is launched on (torch's current stream)."""
     import torch
     from mvin_amd import ops
     g = torch.Generator(device=dev)
@@ -208,13 +209,20 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     q = torch.rand((pairs, D), device=dev, generator=g)
     bias = torch.zeros(D, device=dev)
     args = (table, adj_e, adj_r, parents, t0, t0, W[0], W[1], bias, bias, q, W[2], bias, pairs, 1, K, D, n_rel)
+    if encoded:
+        enc_e, enc_r, cnt = ops.encode_adjacency(adj_e, adj_r)
+        launch = lambda: ops.gather_attn_l2_enc(table, enc_e, enc_r, *args[3:])       # noqa: E731
+        kernel = "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd)"
+    else:
+        launch = lambda: ops.gather_attn_l2(*args)[:2]                                # noqa: E731
+        kernel = "gather_attn_l2_split_kernel (mvin_gather_attn_l2_fwd)"
     for _ in range(warmup):
-        ops.gather_attn_l2(*args)
+        launch()
     evs = []
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = ops.gather_attn_l2(*args)
+        out = launch()
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
@@ -225,8 +233,10 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     s_ = 2 if table_dtype == "bf16" else 4
     bpp = algorithmic_bytes_per_pair(D, K, 2, s=s_)
     del table, adj_e, adj_r
+    if encoded:
+        del enc_e, enc_r, cnt
     torch.cuda.empty_cache()
-    return {"avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
+    return {"kernel": kernel, "avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
             "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows, "table_bytes": n_rows * D * s_,
             "launches": iters, "outputs_finite": finite, "max_abs_err": max_abs, "worst_err_over_bound": worst,
             "verified": bool(ok and finite),
@@ -465,7 +475,8 @@ def main():
     from mvin_amd.params import init_params
 
     if a.hbm_leg_only:
-        leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, iters=max(a.steps, 1), warmup=a.warmup)
+        leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, iters=max(a.steps, 1), warmup=a.warmup,
+                      encoded=os.environ.get("MVIN_L2_ENC", "auto") != "0")
         leg.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", frac=leg["achieved"] / HBM_PEAK_GBS)
         print(json.dumps({"hbm_leg_only": leg}), flush=True)
         return
@@ -690,22 +701,29 @@ def main():
         roofline = timed
         if not a.no_hbm_leg and used_l2 and not hoisted and cache_resident and L == 2:
             # the genuinely HBM-bound measurement of the SAME kernel instance, live, after the timed region
-            leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype)
+            leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=enc is not None)
             pl = pmc_record("pmc_hbm_leg.json")
             leg_traffic = None
             if pl and all(pl.get(k) == v for k, v in (("dim", a.dim), ("fanout", a.fanout), ("table_rows", leg["table_rows"]),
                                                       ("pairs_per_launch", leg["pairs_per_launch"]),
-                                                      ("table_dtype", a.table_dtype))):
+                                                      ("table_dtype", a.table_dtype))) \
+                    and pl.get("kernel", leg["kernel"]).split(" ")[0] == leg["kernel"].split(" ")[0]:
                 leg_traffic = pl["traffic_bytes_per_launch"]
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": leg["achieved"], "peak": HBM_PEAK_GBS,
+            other = None
+            if enc is not None:      # the plain-adjacency kernel on the same table, for comparison (round 3's roofline kernel)
+                o = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=False)
+                other = {k: o[k] for k in ("kernel", "avg_launch_ms", "achieved", "max_abs_err", "verified")}
+                other["frac"] = o["achieved"] / HBM_PEAK_GBS
+            roofline = {"bound": "hbm", "kernel": leg["kernel"], "achieved": leg["achieved"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": leg["achieved"] / HBM_PEAK_GBS, "traffic": leg_traffic,
                         "bytes_per_pair": leg["bytes_per_pair"], "pairs_per_launch": leg["pairs_per_launch"],
                         "avg_launch_ms": leg["avg_launch_ms"], "table_bytes": leg["table_bytes"],
                         "table_rows": leg["table_rows"], "launches": leg["launches"],
                         "max_abs_err": leg["max_abs_err"], "verified": leg["verified"], "verified_how": leg["verified_how"],
-                        "workload": "the timed region's kernel instance (same D, K, dtype, projection + attention on) on a "
-                                    "16 M-row synthetic entity table with uniform adjacency: 16x the Infinity Cache, so "
-                                    "every gathered row comes from HBM; measured after the timed region with HIP events "
+                        "plain_adjacency_kernel": other,
+                        "workload": "the timed region's kernel (same instance: D, K, dtype, projection + attention on) on a "
+                                    "16 M-row synthetic entity table with uniform adjacency (no repeated slots: all K + K^2 "
+                                    "rows per pair are loaded): 16x the Infinity Cache, so every gathered row comes from HBM; measured after the timed region with HIP events "
                                     "around each launch; `traffic` = 2*FETCH_SIZE + WRITE_SIZE per launch from "
                                     "profiles/pmc_hbm_leg.json (rocprofv3 --pmc passes over `bench.py --hbm-leg-only`)",
                         "timed_region": timed}

@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
 def test_hbm_leg_launch_is_verified(hip_lib):
     leg = bench.hbm_leg(torch.device("cuda:0"), 64, 32, "f32", iters=1, warmup=1)
     assert leg["outputs_finite"] and leg["verified"], leg
+    enc = bench.hbm_leg(torch.device("cuda:0"), 64, 32, "f32", iters=1, warmup=1, encoded=True)     # the packed-tile kernel on the same table
+    assert enc["verified"] and "packed" in enc["kernel"], enc
     assert leg["worst_err_over_bound"] <= 1.0
 
 
