@@ -835,6 +835,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         bool have = true;                                // tile s exists
         for (int64_t s = 0; have; ++s) {
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the ids of tile s+1 (issued a step ago)
+            // lane-derived constants re-derived per tile from an opaque copy, as in the dense loop (fewer values live across the loop)
+            asm volatile("" : "+v"(lane));
+            g = lane / G::LPRX;
+            c = lane % G::LPRX;
+            c16 = (unsigned)c * 16u;
             const int par = (int)(s & 1), par1 = par ^ 1;
             tb = tc;
             db = dc;
