@@ -154,3 +154,32 @@ def test_auto_mode_takes_the_encoded_path_only_when_rows_repeat(hip_lib):
                      params=params, device="cuda:0")
         assert (model._enc_for_l2() is not None) == expect
         assert model._enc_for_l2(want_probs=True) is None
+
+
+def test_packed_kernel_is_deterministic(hip_lib):
+    """No atomics anywhere in the packed-tile kernel (per-parent sums are MFMAs over fixed row orders, a straddling parent is
+    carried in a fixed order): the same launch twice gives bit-identical outputs.  The same pairs at another batch position
+    land at other rows of other tiles, so their per-parent sums associate differently: equal to fp32 round-off, not bit for
+    bit (the plain-adjacency kernels, one parent per tile, are position-independent bit for bit)."""
+    D, K, B = 64, 32, 3000
+    args = make_args(**_shape(D, K, B=B))
+    case = synth.small_case(args, n_user=32, n_entity=2500, n_relation=9, seed=191, repeats=True)
+    rng = np.random.default_rng(7)
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)
+    E = f(case.n_entity, D)
+    ae = torch.from_numpy(case.adj_entity.astype(np.int32)).to(dev)
+    ar = torch.from_numpy(case.adj_relation.astype(np.int32)).to(dev)
+    items = torch.from_numpy(case.items).to(dev)
+    t0, t1, W1, W2, b1, b2, q, A0, a0 = f(9), f(9), f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
+    enc_e, enc_r, _ = ops.encode_adjacency(ae, ar)
+    run = lambda it, qq: ops.gather_attn_l2_enc(E, enc_e, enc_r, it, t0, t1, W1, W2, b1, b2, qq, A0, a0, it.shape[0], 1, K, D, 9)
+    a0_, a1_ = run(items, q)
+    b0_, b1_ = run(items, q)
+    torch.cuda.synchronize()
+    assert torch.equal(a0_, b0_) and torch.equal(a1_, b1_)
+    sl = slice(1234, 1234 + 700)                            # other tiles, other workgroups, other straddles
+    c0_, c1_ = run(items[sl].contiguous(), q[sl].contiguous())
+    torch.cuda.synchronize()
+    assert_close(c0_.cpu().numpy(), a0_[sl].cpu().numpy(), "nagg0 at another batch position", rtol=1e-6, atol=1e-7)
+    assert_close(c1_.cpu().numpy(), a1_[sl].cpu().numpy(), "nagg1 at another batch position", rtol=1e-6, atol=1e-7)
