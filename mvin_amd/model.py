@@ -151,6 +151,9 @@ class MVIN(object):
                 return None
         if self.entity_emb_matrix.numel() * self.entity_emb_matrix.element_size() >= (1 << 32):
             return None
+        # the packed-tile kernel addresses the adjacency and its output rows with 32-bit offsets (fused_packed_applies)
+        if self.adj_entity.numel() * 4 >= (1 << 31) or (n_parents is not None and n_parents * self.dim * 4 >= (1 << 31)):
+            return None
         enc = self.encoded_adjacency()
         if enc is None or (mode != "1" and enc[3] > self.ENC_AUTO_MAX_DISTINCT_FRACTION):
             return None
