@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 7
+#define MVIN_ABI_VERSION 8
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
@@ -254,6 +254,25 @@ int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relatio
                                     const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR, int n_entity, int n_user,
                                     float* out, int64_t ldo, int table_bf16, void* stream);
 int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
+/* STATIC per-user records for the grouped form (ABI v8).  A user's ripple sets are built once per data set
+ * (data_loader_user_set.py: user_triplet_set feeds the same (h, r, t) ids for a user in every batch, model.py:66-76), and so
+ * is everything the dense grouped kernel derives from the ids alone: the relation buckets of the memories (which rows share
+ * an R_KGE[r], model.py:214-216), its tile table, the clamped head / tail ids.  mvin_build_user_records writes them once,
+ * one record of mvin_user_records_len(P, Nm, nR) int32 words per user (0: no record form for this shape):
+ *   [0] tiles  [4 ..] members per relation | first bucket row per relation | relation of each tile |
+ *   bucket slots -> row (hop * NmP + m, inside a bucket in row order; -1: empty) | head id per row | tail id per row
+ *   (NmP = Nm rounded up to 16; ids clamped to [0, n_entity); padding rows and unused words -1; whole 256-byte lines),
+ * and mvin_key_addressing_grouped_rec_fwd (same arguments and results as mvin_key_addressing_grouped_fwd, bit for bit) lands a
+ * user's record in LDS a segment ahead instead of bucketing the segment's ids.  user_records == NULL, or a shape / table
+ * type outside mvin_user_records_supported: exactly mvin_key_addressing_grouped_fwd. */
+int mvin_user_records_len(int P, int Nm, int nR);
+int mvin_user_records_supported(int D, int P, int Nm, int nR, int table_bf16);
+int mvin_build_user_records(const int32_t* uts, int n_user, int P, int Nm, int nR, int n_entity, int32_t* records, void* stream);
+int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                        const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
+                                        const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                        const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                        int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream);
 /* The batch in user order for mvin_key_addressing_grouped_fwd, built on the device (counting sort by user id, int
  * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
  * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair
@@ -340,6 +359,7 @@ typedef struct {
     int32_t* group_ws;             /* users feed only, or NULL: workspace of 2 * n_user + 4 * B + 3 int32 -> key addressing in its
                                       GROUPED form (mvin_group_pairs_by_user + mvin_key_addressing_grouped_fwd instead of the V
                                       projection + mvin_key_addressing_users_fwd; V may then be NULL) */
+    const int32_t* user_records;   /* grouped form only, or NULL: mvin_build_user_records(uts) -> mvin_key_addressing_grouped_rec_fwd */
 } mvin_score_l2_args;
 int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

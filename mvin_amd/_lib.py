@@ -68,7 +68,8 @@ class ScoreL2Args(C.Structure):
         "W0", "b0", "W1", "b1", "W2", "b2", "A0", "a0", "A1", "a1", "Wmix", "bmix", "items", "mem_h", "mem_r", "mem_t",
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
-        ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p)]
+        ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p),
+        ("user_records", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -84,6 +85,10 @@ SIGNATURES = {
     "mvin_linear_wgrad_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mvin_shard_space_ids": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mvin_key_addressing_grouped_rec_fwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mvin_user_records_len": (C.c_int, [C.c_int] * 3),
+    "mvin_user_records_supported": (C.c_int, [C.c_int] * 5),
+    "mvin_build_user_records": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_supported": (C.c_int, [C.c_int] * 4),
     "mvin_ent_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mvin_rel_elems": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
@@ -201,8 +206,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 7:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 7")
+    if ver != 8:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 8")
     _lib = lib
     return lib
 

@@ -49,6 +49,7 @@ int mvin_debug_read_trace(long long* host_dst, size_t n) {
     static const bool ka = getenv("MVIN_KA_TRACE") != nullptr;     // which kernel's stamps
     static const bool pk = getenv("MVIN_PACK_TRACE") != nullptr;
     if (pk) return (int)mvin::pack_read_prof(host_dst, n);
+    if (ka && getenv("MVIN_KA_TRACE")[0] == '2') return (int)mvin::kas_read_trace(host_dst, n);     // the kernel over static records
     return (int)(ka ? mvin::ka_read_trace(host_dst, n) : mvin::split_read_trace(host_dst, n));
 }
 
@@ -503,9 +504,9 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         int32_t* pair_index = nseg + 1;
         rc = mvin_group_pairs_by_user(a->users, nullptr, a->B, a->n_user, ws, seg_user, seg_ptr, nseg, pair_index, stream);
         if (rc) return rc;
-        rc = mvin_key_addressing_grouped_fwd(a->entity_emb, a->relation_kge, a->h_set_w, a->uts, seg_user, seg_ptr, nseg, pair_index,
-                                             a->items, nullptr, (int)a->B, (int)a->B, a->P, a->Nm, D, nR, a->n_entity, a->n_user,
-                                             a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
+        rc = mvin_key_addressing_grouped_rec_fwd(a->entity_emb, a->relation_kge, a->h_set_w, a->uts, a->user_records, seg_user, seg_ptr,
+                                                 nseg, pair_index, a->items, nullptr, (int)a->B, (int)a->B, a->P, a->Nm, D, nR,
+                                                 a->n_entity, a->n_user, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
     } else {
         rc = mvin_linear_fwd(&l, stream);
         if (rc) return rc;
@@ -581,11 +582,34 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR) {
     return mvin::key_addr_grouped_supported(D, P, Nm, nR) ? 1 : 0;
 }
 
+int mvin_user_records_len(int P, int Nm, int nR) { return mvin::ka_rec_layout(P, Nm, nR).len; }
+
+int mvin_user_records_supported(int D, int P, int Nm, int nR, int table_bf16) {
+    return !table_bf16 && mvin::key_addr_static_supported(D, P, Nm, nR) ? 1 : 0;
+}
+
+int mvin_build_user_records(const int32_t* uts, int n_user, int P, int Nm, int nR, int n_entity, int32_t* records, void* stream) {
+    const char* who = "mvin_build_user_records";
+    if (!uts || !records) return fail(-1, "%s: null pointer", who);
+    if (n_user <= 0 || n_entity <= 0) return fail(-2, "%s: bad sizes n_user=%d n_entity=%d", who, n_user, n_entity);
+    if (mvin::ka_rec_layout(P, Nm, nR).len == 0) return fail(-3, "%s: no record form for P=%d Nm=%d nR=%d (P 1..8, Nm 1..256, nR 1..4096)", who, P, Nm, nR);
+    return hip_result(mvin::launch_user_records(uts, n_user, P, Nm, nR, n_entity, records, (hipStream_t)stream), who);
+}
+
 int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relation_kge, const float* w,
                                     const int32_t* uts, const int32_t* seg_user, const int32_t* seg_ptr,
                                     const int32_t* nseg_dev, const int32_t* pair_index, const int64_t* items_i64,
                                     const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR,
                                     int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream) {
+    return mvin_key_addressing_grouped_rec_fwd(entity_emb, relation_kge, w, uts, nullptr, seg_user, seg_ptr, nseg_dev, pair_index, items_i64,
+                                               items_i32, nseg, B, P, Nm, D, nR, n_entity, n_user, out, ldo, table_bf16, stream);
+}
+
+int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                        const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
+                                        const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                        const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                        int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream) {
     const char* who = "mvin_key_addressing_grouped_fwd";
     if (!entity_emb || !uts || !seg_user || !seg_ptr || !pair_index || !out) return fail(-1, "%s: null pointer", who);
     if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
@@ -618,6 +642,7 @@ int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relatio
     k.D = D;
     k.nR = nR;
     k.n_entity = n_entity;
+    k.records = user_records;
     return hip_result(mvin::launch_key_addr_grouped(k, table_bf16, (hipStream_t)stream), who);
 }
 

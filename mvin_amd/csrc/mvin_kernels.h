@@ -110,6 +110,12 @@ struct KeyAddrGroupedArgs {
     int nseg, P, Nm, D, nR, NRL;
     int n_entity;              // rows of E: the wave-per-user kernel clamps item ids into the table
     int dbg;                   // wave-per-user kernel, measurement only (MVIN_KA_WAVE_DBG)
+    const int32_t* records;    // [nU, ka_rec_layout(P, Nm, nR).len] static per-user records (mvin_keyaddr_static.hip) or NULL
+};
+
+// the static record of one user: offsets in int32 words (mvin_keyaddr_static.hip); len == 0: shape outside the record form
+struct KaRecLayout {
+    int NmP, rows, maxtiles, o_cnt, o_off, o_trel, o_bidx, o_head, o_tail, len;
 };
 
 struct TailArgs {
@@ -280,6 +286,12 @@ bool key_addr_wave16_applies(const KeyAddrGroupedArgs& a);     // + table small 
 hipError_t launch_key_addr_wave16(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
 bool key_addr_dense_supported(int D, int P, int Nm, int nR);     // dense (all-MFMA) variant, mvin_keyaddr_dense.hip
 hipError_t launch_key_addr_dense(const KeyAddrGroupedArgs& a, int table_bf16, hipStream_t st);
+KaRecLayout ka_rec_layout(int P, int Nm, int nR);               // static per-user records + the kernel over them, mvin_keyaddr_static.hip
+hipError_t launch_user_records(const int32_t* uts, int n_user, int P, int Nm, int nR, int n_entity, int32_t* out, hipStream_t st);
+bool key_addr_static_supported(int D, int P, int Nm, int nR);
+bool key_addr_static_applies(const KeyAddrGroupedArgs& a, int table_bf16);
+hipError_t launch_key_addr_static(const KeyAddrGroupedArgs& a, hipStream_t st);
+hipError_t kas_read_trace(long long* host_dst, size_t n);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 bool key_addr_stream_supported(const KeyAddrArgs& a, int table_bf16);       // LDS-DMA streaming variant, mvin_keyaddr_stream.hip
 hipError_t launch_key_addr_stream(const KeyAddrArgs& a, int table_bf16, hipStream_t st);

@@ -264,19 +264,23 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
             const int hop = tid / NmP, m = tid - hop * NmP;
             if (m < Nm) {
                 const int32_t* ub = a.uts + (int64_t)user * Ph * 3 * Nm;
-                // device-resident ids are not validated per launch: clamped into the table (a fault would kill the process)
-                h = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);
-                t = (int)min((unsigned)ub[(hop * 3 + 2) * Nm + m], emax);
-                r = min((unsigned)ub[(hop * 3 + 1) * Nm + m], (unsigned)(a.nR - 1));
+                // RAW here: three independent loads in flight, consumed a phase later (a clamp at this point made each of them
+                // wait for its own data: three memory latencies in a row in front of the segment's first barrier, 3 k cycles)
+                h = ub[(hop * 3 + 0) * Nm + m];
+                t = ub[(hop * 3 + 2) * Nm + m];
+                r = ub[(hop * 3 + 1) * Nm + m];
             }
         }
     };
     auto put_ids = [&](int par, int h, int t, int r) {
         if (tid < rows) {
             int* b = sIdN + par * 3 * rows;
-            b[tid] = h;
-            b[rows + tid] = t;
-            b[2 * rows + tid] = r;
+            // device-resident ids are not validated per launch: clamped into the table (a fault would kill the process);
+            // padding rows (m >= Nm) keep their -1 / -1 / 0
+            const bool real = tid - (tid / NmP) * NmP < Nm;
+            b[tid] = real ? (int)min((unsigned)h, emax) : -1;
+            b[rows + tid] = real ? (int)min((unsigned)t, emax) : -1;
+            b[2 * rows + tid] = real ? (int)min((unsigned)r, (unsigned)(a.nR - 1)) : 0;
         }
     };
     // this wave's kKaDmaRows rows of sH (LDB = row stride in bytes) or sT, ids from LDS
@@ -425,11 +429,19 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
         // the descriptor of the segment after the next: scalar loads, which EVERY barrier waits for (lgkmcnt) -- issued here, at the
         // start of the longest phase, they cost nothing; at the segment's top they stood in front of its first barrier (~1 k cycles).
         // (Register-staged form: measured slower with the move, 1.336 -> 1.374 ms; it keeps its load at the top.)
+        // (as VECTOR loads through a lane-dependent zero, turned into scalars after the U tiles: left to itself the compiler reads
+        // each with a vector load + readfirstlane + its own vmcnt(0) -- the kernel's stores make them "clobberable", so no s_load --
+        // three memory latencies in a row in front of every wave's U tiles)
+        int d_u = 0, d_p0 = 0, d_p1 = 0;
+        const bool d_have = DMA && seg + 2 * (int)gridDim.x < nseg;
         if constexpr (DMA) {
-            if (seg + 2 * (int)gridDim.x < nseg) {
-                nu2 = a.seg_user[seg + 2 * gridDim.x];
-                np02 = a.seg_ptr[seg + 2 * gridDim.x];
-                np12 = a.seg_ptr[seg + 2 * gridDim.x + 1];
+            if (d_have) {
+                int zv = 0;
+                asm volatile("" : "+v"(zv));
+                const int i = seg + 2 * (int)gridDim.x + zv;
+                d_u = a.seg_user[i];
+                d_p0 = a.seg_ptr[i];
+                d_p1 = a.seg_ptr[i + 1];
             }
         }
         // ---- h-set read (wave 15) next to the U tiles (waves 0..14) ----
@@ -505,6 +517,13 @@ __global__ __launch_bounds__(ka_dense_waves(D) * 64, ka_dense_minw(D)) void key_
 #pragma unroll
                     for (int j = 0; j < 16; ++j) sU[(size_t)row * LDH + 16 * nt + j] = 0.f;
                 }
+            }
+        }
+        if constexpr (DMA) {
+            if (d_have) {
+                nu2 = __builtin_amdgcn_readfirstlane(d_u);
+                np02 = __builtin_amdgcn_readfirstlane(d_p0);
+                np12 = __builtin_amdgcn_readfirstlane(d_p1);
             }
         }
         stamp(4);

@@ -271,8 +271,11 @@ hipError_t launch_key_addr_grouped(const KeyAddrGroupedArgs& a, int table_bf16, 
     if (key_addr_wave16_applies(a)) return launch_key_addr_wave16(a, table_bf16, st);
     // the dense (all-MFMA) form whenever its LDS footprint fits; MVIN_KA_DENSE=0 keeps this file's kernel (A/B)
     static const char* dense_env = getenv("MVIN_KA_DENSE");
-    if (!(dense_env && dense_env[0] == '0') && key_addr_dense_supported(a.D, a.P, a.Nm, a.nR))
+    if (!(dense_env && dense_env[0] == '0') && key_addr_dense_supported(a.D, a.P, a.Nm, a.nR)) {
+        // the same kernel over static per-user records, where the caller built them (MVIN_KA_STATIC=0: A/B)
+        if (key_addr_static_applies(a, table_bf16)) return launch_key_addr_static(a, st);
         return launch_key_addr_dense(a, table_bf16, st);
+    }
     switch (a.D) {
         case 16: return launch_kag<16>(a, table_bf16, st);
         case 32: return launch_kag<32>(a, table_bf16, st);

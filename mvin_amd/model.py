@@ -231,6 +231,33 @@ class MVIN(object):
         # the reference's CPU tf.gather (InvalidArgument).  A user_triplet_set is always checked once, when first seen.
         self.validate_device_ids = os.environ.get("MVIN_CHECK_IDS", "0") == "1"
         self._uts_ok = None
+        # grouped key addressing over STATIC per-user records (mvin_build_user_records: relation buckets, tile table, clamped
+        # head / tail ids of every user's ripple sets, built once per user_triplet_set tensor): None = where the library has
+        # the kernel (MVIN_KA_STATIC=0 turns it off), False = never
+        self.static_user_records = None
+        self._uts_records = None
+
+    USER_RECORDS_MAX_BYTES = 8 << 30
+
+    def user_records(self, uts):
+        """The static per-user records of a device-resident user_triplet_set, or None when the shape / table type has no
+        kernel over them.  Cached per tensor (identity + version counter), like the one-time id check."""
+        if self.static_user_records is False or os.environ.get("MVIN_KA_STATIC", "1") == "0" or self.p_hop < 1:
+            return None
+        if not (uts.is_cuda and uts.dtype == torch.int32 and uts.is_contiguous()):
+            return None
+        bf = self.entity_emb_matrix.dtype == torch.bfloat16
+        if not ops.user_records_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, bf):
+            return None
+        c = self._uts_records
+        if c is not None and c[0]() is uts and c[1] == uts._version and c[2] == (self.n_entity, self.n_relation):
+            return c[3]
+        words = ops.user_records_len(self.p_hop, self.n_memory, self.n_relation)
+        if uts.shape[0] * words * 4 > self.USER_RECORDS_MAX_BYTES:
+            return None
+        rec = ops.build_user_records(uts, self.p_hop, self.n_relation, self.n_entity)
+        self._uts_records = (weakref.ref(uts), uts._version, (self.n_entity, self.n_relation), rec)
+        return rec
 
     def _build_train(self):
         """model.py:378-414 (loss + Adam): the backward path is a later row of the scope
@@ -686,7 +713,9 @@ class MVIN(object):
         s.table_bf16 = 1 if self.entity_emb_matrix.dtype == torch.bfloat16 else 0
         enc = self._enc_for_l2(n_parents=B)
         s.enc_entity, s.enc_relation = (ptr(enc[0]), ptr(enc[1])) if enc is not None else (None, None)
-        st["live"] = (self.entity_emb_matrix, t0, t1, enc)
+        rec = self.user_records(uts) if grouped else None
+        s.user_records = ptr(rec)
+        st["live"] = (self.entity_emb_matrix, t0, t1, enc, rec)
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
         wkey = (B, n_o, stream.cuda_stream, bool(grouped), uts.shape[0] if grouped else 0)
@@ -726,7 +755,7 @@ class MVIN(object):
         w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
         groups = ops.group_pairs_by_user(user, n_user=uts.shape[0])
         ops.key_addressing_grouped(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, uts, groups, item, P,
-                                   o_cat, n_o * D, self.n_relation)
+                                   o_cat, n_o * D, self.n_relation, records=self.user_records(uts))
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,

@@ -454,9 +454,37 @@ def group_pairs_by_user(users, n_user=None):
     return seg_user, seg_ptr, nseg, perm.to(I32)
 
 
-def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, out, ldo, nR):
+def user_records_len(P, Nm, nR):
+    """int32 words of one user's static record (mvin_user_records_len); 0: no record form for this shape."""
+    return int(_lib.load().mvin_user_records_len(P, Nm, nR))
+
+
+def user_records_supported(D, P, Nm, nR, table_bf16=False):
+    """True when mvin_key_addressing_grouped_rec_fwd has a kernel over the static records for this shape."""
+    return bool(_lib.load().mvin_user_records_supported(D, P, Nm, nR, 1 if table_bf16 else 0))
+
+
+def build_user_records(uts, P, nR, n_entity):
+    """mvin_build_user_records: the static per-user records of ``uts`` [n_user, P, 3, Nm] int32 (relation buckets, tile
+    table, clamped head / tail ids) -> [n_user, user_records_len] int32.  Built once per data set, like the adjacency
+    encoding: the user's ripple sets are fixed (data_loader_user_set.py), every batch re-reads them."""
+    _chk(uts, I32, "uts")
+    n_user, Ph, three, Nm = uts.shape
+    if Ph != P or three != 3:
+        raise ValueError(f"uts shape {tuple(uts.shape)} does not match P={P}")
+    n = user_records_len(P, Nm, nR)
+    if n == 0:
+        raise ValueError(f"no record form for P={P} Nm={Nm} nR={nR}")
+    rec = torch.empty((n_user, n), dtype=I32, device=uts.device)
+    _lib.check(_lib.load().mvin_build_user_records(_p(uts), n_user, P, Nm, nR, n_entity, _p(rec), _stream()),
+               "mvin_build_user_records")
+    return rec
+
+
+def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, out, ldo, nR, records=None):
     """mvin_key_addressing_grouped_fwd: the attention reads of a batch whose pairs are grouped by user
-    (``groups`` = group_pairs_by_user(users)); fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...]."""
+    (``groups`` = group_pairs_by_user(users)); fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...].
+    ``records`` = build_user_records(uts, ...): the same results from the kernel over static per-user records."""
     lib = _lib.load()
     bf = _chk_table(entity_emb, "entity_emb")
     _chk(relation_kge, F32, "relation_kge"), _chk(w, F32, "w"), _chk(out, F32, "out"), _chk(uts, I32, "uts")
@@ -468,9 +496,13 @@ def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, o
     i32 = items if items.dtype == I32 else None
     if i64 is None and i32 is None:
         raise TypeError("items must be int64 or int32")
-    _lib.check(lib.mvin_key_addressing_grouped_fwd(_p(entity_emb), _p(relation_kge), _p(w), _p(uts), _p(seg_user),
-                                                   _p(seg_ptr), _p(nseg), _p(perm), _p(i64), _p(i32), B, B, P, Nm, D, nR,
-                                                   entity_emb.shape[0], n_user, _p(out), ldo, bf, _stream()),
+    if records is not None:
+        _chk(records, I32, "records")
+        if tuple(records.shape) != (n_user, user_records_len(P, Nm, nR)):
+            raise ValueError(f"records shape {tuple(records.shape)} is not that of build_user_records(uts, {P}, {nR}, ...)")
+    _lib.check(lib.mvin_key_addressing_grouped_rec_fwd(_p(entity_emb), _p(relation_kge), _p(w), _p(uts), _p(records), _p(seg_user),
+                                                       _p(seg_ptr), _p(nseg), _p(perm), _p(i64), _p(i32), B, B, P, Nm, D, nR,
+                                                       entity_emb.shape[0], n_user, _p(out), ldo, bf, _stream()),
                "mvin_key_addressing_grouped_fwd")
     return out
 

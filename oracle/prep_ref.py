@@ -140,6 +140,59 @@ def encode_adjacency(adj_e, adj_r):
     return enc_e.astype(np.uint32).view(np.int32), enc_r.astype(np.uint32).view(np.int32), cnt      # cnt = 128 sets the sign bit: the word is unsigned
 
 
+def user_records_layout(P, Nm, nR):
+    """Word offsets of one user's static record (mvin_user_records_len / ka_rec_layout, mvin_keyaddr_static.hip)."""
+    pad4 = lambda v: (v + 3) & ~3
+    NmP = (Nm + 15) & ~15
+    rows = P * NmP
+    maxtiles = rows // 16 + min(nR, P * Nm)
+    o_cnt = 4
+    o_off = o_cnt + pad4(nR)
+    o_trel = o_off + pad4(nR)
+    o_bidx = o_trel + pad4(maxtiles)
+    o_head = o_bidx + maxtiles * 16
+    o_tail = o_head + rows
+    return dict(NmP=NmP, rows=rows, maxtiles=maxtiles, o_cnt=o_cnt, o_off=o_off, o_trel=o_trel, o_bidx=o_bidx, o_head=o_head,
+                o_tail=o_tail, len=(o_tail + rows + 63) & ~63)
+
+
+def user_records(uts, nR, n_entity):
+    """Restatement of mvin_build_user_records: what the dense grouped key-addressing kernel derives from a user's ripple
+    sets alone (uts [n_user, P, 3, Nm]: the (h, r, t) memories user_triplet_set feeds for that user in every batch,
+    model.py:66-76 / data_loader_user_set.py), one record per user:
+      [0] tiles, [1..3] 0 | members per relation | first bucket row per relation | relation of each tile |
+      bucket slots -> row hop * NmP + m (rows of a relation -- they share R_KGE[r], model.py:214-216 -- in row order, every
+      bucket padded to whole 16-row tiles) | head id per row | tail id per row; ids clamped into the tables, all other words -1.
+    Pure integer work: bit-exact."""
+    uts = np.asarray(uts, dtype=np.int64)
+    n_user, P, three, Nm = uts.shape
+    assert three == 3
+    L = user_records_layout(P, Nm, nR)
+    rec = np.full((n_user, L["len"]), -1, dtype=np.int32)
+    for u in range(n_user):
+        r_ = rec[u]
+        r_[1:4] = 0
+        members = [[] for _ in range(nR)]
+        for hop in range(P):
+            for m in range(Nm):
+                i = hop * L["NmP"] + m
+                members[min(int(uts[u, hop, 1, m]) & 0xFFFFFFFF, nR - 1)].append(i)      # clamped as unsigned words, like every device id
+                r_[L["o_head"] + i] = min(int(uts[u, hop, 0, m]) & 0xFFFFFFFF, n_entity - 1)
+                r_[L["o_tail"] + i] = min(int(uts[u, hop, 2, m]) & 0xFFFFFFFF, n_entity - 1)
+        tile = 0
+        for r in range(nR):
+            cnt = len(members[r])
+            r_[L["o_cnt"] + r] = cnt
+            r_[L["o_off"] + r] = tile * 16
+            for j, i in enumerate(members[r]):
+                r_[L["o_bidx"] + tile * 16 + j] = i
+            nt = (cnt + 15) // 16
+            r_[L["o_trel"] + tile:L["o_trel"] + tile + nt] = r
+            tile += nt
+        r_[0] = tile
+    return rec
+
+
 def decode_adjacency(enc_e, enc_r):
     """Inverse up to slot order: the multiset of (neighbour, relation) slots of every row, as a sorted [nE, K, 2] array."""
     enc_e = np.asarray(enc_e).astype(np.int32).view(np.uint32).astype(np.int64) & 0xFFFFFF

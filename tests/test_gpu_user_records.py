@@ -1,0 +1,173 @@
+"""-m gpu: static per-user records (mvin_build_user_records) and the grouped key-addressing kernel over them
+(mvin_key_addressing_grouped_rec_fwd, mvin_keyaddr_static.hip): the records bit for bit against the oracle's restatement, the
+kernel bit for bit against the kernel that buckets every segment's ids itself, and against the CPU oracle of
+MVIN._key_addressing (model.py:161-240)."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import synth
+from mvin_amd.config import make_args
+from mvin_amd.params import init_params
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("P,Nm,nR,n_user", [(2, 64, 9, 50), (1, 16, 39, 30), (3, 48, 9, 20), (2, 40, 9, 33), (2, 20, 100, 17),
+                                            (8, 256, 70, 3), (1, 1, 1, 5), (2, 64, 1, 4)],
+                         ids=lambda v: str(v))
+def test_records_equal_the_oracle(P, Nm, nR, n_user, hip_lib):
+    from mvin_amd import ops
+    from oracle import prep_ref
+    n_entity = 777
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=P + Nm + nR)
+    # device ids are never validated per launch: out-of-range heads / tails / relations are clamped as unsigned words
+    uts[0, 0, 0, 0] = n_entity + 5
+    uts[0, 0, 2, 0] = -1
+    uts[1 % n_user, P - 1, 1, Nm - 1] = nR + 3
+    want = prep_ref.user_records(uts, nR, n_entity)
+    L = prep_ref.user_records_layout(P, Nm, nR)
+    assert ops.user_records_len(P, Nm, nR) == L["len"] == want.shape[1]
+    got = ops.build_user_records(torch.from_numpy(uts).cuda(), P, nR, n_entity).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    # every real row sits in exactly one bucket slot, in the bucket of its relation
+    for u in range(n_user):
+        slots = got[u, L["o_bidx"]:L["o_head"]]
+        rows = sorted(int(v) for v in slots if v >= 0)
+        assert rows == [h * L["NmP"] + m for h in range(P) for m in range(Nm)]
+        assert got[u, 0] * 16 <= slots.size
+
+
+def test_no_record_form_outside_the_shape_limits(hip_lib):
+    from mvin_amd import ops
+    assert ops.user_records_len(0, 16, 5) == 0 and ops.user_records_len(9, 16, 5) == 0 and ops.user_records_len(2, 257, 5) == 0
+    assert not ops.user_records_supported(32, 2, 64, 9) and not ops.user_records_supported(64, 1, 16, 39)     # D != 64; < 64 rows
+    assert ops.user_records_supported(64, 2, 64, 9) and not ops.user_records_supported(64, 2, 64, 9, table_bf16=True)
+    assert not ops.user_records_supported(64, 3, 48, 9)                                                         # > 128 rows
+    with pytest.raises(ValueError):
+        ops.build_user_records(torch.zeros((3, 2, 3, 300), dtype=torch.int32, device="cuda:0"), 2, 5, 10)
+
+
+SHAPES = [
+    # (P, Nm, nR, n_user, B, with h-set, item dtype)
+    (2, 64, 9, 40, 700, True, torch.int64),            # BASELINE C3's key-addressing shape; ~17 pairs per user: two tiles
+    (2, 64, 9, 2000, 9000, True, torch.int64),         # eight segments per workgroup: every hand-over of the pipeline
+    (2, 64, 9, 300, 1300, True, torch.int32),          # some workgroups with two segments, most with one
+    (2, 64, 9, 3000, 3500, True, torch.int64),         # most users appear once: one tile per segment
+    (1, 64, 9, 500, 4000, True, torch.int64),          # one hop
+    (2, 40, 9, 1500, 6000, True, torch.int64),         # padding rows (Nm = 40 -> 48 per hop)
+    (3, 32, 9, 700, 3000, False, torch.int64),         # three hops (the side waves take softmax / reads tiles too); no h-set
+    (4, 32, 7, 600, 5000, True, torch.int64),
+    (2, 64, 25, 500, 4000, True, torch.int64),         # more relations than resident fragments: R_KGE tiles fetched per task
+    (2, 32, 70, 400, 3000, False, torch.int64),        # more relations than a hop has memories
+    (2, 56, 9, 600, 2500, True, torch.int64),          # padding rows, 128 rows = the most the staging registers take
+    (2, 64, 9, 5, 3000, True, torch.int64),            # 600 pairs per user: 38 tiles per segment, fewer segments than CUs
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "P%dNm%dnR%d_u%d_B%d%s" % (s[0], s[1], s[2], s[3], s[4], "" if s[5] else "_noset"))
+def test_kernel_over_records_equals_the_bucketing_kernel(shape, hip_lib):
+    from mvin_amd import ops
+    P, Nm, nR, n_user, B, has_set, idt = shape
+    D, n_entity = 64, 5000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(B + Nm)
+    E = torch.rand((n_entity, D), device=dev, generator=g) - 0.5
+    R = torch.rand((nR, D, D), device=dev, generator=g) - 0.5
+    w = (torch.rand(D, device=dev, generator=g) - 0.5) if has_set else None
+    uts = torch.from_numpy(synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=B)).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g).to(idt)
+    assert ops.user_records_supported(D, P, Nm, nR)
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    n_o = P + (1 if has_set else 0)
+    a = torch.full((B, n_o * D), float("nan"), device=dev)
+    b = torch.full((B, n_o * D), float("nan"), device=dev)
+    ops.key_addressing_grouped(E, R, w, uts, groups, items, P, a, n_o * D, nR)
+    for _ in range(2):                                       # twice: nothing of a launch may leak into the next
+        b.fill_(float("nan"))
+        ops.key_addressing_grouped(E, R, w, uts, groups, items, P, b, n_o * D, nR, records=rec)
+        torch.cuda.synchronize()
+        assert torch.isfinite(b).all()
+        if has_set:
+            # the h-set read sums a user's rows in a different order (four rows per step instead of one)
+            assert_close(b[:, :D].cpu().numpy(), a[:, :D].cpu().numpy(), "h-set read", rtol=1e-5, atol=1e-6)
+            assert torch.equal(a[:, D:], b[:, D:])
+        else:
+            assert torch.equal(a, b)
+
+
+CASES = [
+    # (dim, K, H, P, Nm, nR, n_user, B, ablation)
+    (64, 4, 2, 2, 64, 9, 40, 700, "all"),
+    (64, 4, 2, 2, 40, 9, 1500, 6000, "all"),
+    (64, 4, 2, 3, 32, 9, 700, 3000, "no_ps_o_ft"),
+    (64, 4, 2, 2, 64, 30, 300, 1300, "all"),
+]
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["one_native_call", "python_schedule"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "P%dNm%dnR%d_%s" % (c[3], c[4], c[5], c[8]))
+def test_forward_users_over_records_against_the_oracle(case, native, hip_lib):
+    """MVIN.forward_users builds the records once per user_triplet_set tensor and both of its schedules (mvin_score_l2_fwd with
+    group_ws + user_records; op by op) take the kernel over them: against the fp32 mirror of the reference's graph."""
+    from mvin_amd.model import MVIN
+    from oracle import mirror_fp32
+    D, K, H, P, Nm, nR, n_user, B, abl = case
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    n_entity = 500
+    rng = np.random.default_rng(D + Nm + B)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=3)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0")
+    model.group_min_pairs_per_user = 0
+    if not native:
+        model._profile = []                                  # event hooks requested: the Python schedule
+    dev = model.device
+    u_d, i_d, uts_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev), torch.from_numpy(uts).to(dev)
+    got = model.forward_users(u_d, i_d, uts_d)
+    assert model._uts_records is not None and model._uts_records[0]() is uts_d
+    rec = model._uts_records[3]
+    again = model.forward_users(u_d, i_d, uts_d)
+    assert model._uts_records[3] is rec                      # built once per tensor
+    model.static_user_records = False
+    plain = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert torch.equal(got.scores, again.scores)
+    assert_close(got.user_o.cpu().numpy(), plain.user_o.cpu().numpy(), "user_o records vs bucketing kernel")
+    mh, mr, mt = synth.memories_for(uts, users)
+    ref = mirror_fp32.forward(args, params, adj_e, adj_r, users, items, mh, mr, mt)
+    assert_close(got.user_o.cpu().numpy(), ref.user_o.numpy(), "user_o vs fp32 mirror")
+    assert_close(got.scores.cpu().numpy(), ref.scores.numpy(), "scores vs fp32 mirror")
+
+
+def test_records_follow_the_tensor_not_its_address(hip_lib):
+    """The cache is keyed by the tensor object and its version counter: an in-place edit of the ripple sets rebuilds them."""
+    from mvin_amd.model import MVIN
+    args = make_args(dim=64, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=32, batch_size=64)
+    n_user, n_entity, nR = 20, 300, 6
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, 4, seed=1)
+    uts = synth.ripple_sets(n_user, n_entity, nR, 2, 32, seed=2)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, device="cuda:0", seed=3)
+    model.group_min_pairs_per_user = 0
+    rng = np.random.default_rng(1)
+    users = torch.from_numpy(rng.integers(0, n_user, 96)).cuda()
+    items = torch.from_numpy(rng.integers(0, n_entity, 96)).cuda()
+    uts_d = torch.from_numpy(uts).cuda()
+    a = model.forward_users(users, items, uts_d).scores.clone()
+    rec = model._uts_records[3]
+    uts_d[:, :, 2] = torch.flip(uts_d[:, :, 2], dims=[-1]).clone()       # same sets, tails in another order: new reads
+    uts_d[:, 0, 2, 0] = 7
+    b = model.forward_users(users, items, uts_d).scores
+    assert model._uts_records[3] is not rec
+    model.static_user_records = False
+    c = model.forward_users(users, items, uts_d).scores
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b)
+    np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=1e-6)
