@@ -7,17 +7,21 @@
 // written once (user_records_kernel below, like mvin_encode_adjacency for the adjacency) and landed in LDS by the LDS-DMA
 // path a segment ahead: one wave, len / 64 instructions, no registers, no barrier.
 //
-// D = 64, fp32 table (a row = 256 bytes = one global_load_lds_dword of a wave), 64 <= P * NmP <= 144 rows per user.
+// D = 64, fp32 table, 64 <= P * NmP <= 128 rows per user.
 //
-// Per user segment s (one workgroup of 12 waves; waves 0..10 hold the R_KGE fragments, wave 11 does the h-set read, the
-// four "side" waves 8..11 have no logits / softmax / reads tiles at P = 2 and carry every global load of the segment):
-//   top     : [barrier]  wave 11: record of s+1 -> LDS;  side waves: tail rows of s -> sT          (LDS-DMA, fire and forget)
+// Per user segment s (one workgroup of 12 waves; waves 0..10 hold the R_KGE fragments, wave 11 does the h-set read; the four
+// "side" waves 8..11 take no logits / softmax / reads tile and carry the loads of the tile phases instead):
+//   top     : [barrier]  wave 11: record of s+1 -> LDS (LDS-DMA);  every wave: 12 of the segment's tail rows -> registers
 //   U       : U_m = R_KGE[r_m] . h_m as 16-row tiles of memories that share a relation (bucket table of the record),
-//             h-set read (wave 11); head rows were landed during segment s-1
-//   per tile of 16 pairs (four barriers):  item rows -> sEi | logits | softmax | reads -> out
-//             side waves: the next tile's item chain (pair index -> item id -> row), one step per phase;
-//             under tile 0's reads: head rows of s+1 -> sH
-// Results are those of key_addr_dense_kernel bit for bit (the same products in the same order).
+//             h-set read (wave 11); the head rows were landed during segment s-1; behind its own U work a wave writes its
+//             tail rows to sT (their memory latency, ~6 k cycles for the burst, has passed under the MFMA tiles)
+//   per tile of 16 pairs, THREE barriers:  logits | softmax | reads -> out      (main waves 0..7)
+//             side waves: the NEXT tile's item rows -- pair index -> item id -> row, one step per phase -- into the other
+//             sEi buffer; under a segment's first tile also the next segment's head rows -> sH, in two pieces of 16 rows per
+//             side wave, each issued one phase and written the next
+// What was measured on the way and not kept (LDS-DMA for the rows, one relation per wave on v_mfma_f32_4x4x1, ...): HISTORY.md.
+// Results are those of key_addr_dense_kernel up to the order of the h-set read's sum (four rows per step instead of one); the
+// attention reads are the same products in the same order, bit for bit.
 #include <cstdlib>
 #include <utility>
 
@@ -38,7 +42,7 @@ __device__ __forceinline__ float kas_exp(float x) {          // exp for x <= 0, 
 __device__ long long g_kas_trace[64 * 16];    // MVIN_KA_TRACE=1: workgroup 0 stamps its phase boundaries (scripts/trace_keyaddr.py)
 
 constexpr int kSW = 12;       // waves per workgroup (168 VGPRs each: the resident R_KGE fragments; one workgroup per CU)
-constexpr int kSSide = 4;     // the last kSSide waves: item chain + every LDS-DMA batch
+constexpr int kSSide = 4;     // the last kSSide waves: the loads of the tile phases (item chain, the next segment's head rows)
 constexpr int kST = 16;       // pairs per tile
 constexpr int kSMaxRows = 128;  // rows per user (P * NmP) the staging registers hold: 4 side waves x 2 x 4 loads x 4 rows (heads); 12 waves x 3 x 4 (tails)
 
@@ -151,7 +155,7 @@ static KaStaticLds ka_static_layout(int P, const KaRecLayout& RL) {
     constexpr int D = 64;
     int o = 0;
     auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
-    L.rec = take(2 * RL.len);                                // first: the LDS-DMA's M0 base (see dma_record)
+    L.rec = take(2 * RL.len);
     L.h = take(RL.rows * (D + 4));
     L.u = take(RL.rows * (D + 4));
     L.t = take(RL.rows * D);                                 // rows unpadded (16-byte chunks swizzled)
@@ -286,12 +290,11 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             if (q < a.nR * NT) load_bfrag(q / NT, q % NT, rb[sl]);
         }
     }
-    // ---- a user's 2 * PN rows, staged through registers: 16 bytes per lane, four rows per load.  A burst of 128 rows (32 KB) takes
-    //      ~2.7 k cycles to issue whoever issues it and however (what the CU keeps in flight, not the instruction count, bounds it;
-    //      LDS-DMA, one 256-byte row per instruction and no registers, is no faster and costs the issuing wave ~85 cycles per row
-    //      -- _ubench/lds_dma.hip), which is longer than a tile phase: so the rows travel in pieces sized to the phase they hide
-    //      under, issued one phase and written the next, by the waves that would otherwise stand at the barrier --
-    //        tail rows of s   : wave 11, behind its h-set read (the U phase is twice as long as that read), 4 x 32 rows;
+    // ---- a user's 2 * PN rows, staged through registers: 16 bytes per lane, four rows per load.  A burst of 128 rows (32 KB)
+    //      takes 2.5 - 6 k cycles to come back whoever issues it and however (what the CU keeps in flight bounds it; LDS-DMA, one
+    //      256-byte row per instruction and no registers, is no faster and costs the issuing wave ~85 cycles per row --
+    //      _ubench/lds_dma.hip), which is longer than a tile phase: so the rows travel in pieces, issued early and written late --
+    //        tail rows of s   : every wave 12 rows (three loads), issued at the segment's top, written behind the wave's U work;
     //        head rows of s+1 : the side waves, 2 x 16 rows each, under tile 0's logits -> softmax and softmax -> reads phases.
     //      (the registers are local to a piece: one array at function scope was live across the whole segment loop) ----
     const int sj = wave_u - (kSW - kSSide);                  // side wave number (< 0: not a side wave)

@@ -24,6 +24,25 @@ torch.cuda.synchronize()
 buf = np.zeros(64 * 16, dtype=np.int64)
 assert _lib.load().mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 full = buf.reshape(64, 16).astype(np.float64)
+if STATIC:
+    # the kernel over static records: three barriers per tile; per wave, own work per phase (phase start -> arrival at its barrier)
+    print("cycles per segment %d ; U phase (top barrier -> tiles' first barrier) %d ; tile 0: logits %d softmax %d reads %d" % (
+        np.mean(np.diff(full[4:60, 0])), (full[4:60, 5] - full[4:60, 13]).mean(), (full[4:60, 6] - full[4:60, 5]).mean(),
+        (full[4:60, 7] - full[4:60, 6]).mean(), (full[4:60, 8] - full[4:60, 7]).mean()))
+    print("per wave: [top barrier -> U work starts] [-> own U tiles / h-set read done] [-> tail rows written: phase work done] "
+          "[logits: own work] [softmax: own work] [reads: own work] [tile 0 end -> next top]")
+    for wv in range(12):
+        os.environ["MVIN_KA_TRACE_WAVE"] = str(wv)
+        for _ in range(2):
+            ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, 3 * D, nR, records=rec)
+        torch.cuda.synchronize()
+        assert _lib.load().mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+        f = buf.reshape(64, 16).astype(np.float64)[4:60]
+        u_done = (f[:, 9] - f[:, 3]).mean() if wv < 11 else float("nan")     # (wave 11: the h-set read, no stamp of its own)
+        print("  wave %2d: %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f %6.0f" % (wv, (f[:, 3] - f[:, 13]).mean(), u_done, (f[:, 4] - f[:, 3]).mean(),
+                                                                  (f[:, 10] - f[:, 5]).mean(), (f[:, 11] - f[:, 6]).mean(), (f[:, 8] - f[:, 7]).mean(),
+                                                                  (f[1:, 0] - f[:-1, 8]).mean()))
+    sys.exit(0)
 print("U tiles of wave 0 done (cycles since 'rows->LDS'):", round(float(np.mean(full[8:56, 9] - full[8:56, 3]))))
 t = full[:, :9]
 names = ["top", "ids+rank", "tile table", "rows->LDS", "U + hset", "tile0: Ei", "tile0: logits", "tile0: softmax", "tile0: reads"]
@@ -36,22 +55,6 @@ print("   top -> top barrier released %6.0f ; -> DMA / clears issued %6.0f" % ((
 print("   U done -> tile0 barrier + Ei written %6.0f ; -> head-row DMA issued %6.0f ; -> barrier %6.0f" % (
     (ex[:, 10] - ex[:, 4]).mean(), (ex[:, 11] - ex[:, 10]).mean(), (ex[:, 5] - ex[:, 11]).mean()))
 
-if STATIC:
-    # the kernel over static records: three barriers per tile; per wave, own work per phase (phase start -> arrival at its barrier)
-    print("cycles per segment %d ; U phase (top barrier -> tiles' first barrier) %d ; tile 0: logits %d softmax %d reads %d" % (
-        np.mean(np.diff(full[4:60, 0])), (full[4:60, 5] - full[4:60, 13]).mean(), (full[4:60, 6] - full[4:60, 5]).mean(),
-        (full[4:60, 7] - full[4:60, 6]).mean(), (full[4:60, 8] - full[4:60, 7]).mean()))
-    print("per wave: [top barrier -> own U work done] [logits: own work] [softmax: own work] [reads: own work] [tile 0 end -> next top]")
-    for wv in range(12):
-        os.environ["MVIN_KA_TRACE_WAVE"] = str(wv)
-        for _ in range(2):
-            ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, 3 * D, nR, records=rec)
-        torch.cuda.synchronize()
-        assert _lib.load().mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
-        f = buf.reshape(64, 16).astype(np.float64)[4:60]
-        print("  wave %2d: %6.0f %6.0f %6.0f %6.0f %6.0f" % (wv, (f[:, 4] - f[:, 13]).mean(), (f[:, 10] - f[:, 5]).mean(), (f[:, 11] - f[:, 6]).mean(),
-                                                      (f[:, 8] - f[:, 7]).mean(), (f[1:, 0] - f[:-1, 8]).mean()))
-    sys.exit(0)
 # which wave is late where: the same stamps taken by each wave of workgroup 0 in turn (MVIN_KA_TRACE_WAVE)
 print("per wave: [top -> top barrier released] [U phase start -> own U work done] [U done -> tile0 first barrier + Ei] [tile0 reads done -> next top]")
 for wv in range(12):

@@ -118,3 +118,37 @@ def test_encode_adjacency_round_trip_and_order():
             assert np.array_equal(child_cnt, cnt[eu[x, :c] & 0xFFFFFF])
             assert (np.diff(child_cnt) <= 0).all()       # longest lists first
             assert (eu[x, c:] == eu[x, 0]).all()
+
+
+def test_user_records_layout_and_buckets(hip_lib):
+    """oracle.prep_ref.user_records (the restatement of mvin_build_user_records): every memory row sits in exactly one slot of
+    its relation's bucket, in row order; buckets are whole 16-row tiles; ids are clamped; the record length is the library's
+    (mvin_user_records_len is host arithmetic: no GPU needed)."""
+    for P, Nm, nR in [(2, 64, 9), (1, 16, 39), (3, 40, 7), (2, 20, 100), (1, 1, 1)]:
+        n_user, n_entity = 9, 123
+        uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=P * Nm + nR)
+        uts[0, 0, 0, 0] = n_entity + 7                                    # clamped like every device id
+        uts[0, P - 1, 1, Nm - 1] = nR + 2
+        rec = prep_ref.user_records(uts, nR, n_entity)
+        L = prep_ref.user_records_layout(P, Nm, nR)
+        assert rec.shape == (n_user, L["len"]) and L["len"] % 64 == 0
+        assert hip_lib.mvin_user_records_len(P, Nm, nR) == L["len"]
+        for u in range(n_user):
+            r_ = rec[u]
+            cnt, off = r_[L["o_cnt"]:L["o_cnt"] + nR], r_[L["o_off"]:L["o_off"] + nR]
+            assert cnt.sum() == P * Nm and r_[0] == sum((c + 15) // 16 for c in cnt) <= L["maxtiles"]
+            seen = []
+            for r in range(nR):
+                assert off[r] % 16 == 0
+                slots = r_[L["o_bidx"] + off[r]:L["o_bidx"] + off[r] + ((cnt[r] + 15) // 16) * 16]
+                rows = [int(v) for v in slots if v >= 0]
+                assert rows == sorted(rows) and len(rows) == cnt[r] and all(v == -1 for v in slots[cnt[r]:])
+                for i in rows:
+                    hop, m = divmod(i, L["NmP"])
+                    assert min(int(uts[u, hop, 1, m]), nR - 1) == r
+                    assert r_[L["o_head"] + i] == min(int(uts[u, hop, 0, m]), n_entity - 1)
+                    assert r_[L["o_tail"] + i] == min(int(uts[u, hop, 2, m]), n_entity - 1)
+                assert all(r_[L["o_trel"] + off[r] // 16 + t] == r for t in range((cnt[r] + 15) // 16))
+                seen += rows
+            assert sorted(seen) == [h * L["NmP"] + m for h in range(P) for m in range(Nm)]
+    assert hip_lib.mvin_user_records_len(0, 16, 5) == 0 and hip_lib.mvin_user_records_len(2, 300, 5) == 0
