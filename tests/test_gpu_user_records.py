@@ -171,3 +171,67 @@ def test_records_follow_the_tensor_not_its_address(hip_lib):
     torch.cuda.synchronize()
     assert not torch.equal(a, b)
     np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+N_FUZZ = int(__import__("os").environ.get("MVIN_FUZZ_CASES", "24"))      # a longer campaign: MVIN_FUZZ_CASES=400 pytest tests/test_gpu_user_records.py -k fuzz
+
+
+@pytest.mark.parametrize("i", range(N_FUZZ))
+def test_fuzz_kernel_over_records(i, hip_lib):
+    """Random shapes inside the record kernel's range (D = 64, fp32, 64..128 ripple rows per user) against the bucketing kernel
+    and, pair by pair on a sample, against a float64 evaluation of MVIN._key_addressing (model.py:161-240)."""
+    from mvin_amd import ops
+    rng = np.random.default_rng(77000 + i)
+    D = 64
+    while True:
+        P = int(rng.choice([1, 2, 2, 3, 4, 8]))
+        Nm = int(rng.choice([8, 12, 16, 20, 31, 32, 40, 48, 64, 64, 100, 128]))
+        if 64 <= P * ((Nm + 15) // 16 * 16) <= 128:
+            break
+    nR = int(rng.choice([1, 2, 5, 9, 9, 11, 12, 24, 39]))
+    n_user = int(rng.choice([1, 7, 100, 300, 700, 3000]))
+    B = int(rng.choice([1, 17, 300, 2000, 9000, 30000]))
+    n_entity = int(rng.choice([50, 5000, 200000]))
+    has_set = bool(rng.random() < 0.8)
+    idt = torch.int32 if rng.random() < 0.3 else torch.int64
+    if not ops.user_records_supported(D, P, Nm, nR):
+        pytest.skip("record too large for the LDS at this shape")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(i)
+    E = torch.rand((n_entity, D), device=dev, generator=g) - 0.5
+    R = torch.rand((nR, D, D), device=dev, generator=g) - 0.5
+    w = (torch.rand(D, device=dev, generator=g) - 0.5) if has_set else None
+    uts_h = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=i)
+    if rng.random() < 0.3:                                   # a skewed relation histogram: one relation takes most memories
+        mask = rng.random(uts_h[:, :, 1].shape) < 0.7
+        uts_h[:, :, 1][mask] = int(rng.integers(0, nR))
+    uts = torch.from_numpy(uts_h).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g).to(idt)
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    n_o = P + (1 if has_set else 0)
+    a = torch.full((B, n_o * D), float("nan"), device=dev)
+    b = torch.full((B, n_o * D), float("nan"), device=dev)
+    ops.key_addressing_grouped(E, R, w, uts, groups, items, P, a, n_o * D, nR)
+    ops.key_addressing_grouped(E, R, w, uts, groups, items, P, b, n_o * D, nR, records=rec)
+    torch.cuda.synchronize()
+    assert torch.isfinite(b).all()
+    assert_close(b.cpu().numpy(), a.cpu().numpy(), "records kernel vs bucketing kernel", rtol=1e-5, atol=1e-6)
+    # float64, straight from the equations, on up to 64 pairs spread over the batch
+    pick = torch.linspace(0, B - 1, min(B, 64), device=dev).long()
+    E64, R64 = E.double(), R.double()
+    it, us = items[pick].long(), users[pick].long()
+    want = []
+    if has_set:
+        h0 = E64[uts[us, 0, 0].long()]                       # [n, Nm, D]
+        p = torch.softmax(h0 @ w.double(), dim=1)
+        want.append((p[:, :, None] * h0).sum(1))
+    for hop in range(P):
+        h, r, t = (uts[us, hop, j].long() for j in range(3))
+        Rh = torch.einsum("nmij,nmj->nmi", R64[r], E64[h])   # R_KGE[r] . h   (model.py:214-216)
+        p = torch.softmax(torch.einsum("nmi,ni->nm", Rh, E64[it]), dim=1)
+        want.append((p[:, :, None] * E64[t]).sum(1))
+    want = torch.cat(want, dim=1)
+    assert_close(b[pick].double().cpu().numpy(), want.cpu().numpy(), "records kernel vs float64 equations", rtol=1e-5, atol=2e-6)
