@@ -43,7 +43,8 @@ __device__ long long g_kas_trace[64 * 16];    // MVIN_KA_TRACE=1: workgroup 0 st
 
 constexpr int kSW = 12;       // waves per workgroup (168 VGPRs each: the resident R_KGE fragments; one workgroup per CU)
 constexpr int kSSide = 4;     // the last kSSide waves: the loads of the tile phases (item chain, the next segment's head rows)
-constexpr int kST = 16;       // pairs per tile
+constexpr int kRT = 2;        // 16-row MFMA row tiles per tile of pairs: they share every B operand read and every barrier
+constexpr int kST = 16 * kRT; // pairs per tile (a C3 user has ~22 pairs: one pass of the three tile phases instead of two)
 constexpr int kSMaxRows = 128;  // rows per user (P * NmP) the staging registers hold: 4 side waves x 2 x 4 loads x 4 rows (heads); 12 waves x 3 x 4 (tails)
 
 // ---- the record of one user (int32 words; every section starts on a multiple of 4, the record is whole 256-byte lines) ----
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
 #define KAS_Q16 (lane >> 4)
 #define KAS_L16 (lane & 15)
 #define KAS_TID (wave_u * 64 + lane)
-#define KAS_ITID (wave_u * 64 + lane - (NTHR - kST * LPR))   /* >= 0: a thread of the side waves */
+#define KAS_ITID (wave_u * 64 + lane - (NTHR - 16 * LPR))    /* >= 0: a thread of the side waves (16 rows x 16 lanes) */
     const bool has_set = a.w != nullptr;
     const bool side = wave_u >= kSW - kSSide;
     const int G = (int)gridDim.x;
@@ -222,35 +223,43 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
 
     // ---- the item row of a pair hangs on three dependent loads (pair index -> item id -> E row): fetched one tile ahead by the
     //      side waves, one step per tile phase, so that every wait falls where these waves would stand at a barrier anyway ----
-    int st_o = 0;
-    unsigned st_item = 0;
-    bool st_act = false, st_valid = false;
+    int st_o[kRT];
+    unsigned st_item[kRT];
+    bool st_act[kRT], st_valid[kRT];                         // a side thread carries row (its own) of every row tile
     auto chain_a = [&](int t0, int p1) {
-        st_act = KAS_ITID >= 0 && t0 < p1;
-        st_valid = false;
-        st_o = 0, st_item = 0;                               // (assigned on every path: not carried from tile to tile)
-        if (st_act) {
-            const int p = t0 + KAS_ITID / LPR;
-            st_valid = p < p1;
-            st_o = a.pair_index[st_valid ? p : p1 - 1];
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+            st_act[rt] = KAS_ITID >= 0 && t0 + 16 * rt < p1; // (a row tile past the segment's pairs is not fetched at all)
+            st_valid[rt] = false;
+            st_o[rt] = 0, st_item[rt] = 0;                   // (assigned on every path: not carried from tile to tile)
+            if (st_act[rt]) {
+                const int p = t0 + 16 * rt + KAS_ITID / LPR;
+                st_valid[rt] = p < p1;
+                st_o[rt] = a.pair_index[st_valid[rt] ? p : p1 - 1];
+            }
         }
     };
     auto chain_b = [&]() {
-        if (st_act) st_item = item_id(st_o);
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt)
+            if (st_act[rt]) st_item[rt] = item_id(st_o[rt]);
     };
-    auto chain_c = [&](int buf) {                            // row -> sEi[buf] (the wait for it stands here: the side waves are idle)
-        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-        int orig = -1;
-        if (st_act) {
-            e = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.E) + (size_t)st_item * D)[KAS_ITID % LPR];
-            orig = st_valid ? st_o : -1;
+    auto chain_c = [&](int buf) {                            // rows -> sEi[buf] (the wait for them stands here: the side waves are idle)
+        float4 e[kRT];
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) {
+            e[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (st_act[rt]) e[rt] = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.E) + (size_t)st_item[rt] * D)[KAS_ITID % LPR];
         }
         if (KAS_ITID >= 0) {
-            const int i = KAS_ITID / LPR, cc = KAS_ITID % LPR;
-            float* dst = sEi + (buf * kST + i) * LDH + 4 * cc;
-            *reinterpret_cast<float2*>(dst) = make_float2(e.x, e.y);
-            *reinterpret_cast<float2*>(dst + 2) = make_float2(e.z, e.w);
-            if (cc == 0) sOrig[buf * kST + i] = orig;
+#pragma unroll
+            for (int rt = 0; rt < kRT; ++rt) {
+                const int i = 16 * rt + KAS_ITID / LPR, cc = KAS_ITID % LPR;
+                float* dst = sEi + (buf * kST + i) * LDH + 4 * cc;
+                *reinterpret_cast<float2*>(dst) = make_float2(e[rt].x, e[rt].y);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(e[rt].z, e[rt].w);
+                if (cc == 0) sOrig[buf * kST + i] = st_act[rt] && st_valid[rt] ? st_o[rt] : -1;
+            }
         }
     };
 
@@ -541,6 +550,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             relane();
             const bool last = t0 + kST >= p1;                // p00 / p10: by now the NEXT segment's (none: an empty range)
             const bool heads = t0 == p0 && has_next;         // this tile carries the next segment's rows
+            const int nrt = p1 - t0 > 16 ? kRT : 1;          // row tiles of this tile that hold pairs
             float4 stg[kHalf / 4];                           // (side waves, under `heads`; live across one barrier each time)
             const float* sEc = sEi + ep * kST * LDH;
             const int* sOc = sOrig + ep * kST;
@@ -555,19 +565,44 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             } else {
                 // logits L[pair, m] = E[item_pair] . U_m : one 16-memory tile per task
                 for (int mt = wave; mt < PN / 16; mt += kMW) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc[kRT];
                     const float4* ar = reinterpret_cast<const float4*>(sEc + KAS_L16 * LDH + KS * KAS_Q16);
                     const float4* br = reinterpret_cast<const float4*>(sU + (16 * mt + KAS_L16) * LDH + KS * KAS_Q16);
 #pragma unroll
-                    for (int k = 0; k < KS / 4; ++k) {
-                        const float4 av = ar[k], bv = br[k];
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+                    for (int rt = 0; rt < kRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (nrt == kRT) {                        // the row tiles share the B operand; their accumulator chains interleave
+#pragma unroll
+                        for (int k = 0; k < KS / 4; ++k) {
+                            const float4 bv = br[k];
+                            float4 av[kRT];
+#pragma unroll
+                            for (int rt = 0; rt < kRT; ++rt) av[rt] = ar[rt * 16 * LDH / 4 + k];
+#pragma unroll
+                            for (int rt = 0; rt < kRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].x, bv.x, acc[rt], 0, 0, 0);
+#pragma unroll
+                            for (int rt = 0; rt < kRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].y, bv.y, acc[rt], 0, 0, 0);
+#pragma unroll
+                            for (int rt = 0; rt < kRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].z, bv.z, acc[rt], 0, 0, 0);
+#pragma unroll
+                            for (int rt = 0; rt < kRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt].w, bv.w, acc[rt], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < KS / 4; ++k) {
+                            const float4 av = ar[k], bv = br[k];
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[0], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[0], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[0], 0, 0, 0);
+                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[0], 0, 0, 0);
+                        }
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) sL[(size_t)(4 * KAS_Q16 + i) * LDL + 16 * mt + KAS_L16] = acc[i];
+                    for (int rt = 0; rt < kRT; ++rt) {
+                        if (rt < nrt) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sL[(size_t)(16 * rt + 4 * KAS_Q16 + i) * LDL + 16 * mt + KAS_L16] = acc[rt][i];
+                        }
+                    }
                 }
             }
             if (t0 == p0) stamp(10);
@@ -584,9 +619,9 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
                 // softmax over the Nm memories of every (pair, hop) (:223): un-normalised weights back to sL, 1/sum to sZ; four rows
                 // per wave pass, a 16-lane DPP row per (pair, hop)
                 const int rg = lane >> 4, cl = lane & 15;
-                for (int base = wave * 4; base < kST * P; base += kMW * 4) {
+                for (int base = wave * 4; base < 16 * nrt * P; base += kMW * 4) {
                     const int task = base + rg;
-                    const bool ok = task < kST * P;
+                    const bool ok = task < 16 * nrt * P;
                     const int tk = ok ? task : base;
                     const int pi = tk / P, hop = tk - pi * P;
                     float* row = sL + (size_t)pi * LDL + hop * NmP;
@@ -626,29 +661,53 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
                 // reads o[pair, hop, :] = sum_m p[pair, m] t_m : one (hop, 16-column tile) per task
                 for (int task = wave; task < P * NT; task += kMW) {
                     const int hop = task / NT, nt = task - hop * NT;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc[kRT];
+#pragma unroll
+                    for (int rt = 0; rt < kRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const float* ar = sL + (size_t)KAS_L16 * LDL + hop * NmP + KAS_Q16;
                     const float* br = sT + (size_t)(hop * NmP + KAS_Q16) * LDT + 16 * (nt ^ KAS_Q16) + KAS_L16;     // (swizzled chunks: row & 3 == KAS_Q16)
-                    for (int k = 0; k < NmP / 4; k += 4) {
-                        float av[4], bv[4];
+                    if (nrt == kRT) {
+                        for (int k = 0; k < NmP / 4; k += 4) {
+                            float av[kRT][4], bv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            av[u] = ar[4 * (k + u)];
-                            bv[u] = br[(size_t)4 * (k + u) * LDT];
+                            for (int u = 0; u < 4; ++u) {
+                                bv[u] = br[(size_t)4 * (k + u) * LDT];
+#pragma unroll
+                                for (int rt = 0; rt < kRT; ++rt) av[rt][u] = ar[(size_t)16 * rt * LDL + 4 * (k + u)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                                for (int rt = 0; rt < kRT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][u], bv[u], acc[rt], 0, 0, 0);
+                            }
                         }
+                    } else {
+                        for (int k = 0; k < NmP / 4; k += 4) {
+                            float av[4], bv[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+                            for (int u = 0; u < 4; ++u) {
+                                av[u] = ar[4 * (k + u)];
+                                bv[u] = br[(size_t)4 * (k + u) * LDT];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc[0], 0, 0, 0);
+                        }
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int pi = 4 * KAS_Q16 + i;
-                        const int orig = sOc[pi];
-                        if (orig >= 0)
-                            a.out[(int64_t)orig * a.ldo + (size_t)(slot0 + hop) * D + 16 * nt + KAS_L16] = acc[i] * sZ[pi * P + hop];
+                    for (int rt = 0; rt < kRT; ++rt) {
+                        if (rt < nrt) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int pi = 16 * rt + 4 * KAS_Q16 + i;
+                                const int orig = sOc[pi];
+                                if (orig >= 0)
+                                    a.out[(int64_t)orig * a.ldo + (size_t)(slot0 + hop) * D + 16 * nt + KAS_L16] = acc[rt][i] * sZ[pi * P + hop];
+                            }
+                        }
                     }
                 }
                 if (has_set) {
-                    for (int i = KAS_TID; i < kST * LPR; i += kMW * 64) {
+                    for (int i = KAS_TID; i < 16 * nrt * LPR; i += kMW * 64) {
                         const int pi = i / LPR, cc = i - pi * LPR;
                         const int orig = sOc[pi];
                         if (orig >= 0)
