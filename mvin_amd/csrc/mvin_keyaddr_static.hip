@@ -48,23 +48,24 @@ constexpr int kST = 16 * kRT; // pairs per tile (a C3 user has ~22 pairs: one pa
 constexpr int kSMaxRows = 128;  // rows per user (P * NmP) the staging registers hold: 4 side waves x 2 x 4 loads x 4 rows (heads); 12 waves x 3 x 4 (tails)
 
 // ---- the record of one user (int32 words; every section starts on a multiple of 4, the record is whole 256-byte lines) ----
-KaRecLayout ka_rec_layout(int P, int Nm, int nR) {
+__host__ __device__ constexpr int kas_pad4(int v) { return (v + 3) & ~3; }
+__host__ __device__ constexpr KaRecLayout ka_rec_layout_c(int P, int Nm, int nR) {
     KaRecLayout R{};
     if (P < 1 || P > 8 || Nm < 1 || Nm > 256 || nR < 1 || nR > 4096) return R;
-    auto pad4 = [](int v) { return (v + 3) & ~3; };
     R.NmP = (Nm + 15) & ~15;
     R.rows = P * R.NmP;
     const int nrl = nR < P * Nm ? nR : P * Nm;
     R.maxtiles = R.rows / 16 + nrl;                        // every bucket wastes less than one tile
     R.o_cnt = 4;                                           // [0] = number of tiles; [1..3] = 0
-    R.o_off = R.o_cnt + pad4(nR);
-    R.o_trel = R.o_off + pad4(nR);
-    R.o_bidx = R.o_trel + pad4(R.maxtiles);
+    R.o_off = R.o_cnt + kas_pad4(nR);
+    R.o_trel = R.o_off + kas_pad4(nR);
+    R.o_bidx = R.o_trel + kas_pad4(R.maxtiles);
     R.o_head = R.o_bidx + R.maxtiles * 16;
     R.o_tail = R.o_head + R.rows;
     R.len = (R.o_tail + R.rows + 63) & ~63;
     return R;
 }
+KaRecLayout ka_rec_layout(int P, int Nm, int nR) { return ka_rec_layout_c(P, Nm, nR); }
 
 // One wave per user.  Inside a bucket the rows keep their (hop, m) order, so the record is a function of the ids alone.
 __global__ __launch_bounds__(64) void user_records_kernel(const int32_t* __restrict__ uts, int n_user, int P, int Nm, int nR, int n_entity,
@@ -151,7 +152,7 @@ struct KaStaticLds {
     int h, u, t, ei, l, z, hset, rec, orig, desc, total;     // word offsets; total in bytes
 };
 
-static KaStaticLds ka_static_layout(int P, const KaRecLayout& RL) {
+__host__ __device__ constexpr KaStaticLds ka_static_layout(int P, const KaRecLayout& RL) {
     KaStaticLds L{};
     constexpr int D = 64;
     int o = 0;
@@ -181,8 +182,15 @@ __device__ __forceinline__ void kas_dma_lines(const char* p, int lane4, unsigned
     (kas_dma_line<J>(p, lane4, n), ...);
 }
 
-template <bool TRACE>
-__global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGroupedArgs a, KaRecLayout RL, KaStaticLds L) {
+// CP > 0: an instance for ONE shape (P = CP hops of Nm = CNM memories, CNR relations): every offset of the record and of the LDS
+// layout, every row stride and trip count is a constant -- the generic instance keeps ~60 of them in scalar registers, 130-180
+// scalar registers spilled to vector lanes, a v_readlane in front of most address computations
+template <bool TRACE, int CP, int CNM, int CNR>
+__global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGroupedArgs a_, KaRecLayout RL_, KaStaticLds L_) {
+    const KaRecLayout RL = CP > 0 ? ka_rec_layout_c(CP, CNM, CNR) : RL_;
+    const KaStaticLds L = CP > 0 ? ka_static_layout(CP, ka_rec_layout_c(CP > 0 ? CP : 1, CNM > 0 ? CNM : 16, CNR > 0 ? CNR : 1)) : L_;
+    KeyAddrGroupedArgs a = a_;
+    if (CP > 0) a.P = CP, a.Nm = CNM, a.nR = CNR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int D = 64, LPR = 16, RPW = 4, NT = 4, KS = 16, LDH = D + 4, LDT = D, NTHR = kSW * 64;
     const int P = a.P, Nm = a.Nm, NmP = RL.NmP, PN = RL.rows, LDL = PN + 2;
@@ -753,7 +761,10 @@ hipError_t launch_key_addr_static(const KeyAddrGroupedArgs& a, hipStream_t st) {
     const KaRecLayout RL = ka_rec_layout(a.P, a.Nm, a.nR);
     const KaStaticLds L = ka_static_layout(a.P, RL);
     static const bool trace = getenv("MVIN_KA_TRACE") != nullptr;
-    auto k = trace ? key_addr_static_kernel<true> : key_addr_static_kernel<false>;
+    // BASELINE.json's metric config (last-fm: 2 hops of 64 memories, 9 relations) has its own instance
+    const bool c3 = a.P == 2 && a.Nm == 64 && a.nR == 9 && !(getenv("MVIN_KAS_GENERIC") && atoi(getenv("MVIN_KAS_GENERIC")));
+    auto k = c3 ? (trace ? key_addr_static_kernel<true, 2, 64, 9> : key_addr_static_kernel<false, 2, 64, 9>)
+                : (trace ? key_addr_static_kernel<true, 0, 0, 0> : key_addr_static_kernel<false, 0, 0, 0>);
     hipError_t e = hipSuccess;
     if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;
