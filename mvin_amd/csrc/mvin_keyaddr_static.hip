@@ -159,7 +159,7 @@ __host__ __device__ constexpr KaStaticLds ka_static_layout(int P, const KaRecLay
     auto take = [&](int words) { const int at = o; o += (words + 3) & ~3; return at; };
     L.rec = take(2 * RL.len);
     L.h = take(RL.rows * (D + 4));
-    L.u = take(RL.rows * (D + 4));
+    L.u = take((RL.rows + 1) * (D + 4));                     // + a spare row: where the U tiles' padding rows are written
     L.t = take(RL.rows * D);                                 // rows unpadded (16-byte chunks swizzled)
     L.ei = take(2 * kST * (D + 4));                          // this tile's item rows and the next tile's
     L.l = take(kST * (RL.rows + 2));
@@ -373,10 +373,10 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         }
         const int4 io4 = *reinterpret_cast<const int4*>(sBidx + row0 + 4 * KAS_Q16);
         const int io[4] = {io4.x, io4.y, io4.z, io4.w};
+        // unconditional: the rows of an empty bucket slot (-1) go to a spare row behind sU (predicated, each of the four writes
+        // was a compare, an exec-mask save / restore and a branch: 270 cycles per tile)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (io[i] >= 0) sU[io[i] * LDH + 16 * nt + KAS_L16] = acc[i];
-        }
+        for (int i = 0; i < 4; ++i) sU[(io[i] >= 0 ? io[i] : PN) * LDH + 16 * nt + KAS_L16] = acc[i];
     };
 
     // ---- prologue: padding rows are never landed (zero for good); record + head rows of the first segment ----
