@@ -52,6 +52,39 @@ __global__ __launch_bounds__(kBlock) void linear_mfma_kernel(mvin_linear_args a)
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * kTM;
         // ---- stage the row tile (concat or sum of the sources) ----
+        // one contiguous fp32 source of the full input width (the user MLP over o_cat, model.py:232-236; aggregator epilogues): every
+        // 16-byte load of the tile in flight at once.  (The general loop below has run-time bounds: hipcc leaves it rolled, one load
+        // -> wait -> LDS store per trip, six memory latencies in a row per 32-row tile at Din = 192 -- the kernel ran at half its
+        // MFMA rate with four workgroups per CU taking turns to wait.)
+        constexpr int C4 = DIN / 4, PER = kTM * C4 >= kBlock ? kTM * C4 / kBlock : 1;
+        const bool plain = a.nsrc == 1 && !a.ids[0] && !a.sum_sources && !(a.src_bf16 & 1) && a.Dsrc == DIN && PER * kBlock == kTM * C4;
+        if (plain) {
+            const float4* src = reinterpret_cast<const float4*>(a.src[0]);
+            int tl = tid;                                    // laundered: the per-thread (row, chunk) pairs of the loads are recomputed per
+            asm volatile("" : "+v"(tl));                     // tile -- kept across the tile loop they cost the kernel its fourth wave per SIMD
+            // (in rounds of at most three loads per thread: all six at once cost the kernel its fourth wave per SIMD -- 140 registers)
+            constexpr int RND = PER > 3 ? (PER % 3 == 0 ? 3 : 2) : PER;
+#pragma unroll
+            for (int i0 = 0; i0 < PER; i0 += RND) {
+                float4 v[RND];
+#pragma unroll
+                for (int i = 0; i < RND; ++i) {
+                    const int idx = tl + (i0 + i) * kBlock, row = idx / C4, c = idx - row * C4;
+                    const int64_t r = r0 + row;
+                    v[i] = (i0 + i < PER && r < a.rows) ? src[r * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < RND; ++i) {
+                    if (i0 + i < PER) {
+                        const int idx = tl + (i0 + i) * kBlock, row = idx / C4, c = idx - row * C4;
+                        float* dst = sX + row * LDX + c * 4;
+                        *reinterpret_cast<float2*>(dst) = make_float2(v[i].x, v[i].y);
+                        *reinterpret_cast<float2*>(dst + 2) = make_float2(v[i].z, v[i].w);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);           // (or the scheduler hoists the next round's loads up here)
+            }
+        } else
         for (int s = 0; s < a.nsrc; ++s) {
             const float* src = a.src[s];
             const int32_t* ids = a.ids[s];
