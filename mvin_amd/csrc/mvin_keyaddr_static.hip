@@ -226,6 +226,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         return min(v, emax);
     };
     const int slot0 = has_set ? 1 : 0;
+    const unsigned ldo32 = (unsigned)a.ldo;                  // output offsets in 32-bit arithmetic (key_addr_static_applies: B * ldo < 2^31)
     const int nseg = a.nseg_dev ? *a.nseg_dev : a.nseg;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
                                 const int pi = 16 * rt + 4 * KAS_Q16 + i;
                                 const int orig = sOc[pi];
                                 if (orig >= 0)
-                                    a.out[(int64_t)orig * a.ldo + (size_t)(slot0 + hop) * D + 16 * nt + KAS_L16] = acc[rt][i] * sZ[pi * P + hop];
+                                    a.out[(size_t)((unsigned)orig * ldo32 + (unsigned)((slot0 + hop) * D + 16 * nt + KAS_L16))] = acc[rt][i] * sZ[pi * P + hop];
                             }
                         }
                     }
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
                         const int pi = i / LPR, cc = i - pi * LPR;
                         const int orig = sOc[pi];
                         if (orig >= 0)
-                            *reinterpret_cast<float4*>(a.out + (int64_t)orig * a.ldo + 4 * cc) = *reinterpret_cast<const float4*>(sHset + 4 * cc);
+                            *reinterpret_cast<float4*>(a.out + (size_t)((unsigned)orig * ldo32 + (unsigned)(4 * cc))) = *reinterpret_cast<const float4*>(sHset + 4 * cc);
                     }
                 }
             }
@@ -749,7 +750,8 @@ bool key_addr_static_supported(int D, int P, int Nm, int nR) {
 
 bool key_addr_static_applies(const KeyAddrGroupedArgs& a, int table_bf16) {
     static const bool off = getenv("MVIN_KA_STATIC") && atoi(getenv("MVIN_KA_STATIC")) == 0;
-    return !off && a.records != nullptr && !table_bf16 && key_addr_static_supported(a.D, a.P, a.Nm, a.nR);
+    return !off && a.records != nullptr && !table_bf16 && key_addr_static_supported(a.D, a.P, a.Nm, a.nR) &&
+           (int64_t)a.nseg * a.ldo < (int64_t(1) << 31);       // (nseg = the batch size: the bound the caller gives for the segments)
 }
 
 hipError_t kas_read_trace(long long* host_dst, size_t n) {
