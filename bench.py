@@ -744,7 +744,10 @@ def main():
                        "key_addressing_variant": (
                            "pairs (mvin_key_addressing_fwd: 2*P*Nm rows gathered per pair)"
                            if (a.feed == "pairs" or scorer is not None) else
-                           "grouped (mvin_key_addressing_grouped_fwd: a user's rows staged once per user segment)"
+                           ("grouped over static per-user records (mvin_key_addressing_grouped_rec_fwd: relation buckets, tile table "
+                            "and clamped ids of every user's ripple sets built once by mvin_build_user_records; a user's rows staged once "
+                            "per user segment)" if getattr(model, "_uts_records", None) is not None else
+                            "grouped (mvin_key_addressing_grouped_fwd: a user's rows staged once per user segment)")
                            if Bl >= model.group_min_pairs_per_user * min(case.n_user, distinct or case.n_user) else
                            "users (mvin_key_addressing_users_fwd: per pair, lists read out of user_triplet_set)"),
                        "feed": ("user_triplet_set [n_user, P, 3, n_memory] + (user, item) ids resident in HBM; the per-pair "
