@@ -244,6 +244,10 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
         if (!adj_relation) return fail(-1, "%s: null enc_relation", who);
         if (!mvin::fused_packed_applies(f, D))
             return fail(-3, "%s: tables too large (n_entity <= 2^24, table < 4 GiB, adjacency and outputs < 2 GiB)", who);
+        // D = 32, K <= 16 (BASELINE C2): the wave-per-parent kernel reads the encoding too (MVIN_L2_D32ENC=0: the packed-tile kernel, A/B)
+        static const bool d32enc_off = getenv("MVIN_L2_D32ENC") && atoi(getenv("MVIN_L2_D32ENC")) == 0;
+        if (!d32enc_off && mvin::fused_d32_applies(f, D))
+            return hip_result(mvin::launch_gather_attn_l2_d32(f, table_bf16, (hipStream_t)stream, true), who);
         return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
     }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);

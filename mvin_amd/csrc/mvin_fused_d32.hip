@@ -46,7 +46,11 @@ __device__ __forceinline__ float d32_exp(float x) {
     return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
-template <int K, bool BF>
+// ENC: adj_e / adj_r are the duplicate-slot encoding of the adjacency (mvin_encode_adjacency: distinct slots first, entity | cnt << 24,
+// relation | multiplicity << 16 | cnt << 24, padding = slot 0 with multiplicity 0).  A slot then weighs multiplicity x exp(logit), and a
+// padding slot is never fetched: its row id becomes an offset beyond the table, which a buffer load answers with zeros without
+// touching memory -- no branch, no predicate.  A C2 pair loads ~93 rows instead of 273.
+template <int K, bool BF, bool ENC>
 __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(FusedL2Args a) {
     constexpr int D = kD32, LD = kD32Ld;
     constexpr int NCH = K / 8;               // children per lane
@@ -144,11 +148,19 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
         const int x0 = fused_parent_id(a, p);
         // ---- level L-1: this lane's NCH children (model.py:251-252) ----
         int x1[NCH], r1[NCH];
+        float mu1[NCH];                                  // multiplicity of the slot (plain adjacency: 1; a padding slot: 0)
+        constexpr unsigned kNoRow = 0xFFFFFFFFu / (unsigned)RB;      // row offset beyond any table the launcher admits
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const unsigned o1 = ((unsigned)x0 * K + (unsigned)(g + 8 * i)) * 4u;
             x1[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o1, 0, 0);
             r1[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o1, 0, 0);
+            mu1[i] = 1.f;
+            if constexpr (ENC) {
+                mu1[i] = (float)(((unsigned)r1[i] >> 16) & 0xFFu);
+                x1[i] &= 0xFFFFFF;
+                r1[i] &= 0xFFFF;
+            }
         }
         float4 qv;
         {   // no projection: zero records, the load returns 0 without touching memory
@@ -163,11 +175,19 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             int ye[KE];
             float lg[KE];
             float m = -INFINITY;
+            float me[KE];                                // multiplicities of the grandchild slots
 #pragma unroll
             for (int e = 0; e < KE; ++e) {
-                const unsigned o2 = ((unsigned)x1[i] * K + (unsigned)(c + 8 * e)) * 4u;
+                // (ENC: the slots of a padding child are not read at all -- an offset beyond the adjacency reads as 0 = multiplicity 0)
+                const unsigned o2 = (ENC && mu1[i] == 0.f) ? 0xFFFFFFF0u : ((unsigned)x1[i] * K + (unsigned)(c + 8 * e)) * 4u;
                 ye[e] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o2, 0, 0);
-                const int re = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o2, 0, 0);
+                int re = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o2, 0, 0);
+                me[e] = 1.f;
+                if constexpr (ENC) {
+                    me[e] = (float)(((unsigned)re >> 16) & 0xFFu);
+                    ye[e] = me[e] == 0.f ? (int)kNoRow : (ye[e] & 0xFFFFFF);
+                    re &= 0xFFFF;
+                }
                 lg[e] = sT0[re];
                 m = fmaxf(m, lg[e]);
             }
@@ -175,11 +195,11 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             float z = 0.f;
 #pragma unroll
             for (int e = 0; e < KE; ++e) {
-                lg[e] = has_att0 ? d32_exp(lg[e] - m) : 1.f;
+                lg[e] = (has_att0 ? d32_exp(lg[e] - m) : 1.f) * me[e];
                 z += lg[e];
             }
             z = group_sum(z, 3);
-            const float rinv = has_att0 ? invK * __builtin_amdgcn_rcpf(z) : invK;
+            const float rinv = has_att0 ? (ENC && z == 0.f ? 0.f : invK * __builtin_amdgcn_rcpf(z)) : invK;     // (a padding child: no slots)
             const int n = g + 8 * i + 8 * h;             // row of the tile / of the lists
 #pragma unroll
             for (int e = 0; e < KE; ++e) {
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
         // ---- the children's own rows land under the rest ----
         float4 sv[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) sv[i] = row4(x1[i]);
+        for (int i = 0; i < NCH; ++i) sv[i] = row4(ENC && mu1[i] == 0.f ? (int)kNoRow : x1[i]);
         // ---- attention over the parent's K children: aggregator (0,.) -> p0, aggregator (1,.) -> p1 ----
         float p0[NCH], p1[NCH];
         {
@@ -207,7 +227,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 float z = 0.f;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
-                    p0[i] = d32_exp(s0[i] - m0);
+                    p0[i] = d32_exp(s0[i] - m0) * mu1[i];
                     z += p0[i];
                 }
                 const float rz = __builtin_amdgcn_rcpf(over_groups_sum(z));
@@ -215,14 +235,14 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 for (int i = 0; i < NCH; ++i) p0[i] *= rz;
             } else {
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) p0[i] = 1.f;
+                for (int i = 0; i < NCH; ++i) p0[i] = mu1[i];
             }
             if (has_att1) {
                 m1 = over_groups_max(m1);
                 float z = 0.f;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
-                    p1[i] = d32_exp(s1[i] - m1);
+                    p1[i] = d32_exp(s1[i] - m1) * mu1[i];
                     z += p1[i];
                 }
                 const float rz = __builtin_amdgcn_rcpf(over_groups_sum(z));
@@ -230,7 +250,7 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 for (int i = 0; i < NCH; ++i) p1[i] *= rz;
             } else {
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) p1[i] = 1.f;
+                for (int i = 0; i < NCH; ++i) p1[i] = mu1[i];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -368,32 +388,39 @@ bool fused_d32_applies(const FusedL2Args& a, int D) {
     static const char* e = getenv("MVIN_L2_D32");
     if (e && e[0] == '0') return false;                  // A/B: the role-split / symmetric kernel
     return fused_d32_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
-           a.table_bytes > 0 && a.table_bytes < (1ull << 32) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
+           a.table_bytes > 0 && a.table_bytes < (1ull << 32) - 4096 && (uint64_t)a.P * D * 4 < (1ull << 31) &&
            fused_d32_lds_bytes(a.nR, a.K) <= 64 * 1024;     // (default dynamic-LDS limit; larger relation tables keep the pipeline)
 }
 
-template <int K, bool BF>
+template <int K, bool BF, bool ENC>
 static hipError_t launch_d32(const FusedL2Args& a, hipStream_t st) {
     const size_t lds = fused_d32_lds_bytes(a.nR, K);
     const int64_t wgs = (a.P + kD32Waves - 1) / kD32Waves;
     static thread_local int per_cu = 0;
     if (per_cu == 0) {
         int v = 3;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(gather_attn_l2_d32_kernel<K, BF>), kD32Waves * 64, lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(gather_attn_l2_d32_kernel<K, BF, ENC>), kD32Waves * 64, lds) !=
                 hipSuccess || v < 1)
             v = 3;
         per_cu = v;
     }
     const int64_t cap = 256 * (int64_t)per_cu;           // persistent grid
     const int grid = (int)(wgs < cap ? wgs : cap);
-    gather_attn_l2_d32_kernel<K, BF><<<grid, kD32Waves * 64, lds, st>>>(a);
+    gather_attn_l2_d32_kernel<K, BF, ENC><<<grid, kD32Waves * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
-hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st) {
+hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded) {
+    if (encoded) {
+        switch (a.K) {
+            case 8: return table_bf16 ? launch_d32<8, true, true>(a, st) : launch_d32<8, false, true>(a, st);
+            case 16: return table_bf16 ? launch_d32<16, true, true>(a, st) : launch_d32<16, false, true>(a, st);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (a.K) {
-        case 8: return table_bf16 ? launch_d32<8, true>(a, st) : launch_d32<8, false>(a, st);
-        case 16: return table_bf16 ? launch_d32<16, true>(a, st) : launch_d32<16, false>(a, st);
+        case 8: return table_bf16 ? launch_d32<8, true, false>(a, st) : launch_d32<8, false, false>(a, st);
+        case 16: return table_bf16 ? launch_d32<16, true, false>(a, st) : launch_d32<16, false, false>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

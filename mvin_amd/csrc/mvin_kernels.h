@@ -313,7 +313,7 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
 hipError_t launch_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, hipStream_t st);   // mvin_bwd.hip
 bool fused_d32_supported(int D, int K);        // wave-per-parent variant for D = 32, K in {8, 16} (mvin_fused_d32.hip)
 bool fused_d32_applies(const FusedL2Args& a, int D);
-hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st);
+hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded = false);   // encoded: adj_e / adj_r = the duplicate-slot encoding
 bool fused_d16_supported(int D, int K);        // wave-per-parent variant for D = 16, K <= 16 (mvin_fused_d16.hip)
 bool fused_d16_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_d16(const FusedL2Args& a, int table_bf16, hipStream_t st);
