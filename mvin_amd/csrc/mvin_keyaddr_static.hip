@@ -285,8 +285,11 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
     desc((int)blockIdx.x, u0, p00, p10);
     desc((int)blockIdx.x + G, u1, p01, p11);
 
-    // ---- R_KGE fragments resident in registers (as key_addr_dense_kernel): (relation r, column tile nt) number q = r * NT + nt
-    //      belongs to wave q % (kSW - 1), slot q / (kSW - 1); contraction index permuted so that a lane's values are contiguous ----
+    // ---- R_KGE fragments resident in registers (as key_addr_dense_kernel), in PAIRS: task t = (relation r = t / 2, column tiles
+    //      2 (t % 2) and 2 (t % 2) + 1) belongs to wave t % 11, task slot t / 11 (two task slots = four fragments per wave).  One
+    //      read of a row tile's index and A operand then feeds two accumulator chains of 16 MFMAs (a task of one column tile
+    //      spent ~0.6 k cycles on those reads and its loop per 512 of MFMA issue).  Contraction index permuted so that a lane's
+    //      values are contiguous. ----
     constexpr int RES = 4;
     const bool resident = a.nR * NT <= RES * (kSW - 1);
     float rb[RES][KS];
@@ -303,9 +306,12 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
     };
     if (resident && wave < kSW - 1) {
 #pragma unroll
-        for (int sl = 0; sl < RES; ++sl) {
-            const int q = wave_u + (kSW - 1) * sl;
-            if (q < a.nR * NT) load_bfrag(q / NT, q % NT, rb[sl]);
+        for (int ts = 0; ts < RES / 2; ++ts) {
+            const int t = wave_u + (kSW - 1) * ts;           // task: relation t / 2, column tiles 2 (t % 2) + {0, 1}
+            if (t < a.nR * NT / 2) {
+                load_bfrag(t / 2, 2 * (t % 2), rb[2 * ts]);
+                load_bfrag(t / 2, 2 * (t % 2) + 1, rb[2 * ts + 1]);
+            }
         }
     }
     // ---- a user's 2 * PN rows, staged through registers: 16 bytes per lane, four rows per load.  A burst of 128 rows (32 KB)
@@ -378,6 +384,33 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         // was a compare, an exec-mask save / restore and a branch: 270 cycles per tile)
 #pragma unroll
         for (int i = 0; i < 4; ++i) sU[(io[i] >= 0 ? io[i] : PN) * LDH + 16 * nt + KAS_L16] = acc[i];
+    };
+
+    // two column tiles (nt0, nt0 + 1) of one row tile: one index / A operand read, two accumulator chains
+    auto u_tile2 = [&](const int* sBidx, int row0, int nt0, const float (&bfa)[KS], const float (&bfb)[KS]) {
+        const int ia = sBidx[row0 + KAS_L16];
+        const float4* ar = reinterpret_cast<const float4*>(sH + (ia >= 0 ? ia : 0) * LDH + KS * KAS_Q16);
+        f32x4 ca = {0.f, 0.f, 0.f, 0.f}, cb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KS; k += 4) {
+            const float4 av = ar[k >> 2];
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bfa[k], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bfb[k], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bfa[k + 1], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bfb[k + 1], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bfa[k + 2], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bfb[k + 2], cb, 0, 0, 0);
+            ca = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bfa[k + 3], ca, 0, 0, 0);
+            cb = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bfb[k + 3], cb, 0, 0, 0);
+        }
+        const int4 io4 = *reinterpret_cast<const int4*>(sBidx + row0 + 4 * KAS_Q16);
+        const int io[4] = {io4.x, io4.y, io4.z, io4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float* d = sU + (io[i] >= 0 ? io[i] : PN) * LDH + 16 * nt0 + KAS_L16;      // (-1: the spare row, see u_tile)
+            d[0] = ca[i];
+            d[16] = cb[i];
+        }
     };
 
     // ---- prologue: padding rows are never landed (zero for good); record + head rows of the first segment ----
@@ -495,20 +528,20 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             if (resident) {
                 if (wave < kSW - 1) {
                     // wave-uniform task table first (scalars)
-                    int tl[RES], rw[RES];
+                    int ntl[RES / 2], rw[RES / 2];
 #pragma unroll
-                    for (int sl = 0; sl < RES; ++sl) {
-                        const int q = wave_u + (kSW - 1) * sl;
-                        const bool ok = q < a.nR * NT;
-                        const int r = ok ? q / NT : 0;
-                        tl[sl] = ok ? (rec[RL.o_cnt + r] + 15) >> 4 : 0;
-                        rw[sl] = rec[RL.o_off + r];
+                    for (int ts = 0; ts < RES / 2; ++ts) {
+                        const int t = wave_u + (kSW - 1) * ts;
+                        const bool ok = t < a.nR * NT / 2;
+                        const int r = ok ? t / 2 : 0;
+                        ntl[ts] = ok ? (rec[RL.o_cnt + r] + 15) >> 4 : 0;
+                        rw[ts] = rec[RL.o_off + r];
                     }
 #pragma unroll
-                    for (int sl = 0; sl < RES; ++sl) {
-                        const int nt = (wave_u + (kSW - 1) * sl) % NT;
-                        const int tiles = __builtin_amdgcn_readfirstlane(tl[sl]), row0 = __builtin_amdgcn_readfirstlane(rw[sl]);
-                        for (int j = 0; j < tiles; ++j) u_tile(sBidx, row0 + 16 * j, nt, rb[sl]);
+                    for (int ts = 0; ts < RES / 2; ++ts) {
+                        const int nt0 = 2 * ((wave_u + (kSW - 1) * ts) % 2);
+                        const int tiles = __builtin_amdgcn_readfirstlane(ntl[ts]), row0 = __builtin_amdgcn_readfirstlane(rw[ts]);
+                        for (int j = 0; j < tiles; ++j) u_tile2(sBidx, row0 + 16 * j, nt0, rb[2 * ts], rb[2 * ts + 1]);
                     }
                 }
             } else {
