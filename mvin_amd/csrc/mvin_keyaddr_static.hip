@@ -448,7 +448,8 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         // this segment's tail rows (first needed by tile 0's reads): 12 rows per wave, in flight under the wave's U work and
         // written behind it (three loads: the memory latency, ~2.5 k cycles here, is paid once and under the MFMA tiles)
         float4 tl[3];
-        stage_issue(tl, rec + RL.o_tail, wave_u * 12);
+        const bool has_tl = wave_u * 12 < PN;               // (128 rows: waves 0 .. 10; wave 11, the U phase's longest, loads none)
+        if (has_tl) stage_issue(tl, rec + RL.o_tail, wave_u * 12);
         // fire and forget: the record of the next segment (waited for behind this wave's h-set read)
         if (wave_u == kSW - 1 && has_next) dma_record(u1, par ^ 1);
         // the descriptor of the segment after the next: read by wave 11 only (three registers held across the U tiles by every
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             desc_load(d_u, d_p0, d_p1);
             desc_put(d_u, d_p0, d_p1);
         }
-        stage_write(tl, rec + RL.o_tail, wave_u * 12, sT, LDT, true);
+        if (has_tl) stage_write(tl, rec + RL.o_tail, wave_u * 12, sT, LDT, true);
         // wave 11: the next segment's record has landed before the tiles' first barrier
         if (wave_u == kSW - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // behind the phase's barrier: the descriptors move up by one
