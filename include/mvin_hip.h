@@ -32,29 +32,31 @@ extern "C" {
 #endif
 
 #define MVIN_ABI_VERSION 8
+/* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
+#define MVIN_API __attribute__((visibility("default")))
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
 #define MVIN_MAX_SRC 8        /* concatenated sources of mvin_linear_fwd */
 
-int mvin_abi_version(void);
-const char* mvin_last_error(void);
+MVIN_API int mvin_abi_version(void);
+MVIN_API const char* mvin_last_error(void);
 
 /* Development aid, not part of the reference-facing path: with MVIN_SPLIT_DBG=4 in the environment workgroup 0
  * of the role-split fused kernel stamps s_memtime at its phase boundaries; this copies the stamps
  * ([2 roles][64 steps][8 slots] int64) to `host_dst` (synchronous).  scripts/trace_split.py prints them. */
-int mvin_debug_read_trace(long long* host_dst, size_t n);
+MVIN_API int mvin_debug_read_trace(long long* host_dst, size_t n);
 
 /* Number of int32 elements of the flattened id lists mvin_expand_ids writes:
  * entities levels 0..levels (B * sum_{e<=levels} K^e) and relations levels 0..levels-1
  * (B * sum_{1<=e<=levels} K^e).  Level e of `ent_out` starts at B*sum_{i<e}K^i and is
  * [B, K^e]; level e of `rel_out` starts at B*sum_{1<=i<=e}K^i and is [B, K^(e+1)]. */
-size_t mvin_ent_elems(int B, int K, int levels);
-size_t mvin_rel_elems(int B, int K, int levels);
+MVIN_API size_t mvin_ent_elems(int B, int K, int levels);
+MVIN_API size_t mvin_rel_elems(int B, int K, int levels);
 
 /* MVIN.get_neighbors (model.py:243-256): level-by-level expansion of the fixed-fan-out
  * adjacency.  entities[0] = items; entities[e+1][b, j*K+k] = adj_entity[entities[e][b,j], k];
  * relations[e][b, j*K+k] = adj_relation[entities[e][b,j], k].  `levels` expansions.
  * items are int64 (items_i64) or int32 (items_i32); exactly one must be non-NULL. */
-int mvin_expand_ids(const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_expand_ids(const int32_t* adj_entity, const int32_t* adj_relation,
                     const int64_t* items_i64, const int32_t* items_i32,
                     int B, int K, int levels, int n_entity,
                     int32_t* ent_out, int32_t* rel_out, void* stream);
@@ -64,7 +66,7 @@ int mvin_expand_ids(const int32_t* adj_entity, const int32_t* adj_relation,
  * score[b,n,k] = [user; rel_k; self] . urh_weights = const(b,n) + rel_emb[r_k] . urh_w[D:2D];
  * the constant cancels in softmax_k, so t[r] = rel_emb[r,:] . urh_weights[D:2D] is all
  * the kernels need.  t_out is [nR]. */
-int mvin_rel_score(const float* relation_emb, const float* urh_weights, int nR, int D,
+MVIN_API int mvin_rel_score(const float* relation_emb, const float* urh_weights, int nR, int D,
                    float* t_out, void* stream);
 
 /* Generic "rows x small dense" operator behind the stock tf.matmul sites of the path:
@@ -104,7 +106,7 @@ typedef struct {
     int64_t src_rows;          /* rows of the gathered sources (those with ids[s] != NULL): ids are clamped to
                                   [0, src_rows) like every device-resident id; 0 = unknown, no clamp */
 } mvin_linear_args;
-int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
+MVIN_API int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
 
 /* Deepest hop of MVIN.aggregate_delta_whole (model.py:267-283 + :295-305 at hop = L-1,
  * i = 0, n = 0) fused with SumAggregator_urh_matrix._call (aggregators.py:98-146):
@@ -116,7 +118,7 @@ int mvin_linear_fwd(const mvin_linear_args* args, void* stream);
  *           == reduce_mean_k(p_k * ((table[y_k]+q_b) . W_L + b_L)) by linearity, c_child = q_b.W_L + b_L
  *     out[t, :] = relu((self_vec[t, :] + agg) . Wagg + bagg)
  * The K^L child rows are never materialised.  probs ([T, K]) is optional (model.py:294,304). */
-int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation,
                          const int32_t* node_ids, const float* rel_score,
                          const float* self_vec, const float* Wc, const float* c_child,
                          const float* Wagg, const float* bagg,
@@ -138,7 +140,7 @@ int mvin_gather_attn_fwd(const float* table, const int32_t* adj_entity, const in
  * optional (model.py:294,304).  table_bf16 = 1: the entity table holds bf16 rows (BASELINE config C5);
  * arithmetic stays fp32.  Returns -3 when (D, K) is outside the fused kernel's range
  * (D in {16,32,64,128}, K a power of two in [4,256]); callers then use the per-level entry points. */
-int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* parent_ids, const float* t0, const float* t1,
                             const float* W1, const float* W2, const float* b1, const float* b2,
                             const float* q, const float* A0, const float* a0,
@@ -147,14 +149,14 @@ int mvin_gather_attn_l2_fwd(const void* table, const int32_t* adj_entity, const 
                             int table_bf16, void* stream);
 /* The same with the parents given as int64 ids read in place (the item ids of the reference's int64 placeholder,
  * model.py:50: at tree depth 2 the parents ARE the batch's items, so no id-conversion launch precedes the kernel). */
-int mvin_gather_attn_l2_fwd_i64(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_gather_attn_l2_fwd_i64(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                                 const int64_t* parent_ids, const float* t0, const float* t1,
                                 const float* W1, const float* W2, const float* b1, const float* b2,
                                 const float* q, const float* A0, const float* a0,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                                 float* nagg0, float* nagg1, float* probs_parent, float* probs_child,
                                 int table_bf16, void* stream);
-int mvin_gather_attn_l2_supported(int D, int K);
+MVIN_API int mvin_gather_attn_l2_supported(int D, int K);
 /* The same pass over an adjacency in the DUPLICATE-SLOT ENCODING of mvin_encode_adjacency (below): the reference's sampler
  * repeats (neighbour, relation) slots whenever an entity has fewer than K edges (data_loader_user_set.py:383-384); equal
  * slots have equal logits and equal rows, so their softmax weights are added up and every distinct row is gathered once,
@@ -162,13 +164,13 @@ int mvin_gather_attn_l2_supported(int D, int K);
  * arithmetic up to the order of fp32 additions; no attention outputs (those are per slot: use the plain adjacency).
  * parent_ids: int32 [P], or int64 [P] read in place when parent_ids_i64 != 0.  D in {32, 64, 128}, K in {16, 32, 64, 128},
  * nR <= 4096, n_entity <= 2^24, tables below 4 GiB (-3 otherwise). */
-int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, const int32_t* enc_relation,
+MVIN_API int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, const int32_t* enc_relation,
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
                                 const float* W1, const float* W2, const float* b1, const float* b2,
                                 const float* q, const float* A0, const float* a0,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                                 float* nagg0, float* nagg1, int table_bf16, void* stream);
-int mvin_gather_attn_l2_enc_supported(int D, int K);
+MVIN_API int mvin_gather_attn_l2_enc_supported(int D, int K);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
@@ -176,15 +178,15 @@ int mvin_gather_attn_l2_enc_supported(int D, int K);
  * reference's shipped settings: no workgroup phases at all; no probs, table below 4 GiB), 4 = the wave-per-parent
  * kernel for D = 32, K in {8, 16} (BASELINE config C2; same conditions; it takes these shapes ahead of the pipeline).
  * n_parents = B * parents_per_pair.  For tests and benchmarks. */
-int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);     /* fp32 table */
-int mvin_gather_attn_l2_variant_ex(int D, int K, int64_t n_parents, int n_entity, int want_probs, int table_bf16);
+MVIN_API int mvin_gather_attn_l2_variant(int D, int K, int64_t n_parents, int n_entity, int want_probs);     /* fp32 table */
+MVIN_API int mvin_gather_attn_l2_variant_ex(int D, int K, int64_t n_parents, int n_entity, int want_probs, int table_bf16);
 /* Measurement aid: the row gathers of mvin_gather_attn_l2_fwd and nothing else, written the plain way (one wave per
  * parent, 8 loads in flight per lane).  child_ids [n_parents, K] and grandchild_ids [n_parents, K*K] are levels 1 and 2
  * of mvin_expand_ids for the parents; every listed row is read once (the same 16-byte lane loads, ids fetched one round
  * ahead) and all its elements are added into sums[p].  bench.py times it on the timed region's own entity table and
  * pairs as a reference point for the fused kernel's row rate.  Row bytes (D * 4, or D * 2 with table_bf16) in
  * {64, 128, 256, 512}. */
-int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int32_t* grandchild_ids, int64_t n_parents, int K,
+MVIN_API int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int32_t* grandchild_ids, int64_t n_parents, int K,
                          int D, int n_entity, int table_bf16, float* sums, void* stream);
 
 /* SumAggregator_urh_matrix._call on materialised levels (every aggregator application
@@ -193,7 +195,7 @@ int mvin_probe_gather_l2(const void* table, const int32_t* child_ids, const int3
  *     out[t, :] = relu((self_vec[t, :] + agg) . Wagg + bagg)
  * rel_ids == NULL with rel_score != NULL: rel_score holds one logit per child ([T*K]), the form
  * Aggregator.__call__ needs when it is handed relation VECTORS (aggregators.py:29-31). */
-int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids,
+MVIN_API int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_ids,
                  const float* rel_score, const float* Wagg, const float* bagg,
                  int B, int N, int K, int D, float* out, float* probs, void* stream);
 
@@ -203,12 +205,12 @@ int mvin_agg_fwd(const float* self_vec, const float* neigh, const int32_t* rel_i
  *   mode 1 (soft_attention_h_set, :162-197): s_m = E[score_ids[b,m]] . w[0:D]
  *          (the user term and the bias are constant over m and cancel in the softmax);
  *   o[b, :] = sum_m softmax_m(s)_m * E[value_ids[b,m], :]  written at out + b*ldo. */
-int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+MVIN_API int mvin_ripple_attn_fwd(const float* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
                          const int32_t* value_ids, const float* V, const float* w, int mode,
                          int B, int Nm, int D, int nR, float* out, int64_t ldo, void* stream);
 /* The same for either table type (table_bf16 = 1: bf16 rows; arithmetic stays fp32): the general fallback
  * for every (D, Nm) the one-pass kernels of mvin_key_addressing_fwd do not take. */
-int mvin_ripple_attn_fwd_ex(const void* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
+MVIN_API int mvin_ripple_attn_fwd_ex(const void* entity_emb, const int32_t* score_ids, const int32_t* rel_ids,
                             const int32_t* value_ids, const float* V, const float* w, int mode,
                             int B, int Nm, int D, int nR, float* out, int64_t ldo, int table_bf16, void* stream);
 
@@ -223,18 +225,18 @@ int mvin_ripple_attn_fwd_ex(const void* entity_emb, const int32_t* score_ids, co
  * weighted-sum pass; ceil(Nm / (64/ceil_pow2(D/4))) <= 16).  Returns -3 when neither takes the shape;
  * callers then use mvin_ripple_attn_fwd per read.  mvin_key_addressing_supported(Nm, D) answers for the
  * register-resident kernel alone (it does not know nR): sufficient, not necessary. */
-int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
+MVIN_API int mvin_key_addressing_fwd(const void* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r,
                             const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, int n_entity,
                             float* out, int64_t ldo, int table_bf16, void* stream);
-int mvin_key_addressing_supported(int Nm, int D);
+MVIN_API int mvin_key_addressing_supported(int Nm, int D);
 /* The same reads with the feed assembly of train.py:117-120 inside the kernel: pair b uses the ripple sets of user
  * users[b] straight out of user_triplet_set `uts` [n_user, max(1,P), 3, Nm] int32 on the device (h, r, t lists per hop;
  * data_loader_user_set.py:392-441) -- no per-pair [B, Nm] arrays exist.  One of users_i64 / users_i32 is given.  For
  * batches whose users repeat, mvin_key_addressing_grouped_fwd reads a user's rows once instead.
  * Device-resident ids are not validated per launch (the reference's CPU tf.gather raises InvalidArgument; here that
  * is the host wrapper's job): a user id outside [0, n_user) is CLAMPED into the table, never read out of bounds. */
-int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
+MVIN_API int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const float* w, const int32_t* uts,
                                   const int64_t* users_i64, const int32_t* users_i32, int P, int B, int Nm, int D, int nR,
                                   int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream);
 
@@ -248,12 +250,12 @@ int mvin_key_addressing_users_fwd(const void* entity_emb, const float* V, const 
  * items are int64 (items_i64) or int32 (items_i32).  nseg_dev (optional, device) holds the actual segment count
  * when the caller built the segments on the device without a host sync; nseg is then an upper bound (array
  * sizes).  -3: shape outside the LDS budget. */
-int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+MVIN_API int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relation_kge, const float* w,
                                     const int32_t* uts, const int32_t* seg_user, const int32_t* seg_ptr,
                                     const int32_t* nseg_dev, const int32_t* pair_index, const int64_t* items_i64,
                                     const int32_t* items_i32, int nseg, int B, int P, int Nm, int D, int nR, int n_entity, int n_user,
                                     float* out, int64_t ldo, int table_bf16, void* stream);
-int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
+MVIN_API int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
 /* STATIC per-user records for the grouped form (ABI v8).  A user's ripple sets are built once per data set
  * (data_loader_user_set.py: user_triplet_set feeds the same (h, r, t) ids for a user in every batch, model.py:66-76), and so
  * is everything the dense grouped kernel derives from the ids alone: the relation buckets of the memories (which rows share
@@ -265,10 +267,10 @@ int mvin_key_addressing_grouped_supported(int D, int P, int Nm, int nR);
  * and mvin_key_addressing_grouped_rec_fwd (same arguments and results as mvin_key_addressing_grouped_fwd, bit for bit) lands a
  * user's record in LDS a segment ahead instead of bucketing the segment's ids.  user_records == NULL, or a shape / table
  * type outside mvin_user_records_supported: exactly mvin_key_addressing_grouped_fwd. */
-int mvin_user_records_len(int P, int Nm, int nR);
-int mvin_user_records_supported(int D, int P, int Nm, int nR, int table_bf16);
-int mvin_build_user_records(const int32_t* uts, int n_user, int P, int Nm, int nR, int n_entity, int32_t* records, void* stream);
-int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+MVIN_API int mvin_user_records_len(int P, int Nm, int nR);
+MVIN_API int mvin_user_records_supported(int D, int P, int Nm, int nR, int table_bf16);
+MVIN_API int mvin_build_user_records(const int32_t* uts, int n_user, int P, int Nm, int nR, int n_entity, int32_t* records, void* stream);
+MVIN_API int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
                                         const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
                                         const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
                                         const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
@@ -280,7 +282,7 @@ int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* rel
  * CLAMPED into the table (every pair keeps a segment, so no row of `out` stays unwritten); the reference's CPU
  * tf.gather would raise InvalidArgument -- the Python wrapper does that for host feeds and, on request, for device
  * feeds (MVIN.validate_device_ids). */
-int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,
+MVIN_API int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32, int64_t B, int n_user, int32_t* workspace,
                              int32_t* seg_user, int32_t* seg_ptr, int32_t* nseg, int32_t* pair_index, void* stream);
 
 /* out[r, :] = softmax(x[r, :]) over n columns (tf.nn.softmax, model.py:189 / :223).  Building block of the
@@ -288,7 +290,7 @@ int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* users_i32,
  * top-K evaluation): with one ripple set for the whole batch the reads become dense products,
  *   logits = E[items] . A^T,  A[m] = R_KGE[r_m] . E[h_m]   ->  row softmax  ->  o = P . E[t]   (mvin_linear_fwd),
  * instead of 2*Nm row gathers per pair. */
-int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
+MVIN_API int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
 
 /* Everything of MVIN.aggregate_delta_whole (model.py:259-324) above mvin_gather_attn_l2_fwd for the shape
  * n_mix_hop = 1, h_hop = 2 (tree depth 2), in one launch:
@@ -298,12 +300,12 @@ int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* 
  *   scores = sum_d user_o * item_emb ; sig = sigmoid(scores)                          model.py:158-159
  * nagg0 / nagg1 [B, D]: the outputs of mvin_gather_attn_l2_fwd with parents_per_pair = 1.  D in {16, 32, 64}
  * (-3 otherwise: use mvin_linear_fwd per stage).  item_emb and sig may be NULL. */
-int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int32_t* items_i32, const float* q,
+MVIN_API int mvin_l2_tail_fwd(const void* entity_emb, const int64_t* items_i64, const int32_t* items_i32, const float* q,
                      const float* user_o, const float* nagg0, const float* nagg1, const float* W0, const float* b0,
                      const float* A0, const float* a0, const float* A1, const float* a1, const float* Wmix,
                      const float* bmix, int64_t B, int D, int n_entity, float* item_emb, float* scores, float* sig,
                      int table_bf16, void* stream);
-int mvin_l2_tail_supported(int D);
+MVIN_API int mvin_l2_tail_supported(int D);
 
 /* The whole get_scores pass (model.py:125-159, default wiring: preference sets AND high-order part, query =
  * user_o, wide_deep, n_mix_hop = 1, h_hop = 2) enqueued by ONE native call: at the reference's own batch sizes
@@ -361,17 +363,17 @@ typedef struct {
                                       projection + mvin_key_addressing_users_fwd; V may then be NULL) */
     const int32_t* user_records;   /* grouped form only, or NULL: mvin_build_user_records(uts) -> mvin_key_addressing_grouped_rec_fwd */
 } mvin_score_l2_args;
-int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
+MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 
 /* Row movers of the multi-GPU layer (mvin_amd/dist.py; no reference counterpart -- the reference is single
  * device): out[i, :] = table[ids[i], :] (gather) and table[ids[i], :] = rows[i, :] (scatter; ids distinct),
  * rows of `row_bytes` bytes (a multiple of 4: fp32 or bf16 entity rows move untouched). */
-int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream);
-int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, const void* rows, void* stream);
+MVIN_API int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream);
+MVIN_API int mvin_scatter_rows(void* table, const int32_t* ids, int64_t n, int row_bytes, const void* rows, void* stream);
 /* Entity ids into the sharded table's id space (mvin_amd/dist.py: cyclic ownership, owner(x) = x mod world, rank r's rows
  * contiguous): out[i] = (ids[i] mod world) * n_local + ids[i] div world.  ids / out: int64 when ids_are_i64, else int32
  * (same type in and out; out may alias ids).  One launch instead of four elementwise torch kernels per step. */
-int mvin_shard_space_ids(const void* ids, int ids_are_i64, int64_t n, int world, int n_local, void* out, void* stream);
+MVIN_API int mvin_shard_space_ids(const void* ids, int ids_are_i64, int64_t n, int world, int n_local, void* out, void* stream);
 
 /* Entity-table ("hoisted") mode building block -- an inference-side re-association of
  * model.py:295-305 / aggregators.py:118-146 at the two deepest levels (SURVEY.md 7.3-c route 2b):
@@ -381,7 +383,7 @@ int mvin_shard_space_ids(const void* ids, int ids_are_i64, int64_t n, int world,
  * Used twice by mvin_amd/model.py: over ALL entities to build S[e] (the user-independent neighbor mix
  * of aggregator (0,.)), and per level-(L-2) node over the hoisted table R1 with the pair's constant as
  * rowbias.  Returns -3 for K > 256. */
-int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                         const int32_t* node_ids, const float* rel_score, const float* rowbias, int64_t nodes,
                         int nodes_per_group, int K, int D, int n_entity, int nR, int relu, float* out,
                         int table_bf16, void* stream);
@@ -391,12 +393,12 @@ int mvin_gather_mix_fwd(const void* table, const int32_t* adj_entity, const int3
 
 /* mvin_gather_attn_fwd / mvin_agg_fwd with two extra optional outputs:
  * s_out [T,D] = (1/K) sum_k p_k child_k (before the projection), z_out [T,D] = self + neighbors_agg. */
-int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
+MVIN_API int mvin_gather_attn_fwd_ex(const void* table, const int32_t* adj_entity, const int32_t* adj_relation,
                             const int32_t* node_ids, const float* rel_score, const float* self_vec,
                             const float* Wc, const float* c_child, const float* Wagg, const float* bagg,
                             int B, int N, int K, int D, int n_entity, float* out, float* probs,
                             float* s_out, float* z_out, int table_bf16, void* stream);
-int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
+MVIN_API int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* rel_ids, const float* rel_score,
                     const float* Wagg, const float* bagg, int B, int N, int K, int D, float* out, float* probs,
                     float* s_out, float* z_out, void* stream);
 
@@ -405,11 +407,11 @@ int mvin_agg_fwd_ex(const float* self_vec, const float* neigh, const int32_t* re
  * 4 Adam step (x param, y grad, z m, w v, alpha = lr_t) | 5 y[r,:] = beta y[r,:] + alpha z[r] x[r,:] (n = rows*D) |
  * 6 y[g,:] = alpha sum_{q<N} x[g*N+q,:] (n = groups*D) | 7 *accum += alpha sum_r z[r] sum x[r,:]^2 (n = rows*D) |
  * 8 *accum += alpha sum_r sum x[ids[r],:]^2 with ids = (const int32_t*) z (n = rows*D): gathered rows, not materialised. */
-int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha,
+MVIN_API int mvin_eltwise(int mode, int64_t n, float* x, float* y, float* z, float* w, float* accum, float alpha,
                  float beta, float beta1, float beta2, float eps, int D, int N, void* stream);
 /* out[b] += |{i : ids[i] == b}| for b < nbins <= 4096 (the occurrence counts of the relations in a ripple-set list: the
  * weights of the sum(r_emb^2) regulariser's gradient, model.py:383-386); out is accumulated, caller zeroes it. */
-int mvin_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, void* stream);
+MVIN_API int mvin_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, void* stream);
 
 /* All parameters in one launch: the L2 terms of model.py:387-412 and (apply_adam != 0) the
  * tf.train.AdamOptimizer update of model.py:414.  Gradients and Adam moments are flat buffers of
@@ -423,22 +425,22 @@ typedef struct {
     float l2;
     int pad_;
 } mvin_param_seg;
-int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+MVIN_API int mvin_l2_adam_multi(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
                        float* v_flat, float* loss_accum, int apply_adam, float lr_t, float beta1, float beta2,
                        float eps, void* stream);
 /* Same, with the bias-corrected step size lr_t read from device memory when the kernel runs: a training step
  * captured into a hipGraph (mvin_amd/training.py:GraphedTrainer) replays with a new lr_t without re-capture. */
-int mvin_l2_adam_multi_dev(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
+MVIN_API int mvin_l2_adam_multi_dev(const mvin_param_seg* segs_device, int nseg, int64_t total, float* g_flat, float* m_flat,
                            float* v_flat, float* loss_accum, int apply_adam, const float* lr_t_device, float beta1,
                            float beta2, float eps, void* stream);
 
 /* dtable[ids[r], :] += alpha * x[r, :]  -- backward of tf.nn.embedding_lookup (ids int32 or int64). */
-int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D,
+MVIN_API int mvin_scatter_add_rows(float* dtable, const void* ids, int ids64, const float* x, int64_t rows, int D,
                           float alpha, void* stream);
 
 /* dW[z] += X^T . (dY[z] masked by mask > 0), db[z] += column sums; X staged as in mvin_linear_fwd
  * (args->src/ids/nsrc/Dsrc/Dout/rows/nz/sum_sources/ids64 are read, the rest ignored). */
-int mvin_linear_wgrad(const mvin_linear_args* args, const float* dY, int64_t ldy, int64_t dy_zstride,
+MVIN_API int mvin_linear_wgrad(const mvin_linear_args* args, const float* dY, int64_t ldy, int64_t dy_zstride,
                       const float* mask, int64_t ldm, int64_t mask_zstride, float* dW, int64_t dw_zstride,
                       float* db, int64_t db_zstride, void* stream);
 /* n (<= 64) such problems in as few launches as their shapes allow: problems whose (Din, Dout) take the same matrix-core
@@ -456,7 +458,7 @@ typedef struct {
     float* db;                     /* or NULL */
     int64_t db_zstride;
 } mvin_wgrad_problem;
-int mvin_linear_wgrad_multi(const mvin_wgrad_problem* problems, int n, void* stream);
+MVIN_API int mvin_linear_wgrad_multi(const mvin_wgrad_problem* problems, int n, void* stream);
 
 /* backward of the neighbor mix agg[t] = (1/K) sum_k p[t,k] c[t,k], p = softmax_k(t[rel]) (aggregators.py:118-152)
  * given dvec = dL/d agg: children from the table through the adjacency (table/adj/node_ids given: dc_k is added
@@ -465,18 +467,18 @@ int mvin_linear_wgrad_multi(const mvin_wgrad_problem* problems, int n, void* str
  * [T = n_entity, D] holds dL/d agg summed over every tree node carrying that entity -- the backward is linear in
  * dvec and depends on a node only through its entity, so the duplicates of a batch cost one pass; all-zero rows
  * are skipped. */
-int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
+MVIN_API int mvin_agg_bwd(const float* table, const int32_t* adj_entity, const int32_t* adj_relation, const int32_t* node_ids,
                  const float* child, const int32_t* rel_ids, const float* probs, const float* rel_score,
                  const float* dvec, int64_t T, int K, int D, int nR, float* dtable, float* dchild, float* dT,
                  void* stream);
 
 /* backward of mvin_rel_score: drel[r,:] += dT[r] urh_w[D:2D]; durh[D:2D] += sum_r dT[r] rel[r,:]. */
-int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, const float* dT, int nR, int D,
+MVIN_API int mvin_rel_score_bwd(const float* relation_emb, const float* urh_weights, const float* dT, int nR, int D,
                        float* drel, float* durh, void* stream);
 
 /* backward of mvin_key_addressing_fwd (+ the 2*l2*(h,t) regulariser rows of model.py:383-385): dout is the
  * gradient of out; dE [nE,D], dV [B,nR,D], dw [D] are accumulated. */
-int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float* w,
+MVIN_API int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float* w,
                             const int32_t* const* mem_h, const int32_t* const* mem_r, const int32_t* const* mem_t,
                             int P, int B, int Nm, int D, int nR, const float* dout, int64_t ldo, float l2,
                             float* dE, float* dV, float* dw, void* stream);
@@ -487,13 +489,13 @@ int mvin_key_addressing_bwd(const float* entity_emb, const float* V, const float
  * relation_kge [nR, D, D] + items [B] (int64 when items64; both or neither): the kernel also adds the item's share of
  * V = E[item] . R_KGE[r], dE[item_b, :] += sum_r dV[b, r, :] . R_KGE[r]^T, from the dV block it holds in LDS; allowed only
  * where mvin_key_addressing_bwd_adds_item_grad(P, Nm, D, nR) != 0 (else -3: do that product with mvin_linear_fwd). */
-int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
+MVIN_API int mvin_key_addressing_bwd_reg(const float* entity_emb, const float* V, const float* w,
                                 const int32_t* const* mem_h, const int32_t* const* mem_r,
                                 const int32_t* const* mem_t, int P, int B, int Nm, int D, int nR, const float* dout,
                                 int64_t ldo, float l2, float* dE, float* dV, float* dw, int dw_replicas,
                                 float* reg_accum, const float* relation_kge, const void* items, int items64,
                                 void* stream);
-int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR);
+MVIN_API int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR);
 
 /* ---- inputs of the path, built on the GPU (data_loader_user_set.py) ------------------------
  * Both take the undirected KG as CSR: indptr [nE+1] int64, dst/rel [nnz] int32, every triple
@@ -503,7 +505,7 @@ int mvin_key_addressing_bwd_adds_item_grad(int P, int Nm, int D, int nR);
  *
  * mvin_sample_adjacency: contruct_random_adj (:375-388).  adj_entity/adj_relation [nE, K] int32:
  * K distinct edges when deg >= K, K draws with replacement when 0 < deg < K, zero row when deg == 0. */
-int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
+MVIN_API int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
                           uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream);
 
 /* mvin_encode_adjacency: the duplicate-slot encoding of a sampled adjacency (K <= 128, relation ids < 65536), built
@@ -514,14 +516,14 @@ int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32
  *                                                                       own list, known one fetch early; unsigned word)
  *     enc_relation = relation | multiplicity << 16 | cnt[x] << 24     (multiplicity 0: padding; unsigned word)
  * cnt [nE] = distinct slots per row (also written).  adj_relation may be NULL (relations read as 0). */
-int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
+MVIN_API int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
                           int32_t* enc_entity, int32_t* enc_relation, void* stream);
 
 /* mvin_build_ripple_sets: get_user_triplet_set / _get_user_triplet_set (:392-441).
  * hist_ptr [nU+1] int64 / hist_items int32: each user's positive train items in interaction order.
  * out [nU, P, 3, Nm] int32 = (heads, relations, tails) per hop; n_neighbor (16 in the reference, <= 32)
  * edges per seed entity enter the candidate list. */
-int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int32_t* rel,
+MVIN_API int mvin_build_ripple_sets(const int64_t* indptr, const int32_t* dst, const int32_t* rel,
                            const int64_t* hist_ptr, const int32_t* hist_items, int n_user, int P, int Nm,
                            int n_neighbor, uint64_t seed, int32_t* out, void* stream);
 

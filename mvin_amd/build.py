@@ -20,8 +20,9 @@ STAMP_PATH = LIB_PATH + ".stamp"
 OBJ_DIR = os.path.join(PKG_DIR, "_build")
 SOURCES = ["mvin_kernels.hip", "mvin_fused.hip", "mvin_fused_split.hip", "mvin_fused_packed.hip", "mvin_fused_d16.hip", "mvin_fused_d32.hip", "mvin_tail.hip", "mvin_keyaddr.hip", "mvin_keyaddr_stream.hip", "mvin_keyaddr_grouped.hip", "mvin_keyaddr_dense.hip", "mvin_keyaddr_static.hip", "mvin_keyaddr_wave.hip", "mvin_hoist.hip", "mvin_probe.hip", "mvin_group.hip", "mvin_prep.hip", "mvin_linear_mfma.hip", "mvin_bwd.hip", "mvin_abi.hip"]
 HEADERS = ["mvin_common.h", "mvin_kernels.h"]
+VERSION_SCRIPT = os.path.join(CSRC, "libmvin_hip.map")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-shared", f"--offload-arch={ARCH}"]
 
 
 def _hipcc():
@@ -37,7 +38,7 @@ def _existing(names, base):
 
 def _digest():
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for path in _existing(SOURCES + HEADERS, CSRC) + [os.path.join(INCLUDE, "mvin_hip.h")]:
+    for path in _existing(SOURCES + HEADERS, CSRC) + [os.path.join(INCLUDE, "mvin_hip.h"), VERSION_SCRIPT]:
         with open(path, "rb") as f:
             h.update(path.encode())
             h.update(f.read())
@@ -65,8 +66,23 @@ def build(force=False, verbose=False, jobs=None):
     Returns the library path."""
     if not force and not needs_build():
         return LIB_PATH
-    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # several processes may import the package on a fresh checkout at once (torchrun ranks): one builds, the others wait
+    # on the lock and then find the stamp up to date
+    import fcntl
+    with open(os.path.join(OBJ_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB_PATH
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
+    from concurrent.futures import ThreadPoolExecutor
+    tmp_suffix = f".{os.getpid()}.tmp"
     hipcc = _hipcc()
     cflags = [f for f in FLAGS if f != "-shared"]
     todo, objs = [], []
@@ -78,7 +94,7 @@ def build(force=False, verbose=False, jobs=None):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + cflags + ["-c", f"-I{INCLUDE}", f"-I{CSRC}", src, "-o", obj + ".tmp"]
+        cmd = [hipcc] + cflags + ["-c", f"-I{INCLUDE}", f"-I{CSRC}", src, "-o", obj + tmp_suffix]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -86,20 +102,20 @@ def build(force=False, verbose=False, jobs=None):
             raise RuntimeError(f"hipcc failed ({res.returncode}) on {src}:\n{res.stdout}\n{res.stderr}")
         if verbose and res.stderr:
             print(res.stderr, file=sys.stderr)
-        os.replace(obj + ".tmp", obj)
+        os.replace(obj + tmp_suffix, obj)
 
     if todo:
         with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
             list(ex.map(compile_one, todo))
     keep = set(objs)
     for f in os.listdir(OBJ_DIR):        # objects of older source revisions
-        if os.path.join(OBJ_DIR, f) not in keep:
+        if os.path.join(OBJ_DIR, f) not in keep and not f.endswith(".tmp") and f != ".lock":
             os.remove(os.path.join(OBJ_DIR, f))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}"] + objs + ["-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", f"-Wl,--version-script={VERSION_SCRIPT}"] + objs + ["-o", LIB_PATH + tmp_suffix]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    os.replace(LIB_PATH + tmp_suffix, LIB_PATH)
     with open(STAMP_PATH, "w") as f:
         f.write(_digest())
     return LIB_PATH

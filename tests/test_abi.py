@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol(hip_lib):
     assert hip_lib.mvin_abi_version() == 8
 
 
+def test_dynamic_symbol_table_is_exactly_the_header(hip_lib):
+    """The library is built with -fvisibility=hidden and linked with csrc/libmvin_hip.map: what `nm -D` lists as
+    defined is the header's declarations, nothing internal (no mangled mvin:: symbols, no kernel host stubs)."""
+    import subprocess
+    from mvin_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", build.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == header_functions()
+
+
 def test_single_hip_runtime_in_process(hip_lib):
     with open("/proc/self/maps") as f:
         rts = {ln.split()[-1] for ln in f if "libamdhip64" in ln}
