@@ -102,7 +102,26 @@ def parse():
                          "would (user-sorted split, row-shard exchange of the whole table per step); the line is marked "
                          "`emulated_world` and its `value` is per-rank pairs/s x W -- never a measurement of W GPUs")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: launch / join the --gpus N ranks, all-reduce one number through the process group, "
+                         "print {\"launch_check\": ...} on rank 0 and exit before any GPU work (argument plumbing test)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process becomes the launcher --
+    it re-executes the same command line under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1 at a
+    free port) exactly as the driver's own line does, streams the ranks' output through and exits with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MVIN_BENCH_LAUNCHER="self")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def cpu_baseline(args, margs, case, params):
@@ -449,23 +468,52 @@ def training_steps(margs, case, params, dev, users, items, mems, sizes=(512, 409
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # a line that says n_gpus = world while the caller asked for --gpus N would be read as an N-GPU measurement
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    backend = os.environ.get("MVIN_DIST_BACKEND", "nccl")
     if world > 1 or a.force_collectives:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("MVIN_DIST_BACKEND", "nccl")
         if backend == "nccl":       # = RCCL; the production transport
+            if a.launch_check:
+                raise SystemExit("--launch-check is the no-GPU plumbing test: set MVIN_DIST_BACKEND=gloo")
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: --gpus {world} over RCCL needs {world} visible GPUs, found "
+                                 f"{torch.cuda.device_count()} (tests only: MVIN_DIST_BACKEND=gloo time-shares them)")
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device(f"cuda:{local_rank}"))
-        else:                       # tests only: N ranks time-sharing the GPUs of a smaller box over gloo
-            local_rank %= torch.cuda.device_count()
+        else:                       # tests only (explicit MVIN_DIST_BACKEND): N ranks time-sharing the GPUs of a smaller box over gloo
+            if not a.launch_check:
+                local_rank %= torch.cuda.device_count()
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != a.gpus or dist.get_backend() != backend:
+            raise SystemExit(f"bench.py: process group has world size {dist.get_world_size()} / backend {dist.get_backend()}, "
+                             f"asked for {a.gpus} / {backend}")
+    if a.launch_check:
+        one = torch.ones(1, dtype=torch.float64)
+        if dist.is_initialized():
+            dist.all_reduce(one)
+        rec = {"launch_check": {"gpus_asked": a.gpus, "ranks_launched": int(one.item()),
+                                "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                                "backend": dist.get_backend() if dist.is_initialized() else None,
+                                "launcher": os.environ.get("MVIN_BENCH_LAUNCHER", "external")}}
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
@@ -605,10 +653,16 @@ def main():
         barrier()
     prof = model._profile
     model._profile = None
+    ranks_counted = 1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        cnt = torch.ones(1, dtype=torch.float64, device=dev)       # the ranks that really took part, counted by the fabric
+        dist.all_reduce(cnt)
+        ranks_counted = int(cnt.item())
+        if ranks_counted != a.gpus:
+            raise SystemExit(f"bench.py: {ranks_counted} ranks answered the all-reduce, --gpus {a.gpus}")
 
     if rank == 0:
         # HBM/fabric traffic of the dominant kernel comes from separate rocprofv3 --pmc passes
@@ -767,7 +821,9 @@ def main():
         # what the multi-GPU line rests on, printed so that the first real SCALE run verifies itself
         import torch.distributed as tdist
         dinfo = {"world_size": tdist.get_world_size() if tdist.is_initialized() else 1,
-                 "backend": tdist.get_backend() if tdist.is_initialized() else None, "ranks_launched": world}
+                 "backend": tdist.get_backend() if tdist.is_initialized() else None, "ranks_launched": ranks_counted,
+                 "gpus_asked": a.gpus, "launcher": os.environ.get("MVIN_BENCH_LAUNCHER", "external" if world > 1 else "none"),
+                 "production_transport": bool(world == 1 or (tdist.is_initialized() and tdist.get_backend() == "nccl"))}
         if rowshard:
             from mvin_amd.dist import exchange_wire_bytes, n_local_rows
             W_ = split

@@ -137,6 +137,30 @@ def test_bench_two_ranks_one_gpu(hip_lib):
     assert "row-sharded" in rec["config"]["parallelism"] and rec["roofline"]["achieved"] > 0
 
 
+def test_bench_gpus_flag_self_launch_one_gpu(hip_lib):
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts the two ranks itself (the form the driver uses
+    at N = 1 with another N would otherwise print a one-rank line) and the line says who launched and how many answered."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MVIN_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "4096"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    d = rec["distributed"]
+    assert rec["n_gpus"] == 2 and d["ranks_launched"] == 2 and d["launcher"] == "self" and d["backend"] == "gloo"
+    assert d["production_transport"] is False and d["exchange_bytes_received_per_rank_per_step"] > 0
+    # over RCCL two ranks need two GPUs: on a smaller box the command fails instead of printing a one-GPU line
+    if torch.cuda.device_count() < 2:
+        env.pop("MVIN_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                            "--batch", "4096"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
 def test_row_movers_fp32_and_bf16(hip_lib):
     from mvin_amd import ops
     dev = torch.device("cuda:0")

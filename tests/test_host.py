@@ -114,3 +114,27 @@ def test_algorithmic_bytes_per_pair_matches_survey_table():
     assert f(64, 64, 2) == 1098756                  # C4
     assert f(128, 128, 3, s=2) == 558007812         # C5 (bf16 table)
     assert bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must START two ranks (the flag was parsed
+    and never read).  Plumbing only: --launch-check rendezvouses over gloo, counts the ranks with an all-reduce and exits
+    before any GPU work."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MVIN_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                       # rank 0 only
+    lc = json.loads(lines[0])["launch_check"]
+    assert lc == {"gpus_asked": 2, "ranks_launched": 2, "world_size": 2, "backend": "gloo", "launcher": "self"}
+    # a launcher that started a different number of ranks than --gpus says is an error, not a mislabelled line
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
