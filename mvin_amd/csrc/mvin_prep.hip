@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void encode_adjacency_kernel(const int32_t*
         e[i] = s < K ? adj_e[(int64_t)x * K + s] : -1;
         r[i] = s < K ? (adj_r ? adj_r[(int64_t)x * K + s] : 0) : -1;
         if (s < K) {
+            // ids are clamped BEFORE they are compared and packed, as every plain-adjacency kernel clamps them where it
+            // indexes a table: an id outside its field would otherwise overwrite the count / multiplicity bytes
+            e[i] = e[i] < 0 ? 0 : (e[i] >= n_entity ? n_entity - 1 : e[i]);
+            r[i] = r[i] < 0 ? 0 : (r[i] > 0xFFFF ? 0xFFFF : r[i]);
             sE[wave][s] = e[i];
             sR[wave][s] = r[i];
         }
@@ -221,8 +225,7 @@ __global__ __launch_bounds__(kBlock) void encode_adjacency_kernel(const int32_t*
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int s = lane + 64 * i;
-            const int y = e[i] < 0 ? 0 : (e[i] >= n_entity ? n_entity - 1 : e[i]);
-            key[i] = first[i] ? cnt[y] : -1;
+            key[i] = first[i] ? cnt[e[i] < 0 ? 0 : e[i]] : -1;
             if (s < K) sF[wave][s] = key[i];
         }
         __builtin_amdgcn_wave_barrier();

@@ -356,13 +356,16 @@ class ShardedMVIN(object):
 
     def is_dense(self, global_batch):
         """Regime from the GLOBAL batch only (identical on every rank; no device sync): row references of the
-        batch's per-rank share vs table rows."""
+        batch's per-rank share vs table rows.  The static sparse form asks every owner for min(refs, n_local) rows, so from
+        refs >= n_local on it would move the whole table AND pay the id exchange, the sort and the scatter on top: that band
+        is dense too.  The count-exchange form (MVIN_DIST_DYNAMIC=1) moves distinct rows and keeps the table-size
+        threshold."""
         if self.regime != "auto":
             return self.regime == "dense"
         m = self.model
         per_rank = -(-int(global_batch) // self.world)
         refs = per_rank * (sum(m.n_neighbor ** e for e in range(self._depth() + 1)) + 2 * m.n_memory * max(1, m.p_hop))
-        return refs >= self.n_entity
+        return refs >= (self.table.n_local if self.static_sparse else self.n_entity)
 
     def _regime(self, local_batch, global_batch):
         dense = self.is_dense(local_batch * self.world if global_batch is None else global_batch)
@@ -403,6 +406,9 @@ class ShardedMVIN(object):
             # fixed-capacity buffers: no host sync anywhere in the step (capacity = the batch share's row references)
             refs = item_p.shape[0] * (sum(m.n_neighbor ** e for e in range(self._depth() + 1)) + 2 * m.n_memory * max(1, m.p_hop))
             self.table.fetch_static(need, refs, work)
+            if self._check and bool(self.table.overflow):      # debug mode only: reading the flag is a host sync
+                raise RuntimeError("static sparse exchange: a rank needed more rows from one owner than the capacity "
+                                   f"{min(refs, self.table.n_local)} (rows were dropped)")
         else:
             self.table.fetch(need, work)
         self._exchanges += 1

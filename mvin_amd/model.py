@@ -73,6 +73,8 @@ class MVIN(object):
         self._build_inputs()
         self._build_model(n_user, n_entity, n_relation, params, seed)
         self._build_train()
+        self._built = True
+        self.prepare()
 
     # ------------------------------------------------------------------ construction
     def _parse_args(self, args, adj_entity, adj_relation):
@@ -116,6 +118,8 @@ class MVIN(object):
         self._hoisted = None
         self._enc = None             # duplicate-slot encoding, built on first use (encoded_adjacency)
         self._generation = getattr(self, "_generation", 0) + 1
+        if getattr(self, "_built", False):
+            self.prepare()           # the encoding of the NEW adjacency, eagerly (never inside a later forward / capture)
 
     # a sampled adjacency repeats slots whenever deg < K (data_loader_user_set.py:383-384); the packed-tile fused kernel
     # walks the distinct slots only.  It pays when rows repeat: below this mean fraction of distinct slots per row it is
@@ -126,6 +130,10 @@ class MVIN(object):
         """(enc_entity, enc_relation, cnt, mean distinct fraction) of the current adjacency (mvin_encode_adjacency),
         built once per set_adjacency; None when the shape has no packed-tile kernel."""
         if self._enc is None:
+            if torch.cuda.is_current_stream_capturing():
+                # two launches, an allocation and a host sync (.item()): none of that belongs in a captured graph
+                raise RuntimeError("the duplicate-slot encoding of the adjacency is not built yet: call model.prepare() "
+                                   "(or run one eager forward) before capturing a graph")
             K = self.n_neighbor
             if (K > 128 or int(self.n_relation) > 4096 or int(self.n_entity) > (1 << 24)
                     or not ops.encode_adjacency_supported(self.dim, K)):
@@ -252,12 +260,33 @@ class MVIN(object):
         c = self._uts_records
         if c is not None and c[0]() is uts and c[1] == uts._version and c[2] == (self.n_entity, self.n_relation):
             return c[3]
+        if c is not None and c[0]() is None:
+            self._uts_records = None     # the tensor the records were built from is gone: free them (up to 8 GiB)
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the static per-user records of this user_triplet_set are not built yet: call "
+                               "model.prepare(user_triplet_set) before capturing a graph")
         words = ops.user_records_len(self.p_hop, self.n_memory, self.n_relation)
         if uts.shape[0] * words * 4 > self.USER_RECORDS_MAX_BYTES:
             return None
         rec = ops.build_user_records(uts, self.p_hop, self.n_relation, self.n_entity)
         self._uts_records = (weakref.ref(uts), uts._version, (self.n_entity, self.n_relation), rec)
         return rec
+
+    def prepare(self, user_triplet_set=None):
+        """Build, eagerly and on the current stream, everything the forward would otherwise build on first use: the
+        duplicate-slot encoding of the adjacency (two launches + one host sync), the relation-logit tables of the
+        aggregators and -- given a device-resident ``user_triplet_set`` -- its one-time id check and static per-user records
+        (an allocation of up to USER_RECORDS_MAX_BYTES + a kernel).  Called by __init__ and set_adjacency for the encoding;
+        call it yourself before capturing a forward in a hipGraph or running it on a side stream."""
+        if self.fused is not False:
+            self.encoded_adjacency()
+        for agg in self.aggregators:
+            if agg.User_orient_rela:
+                agg.relation_scores()
+        if user_triplet_set is not None:
+            self._check_uts(user_triplet_set)
+            self.user_records(user_triplet_set)
+        return self
 
     def _build_train(self):
         """model.py:378-414 (loss + Adam): the backward path is a later row of the scope

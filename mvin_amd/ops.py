@@ -137,7 +137,10 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     a.ids64 = 1 if ids64 else 0
     a.src_bf16 = src_bf16
     gathered = [srcs[s].numel() // Dsrc for s in range(nsrc) if ids[s] is not None]
-    a.src_rows = min(gathered) if gathered else 0         # ids are clamped into the (smallest) gathered table
+    if len(set(gathered)) > 1:
+        # mvin_linear_args carries ONE src_rows: ids valid for the larger table would be clamped to the smaller one's last row
+        raise ValueError(f"gathered sources of one mvin_linear_fwd call must have the same row count, got {gathered}")
+    a.src_rows = gathered[0] if gathered else 0           # ids are clamped into the gathered table
     a.sum_sources = 1 if sum_sources else 0
     a.out = out.data_ptr() + out_offset * 4
     a.ldo = ldo

@@ -114,7 +114,11 @@ def encode_adjacency(adj_e, adj_r):
     adj_e = np.asarray(adj_e, dtype=np.int64)
     adj_r = np.asarray(adj_r, dtype=np.int64)
     nE, K = adj_e.shape
-    assert K <= 128 and adj_r.max(initial=0) < 65536 and nE <= (1 << 24)
+    assert K <= 128 and nE <= (1 << 24)
+    # ids are clamped into their fields first (neighbour into the table, relation into 16 bits), like every kernel that
+    # indexes a table with a device-resident id; two slots that clamp to the same (neighbour, relation) are one slot
+    adj_e = np.clip(adj_e, 0, nE - 1)
+    adj_r = np.clip(adj_r, 0, 0xFFFF)
     firsts, mults = [], []
     cnt = np.zeros(nE, dtype=np.int32)
     for x in range(nE):

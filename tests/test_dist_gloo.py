@@ -164,3 +164,24 @@ def test_mark_needed_matches_bruteforce_tree():
     got = mark_needed(nE, torch.from_numpy(adj.astype(np.int32)), torch.from_numpy(items), 3,
                       [torch.from_numpy(extra)])
     assert set(got.nonzero(as_tuple=True)[0].tolist()) == want
+
+
+def test_static_sparse_band_is_dense():
+    """with fixed-capacity id buffers every owner is asked for min(refs, n_local) rows, so from refs >= n_local
+    on the 'sparse' step would move the whole table plus ids, a sort and a scatter: that band takes the dense regime.  The
+    count-exchange form keeps the table-size threshold."""
+    from types import SimpleNamespace
+    from mvin_amd.dist import ShardedMVIN, n_local_rows
+    nE, W = 113487, 8
+    model = SimpleNamespace(n_neighbor=64, n_memory=16, p_hop=1, n_mix_hop=1, h_hop=2,
+                            args=SimpleNamespace(PS_only=False, wide_deep=True))
+    stub = SimpleNamespace(regime="auto", model=model, world=W, n_entity=nE, static_sparse=True,
+                           table=SimpleNamespace(n_local=n_local_rows(nE, W)))
+    stub._depth = lambda: ShardedMVIN._depth(stub)
+    per_pair = 1 + 64 + 64 * 64 + 2 * 16
+    just_below = (n_local_rows(nE, W) - 1) // per_pair           # pairs per rank whose references stay below a shard
+    assert not ShardedMVIN.is_dense(stub, just_below * W)
+    assert ShardedMVIN.is_dense(stub, (just_below + 1) * W)       # refs >= n_local: dense, although refs << n_entity
+    stub.static_sparse = False
+    assert not ShardedMVIN.is_dense(stub, (just_below + 1) * W)
+    assert ShardedMVIN.is_dense(stub, (nE // per_pair + 1) * W)

@@ -133,3 +133,17 @@ def test_aggregator_call_surface(rela, hip_lib):
         assert_close(p2.cpu().numpy(), ref_p.numpy(), "probs (ids)")
     else:
         assert p is None and p2 is None and ref_p is None
+
+
+def test_linear_refuses_gathered_sources_of_different_heights(hip_lib):
+    """mvin_linear_args has ONE src_rows; two gathered tables of different heights would have the larger one's
+    ids clamped to the smaller one's last row -- ops.linear raises instead."""
+    import torch
+    from mvin_amd import ops
+    dev = torch.device("cuda:0")
+    big, small = torch.rand(100, 16, device=dev), torch.rand(10, 16, device=dev)
+    ids = torch.tensor([3, 50], dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError, match="same row count"):
+        ops.linear([big, small], torch.eye(16, device=dev), 16, ids=[ids, ids], sum_sources=True)
+    got = ops.linear([big, big], torch.eye(16, device=dev), 16, ids=[ids, ids], sum_sources=True)
+    assert torch.allclose(got, 2 * big[ids.long()], rtol=1e-6, atol=1e-6)

@@ -81,6 +81,34 @@ def test_encode_adjacency_bit_exact(K, kind, hip_lib):
         assert ref_c.mean() < 0.8 * K
 
 
+def test_encoder_clamps_out_of_range_ids(hip_lib):
+    """a neighbour id outside [0, n_entity) or a relation id outside its 16-bit field used to be OR-ed into the
+    packed words raw and overwrite the count / multiplicity bytes; the encoder now clamps them first, as the plain-adjacency
+    kernels clamp where they index (same scores on both paths)."""
+    args = make_args(**_shape(64, 32, B=8))
+    case = synth.small_case(args, n_entity=300, n_relation=11, seed=3, zero_rows=5, repeats=True)
+    ae, ar = case.adj_entity.astype(np.int32).copy(), case.adj_relation.astype(np.int32).copy()
+    rng = np.random.default_rng(0)
+    bad = rng.random(ae.shape) < 0.05
+    ae[bad] = rng.choice(np.array([-7, 300, 1 << 24, (1 << 24) + 5, 2 ** 31 - 1], dtype=np.int64), size=int(bad.sum())).astype(np.int32)
+    badr = rng.random(ar.shape) < 0.05
+    ar[badr] = rng.choice(np.array([-1, 70000, 1 << 20], dtype=np.int64), size=int(badr.sum())).astype(np.int32)
+    enc_e, enc_r, cnt = ops.encode_adjacency(torch.from_numpy(ae).cuda(), torch.from_numpy(ar).cuda())
+    ref_e, ref_r, ref_c = prep_ref.encode_adjacency(ae, ar)
+    assert np.array_equal(cnt.cpu().numpy(), ref_c) and np.array_equal(enc_e.cpu().numpy(), ref_e)
+    assert np.array_equal(enc_r.cpu().numpy(), ref_r)
+    c = cnt.cpu().numpy()
+    assert c.min() >= 1 and c.max() <= 32
+    assert np.array_equal((enc_r.cpu().numpy().view(np.uint32) >> 24), np.broadcast_to(c[:, None], ae.shape))
+    # the model over this adjacency: encoded path == plain path (both clamp; relations clamp to the logit table's last row)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=4, random_agg_bias=True)
+    case2 = copy.copy(case)
+    case2.adj_entity, case2.adj_relation = ae.astype(np.int64), np.clip(ar, 0, case.n_relation - 1).astype(np.int64)
+    _, enc_out = _run(args, case2, params, True)
+    _, plain_out = _run(args, case2, params, False)
+    assert torch.allclose(enc_out.scores, plain_out.scores, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("table", ["f32", "bf16"])
 @pytest.mark.parametrize("kind", ["repeats", "uniform"])
 @pytest.mark.parametrize("dk", DK, ids=lambda dk: "D%dK%d" % dk)
