@@ -195,8 +195,9 @@ __global__ __launch_bounds__(kBlock) void encode_adjacency_kernel(const int32_t*
         if (s < K) {
             // ids are clamped BEFORE they are compared and packed, as every plain-adjacency kernel clamps them where it
             // indexes a table: an id outside its field would otherwise overwrite the count / multiplicity bytes
-            e[i] = e[i] < 0 ? 0 : (e[i] >= n_entity ? n_entity - 1 : e[i]);
-            r[i] = r[i] < 0 ? 0 : (r[i] > 0xFFFF ? 0xFFFF : r[i]);
+            // (the library's rule: an unsigned min -- ids beyond the field, negative ones included, become its last value)
+            e[i] = (int)min((unsigned)e[i], (unsigned)(n_entity - 1));
+            r[i] = (int)min((unsigned)r[i], 0xFFFFu);
             sE[wave][s] = e[i];
             sR[wave][s] = r[i];
         }

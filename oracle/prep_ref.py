@@ -117,8 +117,9 @@ def encode_adjacency(adj_e, adj_r):
     assert K <= 128 and nE <= (1 << 24)
     # ids are clamped into their fields first (neighbour into the table, relation into 16 bits), like every kernel that
     # indexes a table with a device-resident id; two slots that clamp to the same (neighbour, relation) are one slot
-    adj_e = np.clip(adj_e, 0, nE - 1)
-    adj_r = np.clip(adj_r, 0, 0xFFFF)
+    # (unsigned min, the library's rule: a negative id is a huge unsigned one and becomes the field's last value)
+    adj_e = np.where((adj_e < 0) | (adj_e > nE - 1), nE - 1, adj_e)
+    adj_r = np.where((adj_r < 0) | (adj_r > 0xFFFF), 0xFFFF, adj_r)
     firsts, mults = [], []
     cnt = np.zeros(nE, dtype=np.int32)
     for x in range(nE):

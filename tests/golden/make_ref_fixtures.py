@@ -1,6 +1,7 @@
 """Pin the oracles to the REFERENCE'S OWN CODE (build container only; run from the repo root):
 
     python tests/golden/make_ref_fixtures.py            # writes tests/golden/ref/*.npz|*.json
+    python tests/golden/make_ref_fixtures.py --only-hot # only the hot-shape score fixtures (hot__*.npz)
 
 This script imports modules from /root/reference/src/model/MVIN, runs them on seeded synthetic inputs
 and stores inputs + the reference's outputs as small data fixtures.  Nothing of the reference's source
@@ -349,6 +350,36 @@ def fixture_model(shape_name, ablation, seed):
     return path, None
 
 
+def fixture_hot(name, ablation):
+    """The reference's model.py / aggregators.py over the stand-in AT A HOT-KERNEL SHAPE (tests/refpin/hot_cases.py:
+    D 32 / 64, K 16 / 32 / 64, 2 048 level-1 nodes per batch, adjacencies with and without repeated slots).  Stores
+    the reference's scores (fp32 and fp64 arithmetic) and a checksum of the inputs, which the tests regenerate."""
+    from refpin import hot_cases
+    args, case, params, _ = hot_cases.build(name, ablation)
+    labels = np.zeros(args.batch_size, np.float32)
+    d = {"args_json": np.array(json.dumps(dict(hot_cases.HOT_CASES[name]["shape"], ablation=ablation))),
+         "inputs_crc32": np.array(hot_cases.inputs_crc32(case, params), dtype=np.int64)}
+    for tag, fdt in (("32", np.float32), ("64", np.float64)):
+        model, _ = build_ref_model(args, case, params, fdt)
+        sess = tf.Session()
+        feed = feed_of(model, case, labels)
+        items, sn = model.get_scores(sess, feed)
+        assert np.array_equal(items, case.items)
+        d["ref_scores_" + tag] = sess.run(model.scores, feed)
+        d["ref_scores_normalized_" + tag] = sn
+    path = os.path.join(OUT, f"hot__{name}__{ablation}.npz")
+    np.savez_compressed(path, **d)
+    return path
+
+
+def fixture_all_hot():
+    from refpin import hot_cases
+    for name in hot_cases.HOT_CASES:
+        for abl in hot_cases.HOT_ABLATIONS:
+            path = fixture_hot(name, abl)
+            print(f"{os.path.basename(path):52s} {os.path.getsize(path)} B")
+
+
 def fixture_harness():
     """util.py's evaluation loops + train.py's feed assembly, run by the reference over its own
     (stand-in-backed) model on a small synthetic dataset; outputs only."""
@@ -416,6 +447,9 @@ def fixture_harness():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-hot" in sys.argv:
+        fixture_all_hot()
+        return
     fixture_data_loader()
     fixture_metrics()
     fixture_early_stop()
@@ -438,6 +472,7 @@ def main():
     with open(os.path.join(OUT, "reference_raises.json"), "w") as f:
         json.dump(unrunnable, f, indent=1)
     fixture_harness()
+    fixture_all_hot()
     print("done ->", OUT)
 
 

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from parity import ATOL, RTOL, assert_close
-from test_ref_pins import MODEL_FIX, REF, check_adjacency_rule, check_ripple_rule, load_model_fixture
+from test_ref_pins import HOT_FIX, MODEL_FIX, REF, check_adjacency_rule, check_ripple_rule, load_hot_fixture, load_model_fixture
 
 pytestmark = pytest.mark.gpu
 
@@ -57,6 +57,51 @@ def test_hip_matches_reference_graph(path, fused, hip_lib):
         assert_close(imp1, z["ref_importance_1"], "importance_list_1", atol=1e-7)
     elif L == 1:
         assert isinstance(imp1, int) and imp1 == 0                         # model.py:323
+
+
+@pytest.mark.parametrize("path", HOT_FIX, ids=lambda p: os.path.basename(p)[5:-4])
+def test_hot_kernels_match_reference_graph(path, hip_lib):
+    """the reference's own model.py / aggregators.py run at D 32 / 64, K 16 / 32 / 64 (hot__*.npz) against
+    every schedule the HIP path has for those shapes: the one-native-call pass (per-pair feed and users feed), the encoded
+    (packed-tile) and plain (role-split / wave-per-parent) fused kernels, the grouped key addressing over static per-user
+    records, the Python schedule of the same kernels and the per-level kernels."""
+    from mvin_amd import ops
+    from mvin_amd.model import MVIN
+    exp, args, case, params, uts = load_hot_fixture(path)
+    dev = torch.device("cuda:0")
+    users, items = torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev)
+    mem = [[torch.from_numpy(m).to(dev) for m in lst] for lst in (case.memories_h, case.memories_r, case.memories_t)]
+    uts_d = torch.from_numpy(uts).to(dev)
+    D, K = args.dim, args.neighbor_sample_size
+
+    def check(out, what):
+        got = out.scores.cpu().numpy()
+        assert_close(got, exp.scores_64, f"{what}: scores vs reference graph (fp64)")
+        assert_close(got, exp.scores_32, f"{what}: scores vs reference graph (fp32)", rtol=RTOL, atol=2 * ATOL)
+        assert_close(out.scores_normalized.cpu().numpy(), exp.sig_64, f"{what}: sigmoid scores")
+
+    def model(**kw):
+        return MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+                    device=dev, **kw)
+    taken = set()
+    for dedup in (None, True, False):
+        m = model()
+        m.dedup = dedup
+        enc = m._enc_for_l2(n_parents=items.shape[0])
+        taken.add("enc" if enc is not None else "plain")
+        check(m.forward_device(users, items, *mem), f"per-pair feed, dedup={dedup}")
+        # users feed: grouped by user (8 pairs per user) -> key addressing over the static records where the shape has them
+        check(m.forward_users(users, items, uts_d), f"users feed, dedup={dedup}")
+        if ops.user_records_supported(D, args.p_hop, args.n_memory, case.n_relation, False):
+            assert m._uts_records is not None, "the records kernel was expected on this shape"
+        m.static_user_records = False                # the bucketing kernel on the same feed
+        m._uts_records = None
+        check(m.forward_users(users, items, uts_d), f"users feed, no records, dedup={dedup}")
+        # the Python schedule of the same kernels (no one-call pass)
+        m.native_l2_max_batch = 0
+        check(m.forward_device(users, items, *mem), f"python schedule, dedup={dedup}")
+    assert taken == {"enc", "plain"}
+    check(model(fused=False).forward_device(users, items, *mem), "per-level kernels")
 
 
 def _harness_model():

@@ -36,6 +36,38 @@ def load_model_fixture(path):
     return z, args, params, mem
 
 
+HOT_FIX = sorted(glob.glob(os.path.join(REF, "hot__*.npz")))
+
+
+def load_hot_fixture(path):
+    """A hot-shape fixture (tests/refpin/hot_cases.py): inputs regenerated from its seeds and checked against the checksum
+    the generator stored -> (expected, args, case, params, user_triplet_set)."""
+    from refpin import hot_cases
+    name, ablation = os.path.basename(path)[len("hot__"):-4].split("__")
+    exp = hot_cases.expected(path)
+    args, case, params, uts = hot_cases.build(name, ablation)
+    assert hot_cases.inputs_crc32(case, params) == exp.crc, "regenerated inputs differ from the ones the reference ran on"
+    return exp, args, case, params, uts
+
+
+def test_hot_shape_fixtures_present():
+    from refpin import hot_cases
+    assert len(HOT_FIX) == len(hot_cases.HOT_CASES) * len(hot_cases.HOT_ABLATIONS)
+
+
+@pytest.mark.parametrize("path", HOT_FIX, ids=lambda p: os.path.basename(p)[5:-4])
+def test_oracles_match_reference_graph_at_hot_shapes(path):
+    """the reference's own model.py:259-324 / :161-240 at D 32 / 64, K 16 / 32 / 64 -- the shapes the packed,
+    split, records and tail kernels serve -- against both oracles."""
+    exp, args, case, params, _ = load_hot_fixture(path)
+    feed = (case.users, case.items, case.memories_h, case.memories_r, case.memories_t)
+    m = mirror_fp32.forward(args, params, case.adj_entity, case.adj_relation, *feed)
+    np.testing.assert_allclose(m.scores.numpy(), exp.scores_32, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m.scores.numpy(), exp.scores_64, rtol=1e-5, atol=1e-6)
+    e = equations_fp64.forward(args, params, case.adj_entity, case.adj_relation, *feed)
+    np.testing.assert_allclose(e.scores, exp.scores_64, rtol=1e-9, atol=1e-11)
+
+
 def test_reference_fixtures_present():
     assert len(MODEL_FIX) >= 30
     names = {os.path.basename(p)[len("model__"):-4].split("__")[1] for p in MODEL_FIX}
