@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 8
+#define MVIN_ABI_VERSION 9
 /* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
 #define MVIN_API __attribute__((visibility("default")))
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
@@ -362,8 +362,25 @@ typedef struct {
                                       GROUPED form (mvin_group_pairs_by_user + mvin_key_addressing_grouped_fwd instead of the V
                                       projection + mvin_key_addressing_users_fwd; V may then be NULL) */
     const int32_t* user_records;   /* grouped form only, or NULL: mvin_build_user_records(uts) -> mvin_key_addressing_grouped_rec_fwd */
+    int depth;                     /* mvin_score_small_fwd only: tree depth h_hop (n_mix_hop = 1): 0 or 2 = two hops; 1 = ONE hop
+                                      (BASELINE configs[0]: W2 / b2 / A1 / a1 / t1 unused and may be NULL, Wmix is [2D, D]).
+                                      mvin_score_l2_fwd ignores it (depth 2) */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
+
+/* The same pass as ONE KERNEL LAUNCH, for the batch sizes the reference itself calls the path with (512 / 1024 pairs per
+ * sess.run: train.py:62-64, util.py:44-56, src/bash/mvin_*.sh; SURVEY 8(d) sweeps 512 .. 16 384): a workgroup takes
+ * `group` consecutive pairs from their ids to their scores -- V projection, attention reads over the ripple sets
+ * (model.py:161-240), user MLP, the two-level neighbor gather + attention (:259-305, aggregators.py:98-146) and the
+ * mix-hop tail + score (:286-317, :158-159) with nothing but LDS in between.  Same argument block as mvin_score_l2_fwd;
+ * the workspaces (V, o_cat, parents, nagg0, nagg1, group_ws, user_records) are not used and may be NULL.  Per-pair feed
+ * (mem_h / mem_r / mem_t) or users feed (uts + users); plain adjacency or, with enc_entity / enc_relation, its
+ * duplicate-slot encoding (distinct rows only).  group <= 0: chosen from the batch size (1 .. 16 pairs per workgroup).
+ * args->depth = 1: the one-hop tree (model.py:286-317 with h_hop = 1: aggregator (0,0) at hop 0, combiner over [ev0 | out0]).
+ * D in {16, 32, 64}, K <= 64, P in 1..4, Nm <= 64, fp32 table and adjacency below 4 GiB: -3 otherwise
+ * (mvin_score_small_supported). */
+MVIN_API int mvin_score_small_fwd(const mvin_score_l2_args* args, int group, void* stream);
+MVIN_API int mvin_score_small_supported(int D, int K, int P, int Nm, int nR);
 
 /* Row movers of the multi-GPU layer (mvin_amd/dist.py; no reference counterpart -- the reference is single
  * device): out[i, :] = table[ids[i], :] (gather) and table[ids[i], :] = rows[i, :] (scatter; ids distinct),

@@ -48,6 +48,7 @@ int mvin_debug_read_trace(long long* host_dst, size_t n) {
     if (!host_dst) return -1;
     static const bool ka = getenv("MVIN_KA_TRACE") != nullptr;     // which kernel's stamps
     static const bool pk = getenv("MVIN_PACK_TRACE") != nullptr;
+    if (getenv("MVIN_SMALL_TRACE")) return (int)mvin::small_read_trace(host_dst, n);
     if (pk) return (int)mvin::pack_read_prof(host_dst, n);
     if (ka && getenv("MVIN_KA_TRACE")[0] == '2') return (int)mvin::kas_read_trace(host_dst, n);     // the kernel over static records
     return (int)(ka ? mvin::ka_read_trace(host_dst, n) : mvin::split_read_trace(host_dst, n));
@@ -548,6 +549,63 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     return mvin_l2_tail_fwd(a->entity_emb, a->items, nullptr, a->W0 ? a->user_o : nullptr, a->user_o, a->nagg0, a->nagg1,
                             a->W0, a->b0, a->A0, a->a0, a->A1, a->a1, a->Wmix, a->bmix, a->B, D, a->n_entity, a->item_emb,
                             a->scores, a->sig, a->table_bf16, stream);
+}
+
+int mvin_score_small_supported(int D, int K, int P, int Nm, int nR) { return mvin::score_small_supported(D, K, P, Nm, nR) ? 1 : 0; }
+
+int mvin_score_small_fwd(const mvin_score_l2_args* a, int group, void* stream) {
+    const char* who = "mvin_score_small_fwd";
+    if (!a) return fail(-1, "%s: null args", who);
+    if (!mvin::score_small_supported(a->D, a->K, a->P, a->Nm, a->n_relation))
+        return fail(-3, "%s: unsupported shape D=%d K=%d P=%d Nm=%d nR=%d", who, a->D, a->K, a->P, a->Nm, a->n_relation);
+    if (a->depth < 0 || a->depth > 2) return fail(-2, "%s: depth=%d (1 or 2)", who, a->depth);
+    const bool d1 = a->depth == 1;
+    if (!a->entity_emb || !a->adj_entity || !a->relation_kge || !a->user_mlp_W || !a->A0 || (!d1 && !a->A1) || !a->Wmix || !a->items ||
+        !a->user_o || !a->scores)
+        return fail(-1, "%s: null table / weight / items / output", who);
+    if ((a->W0 == nullptr) != (a->W1 == nullptr) || (!d1 && (a->W1 == nullptr) != (a->W2 == nullptr)))
+        return fail(-1, "%s: W0 / W1 (/ W2) must be given together (User_orient) or not at all", who);
+    if (a->uts ? !a->users : (!a->mem_h || !a->mem_r || !a->mem_t))
+        return fail(-1, "%s: needs uts + users, or mem_h / mem_r / mem_t", who);
+    if (a->B <= 0 || a->n_entity <= 0 || (a->uts && a->n_user <= 0)) return fail(-2, "%s: bad sizes B=%lld", who, (long long)a->B);
+    const bool enc = a->enc_entity && a->enc_relation;
+    if (enc && a->n_entity > (1 << 24)) return fail(-2, "%s: the encoded adjacency holds 24-bit ids", who);
+    if (a->table_bf16) return fail(-3, "%s: fp32 entity table only", who);
+    const uint64_t table_bytes = (uint64_t)a->n_entity * a->D * 4, adj_bytes = (uint64_t)a->n_entity * a->K * 4;
+    if (table_bytes >= (1ull << 32) - 4096 || adj_bytes >= (1ull << 32) - 4096)
+        return fail(-3, "%s: entity table / adjacency of 4 GiB or more (32-bit buffer offsets)", who);
+    mvin::ScoreSmallArgs s{};
+    s.E = a->entity_emb;
+    s.adj_e = enc ? a->enc_entity : a->adj_entity;
+    s.adj_r = enc ? a->enc_relation : a->adj_relation;
+    s.R = a->relation_kge;
+    s.w_h = a->h_set_w;
+    s.Wu = a->user_mlp_W;
+    s.bu = a->user_mlp_b;
+    s.t0 = a->t0;
+    s.t1 = a->t1;
+    s.W0 = a->W0, s.b0 = a->b0, s.W1 = a->W1, s.b1 = a->b1, s.W2 = a->W2, s.b2 = a->b2;
+    s.A0 = a->A0, s.a0 = a->a0, s.A1 = a->A1, s.a1 = a->a1, s.Wmix = a->Wmix, s.bmix = a->bmix;
+    s.items = a->items;
+    if (a->uts) {
+        s.uts = a->uts;
+        s.users = a->users;
+    } else {
+        for (int h = 0; h < a->P; ++h) {
+            if (!a->mem_h[h] || !a->mem_r[h] || !a->mem_t[h]) return fail(-1, "%s: null ripple-set array of hop %d", who, h);
+            s.mem_h[h] = a->mem_h[h], s.mem_r[h] = a->mem_r[h], s.mem_t[h] = a->mem_t[h];
+        }
+    }
+    s.user_o = a->user_o, s.item_emb = a->item_emb, s.scores = a->scores, s.sig = a->sig;
+    s.B = a->B;
+    s.G = group;
+    s.K = a->K, s.P = a->P, s.Nm = a->Nm, s.nR = a->n_relation, s.n_entity = a->n_entity, s.n_user = a->n_user > 0 ? a->n_user : 1;
+    s.enc = enc ? 1 : 0;
+    s.depth1 = d1 ? 1 : 0;
+    s.table_bf16 = 0;
+    s.table_bytes = table_bytes;
+    s.adj_bytes = adj_bytes;
+    return hip_result(mvin::launch_score_small(s, a->D, (hipStream_t)stream), who);
 }
 
 int mvin_gather_rows(const void* table, const int32_t* ids, int64_t n, int row_bytes, void* out, void* stream) {

@@ -300,6 +300,42 @@ hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_
 hipError_t launch_shard_space_ids(const void* ids, bool is64, int64_t n, int world, int n_local, void* out, hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
+// ---- the whole depth-2 pass in one launch (mvin_score_small.hip) ----
+struct ScoreSmallArgs {
+    const void* E;               // [nE, D] fp32 or bf16
+    const int32_t* adj_e;        // [nE, K] plain adjacency, or its duplicate-slot encoding (enc != 0)
+    const int32_t* adj_r;
+    const float* R;              // [nR, D, D] relation_emb_KGE_matrix
+    const float* w_h;            // [D] h-set logit weights or NULL (PS_O_ft off)
+    const float* Wu;             // [(P + (w_h != NULL)) * D, D] user MLP
+    const float* bu;
+    const float* t0;             // [nR] relation logits of aggregator (0,0) / (1,0) or NULL (plain mean)
+    const float* t1;
+    const float *W0, *b0, *W1, *b1, *W2, *b2;      // projections of levels 0, 1, 2 or all NULL (User_orient off)
+    const float *A0, *a0, *A1, *a1, *Wmix, *bmix;
+    const int64_t* items;        // [B]
+    const int32_t* mem_h[4];     // per hop [B, Nm] (per-pair feed) ...
+    const int32_t* mem_r[4];
+    const int32_t* mem_t[4];
+    const int32_t* uts;          // ... or user_triplet_set [nU, max(1,P), 3, Nm] + users [B]
+    const int64_t* users;
+    float* user_o;               // out [B, D]
+    float* item_emb;             // out [B, D] or NULL
+    float* scores;               // out [B]
+    float* sig;                  // out [B] or NULL
+    int64_t B;
+    int G;                       // pairs per workgroup (<= 0: chosen by the launcher)
+    int K, P, Nm, nR, n_entity, n_user, enc, table_bf16;
+    int depth1;                  // one-hop tree (h_hop = 1): no grandchildren, no aggregator (1,0)
+    int dbg;                     // timing experiments only (MVIN_SMALL_DBG)
+    uint64_t table_bytes;        // nE * D * 4 and nE * K * 4: buffer descriptor ranges (both below 4 GiB)
+    uint64_t adj_bytes;
+};
+bool score_small_supported(int D, int K, int P, int Nm, int nR);
+int score_small_group(int D, int K, int P, int Nm, int nR, int has_hset, int64_t B);
+hipError_t launch_score_small(ScoreSmallArgs a, int D, hipStream_t st);
+hipError_t small_read_trace(long long* host_dst, size_t n);
+
 bool l2_tail_supported(int D);
 hipError_t launch_l2_tail(const TailArgs& a, int D, hipStream_t st);
 bool fused_l2_supported(int D, int K);

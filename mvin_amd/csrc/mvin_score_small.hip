@@ -1,0 +1,1000 @@
+// The WHOLE get_scores pass (model.py:125-159, default wiring, tree depth 2) in ONE launch, for the batch sizes the
+// reference itself runs (512 / 1024 pairs per sess.run: train.py:62-64, util.py:44-56, src/bash/mvin_*.sh; SURVEY 8(d)
+// sweeps 512 .. 16 384).  At those sizes the pass used to be five dependent launches (V projection, key addressing,
+// user MLP, fused two-level gather, tail) of 5-10 us each: every one of them a few waves per CU chasing its own
+// dependent-load chain, with a kernel boundary in between.  Here a workgroup owns a GROUP of G consecutive pairs from
+// their ids to their scores; nothing goes through HBM between the stages, only LDS:
+//
+//   setup   item / user ids, E[item] rows, the items' adjacency rows                         (one latency, all in flight together)
+//   V       V[g, r, :] = E[item_g] . R_KGE[r]                       model.py:214-220 as (R h).v == h.(v R); MFMA, rows = pairs
+//   reads   per (pair, hop) -- one WAVE each, no workgroup barrier: logits h_m . V[g, r_m] (and h0_m . w_h for the h-set read,
+//           :162-197), softmax over the Nm memories, o = sum_m p_m t_m                        :204-230; all 2*Nm rows in flight
+//   mlp     user_o = [o_hset | o_0 | o_1 ..] . user_mlp + b                                   :232-236; MFMA
+//   tree    the children of ALL pairs of the group as one work list (distinct slots only when the adjacency is given in
+//           the duplicate-slot encoding), walked in chunks of 16 = one MFMA row tile: one lane group per child softmaxes the
+//           child's own list and gathers its rows (S' = sum_k (p_k / K) E[y_k]); then on the tile
+//             self1 = (E[x1] + q) W1 + b1 ; Z = self1 + (S' + c q) W2 + c b2 ; out1 = relu(Z A0 + a0)      :270-305, aggregators.py:98-146
+//           and the per-pair sums nagg0 += p0 self1, nagg1 += p1 out1 (fixed order: deterministic)
+//   tail    ev0 = (E[item] + q) W0 + b0 ; out0 = relu((ev0 + nagg0) A0 + a0) ; out2 = relu((out0 + nagg1) A1 + a1) ;
+//           item = [ev0 | out0 | out2] Wmix + bmix ; score = user_o . item ; sigmoid          :286-317, :158-159
+//
+// Same arithmetic as the separate kernels (mvin_keyaddr.hip, mvin_fused_d32.hip, mvin_tail.hip): projection after the
+// weighted sum, relation logits as an nR-entry table, repeated slots merged with their multiplicities.
+// D in {16, 32, 64}: D/16 waves per workgroup (one 16-column slab of every product each), 16 lane groups of D/4 lanes.
+#include <cstdlib>
+
+#include "mvin_kernels.h"
+
+namespace mvin {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct SmallLds {        // offsets in 4-byte words
+    int t0, t1, item, o, q, n, ids, c0e, c0r, chid, chg, chp0, chp1, chcnt, u;      // persistent
+    int v, part;                                                               // phase "reads" (overlays u)
+    int a1, a2, z, w0, w1, y, wt, sc, ps;                                      // phases "tree" / "tail"
+    int ldo, total;
+};
+
+__host__ __device__ inline SmallLds small_lds(int D, int G, int K, int nR, int NO, int nparts) {
+    SmallLds l{};
+    int off = 0;
+    auto take = [&](int words) {
+        const int o = off;
+        off += (words + 3) & ~3;
+        return o;
+    };
+    const int LD = D + 4, nRp = (nR + 3) & ~3;
+    l.ldo = NO * D + 4;
+    l.t0 = take(nRp);
+    l.t1 = take(nRp);
+    l.item = take(G * LD);
+    l.o = take(G * l.ldo);
+    l.q = take(G * LD);
+    l.n = take(2 * G * D);
+    l.ids = take(2 * 16);
+    l.c0e = take(G * K);
+    l.c0r = take(G * K);
+    l.chid = take(G * K);
+    l.chg = take(G * K);
+    l.chp0 = take(G * K);
+    l.chp1 = take(G * K);
+    l.chcnt = take(G * K);
+    l.y = take(16 * K);                                  // the current chunk's lists: written while V / the records are still live
+    l.wt = take(16 * K);
+    l.u = off;
+    l.v = take(G * nR * D);
+    l.part = take(nparts * (D + 4));                     // unit records of the reads stage
+    const int end_v = off;
+    off = l.u;
+    l.a1 = take(16 * LD);
+    l.a2 = take(16 * LD);
+    l.z = take(16 * LD);
+    l.w0 = take(16 * LD);
+    l.w1 = take(16 * LD);
+    l.sc = take((D / 16) * 16);
+    l.ps = take(16 * ((K + 7) / 8) * D);                 // partial row sums of a chunk's sub-lists
+    l.total = (off > end_v ? off : end_v) * 4;
+    return l;
+}
+
+__device__ __forceinline__ float small_dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// development aid (MVIN_SMALL_DBG=99): s_memtime of every wave of workgroup 0 at the stage boundaries
+constexpr int kSmallStamps = 32;
+__device__ long long g_small_trace[4][kSmallStamps];
+hipError_t small_read_trace(long long* host_dst, size_t n) {
+    const size_t have = 4 * kSmallStamps;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_small_trace), (n < have ? n : have) * sizeof(long long));
+}
+
+// NMT: the ripple-set size the reads stage is unrolled for (rows per lane = NMT * (D/4) / 64): n_memory <= NMT
+template <int D, int NMT>
+__global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a, SmallLds L) {
+    constexpr int NT = D / 16, NTHR = NT * 64, KS = D / 4, LD = D + 4, LPR = D / 4, RPW = 64 / LPR;
+    constexpr int LPR_L2 = LPR == 16 ? 4 : (LPR == 8 ? 3 : 2);
+    // reads stage: a UNIT = one (pair, hop) or, when that would be more than 8 rows per lane, one of its SP equal parts; the
+    // parts' (max, sum, weighted row sum) records are combined through LDS
+    constexpr int NJF = NMT / RPW;                       // memory rows per lane of a whole (pair, hop)
+    constexpr int SP = NJF > 8 ? NJF / 8 : 1;
+    constexpr int NJ = NJF / SP;                         // memory rows per lane of a unit
+    constexpr int MPU = NJ * RPW;                        // memories per unit
+    constexpr int RECW = D + 4;                          // a unit's record: row sum [D] | max | sum | pad
+    constexpr int KLM = (128 / LPR) < 16 ? (128 / LPR) : 16;      // list slots per lane (K <= KLM * LPR)
+    static_assert(NJ >= 1, "NMT too small for this D");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sT0 = smem + L.t0;
+    float* sT1 = smem + L.t1;
+    float* sItem = smem + L.item;
+    float* sO = smem + L.o;
+    float* sQ = smem + L.q;
+    float* sN = smem + L.n;
+    int* sItemId = reinterpret_cast<int*>(smem + L.ids);
+    int* sUserId = sItemId + 16;
+    int* sC0e = reinterpret_cast<int*>(smem + L.c0e);
+    int* sC0r = reinterpret_cast<int*>(smem + L.c0r);
+    int* sChId = reinterpret_cast<int*>(smem + L.chid);
+    int* sChG = reinterpret_cast<int*>(smem + L.chg);
+    float* sChP0 = smem + L.chp0;
+    float* sChP1 = smem + L.chp1;
+    int* sChCnt = reinterpret_cast<int*>(smem + L.chcnt);
+    float* sPS = smem + L.ps;
+    float* sV = smem + L.v;
+    float* sA1 = smem + L.a1;
+    float* sA2 = smem + L.a2;
+    float* sZ = smem + L.z;
+    float* sW0 = smem + L.w0;
+    float* sW1 = smem + L.w1;
+    int* sY = reinterpret_cast<int*>(smem + L.y);
+    float* sWt = smem + L.wt;
+    float* sSc = smem + L.sc;
+    float* sPart = smem + L.part;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q16 = lane >> 4, l16 = lane & 15, col = 16 * wave + l16;
+    const int grp = tid / LPR, c = tid % LPR;            // 16 lane groups: one per tile row
+    const int G = a.G, K = a.K, nR = a.nR, P = a.P, Nm = a.Nm, LDO = L.ldo;
+    const int64_t b0 = (int64_t)blockIdx.x * G;
+    const int ng = (int)((a.B - b0) < (int64_t)G ? (a.B - b0) : (int64_t)G);     // pairs of this group
+    const bool proj = a.W1 != nullptr;
+    const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
+    const bool enc = a.enc != 0;
+    const bool d1 = a.depth1 != 0;                       // one-hop tree: the children have no lists, aggregator (1,0) does not exist
+    const float invK = 1.f / (float)K;
+    const float c2scale = has_att0 ? invK : 1.f;         // sum over a child's slots of (p_k / K)
+    const unsigned emax = (unsigned)(a.n_entity - 1), rmax = (unsigned)(nR - 1);
+    const int slot0 = a.w_h ? 1 : 0, NO = P + slot0, nhop = P > 0 ? P : 1;
+
+    // 32-bit byte offsets through buffer descriptors (the launcher admits tables / adjacencies below 4 GiB only): one address
+    // register per load in flight instead of two
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.E), 0, (int)a.table_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, a.adj_r ? (int)a.adj_bytes : 0,
+                                                                           0x00020000);      // none: relation ids read as 0
+    auto rowc = [&](int id, int chunk) -> float4 {       // 16-byte chunk `chunk` of table row `id`
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, (unsigned)id * (unsigned)(D * 4) + (unsigned)chunk * 16u, 0, 0);
+        return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+    };
+    auto row4 = [&](int id) -> float4 { return rowc(id, c); };
+    // the same under a lane predicate WITHOUT a branch: a false predicate turns the offset into one beyond the descriptor's
+    // range, which the hardware answers with zeros without touching memory.  (`v ? load : 0` compiles to a branch around
+    // the load with its s_waitcnt inside: eight such id loads in a row were eight round trips.)
+    auto rowc_if = [&](bool v, int id, int chunk) -> float4 {
+        const unsigned off = v ? (unsigned)id * (unsigned)(D * 4) + (unsigned)chunk * 16u : 0xFFFFFFF0u;
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, off, 0, 0);
+        return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
+    };
+    const bool tracing = a.dbg == 99 && blockIdx.x == 0;
+    auto stamp = [&](int i) {
+        if (tracing && lane == 0) g_small_trace[wave & 3][i] = (long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    // B fragment of a [D, D] row-major block (global memory, L2-resident weights) for this wave's 16-column slab: MFMA step s
+    // of slot q16 stands for k = KS * q16 + s on both operands, so a lane's A values of four steps are one 16-byte LDS read.
+    // Fragments are LOADED EARLY and used late (ldfrag / mma are separate): a product that loads its own fragment exposes
+    // one L2 latency, and the pass has twenty of them in a row.
+    auto ldfrag = [&](const float* __restrict__ W, float (&bf)[KS]) {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = W[(size_t)(KS * q16 + s) * D + col];
+    };
+    // acc += A . B: A = rows l16 < nrows of an LDS tile (row stride lda; rows beyond read as 0)
+    auto mma = [&](const float* src, int lda, int nrows, const float (&bf)[KS], f32x4& acc) {
+        const bool live = l16 < nrows;
+        const int lrow = live ? l16 : 0;
+#pragma unroll
+        for (int s = 0; s < KS; s += 4) {
+            float4 av = *reinterpret_cast<const float4*>(src + lrow * lda + KS * q16 + s);     // (unconditional read of a live row,
+            av = live ? av : make_float4(0.f, 0.f, 0.f, 0.f);                                  //  then a select: no branch)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bf[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bf[s + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bf[s + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bf[s + 3], acc, 0, 0, 0);
+        }
+    };
+
+    // ------------------------------------------------------------------ setup: ids
+    if (tid < 16) {
+        const bool v = tid < ng;
+        int64_t it = v ? a.items[b0 + tid] : 0;
+        it = (int64_t)min((uint64_t)it, (uint64_t)emax);                     // device-resident ids are clamped into the table
+        sItemId[tid] = (int)it;
+        int64_t u = (v && a.users) ? a.users[b0 + tid] : 0;
+        u = u < 0 ? 0 : (u >= a.n_user ? a.n_user - 1 : u);
+        sUserId[tid] = (int)u;
+    }
+    for (int i = tid; i < nR; i += NTHR) {
+        sT0[i] = has_att0 ? a.t0[i] : 0.f;
+        sT1[i] = has_att1 ? a.t1[i] : 0.f;
+    }
+    for (int i = tid; i < 2 * G * D; i += NTHR) sN[i] = 0.f;
+    // V = E[item] . R_KGE[r] has two forms.  Groups of at most kVSmall pairs: plain FMAs -- lane = output column, a wave takes
+    // every NT-th relation, R streamed in batches of BK rows, the next two batches always in flight (an MFMA tile would spend
+    // 15 of its 16 rows on zeros: 144 MFMAs per wave, 20 k cycles with two workgroups sharing the pipes, for 1/16 of the work).
+    // Larger groups: MFMA, rows = pairs.  The first blocks / batches do not depend on anything: in flight from here.
+    constexpr int kVSmall = 4;
+    constexpr int CPL = 64 / D >= 1 ? 64 / D : 1;        // R rows one wave load covers (D = 64: 1; 32: 2; 16: 4)
+    constexpr int BK = (D / CPL) < 16 ? (D / CPL) : 16;  // loads per batch
+    constexpr int KBN = D / (CPL * BK);                  // batches per relation
+    const bool v_small = ng <= kVSmall;
+    const int vcol = lane % D, vkq = lane / D;
+    const int v_nb = P > 0 && wave < nR ? ((nR - wave + NT - 1) / NT) * KBN : 0;        // this wave's batches
+    // ALL of this wave's share of R (up to NRP batches / blocks = 144 registers at D = 64) is requested here, before the ids
+    // are even read: nothing else is live yet, and the V stage then runs on registers instead of on L2 latency (streamed in
+    // batches behind the row gathers it took 21 k cycles for 3 k cycles of arithmetic)
+    constexpr int NRP = 8;                               // prefetched batches (small form) / relation blocks (MFMA form)
+    constexpr int RW = BK > KS ? BK : KS;
+    float rR[NRP][RW];
+    auto ld_rv = [&](int b, float (&rv)[RW]) {
+        const int r = wave + NT * (b / KBN), k0 = (b % KBN) * BK * CPL + vkq * BK;
+        const float* src = a.R + (size_t)r * D * D + (size_t)k0 * D + vcol;
+#pragma unroll
+        for (int t = 0; t < BK; ++t) rv[t] = src[(size_t)t * D];
+    };
+    auto ld_blk = [&](int r, float (&bf)[RW]) {          // MFMA B fragment of relation block r
+        const float* W = a.R + (size_t)r * D * D;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) bf[s2] = W[(size_t)(KS * q16 + s2) * D + col];
+    };
+    if (P > 0) {
+#pragma unroll
+        for (int t = 0; t < NRP; ++t) {
+            if (v_small) {
+                if (t < v_nb) ld_rv(t, rR[t]);
+            } else {
+                if (t < nR) ld_blk(t, rR[t]);
+            }
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 1) return;
+    stamp(1);
+
+    // ------------------------------------------------------------------ everything the ids alone determine, issued together:
+    // E[item] rows, the items' adjacency rows, and the id lists of this wave's first (pair, hop) of the reads stage
+    const int jr = lane / LPR, cc = lane % LPR;         // reads stage: row slot of the wave / 16-byte chunk of a row
+    const int ntask = ng * nhop, nunit = ntask * SP;
+    struct TaskIds {
+        int hid[NJ], tix[NJ], rid[NJ];
+    };
+    auto load_ids = [&](int unit, TaskIds& t) {
+        const int tk = unit / SP, part = unit - tk * SP;
+        const int g = tk / nhop, hop = tk - g * nhop;
+        const bool do_hop = hop < P;
+        const int32_t *lh, *lr, *lt;
+        if (a.uts) {
+            lh = a.uts + (((int64_t)sUserId[g] * nhop + hop) * 3) * (int64_t)Nm;
+            lr = lh + Nm;
+            lt = lh + 2 * Nm;
+        } else {
+            const int64_t o = (b0 + g) * (int64_t)Nm;
+            lh = a.mem_h[hop] + o;
+            lr = do_hop ? a.mem_r[hop] + o : lh;
+            lt = do_hop ? a.mem_t[hop] + o : lh;
+        }
+        // every load unconditional, from a position clamped into the list (a memory beyond Nm re-reads the last one; its row
+        // load is suppressed later); the clamps only after all of them are issued
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = part * MPU + j * RPW + jr;
+            const int mc = m < Nm ? m : Nm - 1;
+            t.hid[j] = lh[mc];
+            t.tix[j] = lt[mc];
+            t.rid[j] = lr[mc];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            t.hid[j] = (int)min((unsigned)t.hid[j], emax);
+            t.tix[j] = (int)min((unsigned)t.tix[j], emax);
+            t.rid[j] = do_hop ? (int)min((unsigned)t.rid[j], rmax) : 0;
+        }
+    };
+    TaskIds ids;
+    int unit = wave;
+    if (unit < nunit) load_ids(unit, ids);
+    if (grp < ng) *reinterpret_cast<float4*>(sItem + grp * LD + 4 * c) = row4(sItemId[grp]);
+    for (int i = tid; i < ng * K; i += NTHR) {
+        const int g = i / K, k = i - g * K;
+        const unsigned o = ((unsigned)sItemId[g] * (unsigned)K + (unsigned)k) * 4u;
+        sC0e[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjE, o, 0, 0);
+        sC0r[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o, 0, 0);
+    }
+    __syncthreads();
+    if (a.dbg == 2) return;
+    stamp(2);
+
+    // ------------------------------------------------------------------ the rows of the first (pair, hop): in flight under
+    // the list building and the V product
+    float4 hrow[NJ], trow[NJ];
+    auto load_hrows = [&](int un, const TaskIds& t) {
+        const int part = un % SP;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) hrow[j] = rowc_if(part * MPU + j * RPW + jr < Nm, t.hid[j], cc);
+    };
+    auto load_trows = [&](int un, const TaskIds& t) {
+        const int tk = un / SP, part = un - tk * SP;
+        const bool do_hop = tk % nhop < P;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) trow[j] = rowc_if(do_hop && part * MPU + j * RPW + jr < Nm, t.tix[j], cc);
+    };
+    auto load_rows = [&](int un, const TaskIds& t) {
+        load_hrows(un, t);
+        load_trows(un, t);
+    };
+    if (unit < nunit) load_hrows(unit, ids);            // (the tail rows after the V product: its registers are all taken)
+
+    // ------------------------------------------------------------------ the children of every pair: one work list
+    int base[17];                                        // list offset of pair g (every thread: ng <= 16 adds)
+    base[0] = 0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int cnt = g < ng ? (enc ? (int)((unsigned)sC0r[g * K] >> 24) : K) : 0;
+        base[g + 1] = base[g] + (cnt < K ? cnt : K);
+    }
+    const int NC = base[16];
+    for (int g = wave; g < ng; g += NT) {
+        int gb = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) gb = t == g ? base[t] : gb;
+        float s0[2], s1[2], mu[2];
+        int id[2], cn[2];
+        float m0 = -INFINITY, m1 = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = lane + 64 * e;
+            const bool v = k < K;
+            const int kc = v ? k : K - 1;                // (reads unconditional, from a slot of the row; selects afterwards)
+            const unsigned we = (unsigned)sC0e[g * K + kc], wr = (unsigned)sC0r[g * K + kc];
+            mu[e] = v ? (enc ? (float)((wr >> 16) & 0xFFu) : 1.f) : 0.f;
+            id[e] = (int)min(enc ? (we & 0xFFFFFFu) : we, emax);
+            cn[e] = d1 ? 0 : (enc ? (int)min(we >> 24, (unsigned)K) : K);       // the child's own list length rides in its slot word
+            const unsigned rel = min(enc ? (wr & 0xFFFFu) : wr, rmax);
+            const float tv0 = sT0[rel], tv1 = sT1[rel];
+            s0[e] = mu[e] > 0.f ? tv0 : -INFINITY;
+            s1[e] = mu[e] > 0.f ? tv1 : -INFINITY;
+            m0 = fmaxf(m0, s0[e]);
+            m1 = fmaxf(m1, s1[e]);
+        }
+        m0 = wave_max(m0);
+        m1 = wave_max(m1);
+        float p0[2], p1[2], z0 = 0.f, z1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            p0[e] = mu[e] > 0.f ? (has_att0 ? mu[e] * lean_exp(s0[e] - m0) : mu[e]) : 0.f;
+            p1[e] = mu[e] > 0.f ? (has_att1 ? mu[e] * lean_exp(s1[e] - m1) : mu[e]) : 0.f;
+            z0 += p0[e];
+            z1 += p1[e];
+        }
+        const float r0 = has_att0 ? 1.f / wave_sum(z0) : 1.f, r1 = has_att1 ? 1.f / wave_sum(z1) : 1.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int k = lane + 64 * e;
+            // distinct slots come first in the encoding (and every slot of a plain row counts): slot k is list entry k
+            if (k < K && mu[e] > 0.f) {
+                sChId[gb + k] = id[e];
+                sChG[gb + k] = g;
+                sChP0[gb + k] = p0[e] * r0;
+                sChP1[gb + k] = p1[e] * r1;
+                sChCnt[gb + k] = cn[e];
+            }
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 3) return;
+    stamp(3);
+    // the adjacency words and the own row of the first chunk's children: in flight from here (the tree stage starts with them)
+    struct ChunkIn {
+        unsigned we[KLM], wr[KLM];
+        float4 sv;
+        int child, gch;
+        bool valid;
+    };
+    auto load_chunk = [&](int ch, ChunkIn& w) {
+        const int i = ch * 16 + grp;
+        w.valid = i < NC;
+        const int ic = w.valid ? i : 0;
+        const int cid = sChId[ic], cg = sChG[ic];
+        w.child = w.valid ? cid : 0;
+        w.gch = w.valid ? cg : 0;
+#pragma unroll
+        for (int e = 0; e < KLM; ++e) {
+            const int k = c + LPR * e;
+            const bool v = w.valid && k < K && !d1;
+            const unsigned o = v ? ((unsigned)w.child * (unsigned)K + (unsigned)k) * 4u : 0xFFFFFFF0u;      // beyond the range: reads 0
+            w.we[e] = __builtin_amdgcn_raw_buffer_load_b32(adjE, o, 0, 0);
+            w.wr[e] = __builtin_amdgcn_raw_buffer_load_b32(adjR, o, 0, 0);
+        }
+        w.sv = rowc_if(w.valid, w.child, c);
+    };
+    ChunkIn cin;
+    load_chunk(0, cin);
+
+    // ------------------------------------------------------------------ V = E[item] . R_KGE[r] (R in registers since the start)
+    if (P > 0 && v_small) {
+        float vacc[kVSmall];
+        auto v_batch = [&](int b, const float (&rv)[RW]) {
+            const int r = wave + NT * (b / KBN), kb = b % KBN, k0 = kb * BK * CPL + vkq * BK;
+            if (kb == 0) {
+#pragma unroll
+                for (int g = 0; g < kVSmall; ++g) vacc[g] = 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < kVSmall; ++g) {
+                if (g < ng) {
+#pragma unroll
+                    for (int t = 0; t < BK; t += 4) {
+                        const float4 x = *reinterpret_cast<const float4*>(sItem + g * LD + k0 + t);
+                        vacc[g] = fmaf(x.x, rv[t], vacc[g]);
+                        vacc[g] = fmaf(x.y, rv[t + 1], vacc[g]);
+                        vacc[g] = fmaf(x.z, rv[t + 2], vacc[g]);
+                        vacc[g] = fmaf(x.w, rv[t + 3], vacc[g]);
+                    }
+                }
+            }
+            if (kb == KBN - 1) {
+#pragma unroll
+                for (int g = 0; g < kVSmall; ++g) {
+                    float v = vacc[g];
+                    if (CPL >= 4) v = xor16_sum(v);      // the k slices of a row sit D lanes apart
+                    if (CPL >= 2) v = xor32_sum(v);
+                    if (g < ng && vkq == 0) sV[(g * nR + r) * D + vcol] = v;
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < NRP; ++t)
+            if (t < v_nb) v_batch(t, rR[t]);
+        for (int b = NRP; b < v_nb; ++b) {               // (more batches than registers: the rest, one exposed latency each)
+            ld_rv(b, rR[0]);
+            v_batch(b, rR[0]);
+        }
+    } else if (P > 0) {
+        auto v_blk = [&](int r, const float (&bf)[RW]) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const bool live = l16 < ng;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; s2 += 4) {
+                float4 av = *reinterpret_cast<const float4*>(sItem + (live ? l16 : 0) * LD + KS * q16 + s2);
+                av = live ? av : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bf[s2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bf[s2 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bf[s2 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bf[s2 + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 4 * q16 + rr;
+                if (row < ng) sV[(row * nR + r) * D + col] = acc[rr];
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < NRP; ++t)
+            if (t < nR) v_blk(t, rR[t]);
+        for (int r = NRP; r < nR; ++r) {                 // (more relations than registers: one exposed latency each)
+            ld_blk(r, rR[0]);
+            v_blk(r, rR[0]);
+        }
+    }
+    if (unit < nunit) load_trows(unit, ids);
+    if (a.dbg == 4) return;
+    stamp(4);
+
+    // ------------------------------------------------------------------ tree stage, the gathers of a chunk.  Nothing here
+    // depends on the user vector, so the first chunk's gathers are issued BEFORE the attention reads are evaluated and land
+    // under them.  A child's list (its distinct slots) is cut into SUB-LISTS of at most 8 rows; a lane group takes one
+    // sub-list per round, so that a chunk's rows are one round trip however long its longest list is (a hub child's 32 rows
+    // used to be four dependent batches for its wave); the sub-lists' partial sums meet again in LDS, in list order.
+    float4 gsv = make_float4(0.f, 0.f, 0.f, 0.f);        // the chunk's state between issue and finish: own row, pair,
+    int ggch = 0;                                        // the first round of gathered rows and their weights
+    bool gvalid = false;
+    float4 grow[8];
+    float gwt[8];
+    int gni = 0, gitem_n = 0, gioff = 0, gnsub = 0;      // sub-lists of the chunk; this group's first one: its tile row;
+                                                         // this group's OWN tile row: offset / number of its sub-lists
+    auto chunk_layout = [&](int ch) {
+        // sub-list offsets of the chunk's 16 tile rows (every thread; 16 LDS reads): this group's own row and its item's row
+        int off = 0, n_of_item = -1, j_of_item = 0;
+        gioff = 0, gnsub = 0;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int i = ch * 16 + n;
+            const int ns = i < NC ? (sChCnt[i] + 7) >> 3 : 0;
+            if (n == grp) gioff = off, gnsub = ns;
+            if (grp >= off && grp < off + ns) n_of_item = n, j_of_item = grp - off;
+            off += ns;
+        }
+        gni = off;
+        gitem_n = n_of_item >= 0 ? (n_of_item | (j_of_item << 8)) : -1;
+    };
+    auto stage_lists = [&](int ch) {
+        gvalid = cin.valid;
+        ggch = cin.gch;
+        gsv = cin.sv;
+        int ye[KLM];
+        float lg[KLM], mu[KLM];
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < KLM; ++e) {
+            const int k = c + LPR * e;
+            const bool v = gvalid && k < K;
+            const unsigned we = cin.we[e], wr = cin.wr[e];
+            mu[e] = v ? (enc ? (float)((wr >> 16) & 0xFFu) : 1.f) : 0.f;
+            ye[e] = (int)min(enc ? (we & 0xFFFFFFu) : we, emax);
+            const unsigned rel = min(enc ? (wr & 0xFFFFu) : wr, rmax);
+            const float tv = sT0[rel];
+            lg[e] = mu[e] > 0.f ? tv : -INFINITY;
+            m = fmaxf(m, lg[e]);
+        }
+        m = group_max(m, LPR_L2);
+        float z = 0.f;
+#pragma unroll
+        for (int e = 0; e < KLM; ++e) {
+            lg[e] = mu[e] > 0.f ? (has_att0 ? mu[e] * lean_exp(lg[e] - m) : mu[e]) : 0.f;
+            z += lg[e];
+        }
+        z = group_sum(z, LPR_L2);
+        const float rinv = has_att0 ? (z > 0.f ? invK / z : 0.f) : invK;
+#pragma unroll
+        for (int e = 0; e < KLM; ++e) {
+            const int k = c + LPR * e;
+            if (k < K) {
+                sY[grp * K + k] = ye[e];
+                sWt[grp * K + k] = lg[e] * rinv;       // (a padding slot: weight 0)
+            }
+        }
+        chunk_layout(ch);
+        __syncthreads();                                 // the lists of a tile row are read by the groups that take its sub-lists
+        // round 0: sub-list `grp` of the chunk, in flight from here
+        const int n0 = gitem_n & 0xFF, k0 = (gitem_n >> 8) * 8;
+        const int cnt0 = gitem_n >= 0 ? sChCnt[ch * 16 + n0] : 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const bool v = gitem_n >= 0 && k0 + t < cnt0;
+            const int li = v ? n0 * K + k0 + t : 0;
+            const float wv0 = sWt[li];
+            gwt[t] = v ? wv0 : 0.f;
+            grow[t] = rowc_if(v, sY[li], c);
+        }
+    };
+    // finish: S' of this group's tile row = sum of its sub-lists' partial sums (chunk c of the rows)
+    auto gather_finish = [&](int ch) -> float4 {
+        {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = f4_fma(gwt[t], grow[t], acc);
+            if (gitem_n >= 0) *reinterpret_cast<float4*>(sPS + grp * D + 4 * c) = acc;
+        }
+        for (int it0 = 16; it0 < gni; it0 += 16) {       // further rounds (more than 16 sub-lists in the chunk): one round trip each
+            const int item = it0 + grp;
+            int off = 0, n0 = -1, j0 = 0;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const int i = ch * 16 + n;
+                const int ns = i < NC ? (sChCnt[i] + 7) >> 3 : 0;
+                if (item >= off && item < off + ns) n0 = n, j0 = item - off;
+                off += ns;
+            }
+            const int k0 = j0 * 8;
+            const int cnt0 = n0 >= 0 ? sChCnt[ch * 16 + n0] : 0;
+            float4 rows[8];
+            float wts[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const bool v = n0 >= 0 && k0 + t < cnt0;
+                const int li = v ? n0 * K + k0 + t : 0;
+                const float wv0 = sWt[li];
+                wts[t] = v ? wv0 : 0.f;
+                rows[t] = rowc_if(v, sY[li], c);
+            }
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = f4_fma(wts[t], rows[t], acc);
+            if (n0 >= 0) *reinterpret_cast<float4*>(sPS + item * D + 4 * c) = acc;
+        }
+        __syncthreads();
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < gnsub; ++j) {                // fixed order: deterministic
+            const float4 p = *reinterpret_cast<const float4*>(sPS + (gioff + j) * D + 4 * c);
+            sum = make_float4(sum.x + p.x, sum.y + p.y, sum.z + p.z, sum.w + p.w);
+        }
+        return sum;
+    };
+    const int nch = (NC + 15) / 16;
+    if (nch > 0) {
+        stage_lists(0);
+        if (nch > 1) load_chunk(1, cin);
+    }
+    if (a.dbg == 5) return;
+    stamp(5);
+
+    // ------------------------------------------------------------------ attention reads: one wave per unit
+    while (unit < nunit) {
+        const int tk = unit / SP, part = unit - tk * SP;
+        const int g = tk / nhop, hop = tk - g * nhop;
+        const bool do_hop = hop < P, do_set = hop == 0 && a.w_h != nullptr;
+        const int nxt = unit + NT;
+        const float4 wv = do_set ? reinterpret_cast<const float4*>(a.w_h)[cc] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float sh[NJ], ss[NJ];
+        float mxh = -INFINITY, mxs = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float ph = 0.f, ps = 0.f;
+            if (do_hop) ph = small_dot4(hrow[j], *reinterpret_cast<const float4*>(sV + (g * nR + ids.rid[j]) * D + 4 * cc));
+            if (do_set) ps = small_dot4(hrow[j], wv);
+            ph = group_sum(ph, LPR_L2);
+            ps = group_sum(ps, LPR_L2);
+            const bool v = part * MPU + j * RPW + jr < Nm;
+            sh[j] = v ? ph : -INFINITY;
+            ss[j] = v ? ps : -INFINITY;
+            mxh = fmaxf(mxh, sh[j]);
+            mxs = fmaxf(mxs, ss[j]);
+        }
+        // over the RPW row slots of the wave (lanes + LPR, + 2 LPR, ..): rotations inside a 16-lane DPP row keep the chunk
+        // index cc (row_ror:4 / row_ror:8), then the lane swaps across rows
+        auto slots_max = [&](float v) {
+            if (LPR <= 4) v = fmaxf(v, dpp_mov<0x124>(v));
+            if (LPR <= 8) v = fmaxf(v, dpp_mov<0x128>(v));
+            return rows_combine_max(v);
+        };
+        auto over_slots = [&](float v) {
+            if (LPR <= 4) v += dpp_mov<0x124>(v);
+            if (LPR <= 8) v += dpp_mov<0x128>(v);
+            return rows_combine_sum(v);
+        };
+        mxh = slots_max(mxh);
+        mxs = slots_max(mxs);
+        float4 acc_h = make_float4(0.f, 0.f, 0.f, 0.f), acc_s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float zh = 0.f, zs = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool v = part * MPU + j * RPW + jr < Nm;
+            const float eh = (v && do_hop) ? lean_exp(sh[j] - mxh) : 0.f;
+            const float es = (v && do_set) ? lean_exp(ss[j] - mxs) : 0.f;
+            zh += eh;
+            zs += es;
+            acc_h = f4_fma(eh, trow[j], acc_h);
+            acc_s = f4_fma(es, hrow[j], acc_s);
+        }
+        // the unit's records: un-normalised row sum, max, sum (a part with no valid memory: max = -inf, sum = 0)
+        if (do_hop) {
+            zh = over_slots(zh);
+            acc_h = make_float4(over_slots(acc_h.x), over_slots(acc_h.y), over_slots(acc_h.z), over_slots(acc_h.w));
+            float* rec = sPart + unit * RECW;
+            if (jr == 0) *reinterpret_cast<float4*>(rec + 4 * cc) = acc_h;
+            if (lane == 0) rec[D] = mxh, rec[D + 1] = zh;
+        }
+        if (do_set) {
+            zs = over_slots(zs);
+            acc_s = make_float4(over_slots(acc_s.x), over_slots(acc_s.y), over_slots(acc_s.z), over_slots(acc_s.w));
+            float* rec = sPart + (nunit + g * SP + part) * RECW;
+            if (jr == 0) *reinterpret_cast<float4*>(rec + 4 * cc) = acc_s;
+            if (lane == 0) rec[D] = mxs, rec[D + 1] = zs;
+        }
+        unit = nxt;
+        if (unit < nunit) {                              // (groups of more pairs than waves: the next unit, start to end)
+            load_ids(unit, ids);
+            load_rows(unit, ids);
+        }
+    }
+    // the user-MLP blocks, and the tree stage's three (resident over its chunks)
+    float bU[4][KS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < NO) ldfrag(a.Wu + (size_t)t * D * D, bU[t]);
+    float bW1[KS], bW2[KS], bA0[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bW1[s] = bW2[s] = 0.f;
+    if (proj) ldfrag(a.W1, bW1);
+    if (proj && !d1) ldfrag(a.W2, bW2);
+    ldfrag(a.A0, bA0);
+    const float b1v = (proj && a.b1) ? a.b1[col] : 0.f;
+    const float b2v = ((proj && !d1 && a.b2) ? a.b2[col] : 0.f) * c2scale;
+    const float a0v = a.a0 ? a.a0[col] : 0.f;
+    const float buv = a.bu ? a.bu[col] : 0.f;
+    __syncthreads();
+    // the parts of a (pair, hop) -> o = sum_i e^(m_i - M) S_i / sum_i e^(m_i - M) z_i  (softmax over all Nm memories, model.py:189 / :223)
+    {
+        const int nset = a.w_h ? ng : 0;
+        for (int idx = tid; idx < (ntask + nset) * LPR; idx += NTHR) {
+            const int t = idx / LPR, ch4 = idx - t * LPR;
+            const bool is_set = t >= ntask;
+            const int g = is_set ? t - ntask : t / nhop, hop = is_set ? 0 : t - g * nhop;
+            if (!is_set && hop >= P) continue;
+            const float* rec = sPart + (is_set ? nunit + g * SP : t * SP) * RECW;
+            float M = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < SP; ++i) M = fmaxf(M, rec[i * RECW + D]);
+            float z = 0.f;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < SP; ++i) {
+                const float mi = rec[i * RECW + D];
+                const float w = mi == -INFINITY ? 0.f : lean_exp(mi - M);
+                z = fmaf(w, rec[i * RECW + D + 1], z);
+                o = f4_fma(w, *reinterpret_cast<const float4*>(rec + i * RECW + 4 * ch4), o);
+            }
+            const float inv = 1.f / z;
+            *reinterpret_cast<float4*>(sO + g * LDO + (is_set ? 0 : slot0 + hop) * D + 4 * ch4) =
+                make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 6) return;
+    stamp(6);
+
+    // ------------------------------------------------------------------ user_o = o_cat . user_mlp + bias
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < NO) mma(sO + t * D, LDO, ng, bU[t], acc);
+        for (int t = 4; t < NO; ++t) {                   // (P = 4 with the h-set read: a fifth block)
+            float bx[KS];
+            ldfrag(a.Wu + (size_t)t * D * D, bx);
+            mma(sO + t * D, LDO, ng, bx, acc);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * q16 + rr;
+            if (row < ng) {
+                const float v = acc[rr] + buv;
+                sQ[row * LD + col] = v;
+                a.user_o[(b0 + row) * D + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 7) return;
+    stamp(7);
+
+    // ------------------------------------------------------------------ tree: chunks of 16 children, the dense part
+    for (int ch = 0; ch < nch; ++ch) {
+        const float4 acc = gather_finish(ch);
+        if (a.dbg == 81) return;
+        if (ch == 0) stamp(20);
+        const bool valid = gvalid;
+        {
+            float4 qv = *reinterpret_cast<const float4*>(sQ + ggch * LD + 4 * c);       // (ggch = 0 for a row beyond the list)
+            qv = (proj && valid) ? qv : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(sA1 + grp * LD + 4 * c) = make_float4(gsv.x + qv.x, gsv.y + qv.y, gsv.z + qv.z, gsv.w + qv.w);
+            *reinterpret_cast<float4*>(sA2 + grp * LD + 4 * c) = f4_fma(c2scale, qv, acc);
+        }
+        __syncthreads();
+        if (a.dbg == 82) return;
+        if (ch == 0) stamp(21);
+        if (ch + 1 < nch) {                              // the next chunk's lists and gathers under this chunk's products
+            stage_lists(ch + 1);                         // (holds a workgroup barrier: every wave passes here)
+            if (ch + 2 < nch) load_chunk(ch + 2, cin);
+        }
+        // self1 = (E[x1] + q) W1 + b1 ; Z = self1 + (S' + c q) W2 + c b2
+        {
+            float s1v[4], zv[4];
+            if (proj) {
+                f32x4 accE = {0.f, 0.f, 0.f, 0.f}, accS = {0.f, 0.f, 0.f, 0.f};
+                mma(sA1, LD, 16, bW1, accE);
+                if (!d1) mma(sA2, LD, 16, bW2, accS);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    s1v[rr] = accE[rr] + b1v;
+                    zv[rr] = s1v[rr] + (accS[rr] + b2v);
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    s1v[rr] = sA1[(4 * q16 + rr) * LD + col];
+                    zv[rr] = s1v[rr] + sA2[(4 * q16 + rr) * LD + col];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 4 * q16 + rr, i2 = ch * 16 + row;
+                const float p0r = sChP0[i2 < NC ? i2 : 0];
+                const float p0 = i2 < NC ? p0r : 0.f;
+                sZ[row * LD + col] = zv[rr];
+                sW0[row * LD + col] = p0 * s1v[rr];
+            }
+        }
+        __syncthreads();
+        if (a.dbg == 83) return;
+        if (ch == 0) stamp(22);
+        // out1 = relu(Z A0 + a0)   (two-hop trees only)
+        if (!d1) {
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+            mma(sZ, LD, 16, bA0, acc2);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = 4 * q16 + rr, i2 = ch * 16 + row;
+                const float p1r = sChP1[i2 < NC ? i2 : 0];
+                const float p1 = i2 < NC ? p1r : 0.f;
+                sW1[row * LD + col] = p1 * fmaxf(acc2[rr] + a0v, 0.f);
+            }
+            __syncthreads();
+        }
+        if (a.dbg == 84) return;
+        if (ch == 0) stamp(23);
+        // per-pair sums of the weighted rows, in list order (one thread per output column and aggregator: deterministic)
+        if (tid < (d1 ? D : 2 * D)) {
+            const int which = tid / D, cl = tid - which * D;
+            const float* src = which ? sW1 : sW0;
+            float run = 0.f;
+            int gcur = -1;
+            for (int n = 0; n < 16; ++n) {
+                const int i2 = ch * 16 + n;
+                if (i2 >= NC) break;
+                const int g2 = sChG[i2];
+                if (g2 != gcur) {
+                    if (gcur >= 0) sN[(which * G + gcur) * D + cl] += run;
+                    run = 0.f;
+                    gcur = g2;
+                }
+                run += src[n * LD + cl];
+            }
+            if (gcur >= 0) sN[(which * G + gcur) * D + cl] += run;
+        }
+    }
+    __syncthreads();
+    if (a.dbg == 8) return;
+    stamp(8);
+
+    // ------------------------------------------------------------------ tail (rows = the pairs of the group)
+    const bool proj0 = a.W0 != nullptr;
+    float bT[5][KS];                                     // the tail's blocks W0 | A1 | Wmix[0..2]: all five in flight together
+    if (proj0) ldfrag(a.W0, bT[0]);
+    if (!d1) ldfrag(a.A1, bT[1]);
+    ldfrag(a.Wmix, bT[2]);
+    ldfrag(a.Wmix + (size_t)D * D, bT[3]);
+    if (!d1) ldfrag(a.Wmix + (size_t)2 * D * D, bT[4]);
+    if (grp < ng) {
+        float4 x = *reinterpret_cast<const float4*>(sItem + grp * LD + 4 * c);
+        if (proj0) {
+            const float4 qv = *reinterpret_cast<const float4*>(sQ + grp * LD + 4 * c);
+            x = make_float4(x.x + qv.x, x.y + qv.y, x.z + qv.z, x.w + qv.w);
+        }
+        *reinterpret_cast<float4*>(sA1 + grp * LD + 4 * c) = x;
+    }
+    const float b0v = (proj0 && a.b0) ? a.b0[col] : 0.f;
+    const float a1v = a.a1 ? a.a1[col] : 0.f;
+    const float bcv = a.bmix ? a.bmix[col] : 0.f;
+    __syncthreads();
+    stamp(10);
+    {   // ev0 ; Z1 = ev0 + nagg0
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (proj0) mma(sA1, LD, ng, bT[0], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * q16 + rr;
+            if (row < ng) {
+                const float e0 = proj0 ? acc[rr] + b0v : sA1[row * LD + col];
+                sA2[row * LD + col] = e0;
+                sZ[row * LD + col] = e0 + sN[row * D + col] * invK;
+            }
+        }
+    }
+    __syncthreads();
+    stamp(11);
+    {   // out0 = relu(Z1 A0 + a0) ; Z2 = out0 + nagg1
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma(sZ, LD, ng, bA0, acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * q16 + rr;
+            if (row < ng) {
+                const float o0 = fmaxf(acc[rr] + a0v, 0.f);
+                sW0[row * LD + col] = o0;
+                sA1[row * LD + col] = o0 + sN[(G + row) * D + col] * invK;
+            }
+        }
+    }
+    __syncthreads();
+    stamp(12);
+    if (!d1) {   // out2 = relu(Z2 A1 + a1)
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma(sA1, LD, ng, bT[1], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * q16 + rr;
+            if (row < ng) sZ[row * LD + col] = fmaxf(acc[rr] + a1v, 0.f);
+        }
+    }
+    __syncthreads();
+    stamp(13);
+    {   // item = [ev0 | out0 | out2] Wmix + bmix ; score
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        mma(sA2, LD, ng, bT[2], acc);
+        mma(sW0, LD, ng, bT[3], acc);
+        if (!d1) mma(sZ, LD, ng, bT[4], acc);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * q16 + rr;
+            const bool v = row < ng;
+            const float val = acc[rr] + bcv;
+            if (v && a.item_emb) a.item_emb[(b0 + row) * D + col] = val;
+            float part = v ? sQ[row * LD + col] * val : 0.f;
+            part = group_sum(part, 4);                   // the slab's 16 columns of this row
+            if (l16 == 0) sSc[wave * 16 + row] = part;
+        }
+    }
+    __syncthreads();
+    stamp(14);
+    if (tid < ng) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT; ++w) s += sSc[w * 16 + tid];          // fixed order: deterministic
+        a.scores[b0 + tid] = s;
+        if (a.sig) a.sig[b0 + tid] = 1.f / (1.f + expf(-s));
+    }
+    stamp(19);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+bool score_small_supported(int D, int K, int P, int Nm, int nR) {
+    if (!(D == 16 || D == 32 || D == 64)) return false;
+    const int lpr = D / 4, rpw = 64 / lpr;
+    const int klm = (128 / lpr) < 16 ? (128 / lpr) : 16;
+    return K >= 1 && K <= klm * lpr && K <= 64 && P >= 1 && P <= 4 && Nm >= 1 && Nm <= 16 * rpw && Nm <= 64 && nR >= 1 && nR <= 4096;
+}
+
+// parts a (pair, hop) of the reads stage is cut into (the kernel's SP for the instance this shape takes)
+static int small_parts(int D, int Nm) {
+    const int nmt = Nm <= 16 ? 16 : 64, njf = nmt * D / 256;
+    return njf > 8 ? njf / 8 : 1;
+}
+static SmallLds small_lds_for(int D, int G, int K, int nR, int P, int has_hset, int Nm) {
+    return small_lds(D, G, K, nR, P + (has_hset ? 1 : 0), G * (P + (has_hset ? 1 : 0)) * small_parts(D, Nm));
+}
+
+// pairs per workgroup: enough workgroups to fill the chip (>= 2 per CU while the batch allows), groups as large as the LDS of
+// two to three resident workgroups per CU allows beyond that (the weight blocks are re-read per GROUP: 323 KB at C3)
+int score_small_group(int D, int K, int P, int Nm, int nR, int has_hset, int64_t B) {
+    static const char* e = getenv("MVIN_SMALL_G");
+    // measured (scripts/bench_small_batch.py, C3 shape): 512 pairs 43 us at G = 1 (49 at G = 2), 1 024 pairs 58 us at G = 2
+    // (75 at G = 1): one pair per workgroup while two workgroups per CU hold the batch, then two
+    int G = 1;
+    if (e && atoi(e) > 0) {
+        G = atoi(e);
+    } else {
+        while (G < 16 && B > 512 * (int64_t)G) G *= 2;
+    }
+    G = G < 1 ? 1 : (G > 16 ? 16 : G);
+    while (G > 1 && (small_lds_for(D, G, K, nR, P, has_hset, Nm).total > 52 * 1024 || G * K > 2048)) G /= 2;
+    return G;
+}
+
+template <int D, int NMT>
+static hipError_t launch_small(const ScoreSmallArgs& a, const SmallLds& L, hipStream_t st) {
+    auto k = score_small_kernel<D, NMT>;
+    if (L.total > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t grid = (a.B + a.G - 1) / a.G;
+    k<<<(int)grid, D * 4, (size_t)L.total, st>>>(a, L);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_small(ScoreSmallArgs a, int D, hipStream_t st) {
+    if (a.G <= 0) a.G = score_small_group(D, a.K, a.P, a.Nm, a.nR, a.w_h != nullptr, a.B);
+    a.G = a.G > 16 ? 16 : a.G;
+    while (a.G > 1 && (small_lds_for(D, a.G, a.K, a.nR, a.P, a.w_h != nullptr, a.Nm).total > 64 * 1024 || a.G * a.K > 2048))
+        a.G /= 2;                                        // a caller's group, as far as it fits
+    const SmallLds L = small_lds_for(D, a.G, a.K, a.nR, a.P, a.w_h != nullptr, a.Nm);
+    if (L.total > 160 * 1024) return hipErrorInvalidValue;
+    static const char* dbg = getenv("MVIN_SMALL_DBG");   // timing experiments only: return after stage N (results are garbage)
+    a.dbg = dbg ? atoi(dbg) : 0;
+    const int rpw = 64 / (D / 4);
+    const bool nm16 = a.Nm <= 16 && 16 / rpw >= 1;       // the short-list instance (amazon-book's 16 memories)
+    switch (D) {
+        case 16: return nm16 ? launch_small<16, 16>(a, L, st) : launch_small<16, 64>(a, L, st);
+        case 32: return nm16 ? launch_small<32, 16>(a, L, st) : launch_small<32, 64>(a, L, st);
+        case 64: return nm16 ? launch_small<64, 16>(a, L, st) : launch_small<64, 64>(a, L, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mvin

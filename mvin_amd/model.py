@@ -48,6 +48,34 @@ class Placeholder(object):
         return f"<Placeholder {self.name} {self.dtype} {self.shape}>"
 
 
+class _SmallOut(object):
+    """Results of the single-launch pass: one device buffer [user_o | item_embeddings | scores | sigmoid scores]; the four
+    tensors are views created on access (same attribute names as the namespace the other schedules return)."""
+    __slots__ = ("_buf", "_B", "_D", "importance_list")
+
+    def __init__(self, buf, B, D):
+        self._buf, self._B, self._D, self.importance_list = buf, B, D, []
+
+    @property
+    def user_o(self):
+        return self._buf[:self._B * self._D].view(self._B, self._D)
+
+    @property
+    def item_embeddings(self):
+        n = self._B * self._D
+        return self._buf[n:2 * n].view(self._B, self._D)
+
+    @property
+    def scores(self):
+        n = 2 * self._B * self._D
+        return self._buf[n:n + self._B]
+
+    @property
+    def scores_normalized(self):
+        n = 2 * self._B * self._D + self._B
+        return self._buf[n:n + self._B]
+
+
 class MVIN(object):
     def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
                  params=None, device=None, seed=0, fused=None, table_dtype="f32", hoist=False):
@@ -233,6 +261,14 @@ class MVIN(object):
         self._native_l2_ws = {}
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
+        # up to this many pairs the whole pass is ONE kernel launch (mvin_score_small_fwd: the reference's own batch sizes,
+        # 512 / 1024 per sess.run); beyond it the multi-launch schedule is the faster one (measured: 58 vs 60 us at 1 024 pairs,
+        # 112 vs 66 us at 2 048: a workgroup walks its pairs' dependent-load chain alone).  The entry point
+        # itself takes any batch (tests drive it to 16 384).  0 or MVIN_SMALL=0 turns it off; MVIN_SMALL_MAX overrides
+        self.small_max_batch = 0 if os.environ.get("MVIN_SMALL", "1") == "0" else int(os.environ.get("MVIN_SMALL_MAX", "1024"))
+        self.small_group = 0                 # pairs per workgroup of that launch (0: chosen by the library)
+        self._small_state = None
+        self._small_static = None
         # Device-resident feeds (forward_device / forward_users): ids are NOT validated per batch by default (it costs a
         # host sync; the kernels clamp entity / user / relation ids into their tables instead of reading out of bounds).
         # True (or MVIN_CHECK_IDS=1): every batch is checked and raises IndexError like the host-feed path and like
@@ -699,6 +735,93 @@ class MVIN(object):
                 and ops.key_addressing_supported(self.n_memory, self.dim)
                 and (not cap or item.shape[0] <= self.native_l2_max_batch))
 
+    def _small_static_ok(self):
+        """Everything about ``_small_ok`` that does not depend on the batch, cached per parameter generation (the check
+        runs on every call of a path whose whole GPU time is ~20 us)."""
+        key = (self._generation, self.fused, bool(self.hoist), self.entity_emb_matrix.data_ptr())
+        c = self._small_static
+        if c is None or c[0] != key:
+            a = self.args
+            ok = (self.fused is not False and not self.hoist and a.wide_deep and not a.PS_only and not a.HO_only
+                  and a.User_orient_kg_eh and self.n_mix_hop == 1 and self.h_hop in (1, 2) and 1 <= self.p_hop <= 4
+                  and self.entity_emb_matrix.dtype == torch.float32
+                  and self.entity_emb_matrix.numel() * 4 < (1 << 32) - 4096 and self.adj_entity.numel() * 4 < (1 << 32) - 4096
+                  and ops.score_small_supported(self.dim, self.n_neighbor, self.p_hop, self.n_memory, self.n_relation))
+            c = self._small_static = (key, bool(ok))
+        return c[1]
+
+    def _small_ok(self, item, memories_h, want_probs):
+        """The pass can be ONE kernel launch (mvin_score_small_fwd): default wiring, depth-2 trees, fp32 table below 4 GiB,
+        at most ``small_max_batch`` pairs.  ``memories_h`` None = the users feed."""
+        return (item.shape[0] <= self.small_max_batch and not want_probs and self._profile is None
+                and item.dtype == torch.int64 and (memories_h is None or memories_h[0].dim() == 2) and self._small_static_ok())
+
+    def _score_small_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None):
+        """model.py:125-159 as ONE kernel launch (mvin_score_small_fwd).  The argument block is built once per parameter
+        generation; per call only the table / logit-table / feed / output pointers are refreshed and ONE output buffer is
+        allocated (the four result tensors are views made when somebody reads them: the host side of this path is as long
+        as its kernel)."""
+        from . import _lib
+        import ctypes as C
+        D, P, B = self.dim, self.p_hop, item.shape[0]
+        a0, a1 = self._agg[(0, 0)], self._agg.get((1, 0))          # a one-hop tree (h_hop = 1) has aggregator (0,0) only
+        t0 = a0.relation_scores() if a0.User_orient_rela else None
+        t1 = a1.relation_scores() if (a1 is not None and a1.User_orient_rela) else None
+        st = self._small_state
+        if st is None or st["key"] != self._generation or st["dedup"] != self.dedup:
+            a = self.args
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            uo = a.User_orient
+            s = _lib.ScoreL2Args()
+            s.adj_entity, s.adj_relation = ptr(self.adj_entity), ptr(self.adj_relation)
+            s.relation_kge = ptr(self.relation_emb_KGE_matrix)
+            s.h_set_w = ptr(self.h_emb_item_mlp_matrix) if a.PS_O_ft else None
+            s.user_mlp_W, s.user_mlp_b = ptr(self.user_mlp_matrix), ptr(self.user_mlp_bias)
+            L = self.h_hop
+            for e in range(3):
+                setattr(s, f"W{e}", ptr(self.transfer_matrix_list[e]) if (uo and e <= L) else None)
+                setattr(s, f"b{e}", ptr(self.transfer_matrix_bias[e]) if (uo and e <= L) else None)
+            s.A0, s.a0 = ptr(a0.weights), ptr(a0.bias)
+            s.A1, s.a1 = (ptr(a1.weights), ptr(a1.bias)) if a1 is not None else (None, None)
+            s.Wmix, s.bmix = ptr(self.enti_transfer_matrix_list[0]), ptr(self.enti_transfer_bias_list[0])
+            s.D, s.K, s.P, s.Nm, s.depth = D, self.n_neighbor, P, self.n_memory, L
+            s.n_entity, s.n_relation, s.table_bf16 = self.n_entity, self.n_relation, 0
+            # the duplicate-slot encoding whenever the adjacency has one (distinct rows only; a row without repeats costs the
+            # same either way) unless the plain adjacency is forced (MVIN.dedup = False / MVIN_L2_ENC=0)
+            mode = os.environ.get("MVIN_L2_ENC", "auto") if self.dedup is None else ("1" if self.dedup else "0")
+            enc = self.encoded_adjacency() if mode != "0" else None
+            s.enc_entity, s.enc_relation = (ptr(enc[0]), ptr(enc[1])) if enc is not None else (None, None)
+            keep = (self.adj_entity, self.adj_relation, self.relation_emb_KGE_matrix, self.h_emb_item_mlp_matrix,
+                    self.user_mlp_matrix, self.user_mlp_bias, list(self.transfer_matrix_list), list(self.transfer_matrix_bias),
+                    a0.weights, a0.bias, a1.weights if a1 is not None else None, a1.bias if a1 is not None else None,
+                    self.enti_transfer_matrix_list[0], self.enti_transfer_bias_list[0], enc)
+            st = self._small_state = {"key": self._generation, "args": s, "ref": C.byref(s), "keep": keep, "arr": (C.c_void_p * P),
+                                      "dedup": self.dedup, "fn": _lib.load().mvin_score_small_fwd, "live": None}
+        s = st["args"]
+        E = self.entity_emb_matrix
+        s.entity_emb = E.data_ptr()
+        s.t0 = t0.data_ptr() if t0 is not None else None
+        s.t1 = t1.data_ptr() if t1 is not None else None
+        out = torch.empty((2 * B * D + 2 * B,), dtype=torch.float32, device=self.device)      # one allocation for the four outputs
+        s.items = item.data_ptr()
+        if uts is not None:
+            s.uts, s.users, s.n_user = uts.data_ptr(), users.data_ptr(), uts.shape[0]
+            s.mem_h = s.mem_r = s.mem_t = None
+        else:
+            arr = st["arr"]
+            hold = (arr(*[t.data_ptr() for t in mem_h[:P]]), arr(*[t.data_ptr() for t in mem_r[:P]]),
+                    arr(*[t.data_ptr() for t in mem_t[:P]]))
+            st["live"] = hold                 # (read by the call below only; kept until the next call replaces it)
+            s.uts = s.users = None
+            s.mem_h, s.mem_r, s.mem_t = C.addressof(hold[0]), C.addressof(hold[1]), C.addressof(hold[2])
+        base = out.data_ptr()
+        s.user_o, s.item_emb, s.scores, s.sig = base, base + 4 * B * D, base + 8 * B * D, base + 8 * B * D + 4 * B
+        s.B = B
+        rc = st["fn"](st["ref"], self.small_group, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _lib.check(rc, "mvin_score_small_fwd")
+        return _SmallOut(out, B, D)
+
     def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):
         """model.py:125-159 through mvin_score_l2_fwd.  The argument block (every weight pointer) is built once and
         kept until a parameter tensor is replaced; per call only the batch pointers change."""
@@ -787,6 +910,27 @@ class MVIN(object):
                                    o_cat, n_o * D, self.n_relation, records=self.user_records(uts))
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
+    def _forward_small(self, users, items, mem_h, mem_r, mem_t, uts):
+        """The short way into the single-launch pass (the checks of forward_device that matter for it, nothing else): None
+        when the call is not its case."""
+        if not self._small_ok(items, mem_h, False):
+            return None
+        P, B = self.p_hop, items.shape[0]
+        if uts is not None:
+            self._check_uts(uts)
+            if (uts.dtype == torch.int32 and uts.is_contiguous() and uts.shape[1] == P and uts.shape[3] == self.n_memory
+                    and users.dtype == torch.int64 and users.dim() == 1 and users.shape[0] == B and users.is_contiguous()):
+                return self._score_small_native(items, None, None, None, uts=uts, users=users)
+            return None
+        if mem_h is None or len(mem_h) < P or len(mem_r) < P or len(mem_t) < P:
+            return None
+        Nm = self.n_memory
+        for lst in (mem_h, mem_r, mem_t):
+            for m_ in lst[:P]:
+                if m_.dtype != torch.int32 or m_.dim() != 2 or m_.shape[0] != B or m_.shape[1] != Nm or not m_.is_contiguous():
+                    return None
+        return self._score_small_native(items, mem_h, mem_r, mem_t)
+
     def forward_device(self, user_indices, item_indices, memories_h, memories_r, memories_t,
                        want_probs=False, uts=None, distinct_users=None):
         """model.py:125-159 on device-resident inputs (int64/int32 ids [B]; int32 ripple sets
@@ -797,6 +941,11 @@ class MVIN(object):
         a = self.args
         if not item_indices.is_cuda:
             raise RuntimeError("forward_device needs device-resident inputs (no CPU path)")
+        if (self.small_max_batch and not want_probs and not self.validate_device_ids and item_indices.dim() == 1
+                and item_indices.shape[0] <= self.small_max_batch and item_indices.is_contiguous()):
+            out = self._forward_small(user_indices, item_indices, memories_h, memories_r, memories_t, uts)
+            if out is not None:
+                return out
         item32 = item_indices.contiguous()   # int64 (reference dtype) or int32: kernels take both
         user32 = user_indices.contiguous()
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh
@@ -819,9 +968,12 @@ class MVIN(object):
             grouped = (need_ps and self.fused is not False and uts.dtype == torch.int32 and uts.is_contiguous()
                        and item32.shape[0] >= self.group_min_pairs_per_user * min(uts.shape[0], int(distinct_users or uts.shape[0]))
                        and ops.key_addressing_grouped_supported(self.dim, self.p_hop, self.n_memory, self.n_relation))
-            if (need_ps and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
-                    and uts.shape[1] == self.p_hop and uts.shape[3] == self.n_memory and user32.dtype == torch.int64
-                    and user32.shape[0] == item32.shape[0] and self._native_l2_ok(item32, None, want_probs, cap=not grouped)):
+            feed_ok = (need_ps and uts.dtype == torch.int32 and uts.is_contiguous() and uts.dim() == 4
+                       and uts.shape[1] == self.p_hop and uts.shape[3] == self.n_memory and user32.dtype == torch.int64
+                       and user32.shape[0] == item32.shape[0])
+            if feed_ok and self._small_ok(item32, None, want_probs):
+                return self._score_small_native(item32, None, None, None, uts=uts, users=user32)     # ONE launch
+            if (feed_ok and self._native_l2_ok(item32, None, want_probs, cap=not grouped)):
                 # one native call; key addressing indexes user_triplet_set by users[b] itself, or -- grouped -- sorts the
                 # batch by user on the device first (any batch size: the host issues ONE call per step instead of seven)
                 return self._score_l2_native(item32, None, None, None, uts=uts, users=user32, grouped=grouped)
@@ -838,10 +990,13 @@ class MVIN(object):
         else:
             users_kernel = False
         shared = (not grouped) and memories_h is not None and memories_h[0].dim() == 1   # one user's sets for the batch
-        if not grouped and not shared and memories_h is not None and self._native_l2_ok(item32, memories_h, want_probs) \
+        if not grouped and not shared and memories_h is not None \
                 and all(m_.dtype == torch.int32 and m_.is_contiguous() for lst in (memories_h, memories_r, memories_t)
                         for m_ in lst[:self.p_hop]):
-            return self._score_l2_native(item32, memories_h, memories_r, memories_t)
+            if self._small_ok(item32, memories_h, want_probs):
+                return self._score_small_native(item32, memories_h, memories_r, memories_t)          # ONE launch
+            if self._native_l2_ok(item32, memories_h, want_probs):
+                return self._score_l2_native(item32, memories_h, memories_r, memories_t)
         if shared and user32.numel() == 1:
             user32 = user32.reshape(1).expand(item32.shape[0]).contiguous()
         if shared and (self.n_memory % 4 != 0 or self.n_memory > 256):

@@ -155,6 +155,11 @@ def linear(srcs, W, Dout, *, ids=None, bias=None, rowbias=None, rows_per_group=1
     return (out, score, sig) if score_u is not None else out
 
 
+def score_small_supported(D, K, P, Nm, nR):
+    """mvin_score_small_supported: the whole depth-2 pass as one launch exists for this shape."""
+    return bool(_lib.load().mvin_score_small_supported(int(D), int(K), int(P), int(Nm), int(nR)))
+
+
 def gather_attn(table, adj_entity, adj_relation, node_ids, rel_score_t, self_vec, Wc, c_child,
                 Wagg, bagg, B, N, K, D, want_probs=False):
     """mvin_gather_attn_fwd(_ex): deepest hop, children gathered from ``table`` (fp32 or bf16)

@@ -83,9 +83,20 @@ def test_hot_kernels_match_reference_graph(path, hip_lib):
     def model(**kw):
         return MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
                     device=dev, **kw)
+    # the product default at this batch size: the whole pass as ONE launch (mvin_score_small_fwd), every group size
+    if ops.score_small_supported(D, K, args.p_hop, args.n_memory, case.n_relation):
+        for dedup in (None, False):
+            m = model()
+            m.dedup = dedup
+            for G in (0, 1, 4, 16):
+                m.small_group = G
+                check(m.forward_device(users, items, *mem), f"single launch, per-pair feed, G={G}, dedup={dedup}")
+                assert m._small_state is not None, "the single-launch kernel was expected on this shape"
+                check(m.forward_users(users, items, uts_d), f"single launch, users feed, G={G}, dedup={dedup}")
     taken = set()
     for dedup in (None, True, False):
         m = model()
+        m.small_max_batch = 0                        # from here on: the multi-launch schedules and their kernels
         m.dedup = dedup
         enc = m._enc_for_l2(n_parents=items.shape[0])
         taken.add("enc" if enc is not None else "plain")
