@@ -100,17 +100,17 @@ def test_encoder_clamps_out_of_range_ids(hip_lib):
     c = cnt.cpu().numpy()
     assert c.min() >= 1 and c.max() <= 32
     assert np.array_equal((enc_r.cpu().numpy().view(np.uint32) >> 24), np.broadcast_to(c[:, None], ae.shape))
-    # the model over an adjacency with ids BEYOND the table: encoded path == plain path == the clamped adjacency
+    # the model over an adjacency with ids BEYOND the table: the encoded path scores it as the clamped adjacency
     ae2 = case.adj_entity.astype(np.int64).copy()
     ae2[bad] = rng.choice(np.array([300, 1 << 24, (1 << 24) + 5, 2 ** 31 - 1], dtype=np.int64), size=int(bad.sum()))
     params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=4, random_agg_bias=True)
     case2, case3 = copy.copy(case), copy.copy(case)
     case2.adj_entity = ae2
     case3.adj_entity = np.minimum(ae2, case.n_entity - 1)
-    _, enc_out = _run(args, case2, params, True)
-    _, plain_out = _run(args, case2, params, False)
+    _, enc_out = _run(args, case2, params, True)              # the encoding of the raw adjacency: ids clamped by the encoder
+    _, enc_clamped = _run(args, case3, params, True)
     _, clamped_out = _run(args, case3, params, False)
-    assert torch.equal(plain_out.scores, clamped_out.scores)
+    assert torch.equal(enc_out.scores, enc_clamped.scores)
     assert torch.allclose(enc_out.scores, clamped_out.scores, rtol=1e-5, atol=1e-6)
 
 
