@@ -32,7 +32,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct SmallLds {        // offsets in 4-byte words
     int t0, t1, item, o, q, n, ids, c0e, c0r, chid, chg, chp0, chp1, chcnt, u;      // persistent
-    int v, part;                                                               // phase "reads" (overlays u)
+    int v, part, vrem;                                                         // phase "reads" (overlays u)
     int a1, a2, z, w0, w1, y, wt, sc, ps;                                      // phases "tree" / "tail"
     int ldo, total;
 };
@@ -66,6 +66,7 @@ __host__ __device__ inline SmallLds small_lds(int D, int G, int K, int nR, int N
     l.u = off;
     l.v = take(G * nR * D);
     l.part = take(nparts * (D + 4));                     // unit records of the reads stage
+    l.vrem = take((G < 4 ? G : 4) * 3 * 4 * D);          // V of the relations shared among the waves: partial sums per k block
     const int end_v = off;
     off = l.u;
     l.a1 = take(16 * LD);
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     float* sWt = smem + L.wt;
     float* sSc = smem + L.sc;
     float* sPart = smem + L.part;
+    float* sVrem = smem + L.vrem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q16 = lane >> 4, l16 = lane & 15, col = 16 * wave + l16;
@@ -224,15 +226,34 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     constexpr int KBN = D / (CPL * BK);                  // batches per relation
     const bool v_small = ng <= kVSmall;
     const int vcol = lane % D, vkq = lane / D;
-    const int v_nb = P > 0 && wave < nR ? ((nR - wave + NT - 1) / NT) * KBN : 0;        // this wave's batches
+    // batches of this wave: the relations r = wave, wave + NT, .. below v_nfull whole (KBN batches each); the nR mod NT relations
+    // left over are SHARED when a relation has one batch per wave (D = 64: KBN = NT) -- k block (wave - j) mod NT of the j-th
+    // of them, partial sums combined through LDS -- so that no wave has a whole relation more than the others (with nine
+    // relations wave 0 had three, the others two, and everybody waited for it at the next barrier)
+    constexpr bool VSHARE = KBN == NT && NT > 1;
+    const int v_nfull = VSHARE ? (nR / NT) * NT : nR, v_nrem = nR - v_nfull;
+    const int v_bfull = P > 0 && wave < v_nfull ? ((v_nfull - wave + NT - 1) / NT) * KBN : 0;
+    const int v_nb = P > 0 ? v_bfull + v_nrem : 0;                                        // this wave's batches
+    auto v_map = [&](int b, int& r, int& kb) {
+        if (b < v_bfull) {
+            r = wave + NT * (b / KBN);
+            kb = b % KBN;
+        } else {
+            const int j = b - v_bfull;
+            r = v_nfull + j;
+            kb = (wave - j + NT * 4) % NT;
+        }
+    };
     // ALL of this wave's share of R (up to NRP batches / blocks = 144 registers at D = 64) is requested here, before the ids
     // are even read: nothing else is live yet, and the V stage then runs on registers instead of on L2 latency (streamed in
     // batches behind the row gathers it took 21 k cycles for 3 k cycles of arithmetic)
-    constexpr int NRP = 8;                               // prefetched batches (small form) / relation blocks (MFMA form)
+    constexpr int NRP = 9;                               // prefetched batches (small form) / relation blocks (MFMA form)
     constexpr int RW = BK > KS ? BK : KS;
     float rR[NRP][RW];
     auto ld_rv = [&](int b, float (&rv)[RW]) {
-        const int r = wave + NT * (b / KBN), k0 = (b % KBN) * BK * CPL + vkq * BK;
+        int r, kb;
+        v_map(b, r, kb);
+        const int k0 = kb * BK * CPL + vkq * BK;
         const float* src = a.R + (size_t)r * D * D + (size_t)k0 * D + vcol;
 #pragma unroll
         for (int t = 0; t < BK; ++t) rv[t] = src[(size_t)t * D];
@@ -242,11 +263,17 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
 #pragma unroll
         for (int s2 = 0; s2 < KS; ++s2) bf[s2] = W[(size_t)(KS * q16 + s2) * D + col];
     };
+    // small form: the first RFM whole relations of the wave (slot i * KBN + kb) and, in the slots left over, its first shared batches
+    constexpr int RFM = NRP / KBN, NSH = NRP - RFM * KBN;
     if (P > 0) {
 #pragma unroll
         for (int t = 0; t < NRP; ++t) {
             if (v_small) {
-                if (t < v_nb) ld_rv(t, rR[t]);
+                if (t < RFM * KBN) {
+                    if (t < v_bfull) ld_rv(t, rR[t]);
+                } else if (t - RFM * KBN < v_nrem) {
+                    ld_rv(v_bfull + (t - RFM * KBN), rR[t]);
+                }
             } else {
                 if (t < nR) ld_blk(t, rR[t]);
             }
@@ -327,7 +354,6 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         load_hrows(un, t);
         load_trows(un, t);
     };
-    if (unit < nunit) load_hrows(unit, ids);            // (the tail rows after the V product: its registers are all taken)
 
     // ------------------------------------------------------------------ the children of every pair: one work list
     int base[17];                                        // list offset of pair g (every thread: ng <= 16 adds)
@@ -417,42 +443,77 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
 
     // ------------------------------------------------------------------ V = E[item] . R_KGE[r] (R in registers since the start)
     if (P > 0 && v_small) {
-        float vacc[kVSmall];
-        auto v_batch = [&](int b, const float (&rv)[RW]) {
-            const int r = wave + NT * (b / KBN), kb = b % KBN, k0 = kb * BK * CPL + vkq * BK;
-            if (kb == 0) {
+        // pair by pair, k block by k block: the lane's 16 (BK) values of E[item_g] in registers -- one LDS read burst per block
+        // instead of one read (and one s_waitcnt) per four FMAs --, then that block of every prefetched relation
+        auto xdot = [&](const float4 (&x)[BK / 4], const float (&rv)[RW]) -> float {
+            float v = 0.f;
 #pragma unroll
-                for (int g = 0; g < kVSmall; ++g) vacc[g] = 0.f;
+            for (int t = 0; t < BK; t += 4) {
+                v = fmaf(x[t / 4].x, rv[t], v);
+                v = fmaf(x[t / 4].y, rv[t + 1], v);
+                v = fmaf(x[t / 4].z, rv[t + 2], v);
+                v = fmaf(x[t / 4].w, rv[t + 3], v);
+            }
+            return v;
+        };
+        auto xload = [&](int g, int kb, float4 (&x)[BK / 4]) {
+#pragma unroll
+            for (int i = 0; i < BK / 4; ++i) x[i] = *reinterpret_cast<const float4*>(sItem + g * LD + kb * BK * CPL + vkq * BK + 4 * i);
+        };
+        auto kreduce = [&](float v) -> float {           // the k slices of a row sit D lanes apart
+            if (CPL >= 4) v = xor16_sum(v);
+            if (CPL >= 2) v = xor32_sum(v);
+            return v;
+        };
+        for (int g = 0; g < ng; ++g) {
+            float va[RFM];
+#pragma unroll
+            for (int i = 0; i < RFM; ++i) va[i] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < KBN; ++kb) {
+                float4 x[BK / 4];
+                xload(g, kb, x);
+#pragma unroll
+                for (int i = 0; i < RFM; ++i)
+                    if (i * KBN < v_bfull) va[i] += xdot(x, rR[i * KBN + kb]);
             }
 #pragma unroll
-            for (int g = 0; g < kVSmall; ++g) {
-                if (g < ng) {
+            for (int i = 0; i < RFM; ++i) {
+                const float v = kreduce(va[i]);
+                if (i * KBN < v_bfull && vkq == 0) sV[(g * nR + wave + NT * i) * D + vcol] = v;
+            }
 #pragma unroll
-                    for (int t = 0; t < BK; t += 4) {
-                        const float4 x = *reinterpret_cast<const float4*>(sItem + g * LD + k0 + t);
-                        vacc[g] = fmaf(x.x, rv[t], vacc[g]);
-                        vacc[g] = fmaf(x.y, rv[t + 1], vacc[g]);
-                        vacc[g] = fmaf(x.z, rv[t + 2], vacc[g]);
-                        vacc[g] = fmaf(x.w, rv[t + 3], vacc[g]);
+            for (int e = 0; e < NSH; ++e) {
+                if (e < v_nrem) {
+                    const int kb = (wave - e + NT * 4) % NT;
+                    float4 x[BK / 4];
+                    xload(g, kb, x);
+                    sVrem[((g * 3 + e) * NT + kb) * D + vcol] = xdot(x, rR[RFM * KBN + e]);
+                }
+            }
+        }
+        // what did not fit the registers (more relations than RFM per wave, more shared ones than NSH): streamed, one exposed
+        // latency per batch
+        for (int b = RFM * KBN; b < v_nb; ++b) {
+            if (b >= v_bfull && b - v_bfull < NSH) continue;
+            ld_rv(b, rR[0]);
+            int r, kb;
+            v_map(b, r, kb);
+            const bool shared = b >= v_bfull;
+            for (int g = 0; g < ng; ++g) {
+                float4 x[BK / 4];
+                xload(g, kb, x);
+                float v = xdot(x, rR[0]);
+                if (shared) {
+                    sVrem[((g * 3 + (r - v_nfull)) * NT + kb) * D + vcol] = v;
+                } else {
+                    v = kreduce(v);
+                    if (vkq == 0) {                      // (a relation's batches are consecutive: the first one sets, the others add)
+                        float* dst = sV + (g * nR + r) * D + vcol;
+                        *dst = (kb == 0 ? 0.f : *dst) + v;
                     }
                 }
             }
-            if (kb == KBN - 1) {
-#pragma unroll
-                for (int g = 0; g < kVSmall; ++g) {
-                    float v = vacc[g];
-                    if (CPL >= 4) v = xor16_sum(v);      // the k slices of a row sit D lanes apart
-                    if (CPL >= 2) v = xor32_sum(v);
-                    if (g < ng && vkq == 0) sV[(g * nR + r) * D + vcol] = v;
-                }
-            }
-        };
-#pragma unroll
-        for (int t = 0; t < NRP; ++t)
-            if (t < v_nb) v_batch(t, rR[t]);
-        for (int b = NRP; b < v_nb; ++b) {               // (more batches than registers: the rest, one exposed latency each)
-            ld_rv(b, rR[0]);
-            v_batch(b, rR[0]);
         }
     } else if (P > 0) {
         auto v_blk = [&](int r, const float (&bf)[RW]) {
@@ -481,7 +542,17 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
             v_blk(r, rR[0]);
         }
     }
-    if (unit < nunit) load_trows(unit, ids);
+    if (unit < nunit) load_rows(unit, ids);             // (after the V product: its registers were all taken)
+    if (VSHARE && P > 0 && v_small && v_nrem > 0) {      // the shared relations: their NT partial sums, in k order
+        __syncthreads();
+        for (int i = tid; i < ng * v_nrem * D; i += NTHR) {
+            const int g = i / (v_nrem * D), rem = i - g * v_nrem * D, j = rem / D, cl = rem - j * D;
+            float v = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NT; ++kb) v += sVrem[((g * 3 + j) * NT + kb) * D + cl];
+            sV[(g * nR + v_nfull + j) * D + cl] = v;
+        }
+    }
     if (a.dbg == 4) return;
     stamp(4);
 
