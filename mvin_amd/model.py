@@ -329,6 +329,8 @@ class MVIN(object):
         table; nothing is built here yet."""
         self.optimizer = None
         self.trainer = None   # created on the first train() call (mvin_amd.training.Trainer)
+        self._train_graphs, self._train_seen = {}, None      # captured steps per batch size (train())
+        self.train_graph_max_batch = 8192
 
     def parameters_dict(self):
         """All parameters as numpy arrays under the names of mvin_amd/params.py."""
@@ -1092,6 +1094,23 @@ class MVIN(object):
             self.trainer = Trainer(self)
         user, item, mh, mr, mt = self._feed(feed_dict)
         labels = torch.as_tensor(np.asarray(feed_dict[self.labels], dtype=np.float32)).to(self.device)
+        # The reference trains at ONE batch size (train.py:56-64: `start += args.batch_size`, one sess.run per batch) and a step
+        # at 512 / 1 024 pairs is ~60 short launches: from the second step of a batch size on, the step is one hipGraph replay
+        # (training.GraphedTrainer: 0.68 vs 1.00 ms at 512 pairs).  MVIN_TRAIN_GRAPH=0, a multi-rank trainer or a batch above
+        # train_graph_max_batch keep the eager launches; the first step of a size runs eagerly (it is the capture's warm-up).
+        B = int(item.shape[0])
+        if (os.environ.get("MVIN_TRAIN_GRAPH", "1") != "0" and self.trainer.world == 1 and B <= self.train_graph_max_batch):
+            from .training import GraphedTrainer
+            g = self._train_graphs.get(B)
+            if g is not None and g._storage_key() != g._captured:
+                g = None                                   # adjacency / a parameter tensor replaced: capture again
+            if g is None and self._train_seen == B:
+                g = self._train_graphs[B] = GraphedTrainer(self.trainer, B, ids_dtype=item.dtype, warmup=0)
+                if len(self._train_graphs) > 4:
+                    self._train_graphs.pop(next(iter(self._train_graphs)))
+            self._train_seen = B
+            if g is not None:
+                return None, float(g.step(user, item, labels, mh, mr, mt).item())
         return None, self.trainer.step(user, item, labels, mh, mr, mt)
 
     def get_scores(self, sess, feed_dict):

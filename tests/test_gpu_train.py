@@ -183,3 +183,29 @@ def test_graphed_epoch_through_the_harness(hip_lib):
     model_g.set_adjacency(case.adj_entity.copy(), case.adj_relation.copy())
     with pytest.raises(RuntimeError, match="GraphedTrainer"):
         gt.replay()
+
+
+def test_train_wrapper_replays_a_captured_step_when_the_batch_size_repeats(hip_lib, monkeypatch):
+    """MVIN.train (the reference's run wrapper, model.py:416-417): from the second step of a batch size on the step is one
+    hipGraph replay; a sequence that mixes batch sizes gives the losses and parameters of the all-eager twin."""
+    args, case, params, labels, model = build("d8k3h2m1p2")
+    monkeypatch.setenv("MVIN_TRAIN_GRAPH", "0")
+    _, _, _, _, twin = build("d8k3h2m1p2")
+
+    def feed_of(m, n):
+        f = {m.user_indices: case.users[:n], m.item_indices: case.items[:n], m.labels: labels[:n]}
+        for i in range(len(case.memories_h)):
+            f[m.memories_h[i]], f[m.memories_r[i]], f[m.memories_t[i]] = \
+                case.memories_h[i][:n], case.memories_r[i][:n], case.memories_t[i][:n]
+        return f
+    B = len(case.users)
+    sizes = [B, B, B, B - 1, B, B, B - 1, B - 1]
+    ref_losses = [twin.train(None, feed_of(twin, n))[1] for n in sizes]
+    assert not twin._train_graphs
+    monkeypatch.setenv("MVIN_TRAIN_GRAPH", "1")
+    losses = [model.train(None, feed_of(model, n))[1] for n in sizes]
+    assert set(model._train_graphs) == {B, B - 1}          # both sizes were captured once they repeated
+    np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-7)
+    a, b = model.parameters_dict(), twin.parameters_dict()
+    for k in a:
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-5, atol=1e-6, err_msg=k)
