@@ -827,6 +827,9 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     // ------------------------------------------------------------------ tree: chunks of 16 children, the dense part
     for (int ch = 0; ch < nch; ++ch) {
         const float4 acc = gather_finish(ch);
+        const int gfirst = sChG[ch * 16], glast = sChG[(ch * 16 + 15 < NC ? ch * 16 + 15 : NC - 1)];
+        const bool single = gfirst == glast;             // (workgroup-uniform: every thread reads the same two list entries)
+        const int gsingle = gfirst;
         if (a.dbg == 81) return;
         if (ch == 0) stamp(20);
         const bool valid = gvalid;
@@ -862,13 +865,19 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
                     zv[rr] = s1v[rr] + sA2[(4 * q16 + rr) * LD + col];
                 }
             }
+            float part0 = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = 4 * q16 + rr, i2 = ch * 16 + row;
                 const float p0r = sChP0[i2 < NC ? i2 : 0];
                 const float p0 = i2 < NC ? p0r : 0.f;
                 sZ[row * LD + col] = zv[rr];
-                sW0[row * LD + col] = p0 * s1v[rr];
+                if (single) part0 = fmaf(p0, s1v[rr], part0);
+                else sW0[row * LD + col] = p0 * s1v[rr];
+            }
+            if (single) {                                // all sixteen rows belong to ONE pair: its sum stays in registers
+                part0 = xor32_sum(xor16_sum(part0));     // (rows 4 q16 + rr of this column: the four lane quarters)
+                if (q16 == 0) sN[gsingle * D + col] += part0;
             }
         }
         __syncthreads();
@@ -878,19 +887,28 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         if (!d1) {
             f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
             mma(sZ, LD, 16, bA0, acc2);
+            float part1 = 0.f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int row = 4 * q16 + rr, i2 = ch * 16 + row;
                 const float p1r = sChP1[i2 < NC ? i2 : 0];
                 const float p1 = i2 < NC ? p1r : 0.f;
-                sW1[row * LD + col] = p1 * fmaxf(acc2[rr] + a0v, 0.f);
+                const float o1 = fmaxf(acc2[rr] + a0v, 0.f);
+                if (single) part1 = fmaf(p1, o1, part1);
+                else sW1[row * LD + col] = p1 * o1;
             }
-            __syncthreads();
+            if (single) {
+                part1 = xor32_sum(xor16_sum(part1));
+                if (q16 == 0) sN[(G + gsingle) * D + col] += part1;
+            } else {
+                __syncthreads();
+            }
         }
         if (a.dbg == 84) return;
         if (ch == 0) stamp(23);
-        // per-pair sums of the weighted rows, in list order (one thread per output column and aggregator: deterministic)
-        if (tid < (d1 ? D : 2 * D)) {
+        // per-pair sums of the weighted rows of a chunk that spans several pairs, in list order (one thread per output column and
+        // aggregator: deterministic)
+        if (!single && tid < (d1 ? D : 2 * D)) {
             const int which = tid / D, cl = tid - which * D;
             const float* src = which ? sW1 : sW0;
             float run = 0.f;
