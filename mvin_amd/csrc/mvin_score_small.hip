@@ -186,8 +186,31 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
 #pragma unroll
         for (int s = 0; s < KS; ++s) bf[s] = W[(size_t)(KS * q16 + s) * D + col];
     };
-    // acc += A . B: A = rows l16 < nrows of an LDS tile (row stride lda; rows beyond read as 0)
+    // acc += A . B: A = rows l16 < nrows of an LDS tile (row stride lda; rows beyond read as 0).
+    // One or two live rows (a group of one or two pairs: the user MLP and the tail): plain FMAs on the SAME fragment -- a lane's
+    // KS values of B are rows KS q16 .. KS q16 + KS - 1 of its column, so its KS FMAs with the matching slice of the A row and
+    // two lane swaps (over the four q16 quarters) give the column's sum; rows 0 / 1 land in acc[0] / acc[1] of the q16 = 0
+    // lanes, where the MFMA accumulator layout has them.  (A 16-row MFMA tile for one live row is 16 MFMAs = ~1 k cycles of a
+    // pipe two workgroups share; this is 16 FMAs.)
     auto mma = [&](const float* src, int lda, int nrows, const float (&bf)[KS], f32x4& acc) {
+        if (nrows <= 2) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (r < nrows) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int s = 0; s < KS; s += 4) {
+                        const float4 x = *reinterpret_cast<const float4*>(src + r * lda + KS * q16 + s);
+                        v = fmaf(x.x, bf[s], v);
+                        v = fmaf(x.y, bf[s + 1], v);
+                        v = fmaf(x.z, bf[s + 2], v);
+                        v = fmaf(x.w, bf[s + 3], v);
+                    }
+                    acc[r] += xor32_sum(xor16_sum(v));
+                }
+            }
+            return;
+        }
         const bool live = l16 < nrows;
         const int lrow = live ? l16 : 0;
 #pragma unroll
@@ -824,6 +847,13 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     if (a.dbg == 7) return;
     stamp(7);
 
+    // the tail's blocks W0 | A1 | Wmix[0..2].  Only W0 is needed by the tail's FIRST phase: it is requested before the tree's
+    // dense part (16 registers over the chunk loop); the other four at the tail's start -- each is used a phase or more later,
+    // so their L2 latency passes under the phases before (all five at the tail's start were 2 k cycles on the critical path;
+    // all five before the loop were 55 spilled registers)
+    const bool proj0 = a.W0 != nullptr;
+    float bT[5][KS];
+    if (proj0) ldfrag(a.W0, bT[0]);
     // ------------------------------------------------------------------ tree: chunks of 16 children, the dense part
     for (int ch = 0; ch < nch; ++ch) {
         const float4 acc = gather_finish(ch);
@@ -932,11 +962,8 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     stamp(8);
 
     // ------------------------------------------------------------------ tail (rows = the pairs of the group)
-    const bool proj0 = a.W0 != nullptr;
-    float bT[5][KS];                                     // the tail's blocks W0 | A1 | Wmix[0..2]: all five in flight together
-    if (proj0) ldfrag(a.W0, bT[0]);
-    if (!d1) ldfrag(a.A1, bT[1]);
     ldfrag(a.Wmix, bT[2]);
+    if (!d1) ldfrag(a.A1, bT[1]);
     ldfrag(a.Wmix + (size_t)D * D, bT[3]);
     if (!d1) ldfrag(a.Wmix + (size_t)2 * D * D, bT[4]);
     if (grp < ng) {
@@ -952,6 +979,10 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     const float bcv = a.bmix ? a.bmix[col] : 0.f;
     __syncthreads();
     stamp(10);
+    // the combiner's three blocks are spread over the phases: [ev0 | out0 | out2] Wmix is accumulated as its operands appear,
+    // each product in the phase AFTER the one that wrote its operand (the MFMA pipe idles there), so that the last phase holds
+    // one product instead of three
+    f32x4 acc_item = {0.f, 0.f, 0.f, 0.f};
     {   // ev0 ; Z1 = ev0 + nagg0
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (proj0) mma(sA1, LD, ng, bT[0], acc);
@@ -967,9 +998,10 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     }
     __syncthreads();
     stamp(11);
-    {   // out0 = relu(Z1 A0 + a0) ; Z2 = out0 + nagg1
+    {   // out0 = relu(Z1 A0 + a0) ; Z2 = out0 + nagg1 ; item += ev0 Wmix[0]
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mma(sZ, LD, ng, bA0, acc);
+        mma(sA2, LD, ng, bT[2], acc_item);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = 4 * q16 + rr;
@@ -982,9 +1014,10 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     }
     __syncthreads();
     stamp(12);
-    if (!d1) {   // out2 = relu(Z2 A1 + a1)
+    if (!d1) {   // out2 = relu(Z2 A1 + a1) ; item += out0 Wmix[1]
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         mma(sA1, LD, ng, bT[1], acc);
+        mma(sW0, LD, ng, bT[3], acc_item);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = 4 * q16 + rr;
@@ -994,10 +1027,9 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
     __syncthreads();
     stamp(13);
     {   // item = [ev0 | out0 | out2] Wmix + bmix ; score
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        mma(sA2, LD, ng, bT[2], acc);
-        mma(sW0, LD, ng, bT[3], acc);
-        if (!d1) mma(sZ, LD, ng, bT[4], acc);
+        f32x4 acc = acc_item;
+        if (d1) mma(sW0, LD, ng, bT[3], acc);
+        else mma(sZ, LD, ng, bT[4], acc);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = 4 * q16 + rr;
