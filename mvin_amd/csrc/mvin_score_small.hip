@@ -97,7 +97,9 @@ hipError_t small_read_trace(long long* host_dst, size_t n) {
 }
 
 // NMT: the ripple-set size the reads stage is unrolled for (rows per lane = NMT * (D/4) / 64): n_memory <= NMT
-template <int D, int NMT>
+// DBG: the timing aids compiled in (MVIN_SMALL_DBG: cut after stage N / cycle stamps); the product instance has none of them
+// (each `a.dbg == N` test was a scalar load from the kernel arguments and an s_waitcnt in front of a barrier).
+template <int D, int NMT, bool DBG>
 __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a, SmallLds L) {
     constexpr int NT = D / 16, NTHR = NT * 64, KS = D / 4, LD = D + 4, LPR = D / 4, RPW = 64 / LPR;
     constexpr int LPR_L2 = LPR == 16 ? 4 : (LPR == 8 ? 3 : 2);
@@ -173,9 +175,11 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, off, 0, 0);
         return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
     };
-    const bool tracing = a.dbg == 99 && blockIdx.x == 0;
+    const bool tracing = DBG && a.dbg == 99 && blockIdx.x == 0;
     auto stamp = [&](int i) {
-        if (tracing && lane == 0) g_small_trace[wave & 3][i] = (long long)__builtin_amdgcn_s_memtime();
+        if constexpr (DBG) {
+            if (tracing && lane == 0) g_small_trace[wave & 3][i] = (long long)__builtin_amdgcn_s_memtime();
+        }
     };
     stamp(0);
     // B fragment of a [D, D] row-major block (global memory, L2-resident weights) for this wave's 16-column slab: MFMA step s
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         }
     }
     __syncthreads();
-    if (a.dbg == 1) return;
+    if constexpr (DBG) { if (a.dbg == 1) return; }
     stamp(1);
 
     // ------------------------------------------------------------------ everything the ids alone determine, issued together:
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         sC0r[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(adjR, o, 0, 0);
     }
     __syncthreads();
-    if (a.dbg == 2) return;
+    if constexpr (DBG) { if (a.dbg == 2) return; }
     stamp(2);
 
     // ------------------------------------------------------------------ the rows of the first (pair, hop): in flight under
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         }
     }
     __syncthreads();
-    if (a.dbg == 3) return;
+    if constexpr (DBG) { if (a.dbg == 3) return; }
     stamp(3);
     // the adjacency words and the own row of the first chunk's children: in flight from here (the tree stage starts with them)
     struct ChunkIn {
@@ -576,7 +580,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
             sV[(g * nR + v_nfull + j) * D + cl] = v;
         }
     }
-    if (a.dbg == 4) return;
+    if constexpr (DBG) { if (a.dbg == 4) return; }
     stamp(4);
 
     // ------------------------------------------------------------------ tree stage, the gathers of a chunk.  Nothing here
@@ -704,7 +708,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         stage_lists(0);
         if (nch > 1) load_chunk(1, cin);
     }
-    if (a.dbg == 5) return;
+    if constexpr (DBG) { if (a.dbg == 5) return; }
     stamp(5);
 
     // ------------------------------------------------------------------ attention reads: one wave per unit
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         }
     }
     __syncthreads();
-    if (a.dbg == 6) return;
+    if constexpr (DBG) { if (a.dbg == 6) return; }
     stamp(6);
 
     // ------------------------------------------------------------------ user_o = o_cat . user_mlp + bias
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         }
     }
     __syncthreads();
-    if (a.dbg == 7) return;
+    if constexpr (DBG) { if (a.dbg == 7) return; }
     stamp(7);
 
     // the tail's blocks W0 | A1 | Wmix[0..2].  Only W0 is needed by the tail's FIRST phase: it is requested before the tree's
@@ -860,7 +864,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         const int gfirst = sChG[ch * 16], glast = sChG[(ch * 16 + 15 < NC ? ch * 16 + 15 : NC - 1)];
         const bool single = gfirst == glast;             // (workgroup-uniform: every thread reads the same two list entries)
         const int gsingle = gfirst;
-        if (a.dbg == 81) return;
+        if constexpr (DBG) { if (a.dbg == 81) return; }
         if (ch == 0) stamp(20);
         const bool valid = gvalid;
         {
@@ -870,7 +874,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
             *reinterpret_cast<float4*>(sA2 + grp * LD + 4 * c) = f4_fma(c2scale, qv, acc);
         }
         __syncthreads();
-        if (a.dbg == 82) return;
+        if constexpr (DBG) { if (a.dbg == 82) return; }
         if (ch == 0) stamp(21);
         if (ch + 1 < nch) {                              // the next chunk's lists and gathers under this chunk's products
             stage_lists(ch + 1);                         // (holds a workgroup barrier: every wave passes here)
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
             }
         }
         __syncthreads();
-        if (a.dbg == 83) return;
+        if constexpr (DBG) { if (a.dbg == 83) return; }
         if (ch == 0) stamp(22);
         // out1 = relu(Z A0 + a0)   (two-hop trees only)
         if (!d1) {
@@ -934,7 +938,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
                 __syncthreads();
             }
         }
-        if (a.dbg == 84) return;
+        if constexpr (DBG) { if (a.dbg == 84) return; }
         if (ch == 0) stamp(23);
         // per-pair sums of the weighted rows of a chunk that spans several pairs, in list order (one thread per output column and
         // aggregator: deterministic)
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(D * 4, 2) void score_small_kernel(ScoreSmallArgs a,
         }
     }
     __syncthreads();
-    if (a.dbg == 8) return;
+    if constexpr (DBG) { if (a.dbg == 8) return; }
     stamp(8);
 
     // ------------------------------------------------------------------ tail (rows = the pairs of the group)
@@ -1087,9 +1091,9 @@ int score_small_group(int D, int K, int P, int Nm, int nR, int has_hset, int64_t
     return G;
 }
 
-template <int D, int NMT>
-static hipError_t launch_small(const ScoreSmallArgs& a, const SmallLds& L, hipStream_t st) {
-    auto k = score_small_kernel<D, NMT>;
+template <int D, int NMT, bool DBG>
+static hipError_t launch_small_d(const ScoreSmallArgs& a, const SmallLds& L, hipStream_t st) {
+    auto k = score_small_kernel<D, NMT, DBG>;
     if (L.total > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
         if (e != hipSuccess) return e;
@@ -1097,6 +1101,14 @@ static hipError_t launch_small(const ScoreSmallArgs& a, const SmallLds& L, hipSt
     const int64_t grid = (a.B + a.G - 1) / a.G;
     k<<<(int)grid, D * 4, (size_t)L.total, st>>>(a, L);
     return hipGetLastError();
+}
+
+template <int D, int NMT>
+static hipError_t launch_small(const ScoreSmallArgs& a, const SmallLds& L, hipStream_t st) {
+    if constexpr (D == 64 && NMT == 64) {                // the timing aids exist for the metric shape's instance only
+        if (a.dbg != 0) return launch_small_d<D, NMT, true>(a, L, st);
+    }
+    return launch_small_d<D, NMT, false>(a, L, st);
 }
 
 hipError_t launch_score_small(ScoreSmallArgs a, int D, hipStream_t st) {
