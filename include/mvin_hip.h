@@ -292,6 +292,18 @@ MVIN_API int mvin_group_pairs_by_user(const int64_t* users_i64, const int32_t* u
  * instead of 2*Nm row gathers per pair. */
 MVIN_API int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* stream);
 
+/* Aggregator._mix_neighbor_vectors / _mix_neighbor_vectors_urv (aggregators.py:37-77: KGCN's user-relation mixer; defined by
+ * the reference, never called by MVIN) on materialised tensors:
+ *   s[b,n,k] = mean_d(user_embeddings[b,d] * neighbor_relations[b,n,k,d]) ; p = softmax_k(s) ;
+ *   out[b,n,:] = mean_k(p[b,n,k] * neighbor_vectors[b,n,k,:])
+ * neighbor_vectors / neighbor_relations [B, N, K, D], user_embeddings [B, D], out [B, N, D], probs [B, N, K] or NULL.  K <= 64.
+ * logits_or_null [B, N, K]: the scores s are taken from there instead (SumAggregator_urh_matrix._mix_neighbor_vectors_urh,
+ * aggregators.py:118-146, with s = relation . urh_weights[D:2D]: the user and self terms cancel in the softmax); with neither
+ * logits nor relations / user every weight is 1 (_mix_neighbor_vectors_no_ur, :148-152: the plain mean over K). */
+MVIN_API int mvin_mix_neighbor_vectors_fwd(const float* neighbor_vectors, const float* neighbor_relations, const float* user_embeddings,
+                                           const float* logits_or_null, int B, int N, int K, int D, float* out, float* probs_or_null,
+                                           void* stream);
+
 /* Everything of MVIN.aggregate_delta_whole (model.py:259-324) above mvin_gather_attn_l2_fwd for the shape
  * n_mix_hop = 1, h_hop = 2 (tree depth 2), in one launch:
  *   ev0 = (E[item] + q) W0 + b0  (W0 == NULL: ev0 = E[item], User_orient off)        model.py:270-283

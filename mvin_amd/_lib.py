@@ -81,6 +81,7 @@ SIGNATURES = {
     "mvin_l2_tail_supported": (C.c_int, [C.c_int]),
     "mvin_score_l2_fwd": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mvin_score_small_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "mvin_mix_neighbor_vectors_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
     "mvin_score_small_supported": (C.c_int, [C.c_int] * 5),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

@@ -55,10 +55,12 @@ class Aggregator(object):
         pass
 
     def _mix_neighbor_vectors(self, neighbor_vectors, neighbor_relations, user_embeddings):
-        """aggregators.py:37-56 (KGCN-style mean(u*r) scores).  Defined by the reference but
-        never called by MVIN; not on the hot path and not built here."""
-        raise NotImplementedError("Aggregator._mix_neighbor_vectors is dead code in the reference "
-                                  "(aggregators.py:37-77) and is not part of the MVIN path")
+        """aggregators.py:37-56 (KGCN's mixer: p = softmax_k(mean_d(user * relation)), mean_k(p * neighbor)).  Defined by the
+        reference and never called by MVIN; built for the completeness of the class surface (mvin_mix_neighbor_vectors_fwd).
+        neighbor_vectors / neighbor_relations [B,N,K,D] device tensors, user_embeddings [B,D] -> [B,N,D]."""
+        B = neighbor_vectors.shape[0]
+        nv = neighbor_vectors.contiguous()
+        return ops.mix_neighbor_vectors(nv, neighbor_relations.contiguous().view_as(nv), user_embeddings.contiguous().view(B, self.dim))
 
     _mix_neighbor_vectors_urv = _mix_neighbor_vectors
 
@@ -136,7 +138,21 @@ class SumAggregator_urh_matrix(Aggregator):
         return out, probs
 
     def _mix_neighbor_vectors_urh(self, self_vectors, user_embeddings, neighbor_vectors, neighbor_relations):
-        raise NotImplementedError("fused into _call (mvin_agg_fwd / mvin_gather_attn_fwd)")
+        """aggregators.py:118-146 on its own -> (neighbors_aggregated [B,N,D], probs_normalized [B,N,K]).  ``_call`` does not
+        come through here (it runs the fused mvin_agg_fwd / mvin_gather_attn_fwd); this is the standalone form of the class
+        surface.  The logit of child k is [user ; relation_k ; self] . urh_weights: the user and self terms do not depend on k
+        and cancel in the softmax, so only relation_k . urh_weights[D:2D] is computed.  ``neighbor_relations``: relation
+        vectors [B,N,K,D] (the reference's form) or int relation ids [B,N,K]."""
+        D = self.dim
+        nv = neighbor_vectors.contiguous()
+        B, N, K = nv.shape[0], nv.shape[1], nv.shape[2]
+        if neighbor_relations.dtype in (torch.int32, torch.int64):
+            rv = ops.linear([self._relation_emb], None, D, ids=[neighbor_relations.to(torch.int32).contiguous().view(-1)])
+        else:
+            rv = neighbor_relations.contiguous().view(B * N * K, D)
+        logits = ops.linear([rv], self.urh_weights[D:2 * D].contiguous(), 1).view(B, N, K)
+        return ops.mix_neighbor_vectors(nv, want_probs=True, logits=logits)
 
     def _mix_neighbor_vectors_no_ur(self, self_vectors, user_embeddings, neighbor_vectors, neighbor_relations):
-        raise NotImplementedError("fused into _call (mvin_agg_fwd with rel_score = NULL)")
+        """aggregators.py:148-152 on its own: the plain mean over the K neighbours."""
+        return ops.mix_neighbor_vectors(neighbor_vectors.contiguous())

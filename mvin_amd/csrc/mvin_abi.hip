@@ -746,6 +746,18 @@ int mvin_row_softmax_fwd(const float* x, int64_t rows, int n, float* out, void* 
     return hip_result(mvin::launch_row_softmax(x, rows, n, out, (hipStream_t)stream), "mvin_row_softmax_fwd");
 }
 
+int mvin_mix_neighbor_vectors_fwd(const float* neighbor_vectors, const float* neighbor_relations, const float* user_embeddings,
+                                  const float* logits_or_null, int B, int N, int K, int D, float* out, float* probs_or_null,
+                                  void* stream) {
+    const char* who = "mvin_mix_neighbor_vectors_fwd";
+    if (!neighbor_vectors || !out) return fail(-1, "%s: null pointer", who);
+    if ((neighbor_relations == nullptr) != (user_embeddings == nullptr))
+        return fail(-1, "%s: neighbor_relations and user_embeddings go together", who);
+    if (B <= 0 || N <= 0 || K <= 0 || K > 64 || D <= 0) return fail(-2, "%s: bad sizes B=%d N=%d K=%d D=%d (K <= 64)", who, B, N, K, D);
+    return hip_result(mvin::launch_mix_urv(neighbor_vectors, neighbor_relations, user_embeddings, logits_or_null, (int64_t)B * N, N, K,
+                                           D, out, probs_or_null, (hipStream_t)stream), who);
+}
+
 int mvin_sample_adjacency(const int64_t* indptr, const int32_t* dst, const int32_t* rel, int n_entity, int K,
                           uint64_t seed, int32_t* adj_entity, int32_t* adj_relation, void* stream) {
     if (!indptr || !dst || !rel || !adj_entity || !adj_relation) return fail(-1, "mvin_sample_adjacency: null pointer");

@@ -299,6 +299,8 @@ hipError_t launch_move_rows(void* table, const int32_t* ids, int64_t n, int row_
                             hipStream_t st);
 hipError_t launch_shard_space_ids(const void* ids, bool is64, int64_t n, int world, int n_local, void* out, hipStream_t st);
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st);
+hipError_t launch_mix_urv(const float* neigh, const float* rel, const float* user, const float* logits, int64_t nodes, int N, int K,
+                          int D, float* out, float* probs, hipStream_t st);
 hipError_t launch_gather_mix(const GatherMixArgs& a, hipStream_t st);
 // ---- the whole depth-2 pass in one launch (mvin_score_small.hip) ----
 struct ScoreSmallArgs {

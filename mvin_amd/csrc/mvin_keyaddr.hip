@@ -195,6 +195,56 @@ __global__ __launch_bounds__(kBlock) void row_softmax_kernel(const float* __rest
     }
 }
 
+// Aggregator._mix_neighbor_vectors / _mix_neighbor_vectors_urv (aggregators.py:37-77; KGCN's mixer, defined by the reference and
+// never called by MVIN) on materialised tensors:
+//   s[b,n,k] = mean_d(user[b,d] * rel[b,n,k,d]) ; p = softmax_k(s) ; out[b,n,:] = mean_k(p[b,n,k] * neigh[b,n,k,:])
+// With `logits` [nodes, K] given the scores are taken from there (SumAggregator_urh_matrix._mix_neighbor_vectors_urh,
+// aggregators.py:118-146: the caller computes relation . urh_weights[D:2D]; the user / self terms cancel in the softmax); with
+// neither logits nor rel / user every weight is 1 (_mix_neighbor_vectors_no_ur, :148-152: the plain mean).
+// One wave per node (b, n): a lane owns D/64-strided columns; the K logits are wave reductions.  K <= 64.
+__global__ __launch_bounds__(kBlock) void mix_urv_kernel(const float* __restrict__ neigh, const float* __restrict__ rel,
+                                                         const float* __restrict__ user, const float* __restrict__ logits,
+                                                         int64_t nodes, int N, int K, int D,
+                                                         float* __restrict__ out, float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < nodes; t += (int64_t)gridDim.x * 4) {
+        const float* nv = neigh + t * K * D;
+        float p = lane < K ? 1.f : 0.f;
+        if (logits || (rel && user)) {
+            float logit = -INFINITY;                     // lane k keeps the logit of child k
+            if (logits) {
+                if (lane < K) logit = logits[t * K + lane];
+            } else {
+                const float* u = user + (t / N) * D;
+                const float* rv = rel + t * K * D;
+                for (int k = 0; k < K; ++k) {
+                    float part = 0.f;
+                    for (int d = lane; d < D; d += kWave) part = fmaf(u[d], rv[(int64_t)k * D + d], part);
+                    part = wave_sum(part) / (float)D;    // tf.reduce_mean(user * relation, axis=-1)
+                    logit = lane == k ? part : logit;
+                }
+            }
+            const float m = wave_max(logit);
+            const float e = lane < K ? expf(logit - m) : 0.f;
+            p = e / wave_sum(e);
+        }
+        if (probs && lane < K) probs[t * K + lane] = p;
+        for (int d = lane; d < D; d += kWave) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) acc = fmaf(__shfl(p, k, kWave), nv[(int64_t)k * D + d], acc);
+            out[t * D + d] = acc / (float)K;             // tf.reduce_mean(p * neighbor_vectors, axis=2)
+        }
+    }
+}
+
+hipError_t launch_mix_urv(const float* neigh, const float* rel, const float* user, const float* logits, int64_t nodes, int N, int K,
+                          int D, float* out, float* probs, hipStream_t st) {
+    const int64_t nblk = (nodes + 3) / 4;
+    const int64_t cap = 256 * 16;
+    mix_urv_kernel<<<(int)(nblk < cap ? nblk : cap), kBlock, 0, st>>>(neigh, rel, user, logits, nodes, N, K, D, out, probs);
+    return hipGetLastError();
+}
+
 hipError_t launch_row_softmax(const float* x, int64_t rows, int n, float* out, hipStream_t st) {
     const int64_t nblk = (rows + 3) / 4;
     const int64_t cap = 256 * 16;

@@ -327,6 +327,30 @@ def row_softmax(x):
     return out
 
 
+def mix_neighbor_vectors(neighbor_vectors, neighbor_relations=None, user_embeddings=None, want_probs=False, logits=None):
+    """mvin_mix_neighbor_vectors_fwd (aggregators.py:37-77 / :118-152): neighbor_vectors [B,N,K,D] -> mean_k(p * neighbor) [B,N,D]
+    (and p [B,N,K]); p = softmax_k(mean_d(user * relation)), or softmax_k(logits [B,N,K]), or 1 when neither is given."""
+    lib = _lib.load()
+    _chk(neighbor_vectors, F32, "neighbor_vectors")
+    B, N, K, D = neighbor_vectors.shape
+    if logits is not None:
+        _chk(logits, F32, "logits")
+        if logits.numel() != B * N * K:
+            raise ValueError("logits must be [B,N,K]")
+    elif neighbor_relations is not None:
+        _chk(neighbor_relations, F32, "neighbor_relations")
+        _chk(user_embeddings, F32, "user_embeddings")
+        if tuple(neighbor_relations.shape) != (B, N, K, D) or tuple(user_embeddings.shape) != (B, D):
+            raise ValueError("neighbor_relations must be [B,N,K,D] and user_embeddings [B,D]")
+    out = torch.empty((B, N, D), dtype=F32, device=neighbor_vectors.device)
+    probs = torch.empty((B, N, K), dtype=F32, device=neighbor_vectors.device) if want_probs else None
+    use_rel = logits is None and neighbor_relations is not None
+    _lib.check(lib.mvin_mix_neighbor_vectors_fwd(_p(neighbor_vectors), _p(neighbor_relations) if use_rel else None,
+                                                 _p(user_embeddings) if use_rel else None, _p(logits), B, N, K, D,
+                                                 _p(out), _p(probs), _stream()), "mvin_mix_neighbor_vectors_fwd")
+    return (out, probs) if want_probs else out
+
+
 def key_addressing_supported(Nm, D):
     return bool(_lib.load().mvin_key_addressing_supported(Nm, D))
 

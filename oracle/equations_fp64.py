@@ -163,3 +163,17 @@ def forward(args, params, adj_entity, adj_relation, user_indices, item_indices,
     return SimpleNamespace(scores=scores, scores_normalized=1.0 / (1.0 + np.exp(-scores)),
                            user_o=np.stack(user_os), item_embeddings=np.stack(item_embs),
                            importance_list=importance)
+
+
+def mix_neighbor_vectors(neighbor_vectors, neighbor_relations, user_embeddings):
+    """Aggregator._mix_neighbor_vectors / _mix_neighbor_vectors_urv (aggregators.py:37-77; the `avg = False` branch, the only
+    one reachable): scores = mean_d(user[:, None, None, :] * relations) (:43 / :65), softmax over the K neighbours (:44 / :66),
+    mean over K of p * neighbour vectors (:50 / :72).  float64.  -> (aggregated [B,N,D], p [B,N,K])"""
+    nv = np.asarray(neighbor_vectors, dtype=np.float64)
+    nr = np.asarray(neighbor_relations, dtype=np.float64)
+    u = np.asarray(user_embeddings, dtype=np.float64).reshape(nv.shape[0], 1, 1, nv.shape[-1])
+    s = (u * nr).mean(-1)
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(-1, keepdims=True)
+    return (p[..., None] * nv).mean(2), p

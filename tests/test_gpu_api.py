@@ -147,3 +147,39 @@ def test_linear_refuses_gathered_sources_of_different_heights(hip_lib):
         ops.linear([big, small], torch.eye(16, device=dev), 16, ids=[ids, ids], sum_sources=True)
     got = ops.linear([big, big], torch.eye(16, device=dev), 16, ids=[ids, ids], sum_sources=True)
     assert torch.allclose(got, 2 * big[ids.long()], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 8, 16), (2, 4, 4, 64), (5, 3, 64, 12), (1, 7, 1, 8)])
+def test_kgcn_style_mixer_of_the_aggregator_base(shape, hip_lib):
+    """Aggregator._mix_neighbor_vectors / _urv (aggregators.py:37-77): defined by the reference, never called by MVIN; built on
+    mvin_mix_neighbor_vectors_fwd and checked against the float64 restatement."""
+    from mvin_amd import ops
+    from mvin_amd.aggregators import SumAggregator_urh_matrix
+    from oracle import equations_fp64
+    B, N, K, D = shape
+    rng = np.random.default_rng(B + K)
+    nv, nr = rng.standard_normal((B, N, K, D)).astype(np.float32), rng.standard_normal((B, N, K, D)).astype(np.float32)
+    u = rng.standard_normal((B, D)).astype(np.float32)
+    want, want_p = equations_fp64.mix_neighbor_vectors(nv, nr, u)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a).to(dev)
+    got, probs = ops.mix_neighbor_vectors(t(nv), t(nr), t(u), want_probs=True)
+    assert_close(got.cpu().numpy(), want, "aggregated neighbours")
+    assert_close(probs.cpu().numpy(), want_p, "user-relation scores (softmax)", atol=1e-7)
+    agg = SumAggregator_urh_matrix("m", B, D, name="0_0", weights=np.eye(D, dtype=np.float32), bias=np.zeros(D, np.float32),
+                                   urh_weights=np.zeros((3 * D, 1), np.float32), urh_bias=np.zeros(1, np.float32), device=dev)
+    for fn in (agg._mix_neighbor_vectors, agg._mix_neighbor_vectors_urv):
+        assert_close(fn(t(nv), t(nr), t(u)).cpu().numpy(), want, "class surface")
+    # SumAggregator_urh_matrix's own mixers on their own (aggregators.py:118-152): the fused _call does not come through them
+    w = rng.standard_normal((3 * D, 1)).astype(np.float32)
+    agg2 = SumAggregator_urh_matrix("m", B, D, name="0_0", weights=np.eye(D, dtype=np.float32), bias=np.zeros(D, np.float32),
+                                    urh_weights=w, urh_bias=np.zeros(1, np.float32), device=dev)
+    sv = rng.standard_normal((B, N, D)).astype(np.float32)
+    cat = np.concatenate([np.broadcast_to(u[:, None, None, :], nr.shape), nr, np.broadcast_to(sv[:, :, None, :], nr.shape)], -1)
+    s_ = (cat.astype(np.float64) @ w.astype(np.float64))[..., 0]                    # [user ; relation ; self] . urh_weights (:130-133)
+    p_ = np.exp(s_ - s_.max(-1, keepdims=True))
+    p_ /= p_.sum(-1, keepdims=True)
+    got_a, got_p = agg2._mix_neighbor_vectors_urh(t(sv), t(u), t(nv), t(nr))
+    assert_close(got_p.cpu().numpy(), p_, "urh probs", atol=1e-6)
+    assert_close(got_a.cpu().numpy(), (p_[..., None] * nv).mean(2), "urh aggregate", rtol=1e-5, atol=2e-6)
+    assert_close(agg2._mix_neighbor_vectors_no_ur(t(sv), t(u), t(nv), t(nr)).cpu().numpy(), nv.astype(np.float64).mean(2), "plain mean")
