@@ -229,10 +229,16 @@ __global__ __launch_bounds__(kBlock) void mix_urv_kernel(const float* __restrict
             p = e / wave_sum(e);
         }
         if (probs && lane < K) probs[t * K + lane] = p;
-        for (int d = lane; d < D; d += kWave) {
+        for (int d0 = 0; d0 < D; d0 += kWave) {          // (wave-uniform trip count: the broadcasts below need every lane awake)
+            const int d = d0 + lane;
+            const bool live = d < D;
             float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc = fmaf(__shfl(p, k, kWave), nv[(int64_t)k * D + d], acc);
-            out[t * D + d] = acc / (float)K;             // tf.reduce_mean(p * neighbor_vectors, axis=2)
+            for (int k = 0; k < K; ++k) {
+                const float pk = __shfl(p, k, kWave);
+                const float x = nv[(int64_t)k * D + (live ? d : 0)];
+                acc = fmaf(pk, live ? x : 0.f, acc);
+            }
+            if (live) out[t * D + d] = acc / (float)K;   // tf.reduce_mean(p * neighbor_vectors, axis=2)
         }
     }
 }
