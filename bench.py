@@ -101,6 +101,9 @@ def parse():
                     help="builder-side projection on ONE GPU: score rank 0's share of the global batch as one of W ranks "
                          "would (user-sorted split, row-shard exchange of the whole table per step); the line is marked "
                          "`emulated_world` and its `value` is per-rank pairs/s x W -- never a measurement of W GPUs")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent steps are enqueued round-robin on this many HIP streams (single GPU, tables replicated, no "
+                         "hipGraph replay): the drain of one step's kernels overlaps the ramp of the next one's; 1 = one stream")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: launch / join the --gpus N ranks, all-reduce one number through the process group, "
@@ -676,8 +679,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        out = step()
+    # Steps are independent scoring passes: they go round-robin to `--streams` HIP streams (every step still runs its kernels in
+    # order on ITS stream; the workspaces of the one-call schedule are per stream).  Not for the row-sharded runner (it has its own
+    # two-stream exchange / score protocol) nor for a hipGraph replay.
+    nstreams = a.streams if (a.streams > 1 and not rowshard and scorer is None) else 1
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else None
+    if lanes:
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream())
+    plain_step = step
+
+    def step_on(i):
+        if lanes is None:
+            return plain_step()
+        with torch.cuda.stream(lanes[i % nstreams]):
+            return plain_step()
+
+    for i in range(max(a.warmup, nstreams)):
+        out = step_on(i)
     barrier()
     # The dominant kernel is timed with HIP events around its launches inside the timed steps (model._profile).  At
     # small batches the pass is ONE native call (mvin_score_l2_fwd, no event hooks inside): there the timed steps run
@@ -685,12 +704,20 @@ def main():
     grouped_now = by_user and Bl >= model.group_min_pairs_per_user * min(case.n_user, distinct or case.n_user)
     one_call = (scorer is None and (Bl <= model.native_l2_max_batch or grouped_now)
                 and model._native_l2_ok(items, None if by_user else mh, False, cap=not grouped_now))
+    one_call = one_call or lanes is not None          # (several streams: the kernel is timed in the single-stream repeat, not overlapped)
     model._profile = None if one_call else []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
+    for i in range(a.steps):
+        out = step_on(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    single_stream = None
+    if lanes is not None:                              # the same K steps on ONE stream, after the clock stopped (continuity with rounds 1-4)
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        barrier()
+        single_stream = (time.perf_counter() - t1) / a.steps
     if one_call:
         model._profile = []
         for _ in range(a.steps):
@@ -846,7 +873,7 @@ def main():
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
-                       "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer),
+                       "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer), "streams": nstreams,
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",
                        "key_addressing_variant": (
@@ -892,6 +919,11 @@ def main():
                                         else "all_to_all_single (ids) + all_to_all_single (rows), static equal splits",
                           "world_in_formula": W_})
         rec["distributed"] = dinfo
+        if single_stream is not None:
+            rec.setdefault("other_modes", {})["single_stream"] = {
+                "value": (Bl if emulated else a.batch) / single_stream, "unit": "pairs/s", "ms_per_step": 1e3 * single_stream,
+                "note": "the same K steps enqueued on ONE stream (how rounds 1-4 ran the line): every kernel waits for the last workgroup "
+                        "of the one before; with `config.streams` streams the independent steps' kernels fill those drains"}
         if a.emulate_world > 1 and world == 1:
             rec["projected_value"] = a.batch * a.steps / elapsed
             rec["emulated_world"] = {"world": a.emulate_world, "per_rank_pairs_per_s": Bl * a.steps / elapsed,
