@@ -308,10 +308,13 @@ def pmc_record(name):
 def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5, uts=None):
     """Whole get_scores path at the reference's own batch sizes: per-pair feeds (the contents of the
     reference's feed_dict) as eager launches and replayed as one hipGraph (mvin_amd.graph.GraphedScorer), and -- ``uts``
-    given -- the users feed (user_triplet_set resident, MVIN.forward_users) as eager launches."""
+    given -- the users feed (user_triplet_set resident, MVIN.forward_users) as eager launches.  `*_two_streams`: the same
+    back-to-back batches enqueued round-robin on two HIP streams, as mvin_amd.harness.ctr_eval_device scores the batches of an
+    evaluation: a pass at these sizes is a dependent chain of loads, two passes in flight overlap their waits."""
     import torch
     from mvin_amd.graph import GraphedScorer
     out = []
+    steps = max(steps, 60)
     for B in sizes:
         if B > users.shape[0]:
             continue
@@ -319,8 +322,22 @@ def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5, uts=
         feed = (users[sl].contiguous(), items[sl].contiguous(), [m[sl].contiguous() for m in mh],
                 [m[sl].contiguous() for m in mr], [m[sl].contiguous() for m in mt])
         rec = {"batch": B}
-        for mode in ("eager", "hipgraph", "users_feed"):
-            if mode == "hipgraph":
+        lanes = [torch.cuda.Stream(device=users.device) for _ in range(2)]
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream())
+        for mode in ("eager", "eager_two_streams", "hipgraph", "users_feed", "users_feed_two_streams"):
+            if mode.endswith("two_streams"):
+                if mode.startswith("users") and uts is None:
+                    continue
+                one = ((lambda: model.forward_users(feed[0], feed[1], uts)) if mode.startswith("users")
+                       else (lambda: model.forward_device(*feed)))
+                turn = {"i": 0}
+
+                def fn(one=one, turn=turn):          # independent batches round-robin on two streams (harness.ctr_eval_device)
+                    turn["i"] ^= 1
+                    with torch.cuda.stream(lanes[turn["i"]]):
+                        return one()
+            elif mode == "hipgraph":
                 sc = GraphedScorer(model, B)
                 sc.load(*feed)
                 fn = sc.replay

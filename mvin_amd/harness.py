@@ -189,20 +189,47 @@ def ctr_eval(args, model, data, user_triplet_set, batch_size, sess=None):
     return aucs, accs, f1s, float(np.mean(aucs)), float(np.mean(accs)), float(np.mean(f1s))
 
 
-def ctr_eval_device(feeder, data, batch_size):
-    """Same numbers as ctr_eval, feeds assembled on the device."""
+def ctr_eval_device(feeder, data, batch_size, streams=2, window=16):
+    """Same numbers as ctr_eval, feeds assembled on the device.  The batches of an evaluation are independent: they are
+    enqueued round-robin on ``streams`` HIP streams (at the reference's batch sizes a scoring pass is one launch that walks a
+    dependent chain of loads -- two passes in flight overlap their waits: 24 vs 36 us per 512-pair batch at C3), ``window``
+    batches ahead of the host-side metrics; ``streams=1`` scores and reads back one batch at a time."""
+    import torch
     from sklearn.metrics import f1_score, roc_auc_score
     aucs, accs, f1s = [], [], []
-    start = 0
-    while start + batch_size <= data.shape[0]:
-        blk = data[start:start + batch_size]
-        s = feeder.scores(blk[:, 0], blk[:, 1]).cpu().numpy()
+    starts = list(range(0, data.shape[0] - batch_size + 1, batch_size))
+    dev = feeder.model.device
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+    if lanes:
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream(dev))
+    pending = []
+
+    def finish(entry):
+        blk, s, ev = entry
+        if ev is not None:
+            ev.synchronize()
+        s = s.cpu().numpy()
         labels = blk[:, 2].astype(np.float32)
         aucs.append(roc_auc_score(y_true=labels, y_score=s))
         pred = (s >= 0.5).astype(np.float32)
         f1s.append(f1_score(y_true=labels, y_pred=pred))
         accs.append(float(np.mean(pred == labels)))
-        start += batch_size
+
+    for i, start in enumerate(starts):
+        blk = data[start:start + batch_size]
+        if lanes:
+            with torch.cuda.stream(lanes[i % streams]):
+                s = feeder.scores(blk[:, 0], blk[:, 1])
+                ev = torch.cuda.Event()
+                ev.record()
+        else:
+            s, ev = feeder.scores(blk[:, 0], blk[:, 1]), None
+        pending.append((blk, s, ev))
+        if len(pending) > (window if lanes else 0):
+            finish(pending.pop(0))
+    while pending:
+        finish(pending.pop(0))
     return aucs, accs, f1s, float(np.mean(aucs)), float(np.mean(accs)), float(np.mean(f1s))
 
 
