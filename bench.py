@@ -305,6 +305,12 @@ def pmc_record(name):
         return None
 
 
+def get_lanes(dev, n=2):
+    """The process's scoring streams (mvin_amd.graph.scoring_streams: created once -- streams that share a hardware queue serialise)."""
+    from mvin_amd.graph import scoring_streams
+    return scoring_streams(dev, n)
+
+
 def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5, uts=None):
     """Whole get_scores path at the reference's own batch sizes: per-pair feeds (the contents of the
     reference's feed_dict) as eager launches and replayed as one hipGraph (mvin_amd.graph.GraphedScorer), and -- ``uts``
@@ -322,7 +328,7 @@ def batch_sweep(model, users, items, mh, mr, mt, sizes, steps=30, warmup=5, uts=
         feed = (users[sl].contiguous(), items[sl].contiguous(), [m[sl].contiguous() for m in mh],
                 [m[sl].contiguous() for m in mr], [m[sl].contiguous() for m in mt])
         rec = {"batch": B}
-        lanes = [torch.cuda.Stream(device=users.device) for _ in range(2)]
+        lanes = get_lanes(users.device, 2)
         for ln in lanes:
             ln.wait_stream(torch.cuda.current_stream())
         for mode in ("eager", "eager_two_streams", "hipgraph", "users_feed", "users_feed_two_streams"):
@@ -700,7 +706,7 @@ def main():
     # order on ITS stream; the workspaces of the one-call schedule are per stream).  Not for the row-sharded runner (it has its own
     # two-stream exchange / score protocol) nor for a hipGraph replay.
     nstreams = a.streams if (a.streams > 1 and not rowshard and scorer is None) else 1
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else None
+    lanes = get_lanes(dev, nstreams) if nstreams > 1 else None
     if lanes:
         for ln in lanes:
             ln.wait_stream(torch.cuda.current_stream())

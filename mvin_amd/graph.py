@@ -8,6 +8,20 @@ replays it per batch: one graph launch instead of ~10 kernel launches plus Pytho
 """
 import torch
 
+_STREAMS = {}
+
+
+def scoring_streams(device, n=2):
+    """The process's ``n`` streams for independent scoring passes, created ONCE per device.  HIP maps streams onto a handful
+    of hardware queues round-robin and two streams that share a queue serialise: a pair of streams created late in a process
+    that already holds several landed on one queue (the two-stream rate at 512 pairs was 36 us instead of 24).  Callers that
+    pipeline independent batches (mvin_amd.harness.ctr_eval_device, bench.py) take their streams from here."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _STREAMS:
+        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _STREAMS[key]
+
 
 class GraphedScorer(object):
     def __init__(self, model, batch_size, warmup=2):

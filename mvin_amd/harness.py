@@ -199,7 +199,8 @@ def ctr_eval_device(feeder, data, batch_size, streams=2, window=16):
     aucs, accs, f1s = [], [], []
     starts = list(range(0, data.shape[0] - batch_size + 1, batch_size))
     dev = feeder.model.device
-    lanes = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+    from .graph import scoring_streams
+    lanes = scoring_streams(dev, streams) if streams > 1 else None
     if lanes:
         for ln in lanes:
             ln.wait_stream(torch.cuda.current_stream(dev))

@@ -23,5 +23,7 @@ def run(nstreams, steps=200 if B <= 65536 else 40):
             model.forward_users(users, items, uts)
     torch.cuda.synchronize()
     return (time.perf_counter()-t0)/steps*1e3
+import sys
+ST=int(sys.argv[2]) if len(sys.argv)>2 else None
 for n in (1,2,3,1,2):
-    print(B, n, "streams:", round(1e3*run(n),1), "us/step")
+    print(B, n, "streams:", round(1e3*(run(n, ST) if ST else run(n)),1), "us/step")
