@@ -703,9 +703,13 @@ def main():
         torch.cuda.synchronize()
 
     # Steps are independent scoring passes: they go round-robin to `--streams` HIP streams (every step still runs its kernels in
-    # order on ITS stream; the workspaces of the one-call schedule are per stream).  Not for the row-sharded runner (it has its own
-    # two-stream exchange / score protocol) nor for a hipGraph replay.
-    nstreams = a.streams if (a.streams > 1 and not rowshard and scorer is None) else 1
+    # order on ITS stream; the workspaces of the one-call schedule are per stream).  Not for a hipGraph replay.  The row-sharded
+    # runner in its pipelined form takes exactly two: step i scores working table i % 2 on stream i % 2 while the exchange for step
+    # i + 1 fills the other table on the runner's side stream (the buffer's ready / free events order the three streams); its
+    # serialised form (--no-overlap: one working table) keeps one.
+    nstreams = a.streams if (a.streams > 1 and scorer is None and (not rowshard or overlap)) else 1
+    if rowshard and nstreams > 1:
+        nstreams = 2
     lanes = get_lanes(dev, nstreams) if nstreams > 1 else None
     if lanes:
         for ln in lanes:

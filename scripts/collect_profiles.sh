@@ -15,7 +15,10 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-bargs="--steps 5 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-sweep $*"
+# --streams 1: the per-kernel durations and counters are those of kernels running ALONE (the default line interleaves independent steps on
+# two streams: kernels of different steps overlap, and rocprofv3 then reports inflated, mixed per-kernel figures -- 2.03 ms for the packed
+# kernel against 1.69 ms un-overlapped); bench.py times the kernel the same way (single-stream repeat after the clock stops)
+bargs="--steps 5 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-sweep --streams 1 $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/bench.py" $bargs > "$out/bench_stats.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/pmc_$c" -- python "$root/bench.py" $bargs > "$out/bench_pmc_$c.log" 2>&1

@@ -5,7 +5,7 @@ tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 o=$root/gpurun_out/ks_$tag; mkdir -p "$o"
 cd /tmp && export TMPDIR=/tmp
-timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$o" -- python "$root/bench.py" --no-hbm-leg --no-sweep --no-cpu-baseline --steps 5 --warmup 1 "$@" > "$o/log" 2>&1 < /dev/null
+timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$o" -- python "$root/bench.py" --no-hbm-leg --no-sweep --no-cpu-baseline --steps 5 --warmup 1 --streams 1 "$@" > "$o/log" 2>&1 < /dev/null
 f=$(ls "$o"/*/*kernel_stats.csv 2>/dev/null | head -1)
 echo "== $tag: $*"
 [ -n "$f" ] && head -7 "$f" | python3 -c "

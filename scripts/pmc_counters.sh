@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/pmc_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-bargs="--steps 3 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-sweep $*"
+bargs="--steps 3 --warmup 1 --no-cpu-baseline --no-hbm-leg --no-sweep --streams 1 $*"     # (kernels alone: see collect_profiles.sh)
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
            "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
