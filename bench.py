@@ -105,6 +105,9 @@ def parse():
                     help="independent steps are enqueued round-robin on this many HIP streams (single GPU, tables replicated, no "
                          "hipGraph replay): the drain of one step's kernels overlaps the ramp of the next one's; 1 = one stream")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--ablation", default="all",
+                    help="the reference's --ablation preset (parameter_ablation.py); anything but 'all' is a different workload, "
+                         "named in config.ablation")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only: launch / join the --gpus N ranks, all-reduce one number through the process group, "
                          "print {\"launch_check\": ...} on rank 0 and exit before any GPU work (argument plumbing test)")
@@ -606,7 +609,7 @@ def main():
         raise SystemExit("--batch must be divisible by the number of ranks")
     Bl = a.batch // split                       # pairs this rank scores per step
     margs = make_args(dataset=a.dataset, dim=a.dim, neighbor_sample_size=a.fanout, h_hop=a.hop,
-                      n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=Bl)
+                      n_mix_hop=a.mix, p_hop=d["p_hop"], n_memory=d["n_memory"], batch_size=Bl, ablation=a.ablation)
     # one global synthetic batch (same seed everywhere); rank r scores pairs [r*Bl, (r+1)*Bl).
     # Pairs are independent: no data-path reduction across ranks.
     if a.n_entity:   # HBM-bound variant: same workload on a table far larger than the Infinity Cache
@@ -745,6 +748,20 @@ def main():
             out = step()
         barrier()
         single_stream = (time.perf_counter() - t1) / a.steps
+    faithful = None
+    if scorer is None and not rowshard and model.prj is None and model._prj_for_l2(Bl, Bl * a.fanout ** (a.hop * a.mix - 2)) \
+            and model._enc_for_l2(n_parents=Bl * a.fanout ** (a.hop * a.mix - 2)) is not None:
+        # the same K steps with the two deepest levels in their round-4 form (W1 / W2 products per distinct child), one stream
+        model.prj = False
+        for _ in range(3):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            out_f = step()
+        barrier()
+        faithful = ((time.perf_counter() - t1) / a.steps, float((out_f.scores - out.scores).abs().max()))
+        model.prj = None
     if one_call:
         model._profile = []
         for _ in range(a.steps):
@@ -801,8 +818,13 @@ def main():
         table_bytes = case.n_entity * a.dim * s_
         cache_resident = table_bytes <= 256 * 2 ** 20        # Infinity Cache (MI355X_MICROARCH.md)
         enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
+        prj_now = enc is not None and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "gather_attn_l2_packed_kernel<..., PRJ> (mvin_gather_attn_l2_prj_fwd: duplicate-slot encoding of the adjacency, rows "
+                      "gathered from the projected tables E.W1 | E.W2 that mvin_project_rows rebuilds every step -- same ids, rows and "
+                      "bytes per pair as mvin_gather_attn_l2_enc_fwd, no W1 / W2 product per distinct child)"
+                 if prj_now
                  else "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd: duplicate-slot encoding of the adjacency)"
                  if enc is not None
                  else "gather_attn_l2_kernel (mvin_gather_attn_l2_fwd)" if used_l2
@@ -900,7 +922,10 @@ def main():
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
-                       "adjacency": a.adj, "items": a.items, "hipgraph_replay": bool(scorer), "streams": nstreams,
+                       "adjacency": a.adj, "items": a.items, "ablation": a.ablation, "hipgraph_replay": bool(scorer), "streams": nstreams,
+                       "two_level_form": ("projected tables (E.W1 | E.W2 rebuilt inside every timed step: mvin_project_rows + "
+                                          "mvin_gather_attn_l2_prj_fwd)" if prj_now else
+                                          "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",
                        "key_addressing_variant": (
@@ -951,6 +976,12 @@ def main():
                 "value": (Bl if emulated else a.batch) / single_stream, "unit": "pairs/s", "ms_per_step": 1e3 * single_stream,
                 "note": "the same K steps enqueued on ONE stream (how rounds 1-4 ran the line): every kernel waits for the last workgroup "
                         "of the one before; with `config.streams` streams the independent steps' kernels fill those drains"}
+        if faithful is not None:
+            rec.setdefault("other_modes", {})["unprojected_two_level"] = {
+                "value": (Bl if emulated else a.batch) / faithful[0], "unit": "pairs/s", "ms_per_step": 1e3 * faithful[0], "streams": 1,
+                "max_abs_diff_vs_timed_scores": faithful[1],
+                "note": "the same steps on one stream with mvin_gather_attn_l2_enc_fwd (W1 / W2 applied per distinct child: rounds 1-4) "
+                        "instead of the projected tables; compare with other_modes.single_stream"}
         if a.emulate_world > 1 and world == 1:
             rec["projected_value"] = a.batch * a.steps / elapsed
             rec["emulated_world"] = {"world": a.emulate_world, "per_rank_pairs_per_s": Bl * a.steps / elapsed,

@@ -69,7 +69,7 @@ class ScoreL2Args(C.Structure):
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
         ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p),
-        ("user_records", C.c_void_p), ("depth", C.c_int)]
+        ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -83,6 +83,8 @@ SIGNATURES = {
     "mvin_score_small_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "mvin_mix_neighbor_vectors_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 3),
     "mvin_score_small_supported": (C.c_int, [C.c_int] * 5),
+    "mvin_project_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6),
+    "mvin_gather_attn_l2_prj_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 9 + [C.c_int] * 6 + [C.c_void_p] * 3),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_linear_wgrad_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -209,8 +211,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 9:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 9")
+    if ver != 10:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 10")
     _lib = lib
     return lib
 

@@ -193,8 +193,10 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D,
                                int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
-                               float* probs_child, int table_bf16, void* stream, bool encoded = false) {
-    const char* who = encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
+                               float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false) {
+    const char* who = prj ? "mvin_gather_attn_l2_prj_fwd" : encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
+    if (prj && (!encoded || table_bf16 || !W1 || !W2 || !q))
+        return fail(-1, "%s: projected tables are fp32 and go with the encoded adjacency, the projection matrices and the queries", who);
     if (encoded && !mvin::fused_packed_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {32,64,128}, K in {16,32,64,128})", who, D, K);
     if (!mvin::fused_l2_supported(D, K))
@@ -234,6 +236,7 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
     f.nR = nR;
     f.pid_stride = pid_stride;
     f.max_id = (unsigned)(n_entity - 1);
+    f.prj = prj ? 1 : 0;
     int l = 0;
     while ((4 << l) < K) ++l;
     f.lpn_log2 = l;
@@ -247,7 +250,7 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
             return fail(-3, "%s: tables too large (n_entity <= 2^24, table < 4 GiB, adjacency and outputs < 2 GiB)", who);
         // D = 32, K <= 16 (BASELINE C2): the wave-per-parent kernel reads the encoding too (MVIN_L2_D32ENC=0: the packed-tile kernel, A/B)
         static const bool d32enc_off = getenv("MVIN_L2_D32ENC") && atoi(getenv("MVIN_L2_D32ENC")) == 0;
-        if (!d32enc_off && mvin::fused_d32_applies(f, D))
+        if (!prj && !d32enc_off && mvin::fused_d32_applies(f, D))
             return hip_result(mvin::launch_gather_attn_l2_d32(f, table_bf16, (hipStream_t)stream, true), who);
         return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
     }
@@ -264,6 +267,46 @@ int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_entity, co
     return gather_attn_l2_impl(table, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
                                parent_ids_i64 ? 2 : 1, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K, D, n_entity,
                                nR, nagg0, nagg1, nullptr, nullptr, table_bf16, stream, true);
+}
+
+// out[z] = src . W_z (+ b_z), z = 0, 1: the two projections of the levels the fused kernel gathers, of table rows or of queries
+static int prj_linear(const float* src, int64_t rows, int D, const float* W1, const float* W2, const float* b1, const float* b2,
+                      float* out, void* stream) {
+    mvin_linear_args l{};
+    l.src[0] = src;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = rows;
+    l.rows_per_group = 1;
+    l.W = W1;
+    l.w_zstride = W2 - W1;                    // (elements; the two matrices need not be adjacent)
+    l.bias = b1;
+    l.bias_zstride = b1 ? b2 - b1 : 0;
+    l.out = out;
+    l.ldo = D;
+    l.nz = 2;
+    l.out_zstride = rows * D;
+    return mvin_linear_fwd(&l, stream);
+}
+
+int mvin_project_rows(const float* src, int64_t rows, int D, const float* W1, const float* W2, const float* b1, const float* b2,
+                      float* out, void* stream) {
+    const char* who = "mvin_project_rows";
+    if (!src || !W1 || !W2 || !out) return fail(-1, "%s: null pointer", who);
+    if ((b1 == nullptr) != (b2 == nullptr)) return fail(-1, "%s: b1 and b2 go together", who);
+    if (rows <= 0 || D <= 0) return fail(-2, "%s: rows=%lld D=%d", who, (long long)rows, D);
+    return prj_linear(src, rows, D, W1, W2, b1, b2, out, stream);
+}
+
+int mvin_gather_attn_l2_prj_fwd(const float* tables, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
+                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
+                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity,
+                                int nR, float* nagg0, float* nagg1, void* stream) {
+    return gather_attn_l2_impl(tables, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
+                               parent_ids_i64 ? 2 : 1, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K,
+                               D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, true, true);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -540,6 +583,15 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
+    if (enc && a->prj_tables && a->W1 && !a->table_bf16) {
+        // projected-tables form: E.W1 | E.W2 once per entity from the CURRENT parameters (nothing is kept between calls), then
+        // the packed kernel without its W1 / W2 products per distinct child
+        rc = prj_linear(reinterpret_cast<const float*>(a->entity_emb), a->n_entity, D, a->W1, a->W2, nullptr, nullptr, a->prj_tables, stream);
+        if (rc) return rc;
+        rc = gather_attn_l2_impl(a->prj_tables, a->enc_entity, a->enc_relation, reinterpret_cast<const int32_t*>(a->items), 2,
+                                 a->t0, a->t1, a->W1, a->W2, a->b1, a->b2, a->user_o, a->A0, a->a0, (int)a->B, 1, a->K, D,
+                                 a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr, 0, stream, true, true);
+    } else
     rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                              reinterpret_cast<const int32_t*>(a->items), 2,
                              a->t0, a->t1, a->W1, a->W2, a->b1, a->b2, a->W1 ? a->user_o : nullptr, a->A0, a->a0,

@@ -99,14 +99,15 @@ struct PackGeom {
 
 // LDS layout (words unless noted); the same function sizes the launch
 struct PackLds {
-    size_t sA, sZ, sYP, sW0, sW1, sSeg, sSegP, sSegF, sMeta, sPR, sSt, sCarry, sCnt, sT0, sT1, sBias, sPid, sPq, sPcnt, total;
+    size_t sA, sZ, sYP, sW0, sW1, sSeg, sSegP, sSegF, sMeta, sPR, sSt, sCarry, sCnt, sT0, sT1, sBias, sPid, sPq, sPcnt, sU, total;
 };
 // the dense waves gather the second round of a tile (see HELP in the kernel): its lists are double-buffered
 __host__ __device__ constexpr bool pack_help(int D, int K, bool bf, int NG) {
     const int epl = (bf && D == 128) ? 8 : 4, rpwx = 64 / (D / epl), nrnd = (32 / NG) / rpwx;
     return nrnd == 2 && !(bf && D == 128) && K <= 32;
 }
-__host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool bf) {
+constexpr int kPackUR = 32;         // projected-tables form: parents whose projected queries a dense wave keeps (a ring, two batches of 16)
+__host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool bf, bool prj = false) {
     PackLds l{};
     const size_t NM = D / 16, nRp = (nR + 1) & ~1;
     size_t o = 0;
@@ -132,6 +133,7 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool b
     l.sPid = take(kPackCH);
     l.sPq = take(kPackCH);
     l.sPcnt = take(kPackCH / 4);                        // bytes
+    l.sU = take(prj ? NM * kPackUR * 32 : 0);           // per dense wave: [kPackUR][2][16]  (q.W1 + b1 | q.W2 + b2), its 16 columns
     l.total = o * 4;
     return l;
 }
@@ -140,12 +142,19 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool b
 // dense and first front wave (s_memtime), read back with mvin_debug_read_trace under MVIN_PACK_TRACE (scripts/trace_packed.py)
 __device__ unsigned long long g_pack_prof[2 * 8];
 
-template <int D, int KT, bool BF, int NG, bool PROF = false>
+// PRJ: the projected-tables form (mvin_gather_attn_l2_prj_fwd).  The user-oriented projection is linear and the attention
+// weights are scalars, so  (S' + c q) W2 + c b2 = sum_k w_k (E.W2)[y_k] + c (q.W2 + b2)  and  (E[x1] + q) W1 + b1 =
+// (E.W1)[x1] + (q.W1 + b1): with the two products taken once per ENTITY (a.table = [E.W1 ; E.W2]) the rows this kernel
+// gathers are already projected -- the same rows, ids and bytes per pair, no W1 / W2 product per distinct child (two thirds
+// of the MFMA work of a tile) -- and phase B is the plain sum plus the PARENT's projected query: u1 = q.W1 + b1, u2 = q.W2 + b2,
+// one 16-parent MFMA batch per dense wave every ~4 tiles (a wave-private ring in LDS; the front loads no query rows at all).
+template <int D, int KT, bool BF, int NG, bool PROF = false, bool PRJ = false>
 __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_attn_l2_packed_kernel(FusedL2Args a, int ppw) {
+    static_assert(!(PRJ && BF), "projected tables are fp32");
     using G = PackGeom<D, KT, BF, NG>;
     constexpr int TM = G::TM, NM = G::NM, KS = G::KS, LDA = G::LDA, LDZ = G::LDZ, YLD = G::YLD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const PackLds L = pack_lds(D, KT, a.nR, NG, BF);
+    const PackLds L = pack_lds(D, KT, a.nR, NG, BF, PRJ);
     float* sA = smem + L.sA;                            // [2][TM][LDA]  {E[x1] + q | S' + (sum p / K) q}
     float* sZ = smem + L.sZ;                            // [TM][LDZ]
     int* sYI = reinterpret_cast<int*>(smem + L.sYP);    // [TM][YLD]  grandchild ids; rows private to a front wave
@@ -171,7 +180,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     int lane = tid & 63;                                // (not const: the dense loop re-defines it, see there)
     const int wave = tid >> 6;
     const bool is_dense = wave < NM;
-    const bool has_proj = a.W1 != nullptr;
+    const bool has_proj = PRJ ? false : a.W1 != nullptr;
     const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
     const float invK = 1.f / (float)KT;
     long long prof_last = 0;
@@ -204,8 +213,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     if (tid == 0) sCnt[0] = 0;
     for (int i = tid; i < D; i += G::NW * 64) {
         sBias[i] = a.a0 ? a.a0[i] : 0.f;
-        sBias[D + i] = (has_proj && a.b1) ? a.b1[i] : 0.f;
-        sBias[2 * D + i] = (has_proj && a.b2) ? a.b2[i] : 0.f;
+        sBias[D + i] = ((has_proj || PRJ) && a.b1) ? a.b1[i] : 0.f;       // (PRJ: added to the projected queries, not in phase B)
+        sBias[2 * D + i] = ((has_proj || PRJ) && a.b2) ? a.b2[i] : 0.f;
     }
     for (int i = tid; i < n_loc; i += G::NW * 64) {
         const int pid = fused_parent_id(a, p_base + i);
@@ -223,12 +232,14 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     const float c2scale = has_att0 ? invK : 1.f;        // (sum_k p_k) / K
     int g = lane / G::LPRX, c = lane % G::LPRX;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
+        const_cast<void*>(a.table), 0, (int)(PRJ ? 2 * a.table_bytes : a.table_bytes), 0x00020000);
+    const unsigned q_bytes = (unsigned)((a.P / a.parents_per_pair) * D * 4);
     const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
+        const_cast<float*>(a.q), 0, has_proj ? (int)q_bytes : 0, 0x00020000);
+    const unsigned t2_off = PRJ ? (unsigned)a.table_bytes : 0u;      // grandchild rows come from the second table
     unsigned c16 = (unsigned)c * 16u;
     // a table row as this lane's EPL elements
-    auto rowload = [&](int id, float4& lo, float4& hi) {
+    auto rowload = [&](int id, float4& lo, float4& hi, unsigned toff = 0u) {
         if constexpr (G::WIDE) {
             const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 2)) + c16, 0, 0);
             lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
@@ -237,7 +248,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             const auto raw = __builtin_amdgcn_raw_buffer_load_b64(rsrc, ((unsigned)id * (unsigned)(D * 2)) + (unsigned)c * 8u, 0, 0);
             lo = bf16x4_to_f32(make_uint2(raw[0], raw[1]));
         } else {
-            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16, 0, 0);
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((unsigned)id * (unsigned)(D * 4)) + c16 + toff, 0, 0);
             lo = make_float4(__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]), __uint_as_float(raw[3]));
         }
     };
@@ -311,18 +322,24 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     rowload(xx[h], sv, sv1);
                     // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
                     const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
-                    qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
-                    if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
+                    if constexpr (!PRJ) {
+                        qa = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff, 0, 0);
+                        if constexpr (G::WIDE) qb = __builtin_amdgcn_raw_buffer_load_b128(qsrc, qoff + 16u, 0, 0);
+                    }
                 }
                 float4 lo[NB], hi[NB];
 #pragma unroll
-                for (int i = 0; i < NB; ++i) rowload(sYI[lb + k0 + i], lo[i], hi[i]);
+                for (int i = 0; i < NB; ++i) rowload(sYI[lb + k0 + i], lo[i], hi[i], t2_off);
                 if constexpr (FIRST) {
                     const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
                     const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
-                    put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));                  // E[x1] + q
-                    acc = f4_fma(c2scale, q0, acc);                                        // S' + (sum p / K) q
-                    if constexpr (G::WIDE) acc1 = f4_fma(c2scale, q1, acc1);
+                    if constexpr (PRJ) {
+                        put(arow, sv, sv1);                                                // (E.W1)[x1]; the parent's u1 / u2 join in phase B
+                    } else {
+                        put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));              // E[x1] + q
+                        acc = f4_fma(c2scale, q0, acc);                                    // S' + (sum p / K) q
+                        if constexpr (G::WIDE) acc1 = f4_fma(c2scale, q1, acc1);
+                    }
                 }
                 // the weights are read when the rows are consumed: not live while the loads are in flight
 #pragma unroll
@@ -357,7 +374,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     };
 
     // DPAR: the parent softmax (segment tables of the next tile) runs on the dense waves, in their slack, not on the front
-    constexpr bool DPAR = HELP && NM >= NG;
+    constexpr bool DPAR = HELP && NM >= NG;         // (PRJ with the parent softmax left on the front: 1.495 vs 1.492 ms -- the same)
     struct Tile {
         int i0, c0;          // first parent (local index), children of it placed in earlier tiles
         int nseg, rows;      // parents in the tile (0: no tile), child rows
@@ -511,6 +528,65 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             bA0[s] = a.A0[kk * D + col];
         }
         float* carry = sCarry + wave * 32;
+        // PRJ: the projected queries u1 = q.W1 + b1, u2 = q.W2 + b2 of the workgroup's parents, sixteen parents per batch, this
+        // wave's 16 columns of each; lane group q16 contracts k = KS q16 .. KS q16 + KS - 1 (its A values are one contiguous run
+        // of the query row).  A tile spans at most 16 parents, so a ring of kPackUR = 32 always holds the tile at hand
+        float* sUw = smem + L.sU + (PRJ ? wave * (kPackUR * 32) : 0);
+        int ucount = 0;
+        // (buffer loads: ONE offset register per operand and the step in the instruction's immediate -- with flat loads hipcc
+        //  precomputed 2 KS 64-bit addresses, ran out of registers and issued load -> vmcnt(0) -> MFMA 2 KS times per batch)
+        const __amdgpu_buffer_rsrc_t w1src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W1), 0, PRJ ? D * D * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t w2src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W2), 0, PRJ ? D * D * 4 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t uqsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.q), 0, PRJ ? (int)q_bytes : 0, 0x00020000);
+        constexpr int UKC = KS < 16 ? KS : 16;       // MFMA steps per round of a batch (D = 128: two rounds)
+        struct UQ {
+            u32x4 v[UKC / 4];                            // a lane's run of the parent's query row (one round)
+        };
+        auto u_issue_q = [&](UQ& o, int k0) {
+            if constexpr (PRJ) {
+                const int pi = ucount + l16 < n_loc ? ucount + l16 : n_loc - 1;
+                const unsigned qo = ((unsigned)sPq[pi] * (unsigned)D + (unsigned)(KS * q16)) * 4u;
+#pragma unroll
+                for (int k4 = 0; k4 < UKC / 4; ++k4) o.v[k4] = __builtin_amdgcn_raw_buffer_load_b128(uqsrc, qo + 4u * (unsigned)k0 + 16u * (unsigned)k4, 0, 0);
+            }
+        };
+        // one batch: the next 16 parents (prefetching the query rows a tile ahead was measured: no gain, 1.52 vs 1.49 ms)
+        auto u_batch = [&] {
+            if constexpr (PRJ) {
+                UQ o;
+                u_issue_q(o, 0);
+                const unsigned wo = ((unsigned)(KS * q16) * (unsigned)D + (unsigned)col) * 4u;
+                f32x4 u1 = (f32x4){0.f, 0.f, 0.f, 0.f}, u2 = u1;
+#pragma unroll
+                for (int k0 = 0; k0 < KS; k0 += UKC) {
+                    unsigned w1v[UKC], w2v[UKC];
+                    if (k0 > 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        u_issue_q(o, k0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < UKC; ++k) {
+                        w1v[k] = __builtin_amdgcn_raw_buffer_load_b32(w1src, wo, (k0 + k) * D * 4, 0);
+                        w2v[k] = __builtin_amdgcn_raw_buffer_load_b32(w2src, wo, (k0 + k) * D * 4, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < UKC; ++k) {
+                        const float av = __uint_as_float(o.v[k >> 2][k & 3]);
+                        u1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(w1v[k]), u1, 0, 0, 0);
+                        u2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(w2v[k]), u2, 0, 0, 0);
+                    }
+                }
+                const float b1v = sBias[D + col], b2v = sBias[2 * D + col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* d = sUw + ((ucount + 4 * q16 + r) & (kPackUR - 1)) * 32 + l16;
+                    d[0] = u1[r] + b1v;
+                    d[16] = u2[r] + b2v;
+                }
+                ucount += 16;
+                wave_lds_sync();
+            }
+        };
         int dense_iter = 0;
         constexpr int DMAXB = 8;                         // list rows in flight in the helping gather (the weights stay resident)
         // DPAR: dense wave w < NG walks the tiles itself (same packing as the front), one tile ahead of the front's gather, and
@@ -556,13 +632,20 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             const int mb = (int)((s - 1) % 3);         // segment tables: ring of three
             const int nseg = sMeta[2 * mb], rows = sMeta[2 * mb + 1];
             if (nseg == 0) break;
+            int i0t = 0;                                // PRJ: local index of the tile's first parent
+            if constexpr (PRJ) {
+                i0t = __builtin_amdgcn_readfirstlane(sSegP[mb * 16]) - (int)p_base;
+                while (i0t + nseg > ucount) u_batch();
+            }
             const float* tA = sA + buf * TM * LDA;
             const bool two = rows > 16;                 // second 16-row MFMA tile in use
             // weights of this lane's rows in the per-parent sums: A operand of the segment products, row 16 m + 4 q16 + r
             float wa0[G::RT][4], wa1[G::RT][4];
+            int sgi[G::RT][4];                          // (PRJ: the rows' segments pick the parent's projected query)
 #pragma unroll
             for (int m = 0; m < G::RT; ++m) {
                 const int4 sg = *reinterpret_cast<const int4*>(sSeg + mb * TM + 16 * m + 4 * q16);
+                sgi[m][0] = sg.x, sgi[m][1] = sg.y, sgi[m][2] = sg.z, sgi[m][3] = sg.w;
                 const float4 w0 = *reinterpret_cast<const float4*>(sW0 + mb * TM + 16 * m + 4 * q16);
                 const float4 w1 = *reinterpret_cast<const float4*>(sW1 + mb * TM + 16 * m + 4 * q16);
                 wa0[m][0] = sg.x == l16 ? w0.x : 0.f;
@@ -618,7 +701,13 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                             zv = s1v + (accS[m][r] + c2v);
                         } else {
                             s1v = tA[row * LDA + col];
-                            zv = s1v + tA[row * LDA + D + col];
+                            zv = tA[row * LDA + D + col];
+                            if constexpr (PRJ) {        // (E.W1)[x1] + u1 ;  sum_k w_k (E.W2)[y_k] + (sum p / K) u2
+                                const float* up = sUw + ((i0t + sgi[m][r]) & (kPackUR - 1)) * 32 + l16;
+                                s1v += up[0];
+                                zv = fmaf(c2scale, up[16], zv);
+                            }
+                            zv += s1v;
                         }
                         // nagg0[segment] += w0[row] self1[row]: contraction over this accumulator register's four rows
                         accN0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[m][r], s1v, accN0, 0, 0, 0);
@@ -876,11 +965,11 @@ hipError_t pack_read_prof(long long* host_dst, size_t n) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_pack_prof), zeros, sizeof(zeros));
 }
 
-template <int D, int KT, bool BF, int NG, bool PROF = false>
+template <int D, int KT, bool BF, int NG, bool PROF = false, bool PRJ = false>
 static hipError_t launch_packed(const FusedL2Args& a, hipStream_t st) {
     using G = PackGeom<D, KT, BF, NG>;
-    const size_t lds = pack_lds(D, KT, a.nR, NG, BF).total;
-    auto kern = gather_attn_l2_packed_kernel<D, KT, BF, NG, PROF>;
+    const size_t lds = pack_lds(D, KT, a.nR, NG, BF, PRJ).total;
+    auto kern = gather_attn_l2_packed_kernel<D, KT, BF, NG, PROF, PRJ>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -908,13 +997,28 @@ bool fused_packed_supported(int D, int K) {
 // 32-bit byte offsets, output rows indexable with an int
 bool fused_packed_applies(const FusedL2Args& a, int D) {
     return fused_packed_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_r && a.adj_bytes > 0 &&
-           a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31) && a.table_bytes < (1ull << 32) &&
+           a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31) && a.table_bytes < (a.prj ? (1ull << 31) : (1ull << 32)) &&
            a.max_id < (1u << 24) &&
-           (uint64_t)a.P / (uint64_t)a.parents_per_pair * D * 4 < (1ull << 31);
+           (uint64_t)a.P / (uint64_t)a.parents_per_pair * D * 4 < (a.prj ? (1ull << 30) : (1ull << 31));
 }
 
 template <int D, bool BF>
 static hipError_t launch_packed_k(const FusedL2Args& a, hipStream_t st) {
+    if constexpr (!BF) {
+        if (a.prj) {
+            switch (a.K) {
+                case 16: return launch_packed<D, 16, BF, 4, false, true>(a, st);
+                case 32:
+                    if constexpr (D == 64) {
+                        if (a.dbg & 8) return launch_packed<D, 32, BF, 4, true, true>(a, st);      // MVIN_SPLIT_DBG=8: profiled build
+                    }
+                    return launch_packed<D, 32, BF, 4, false, true>(a, st);
+                case 64: return launch_packed<D, 64, BF, 4, false, true>(a, st);
+                case 128: return launch_packed<D, 128, BF, 4, false, true>(a, st);
+                default: return hipErrorInvalidValue;
+            }
+        }
+    } else if (a.prj) return hipErrorInvalidValue;
     switch (a.K) {
         case 16: return launch_packed<D, 16, BF, 4>(a, st);
         case 32:

@@ -179,6 +179,8 @@ struct FusedL2Args {
     int pid_stride;              // 1: parent_ids is int32 [P]; 2: the low words of an int64 [P] array (little endian)
     unsigned max_id;             // n_entity - 1: parent ids are clamped (a fault would kill the process)
     int dbg;                     // timing experiments only (MVIN_SPLIT_DBG): 1 = skip the MFMAs, 2 = skip the row loads
+    int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [2][nE][D] fp32
+                                 // (E.W1 | E.W2); W1 / W2 / b1 / b2 / q project the PARENTS' queries only
 };
 
 __device__ __forceinline__ int fused_parent_id(const FusedL2Args& a, int64_t i) {

@@ -259,6 +259,9 @@ class MVIN(object):
         self._profile = None
         self._native_l2_state = None
         self._native_l2_ws = {}
+        # projected-tables form of the fused two-level pass inside mvin_score_l2_fwd (_prj_for_l2): None = by batch size
+        self.prj = {"0": False, "1": True}.get(os.environ.get("MVIN_PRJ", ""), None)
+        self._prj_tables = {}                # per stream: [2, n_entity, D] workspace, rewritten by every call
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
         # up to this many pairs the whole pass is ONE kernel launch (mvin_score_small_fwd: the reference's own batch sizes,
@@ -620,6 +623,12 @@ class MVIN(object):
         elif use_l2:
             a0, a1 = self._agg[(0, 0)], self._agg[(1, 0)]
             uo = self.args.User_orient
+            enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
+            tabs = None
+            if enc is not None and self._prj_for_l2(B, B * K ** (L - 2)):
+                # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W2 from the current parameters, per call
+                Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
+                tabs = ops.project_rows(self.entity_emb_matrix, Wp[L - 1], Wp[L])
             if self._profile is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -628,8 +637,10 @@ class MVIN(object):
                        self.transfer_matrix_list[L - 1] if uo else None, self.transfer_matrix_list[L] if uo else None,
                        self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
                        q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
-            enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
-            if enc is not None:
+            if tabs is not None:
+                n0, n1 = ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
+                pp = pc = None
+            elif enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
                 pp = pc = None
             else:
@@ -824,6 +835,17 @@ class MVIN(object):
             _lib.check(rc, "mvin_score_small_fwd")
         return _SmallOut(out, B, D)
 
+    def _prj_for_l2(self, B, n_parents=None):
+        """Projected-tables form of the fused two-level pass for a batch of B pairs (``n_parents`` level-(L-2) nodes)?
+        ``self.prj``: None = automatic (MVIN_PRJ=0 / 1 overrides), True / False."""
+        if not (self.args.User_orient and self.entity_emb_matrix.dtype == torch.float32
+                and self.entity_emb_matrix.numel() * 4 < (1 << 31) and B * self.dim * 4 < (1 << 30)):
+            return False
+        want = self.prj
+        if want is None:      # (D = 128: that instance of the kernel spills registers -- on request only)
+            want = self.dim <= 64 and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
+        return bool(want)
+
     def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):
         """model.py:125-159 through mvin_score_l2_fwd.  The argument block (every weight pointer) is built once and
         kept until a parameter tensor is replaced; per call only the batch pointers change."""
@@ -872,6 +894,17 @@ class MVIN(object):
         st["live"] = (self.entity_emb_matrix, t0, t1, enc, rec)
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
+        # projected-tables form of the two deepest levels (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W2 is rebuilt by every call
+        # from the current parameters -- worth it when the batch's distinct children outnumber the entities (the per-entity
+        # products cost ~n_entity rows of work, the per-child products they replace ~B K / 4)
+        prj = enc is not None and self._prj_for_l2(B)
+        if prj:
+            pt = self._prj_tables.get(stream.cuda_stream)
+            if pt is None or pt.shape[1] != self.n_entity:
+                pt = self._prj_tables[stream.cuda_stream] = torch.empty((2, self.n_entity, D), dtype=torch.float32, device=self.device)
+            s.prj_tables = pt.data_ptr()
+        else:
+            s.prj_tables = None
         wkey = (B, n_o, stream.cuda_stream, bool(grouped), uts.shape[0] if grouped else 0)
         ws = self._native_l2_ws.get(wkey)
         if ws is None:        # reused across calls of the same batch size ON THE SAME STREAM (which orders the reuse)

@@ -301,6 +301,39 @@ def gather_attn_l2_enc(table, enc_entity, enc_relation, parent_ids, t0, t1, W1, 
     return nagg0, nagg1
 
 
+def project_rows(src, W1, W2, b1=None, b2=None):
+    """mvin_project_rows: [2, rows, D] = (src . W1 (+ b1), src . W2 (+ b2)) -- the two projections of the levels the fused
+    two-level kernel gathers, of the entity table's rows or of the pairs' query vectors."""
+    lib = _lib.load()
+    for t, nm in ((src, "src"), (W1, "W1"), (W2, "W2"), (b1, "b1"), (b2, "b2")):
+        _chk(t, F32, nm)
+    rows, D = src.shape
+    out = torch.empty((2, rows, D), dtype=F32, device=src.device)
+    _lib.check(lib.mvin_project_rows(_p(src), rows, D, _p(W1), _p(W2), _p(b1), _p(b2), _p(out), _stream()), "mvin_project_rows")
+    return out
+
+
+def gather_attn_l2_prj(tables, enc_entity, enc_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K, D, nR):
+    """mvin_gather_attn_l2_prj_fwd: gather_attn_l2_enc over projected tables (``project_rows`` of the entity table); the
+    parents' queries are projected inside the kernel.  Returns (nagg0 [P,D], nagg1 [P,D])."""
+    lib = _lib.load()
+    for t, dt, nm in ((tables, F32, "tables"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
+                      (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"),
+                      (t1, F32, "t1"), (W1, F32, "W1"), (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"),
+                      (A0, F32, "A0"), (a0, F32, "a0")):
+        _chk(t, dt, nm)
+    if tables.dim() != 3 or tables.shape[0] != 2 or tables.shape[2] != D or q is None or tuple(q.shape) != (B, D):
+        raise ValueError("gather_attn_l2_prj: tables [2, n_entity, D] and q [B, D] expected")
+    P = B * parents_per_pair
+    nagg0 = torch.empty((P, D), dtype=F32, device=tables.device)
+    nagg1 = torch.empty((P, D), dtype=F32, device=tables.device)
+    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(tables), _p(enc_entity), _p(enc_relation), _p(parent_ids),
+                                               int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(W1), _p(W2), _p(b1),
+                                               _p(b2), _p(q), _p(A0), _p(a0), B, parents_per_pair, K, D, tables.shape[1], nR,
+                                               _p(nagg0), _p(nagg1), _stream()), "mvin_gather_attn_l2_prj_fwd")
+    return nagg0, nagg1
+
+
 def gather_mix(table, adj_entity, adj_relation, node_ids, rel_score_t, rowbias, nodes, nodes_per_group, K, nR,
                relu=False):
     """mvin_gather_mix_fwd: out[i] = (1/K) sum_k w_k f(table[adj_entity[x_i,k]] + rowbias[i // npg]) ->

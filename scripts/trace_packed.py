@@ -23,14 +23,18 @@ enc_e, enc_r, cnt = ops.encode_adjacency(adj_e, adj_r)
 t0 = torch.rand(9, device=dev, generator=g); W = torch.rand((D, D), device=dev, generator=g) - 0.5
 c = torch.rand((B, D), device=dev, generator=g); bias = torch.zeros(D, device=dev)
 args = (table, enc_e, enc_r, parents, t0, t0, W, W, bias, bias, c, W, bias, B, 1, K, D, 9)
+run = ops.gather_attn_l2_enc
+if "--prj" in sys.argv:                      # the projected-tables form of the same pass
+    args = (ops.project_rows(table, W, W),) + args[1:]
+    run = ops.gather_attn_l2_prj
 buf = np.zeros(16, dtype=np.int64)
 lib = _lib.load()
 for _ in range(2):
-    ops.gather_attn_l2_enc(*args)
+    run(*args)
 torch.cuda.synchronize()
 lib.mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size)      # reads and clears
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); ops.gather_attn_l2_enc(*args); e1.record(); torch.cuda.synchronize()
+e0.record(); run(*args); e1.record(); torch.cuda.synchronize()
 lib.mvin_debug_read_trace(buf.ctypes.data_as(C.c_void_p), buf.size)
 t = buf.reshape(2, 8).astype(np.float64)
 print("launch %.3f ms, distinct children per parent %.2f" % (e0.elapsed_time(e1), float(cnt[parents.long()].float().mean())))

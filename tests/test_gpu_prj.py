@@ -1,0 +1,202 @@
+"""-m gpu: the PROJECTED-TABLES form of the fused two-level pass (mvin_project_rows + mvin_gather_attn_l2_prj_fwd).
+
+The user-oriented projection (reference model.py:270-283) is linear and the attention weights are scalars, so
+(sum_k w_k E[y_k] + c q) W2 + c b2 = sum_k w_k (E W2)[y_k] + c (q W2 + b2): the packed-tile kernel gathers rows of E.W1 /
+E.W2 (built once per call, per ENTITY) and adds q.W1 + b1 / q.W2 + b2 (once per PARENT, inside the kernel) instead of
+multiplying every distinct child by W1 and W2.  Same ids, same rows per pair; results equal to fp32 round-off -- checked here against the
+faithful encoded kernel, the fp32 mirror of the reference graph and the float64 equations."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import ops, synth
+from mvin_amd.config import make_args
+from mvin_amd.model import MVIN
+from mvin_amd.params import init_params
+
+from parity import assert_close, run_oracles
+
+pytestmark = pytest.mark.gpu
+
+DK = [(32, 16), (32, 32), (32, 64), (64, 16), (64, 32), (64, 64), (64, 128), (128, 32), (128, 64), (128, 128)]
+
+
+def _shape(D, K, H=2, B=None):
+    if B is None:
+        B = max(2, min(37, 4096 // (K * K)))
+    return dict(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=2, n_memory=8, batch_size=B)
+
+
+def _model(args, case, params, prj):
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                 params=params, device="cuda:0")
+    model.dedup = True
+    model.prj = prj
+    return model
+
+
+def _pairs(model, case):
+    dev = model.device
+    out = model.forward_device(
+        torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+        [torch.from_numpy(m).to(dev) for m in case.memories_h],
+        [torch.from_numpy(m).to(dev) for m in case.memories_r],
+        [torch.from_numpy(m).to(dev) for m in case.memories_t])
+    torch.cuda.synchronize()
+    return out
+
+
+def test_project_rows_is_the_two_products(hip_lib):
+    rng = np.random.default_rng(0)
+    for rows, D in ((1, 64), (37, 32), (1000, 64), (513, 128)):
+        f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).cuda()
+        src, W1, W2, b1, b2 = f(rows, D), f(D, D), f(D, D), f(D), f(D)
+        out = ops.project_rows(src, W1, W2, b1, b2)
+        want = torch.stack([src.double() @ W1.double() + b1.double(), src.double() @ W2.double() + b2.double()])
+        assert_close(out.cpu().numpy(), want.float().cpu().numpy(), "project_rows", rtol=1e-5, atol=1e-6)
+        out = ops.project_rows(src, W2, W1)                  # no biases; the matrices in the other order in memory
+        want = torch.stack([src.double() @ W2.double(), src.double() @ W1.double()])
+        assert_close(out.cpu().numpy(), want.float().cpu().numpy(), "project_rows without biases", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("att", ["both", "none", "t0", "t1"])
+@pytest.mark.parametrize("ppp", [1, "K"])
+@pytest.mark.parametrize("kind", ["repeats", "uniform"])
+@pytest.mark.parametrize("dk", DK, ids=lambda dk: "D%dK%d" % dk)
+def test_projected_kernel_matches_faithful_kernel(dk, kind, ppp, att, hip_lib):
+    """The two entry points on the same inputs: per-parent neighbor aggregates to fp32 round-off."""
+    D, K = dk
+    if att != "both" and (kind == "uniform" or ppp != 1):
+        pytest.skip("attention variants: one adjacency kind and tree depth")
+    ppp = K if ppp == "K" else 1
+    B = max(2, min(19, 2048 // (K * ppp)))
+    args = make_args(**_shape(D, K, B=B))
+    case = synth.small_case(args, n_user=8, n_entity=1200, n_relation=7, seed=11 + D + K, zero_rows=4, repeats=kind == "repeats")
+    rng = np.random.default_rng(D * K)
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)
+    E = f(case.n_entity, D)
+    ae = torch.from_numpy(case.adj_entity.astype(np.int32)).to(dev)
+    ar = torch.from_numpy(case.adj_relation.astype(np.int32)).to(dev)
+    enc_e, enc_r, _ = ops.encode_adjacency(ae, ar)
+    parents = torch.from_numpy(rng.integers(0, case.n_entity, size=B * ppp).astype(np.int32)).to(dev)
+    parents[0] = int(np.flatnonzero((case.adj_entity == 0).all(1))[0])       # a zero-row parent
+    t0 = f(7) if att in ("both", "t0") else None
+    t1 = f(7) if att in ("both", "t1") else None
+    W1, W2, b1, b2, q, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
+    want0, want1 = ops.gather_attn_l2_enc(E, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    tabs = ops.project_rows(E, W1, W2)
+    got0, got1 = ops.gather_attn_l2_prj(tabs, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    torch.cuda.synchronize()
+    assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0", rtol=3e-5, atol=6e-6)       # two fp32 programs, sums of up to 128 x 128 terms
+    assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1", rtol=3e-5, atol=6e-6)
+    # int64 parent ids read in place, and the launch is deterministic
+    again0, again1 = ops.gather_attn_l2_prj(tabs, enc_e, enc_r, parents.long(), t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    assert torch.equal(again0, got0) and torch.equal(again1, got1)
+
+
+@pytest.mark.parametrize("feed", ["pairs", "users", "python-schedule"])
+@pytest.mark.parametrize("kind", ["repeats", "uniform"])
+@pytest.mark.parametrize("dk", [(32, 32), (64, 16), (64, 32), (64, 64), (128, 32)], ids=lambda dk: "D%dK%d" % dk)
+def test_model_with_projected_tables_vs_oracles(dk, kind, feed, hip_lib):
+    D, K = dk
+    args = make_args(**_shape(D, K))
+    case = synth.small_case(args, n_user=16, n_entity=900, n_relation=7, seed=241 + D + K, zero_rows=4, repeats=kind == "repeats")
+    case.items[0] = np.flatnonzero((case.adj_entity == 0).all(1))[0]
+    # the per-pair arrays as train.py:117-120 assembles them from the users' ripple sets: both feeds hold the same ids
+    uts_np = synth.ripple_sets(16, 900, 7, 2, 8, seed=77)
+    mem = synth.memories_for(uts_np, case.users)
+    case.memories_h, case.memories_r, case.memories_t = [[np.ascontiguousarray(x) for x in lst] for lst in mem]
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=43, random_agg_bias=True)
+    model = _model(args, case, params, True)
+    if feed == "python-schedule":
+        model.native_l2_max_batch = 0                       # the per-step Python schedule (what a big pairs-feed batch takes)
+    if feed == "users":
+        dev = model.device
+        uts = torch.from_numpy(uts_np).to(dev)
+        out = model.forward_users(torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev), uts)
+        torch.cuda.synchronize()
+    else:
+        out = _pairs(model, case)
+    assert model._prj_for_l2(len(case.items)), "the projected-tables form was not taken"
+    m, e = run_oracles(args, case, params)
+    got = out.scores.cpu().numpy()
+    assert_close(got, m.scores.numpy(), "projected-tables scores vs fp32 mirror", rtol=1e-5, atol=1e-6)
+    assert_close(out.item_embeddings.cpu().numpy(), m.item_embeddings.numpy(), "item_embeddings", rtol=1e-5, atol=1e-6)
+    err_hip = np.abs(got - e.scores).max()
+    err_mir = np.abs(m.scores.numpy() - e.scores).max()
+    assert err_hip <= 4 * err_mir + 1e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}"
+    # and against the faithful encoded kernel on the same model
+    model.prj = False
+    ref = _pairs(model, case) if feed != "users" else model.forward_users(
+        torch.from_numpy(case.users).to(model.device), torch.from_numpy(case.items).to(model.device), uts)
+    assert_close(got, ref.scores.cpu().numpy(), "projected vs faithful encoded kernel", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("ablation", ["no_uor", "no_uor_and_no_kg_eh_uo"])
+def test_projected_tables_without_relation_attention(ablation, hip_lib):
+    args = make_args(ablation=ablation, **_shape(64, 32, B=11))
+    case = synth.small_case(args, n_user=8, n_entity=600, n_relation=6, seed=161, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=62, random_agg_bias=True)
+    out = _pairs(_model(args, case, params, True), case)
+    m, _ = run_oracles(args, case, params)
+    assert_close(out.scores.cpu().numpy(), m.scores.numpy(), "scores vs fp32 mirror", rtol=1e-5, atol=1e-6)
+
+
+def test_projected_tables_depth3(hip_lib):
+    args = make_args(**_shape(64, 16, H=3, B=3))
+    case = synth.small_case(args, n_user=8, n_entity=700, n_relation=5, seed=151, zero_rows=3, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=52, random_agg_bias=True)
+    model = _model(args, case, params, True)
+    out = _pairs(model, case)
+    m, _ = run_oracles(args, case, params)
+    assert_close(out.scores.cpu().numpy(), m.scores.numpy(), "scores vs fp32 mirror", rtol=1e-5, atol=1e-6)
+
+
+def test_auto_rule_and_refusals(hip_lib):
+    """Automatic: only when the batch's children outnumber the entities (B K >= 16 n_entity); never for a bf16 table or
+    without the projection; the entry point refuses what it cannot do."""
+    args = make_args(**_shape(64, 32, B=8))
+    case = synth.small_case(args, n_user=8, n_entity=500, n_relation=6, seed=5, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=6)
+    model = _model(args, case, params, None)
+    assert not model._prj_for_l2(8) and not model._prj_for_l2(249)
+    assert model._prj_for_l2(250) and model._prj_for_l2(4, n_parents=250)
+    model.prj = False
+    assert not model._prj_for_l2(1 << 20)
+    bf = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
+              device="cuda:0", table_dtype="bf16")
+    bf.prj = True
+    assert not bf._prj_for_l2(1 << 20)
+    a2 = make_args(ablation="no_uo", **_shape(64, 32, B=8))
+    nouo = MVIN(a2, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation,
+                params=init_params(a2, case.n_user, case.n_entity, case.n_relation, seed=6), device="cuda:0")
+    nouo.prj = True
+    assert not nouo._prj_for_l2(1 << 20)
+    from mvin_amd._lib import MvinHipError
+    tabs = torch.zeros(2, 500, 64, device="cuda:0")
+    enc = model.encoded_adjacency()
+    ids, W, q = torch.zeros(4, dtype=torch.int32, device="cuda:0"), model._agg[(0, 0)].weights, torch.zeros(4, 64, device="cuda:0")
+    with pytest.raises(ValueError):                          # queries of another batch size
+        ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ids, None, None, W, W, None, None, torch.zeros(5, 64, device="cuda:0"), W, None,
+                               4, 1, 32, 64, 6)
+    with pytest.raises(MvinHipError):                        # no projection matrices: nothing to project the queries with
+        ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ids, None, None, None, None, None, None, q, W, None, 4, 1, 32, 64, 6)
+
+
+def test_parameters_changed_between_calls_are_seen(hip_lib):
+    """Nothing of the projected tables is kept between calls: an in-place change of the entity table or of a projection
+    matrix shows in the next call's scores exactly as on the faithful path."""
+    args = make_args(**_shape(64, 32, B=9))
+    case = synth.small_case(args, n_user=8, n_entity=400, n_relation=6, seed=9, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=10, random_agg_bias=True)
+    model = _model(args, case, params, True)
+    before = _pairs(model, case).scores.clone()
+    with torch.no_grad():
+        model.entity_emb_matrix.mul_(1.25)
+        model.transfer_matrix_list[2].add_(0.05)
+    after = _pairs(model, case).scores.clone()
+    model.prj = False
+    want = _pairs(model, case).scores
+    assert not torch.allclose(before, after)
+    assert_close(after.cpu().numpy(), want.cpu().numpy(), "scores after an in-place parameter change", rtol=1e-5, atol=1e-6)
