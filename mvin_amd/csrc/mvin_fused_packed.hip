@@ -106,7 +106,7 @@ __host__ __device__ constexpr bool pack_help(int D, int K, bool bf, int NG) {
     const int epl = (bf && D == 128) ? 8 : 4, rpwx = 64 / (D / epl), nrnd = (32 / NG) / rpwx;
     return nrnd == 2 && !(bf && D == 128) && K <= 32;
 }
-constexpr int kPackUR = 32;         // projected-tables form: parents whose projected queries a dense wave keeps (a ring, two batches of 16)
+constexpr int kPackUR = 16;         // projected-tables form: parents whose projected queries a dense wave keeps (one MFMA batch)
 __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool bf, bool prj = false) {
     PackLds l{};
     const size_t NM = D / 16, nRp = (nR + 1) & ~1;
@@ -530,9 +530,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
         float* carry = sCarry + wave * 32;
         // PRJ: the projected queries u1 = q.W1 + b1, u2 = q.W2 + b2 of the workgroup's parents, sixteen parents per batch, this
         // wave's 16 columns of each; lane group q16 contracts k = KS q16 .. KS q16 + KS - 1 (its A values are one contiguous run
-        // of the query row).  A tile spans at most 16 parents, so a ring of kPackUR = 32 always holds the tile at hand
+        // of the query row).  A tile spans at most 16 parents: the batch starts at the first parent of the tile that ran past the
+        // previous one (a straddling parent is projected twice: ~20 batches per 256 parents instead of 16, for half the LDS of a
+        // two-batch ring -- which cost the K = 64 instances their second workgroup per CU: 1.09 -> 1.32 ms at C4)
         float* sUw = smem + L.sU + (PRJ ? wave * (kPackUR * 32) : 0);
-        int ucount = 0;
+        int ucount = -(1 << 20);                         // first parent (local index) of the batch at hand
         // (buffer loads: ONE offset register per operand and the step in the instruction's immediate -- with flat loads hipcc
         //  precomputed 2 KS 64-bit addresses, ran out of registers and issued load -> vmcnt(0) -> MFMA 2 KS times per batch)
         const __amdgpu_buffer_rsrc_t w1src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W1), 0, PRJ ? D * D * 4 : 0, 0x00020000);
@@ -579,11 +581,10 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 const float b1v = sBias[D + col], b2v = sBias[2 * D + col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* d = sUw + ((ucount + 4 * q16 + r) & (kPackUR - 1)) * 32 + l16;
+                    float* d = sUw + (4 * q16 + r) * 32 + l16;
                     d[0] = u1[r] + b1v;
                     d[16] = u2[r] + b2v;
                 }
-                ucount += 16;
                 wave_lds_sync();
             }
         };
@@ -635,7 +636,11 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             int i0t = 0;                                // PRJ: local index of the tile's first parent
             if constexpr (PRJ) {
                 i0t = __builtin_amdgcn_readfirstlane(sSegP[mb * 16]) - (int)p_base;
-                while (i0t + nseg > ucount) u_batch();
+                if (i0t + nseg > ucount + kPackUR) {
+                    wave_lds_sync();                    // (the previous tile's reads of the batch are done)
+                    ucount = i0t;
+                    u_batch();
+                }
             }
             const float* tA = sA + buf * TM * LDA;
             const bool two = rows > 16;                 // second 16-row MFMA tile in use
@@ -703,7 +708,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                             s1v = tA[row * LDA + col];
                             zv = tA[row * LDA + D + col];
                             if constexpr (PRJ) {        // (E.W1)[x1] + u1 ;  sum_k w_k (E.W2)[y_k] + (sum p / K) u2
-                                const float* up = sUw + ((i0t + sgi[m][r]) & (kPackUR - 1)) * 32 + l16;
+                                const float* up = sUw + ((i0t - ucount + sgi[m][r]) & (kPackUR - 1)) * 32 + l16;
                                 s1v += up[0];
                                 zv = fmaf(c2scale, up[16], zv);
                             }
