@@ -171,23 +171,30 @@ MVIN_API int mvin_gather_attn_l2_enc_fwd(const void* table, const int32_t* enc_e
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR,
                                 float* nagg0, float* nagg1, int table_bf16, void* stream);
 MVIN_API int mvin_gather_attn_l2_enc_supported(int D, int K);
-/* The encoded pass over PROJECTED tables.  The user-oriented projection (model.py:270-283) is linear and the attention weights
- * are scalars, so the projection of a weighted sum of rows is the weighted sum of projected rows:
- *     (E[x1] + q) W1 + b1                      = (E W1)[x1] + (q W1 + b1)
- *     (sum_k w_k E[y_k] + c q) W2 + c b2       = sum_k w_k (E W2)[y_k] + c (q W2 + b2)          (c = sum_k w_k)
- * an exact re-association like project-after-sum and the duplicate-slot encoding.  With the products taken once per ENTITY
- * (mvin_project_rows: out[0] = src W1 (+ b1), out[1] = src W2 (+ b2), fp32) the kernel gathers the same ids, the same
- * number of rows and bytes per pair -- from `tables` = [2, nE, D] = mvin_project_rows(E) instead of E -- and skips the two
- * D x D products per distinct child (two thirds of its MFMA work); the query terms are projected once per PARENT inside the
- * kernel (W1, W2, b1, b2, q as for mvin_gather_attn_l2_enc_fwd; W1 / W2 required).  Everything else as
- * mvin_gather_attn_l2_enc_fwd; tables below 2 GiB each. */
+/* The encoded pass over PROJECTED tables.  Everything the pass applies to a gathered row before the ReLU of
+ * aggregators.py:116 is linear -- the user-oriented projection (model.py:270-283) and the aggregator's matrix (aggregators.py:
+ * 108-116) -- and the attention weights are scalars, so the matrices move from the gathered rows to the table:
+ *     self1      = (E[x1] + q) W1 + b1                                  = T1[x1] + u1
+ *     Z A0 + a0  = (self1 + (sum_k w_k E[y_k] + c q) W2 + c b2) A0 + a0 = TA1[x1] + sum_k w_k TA2[y_k] + v        (c = sum_k w_k)
+ * T1 = E W1, TA1 = E W1 A0, TA2 = E W2 A0 (once per ENTITY);  u1 = q W1 + b1, v = q (W1 + c W2) A0 + (b1 + c b2) A0 + a0 (once
+ * per PARENT, inside the kernel).  An exact re-association, like project-after-sum and the duplicate-slot encoding: the kernel
+ * gathers the same ids and grandchild rows per pair (one more self row per distinct child) and has no D x D product per
+ * distinct child left.  mvin_project_tables writes the three tables and the per-call parameter block into `ws`
+ * (mvin_project_tables_elems floats; fp32 entity table; `attention` = whether t0 will be given: it fixes c = 1/K or 1) and
+ * must be called again whenever E, W1, W2, b1, b2, A0 or a0 changed -- mvin_score_l2_fwd and mvin_amd.MVIN call it in
+ * every pass.  mvin_gather_attn_l2_prj_fwd: as mvin_gather_attn_l2_enc_fwd with `ws` in place of the table and the weights;
+ * D in {32, 64, 128}, tables below 1 GiB each.  mvin_project_rows is the plain two-matrix form (out[0] = src W1 (+ b1),
+ * out[1] = src W2 (+ b2)). */
 MVIN_API int mvin_project_rows(const float* src, int64_t rows, int D, const float* W1, const float* W2, const float* b1,
                                const float* b2, float* out, void* stream);
-MVIN_API int mvin_gather_attn_l2_prj_fwd(const float* tables, const int32_t* enc_entity, const int32_t* enc_relation,
-                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
-                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
-                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity,
-                                int nR, float* nagg0, float* nagg1, void* stream);
+MVIN_API size_t mvin_project_tables_elems(int n_entity, int D);
+MVIN_API int mvin_project_tables(const float* entity_emb, const float* W1, const float* W2, const float* b1, const float* b2,
+                                 const float* A0, const float* a0, int attention, int K, int n_entity, int D, float* ws,
+                                 void* stream);
+MVIN_API int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
+                                int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
+                                void* stream);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
@@ -394,9 +401,10 @@ typedef struct {
     int depth;                     /* mvin_score_small_fwd only: tree depth h_hop (n_mix_hop = 1): 0 or 2 = two hops; 1 = ONE hop
                                       (BASELINE configs[0]: W2 / b2 / A1 / a1 / t1 unused and may be NULL, Wmix is [2D, D]).
                                       mvin_score_l2_fwd ignores it (depth 2) */
-    float* prj_tables;             /* mvin_score_l2_fwd only, or NULL: workspace [2, nE, D] fp32 -- with an fp32 table, the encoded
-                                      adjacency and the projection on (W1), the two deepest levels run in their PROJECTED-TABLES form:
-                                      mvin_project_rows (E) -> mvin_gather_attn_l2_prj_fwd.  Rewritten by every call (nothing cached) */
+    float* prj_tables;             /* mvin_score_l2_fwd only, or NULL: workspace of mvin_project_tables_elems(nE, D) floats -- with an
+                                      fp32 table, the encoded adjacency and the projection on (W1), the two deepest levels run in their
+                                      PROJECTED-TABLES form: mvin_project_tables -> mvin_gather_attn_l2_prj_fwd.  Rewritten by every
+                                      call (nothing cached) */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

@@ -196,7 +196,7 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false) {
     const char* who = prj ? "mvin_gather_attn_l2_prj_fwd" : encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
     if (prj && (!encoded || table_bf16 || !W1 || !W2 || !q))
-        return fail(-1, "%s: projected tables are fp32 and go with the encoded adjacency, the projection matrices and the queries", who);
+        return fail(-1, "%s: projected tables are fp32 and go with the encoded adjacency and the queries", who);
     if (encoded && !mvin::fused_packed_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {32,64,128}, K in {16,32,64,128})", who, D, K);
     if (!mvin::fused_l2_supported(D, K))
@@ -299,13 +299,48 @@ int mvin_project_rows(const float* src, int64_t rows, int D, const float* W1, co
     return prj_linear(src, rows, D, W1, W2, b1, b2, out, stream);
 }
 
-int mvin_gather_attn_l2_prj_fwd(const float* tables, const int32_t* enc_entity, const int32_t* enc_relation,
-                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1,
-                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
-                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D, int n_entity,
-                                int nR, float* nagg0, float* nagg1, void* stream) {
-    return gather_attn_l2_impl(tables, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
-                               parent_ids_i64 ? 2 : 1, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K,
+size_t mvin_project_tables_elems(int n_entity, int D) {
+    if (n_entity <= 0 || D <= 0) return 0;
+    return (size_t)3 * n_entity * D + (size_t)4 * D * D + (size_t)2 * D;
+}
+
+int mvin_project_tables(const float* entity_emb, const float* W1, const float* W2, const float* b1, const float* b2, const float* A0,
+                        const float* a0, int attention, int K, int n_entity, int D, float* ws, void* stream) {
+    const char* who = "mvin_project_tables";
+    if (!entity_emb || !W1 || !W2 || !A0 || !ws) return fail(-1, "%s: null pointer", who);
+    if ((b1 == nullptr) != (b2 == nullptr)) return fail(-1, "%s: b1 and b2 go together", who);
+    if (n_entity <= 0 || K <= 0 || (D != 32 && D != 64 && D != 128)) return fail(-2, "%s: n_entity=%d K=%d D=%d", who, n_entity, K, D);
+    float* blk = ws + (size_t)3 * n_entity * D;
+    // c = (sum of the K attention weights) / K: softmax weights sum to 1, plain-mean weights to K  (aggregators.py:139-152)
+    const float c = attention ? 1.f / (float)K : 1.f;
+    if (int rc = hip_result(mvin::launch_prj_prepare(W1, W2, b1, b2, A0, a0, c, D, blk, (hipStream_t)stream), who)) return rc;
+    mvin_linear_args l{};
+    l.src[0] = entity_emb;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = n_entity;
+    l.rows_per_group = 1;
+    l.W = blk;                                // W1 | W1.A0 | W2.A0
+    l.w_zstride = (int64_t)D * D;
+    l.out = ws;
+    l.ldo = D;
+    l.nz = 3;
+    l.out_zstride = (int64_t)n_entity * D;
+    return mvin_linear_fwd(&l, stream);
+}
+
+int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
+                                int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
+                                void* stream) {
+    if (!ws || n_entity <= 0 || D <= 0) return fail(-1, "mvin_gather_attn_l2_prj_fwd: null workspace / bad sizes");
+    const float* blk = ws + (size_t)3 * n_entity * D;
+    const float* Wv = blk + (size_t)3 * D * D;
+    const float* b1c = Wv + (size_t)D * D;
+    // (W1, b1) and (the combined matrix, its bias) project the parents' queries; A0 / a0 are inside the tables and the bias
+    return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
+                               parent_ids_i64 ? 2 : 1, t0, t1, blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K,
                                D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, true, true);
 }
 
@@ -584,13 +619,13 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
     if (enc && a->prj_tables && a->W1 && !a->table_bf16) {
-        // projected-tables form: E.W1 | E.W2 once per entity from the CURRENT parameters (nothing is kept between calls), then
-        // the packed kernel without its W1 / W2 products per distinct child
-        rc = prj_linear(reinterpret_cast<const float*>(a->entity_emb), a->n_entity, D, a->W1, a->W2, nullptr, nullptr, a->prj_tables, stream);
+        // projected-tables form: E.W1 | E.W1.A0 | E.W2.A0 once per entity from the CURRENT parameters (nothing is kept between
+        // calls), then the packed kernel without any product per distinct child
+        rc = mvin_project_tables(reinterpret_cast<const float*>(a->entity_emb), a->W1, a->W2, a->b1, a->b2, a->A0, a->a0,
+                                 a->t0 != nullptr, a->K, a->n_entity, D, a->prj_tables, stream);
         if (rc) return rc;
-        rc = gather_attn_l2_impl(a->prj_tables, a->enc_entity, a->enc_relation, reinterpret_cast<const int32_t*>(a->items), 2,
-                                 a->t0, a->t1, a->W1, a->W2, a->b1, a->b2, a->user_o, a->A0, a->a0, (int)a->B, 1, a->K, D,
-                                 a->n_entity, nR, a->nagg0, a->nagg1, nullptr, nullptr, 0, stream, true, true);
+        rc = mvin_gather_attn_l2_prj_fwd(a->prj_tables, a->enc_entity, a->enc_relation, a->items, 1, a->t0, a->t1, a->user_o, (int)a->B, 1,
+                                         a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, stream);
     } else
     rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                              reinterpret_cast<const int32_t*>(a->items), 2,

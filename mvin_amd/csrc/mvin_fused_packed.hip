@@ -113,7 +113,7 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool b
     size_t o = 0;
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };   // 16-byte aligned pieces
     l.sA = take(2 * 32 * (size_t)(2 * D + 2));
-    l.sZ = take(32 * (size_t)(D + 2));
+    l.sZ = take(prj ? 0 : 32 * (size_t)(D + 2));        // (no Z tile in the projected-tables form)
     const size_t lrows = pack_help(D, K, bf, NG) ? 48 : 32;
     l.sYP = take(lrows * (size_t)(K + 1) * 2);          // ids [lrows][K+1], then weights likewise (48: the lists of the second
                                                         // gather round are double-buffered, see list_base)
@@ -142,12 +142,16 @@ __host__ __device__ inline PackLds pack_lds(int D, int K, int nR, int NG, bool b
 // dense and first front wave (s_memtime), read back with mvin_debug_read_trace under MVIN_PACK_TRACE (scripts/trace_packed.py)
 __device__ unsigned long long g_pack_prof[2 * 8];
 
-// PRJ: the projected-tables form (mvin_gather_attn_l2_prj_fwd).  The user-oriented projection is linear and the attention
-// weights are scalars, so  (S' + c q) W2 + c b2 = sum_k w_k (E.W2)[y_k] + c (q.W2 + b2)  and  (E[x1] + q) W1 + b1 =
-// (E.W1)[x1] + (q.W1 + b1): with the two products taken once per ENTITY (a.table = [E.W1 ; E.W2]) the rows this kernel
-// gathers are already projected -- the same rows, ids and bytes per pair, no W1 / W2 product per distinct child (two thirds
-// of the MFMA work of a tile) -- and phase B is the plain sum plus the PARENT's projected query: u1 = q.W1 + b1, u2 = q.W2 + b2,
-// one 16-parent MFMA batch per dense wave every ~4 tiles (a wave-private ring in LDS; the front loads no query rows at all).
+// PRJ: the projected-tables form (mvin_gather_attn_l2_prj_fwd).  Everything the kernel applies to a gathered row before the
+// ReLU is linear and the attention weights are scalars, so the matrices move from the rows to the TABLE:
+//     self1 = (E[x1] + q) W1 + b1                                        = T1[x1] + u1
+//     Z A0 + a0 = (self1 + (S' + c q) W2 + c b2) A0 + a0                 = TA1[x1] + sum_k w_k TA2[y_k] + v
+// with T1 = E.W1, TA1 = E.W1.A0, TA2 = E.W2.A0 taken once per ENTITY (mvin_project_tables: a.table = [T1 ; TA1 ; TA2], rebuilt
+// by every call) and u1 = q.W1 + b1, v = q.(W1 + c W2).A0 + (b1 + c b2).A0 + a0 once per PARENT (a.W1 / a.b1 and a.W2 / a.b2 =
+// the combined matrix / bias, built by the same call).  The kernel gathers the same ids and the same number of grandchild rows
+// (one more self row per distinct child) and has NO D x D product per distinct child left: a dense wave's work per tile is
+// out1 = relu(row + v), the per-parent sums (16 MFMAs) and, every ~4 tiles, the projected queries of the next 16 parents.
+// The front loads no query rows at all.
 template <int D, int KT, bool BF, int NG, bool PROF = false, bool PRJ = false>
 __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_attn_l2_packed_kernel(FusedL2Args a, int ppw) {
     static_assert(!(PRJ && BF), "projected tables are fp32");
@@ -232,11 +236,12 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     const float c2scale = has_att0 ? invK : 1.f;        // (sum_k p_k) / K
     int g = lane / G::LPRX, c = lane % G::LPRX;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(a.table), 0, (int)(PRJ ? 2 * a.table_bytes : a.table_bytes), 0x00020000);
+        const_cast<void*>(a.table), 0, (int)(PRJ ? 3 * a.table_bytes : a.table_bytes), 0x00020000);
     const unsigned q_bytes = (unsigned)((a.P / a.parents_per_pair) * D * 4);
     const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.q), 0, has_proj ? (int)q_bytes : 0, 0x00020000);
-    const unsigned t2_off = PRJ ? (unsigned)a.table_bytes : 0u;      // grandchild rows come from the second table
+    const unsigned ta1_off = PRJ ? (unsigned)a.table_bytes : 0u;     // PRJ: a child's second self row (TA1) ...
+    const unsigned t2_off = PRJ ? 2u * (unsigned)a.table_bytes : 0u; // ... and the grandchild rows (TA2)
     unsigned c16 = (unsigned)c * 16u;
     // a table row as this lane's EPL elements
     auto rowload = [&](int id, float4& lo, float4& hi, unsigned toff = 0u) {
@@ -318,8 +323,10 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 constexpr bool FIRST = decltype(first_c)::value;
                 float4 sv, sv1 = make_float4(0.f, 0.f, 0.f, 0.f);
                 u32x4 qa = (u32x4){0u, 0u, 0u, 0u}, qb = qa;
+                float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sa1 = sa;
                 if constexpr (FIRST) {
                     rowload(xx[h], sv, sv1);
+                    if constexpr (PRJ) rowload(xx[h], sa, sa1, ta1_off);
                     // this lane's elements of the pair's query (zero records without the projection: the loads return 0)
                     const unsigned qoff = ((unsigned)qq[h] * (unsigned)D + (unsigned)(G::EPL * c)) * 4u;
                     if constexpr (!PRJ) {
@@ -334,7 +341,8 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     const float4 q0 = make_float4(__uint_as_float(qa[0]), __uint_as_float(qa[1]), __uint_as_float(qa[2]), __uint_as_float(qa[3]));
                     const float4 q1 = make_float4(__uint_as_float(qb[0]), __uint_as_float(qb[1]), __uint_as_float(qb[2]), __uint_as_float(qb[3]));
                     if constexpr (PRJ) {
-                        put(arow, sv, sv1);                                                // (E.W1)[x1]; the parent's u1 / u2 join in phase B
+                        put(arow, sv, sv1);                                                // T1[x1]; the parent's u1 / v join on the dense side
+                        acc = sa;                                                          // TA1[x1] + sum_k w_k TA2[y_k]
                     } else {
                         put(arow, f4_fma(1.f, q0, sv), f4_fma(1.f, q1, sv1));              // E[x1] + q
                         acc = f4_fma(c2scale, q0, acc);                                    // S' + (sum p / K) q
@@ -525,7 +533,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
             const int kk = 4 * s + q16;
             bW1[s] = has_proj ? a.W1[kk * D + col] : 0.f;
             bW2[s] = has_proj ? a.W2[kk * D + col] : 0.f;
-            bA0[s] = a.A0[kk * D + col];
+            bA0[s] = PRJ ? 0.f : a.A0[kk * D + col];
         }
         float* carry = sCarry + wave * 32;
         // PRJ: the projected queries u1 = q.W1 + b1, u2 = q.W2 + b2 of the workgroup's parents, sixteen parents per batch, this
@@ -662,6 +670,26 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                 wa1[m][2] = sg.z == l16 ? w1.z : 0.f;
                 wa1[m][3] = sg.w == l16 ? w1.w : 0.f;
             }
+            f32x4 accN0 = (f32x4){0.f, 0.f, 0.f, 0.f}, accN1 = accN0;
+            if constexpr (PRJ) {
+                // self1 = T1[x1] + u1 ; out1 = relu(TA1[x1] + sum_k w_k TA2[y_k] + v) ; the per-parent sums.  No phase C, no Z tile.
+#pragma unroll
+                for (int m = 0; m < G::RT; ++m) {
+                    if (m == 0 || two) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 16 * m + 4 * q16 + r;
+                            const float* up = sUw + ((i0t - ucount + sgi[m][r]) & (kPackUR - 1)) * 32 + l16;
+                            const float s1v = tA[row * LDA + col] + up[0];
+                            const float o = fmaxf(tA[row * LDA + D + col] + up[16], 0.f);
+                            accN0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[m][r], s1v, accN0, 0, 0, 0);
+                            accN1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[m][r], o, accN1, 0, 0, 0);
+                        }
+                    }
+                }
+                tick(1);
+                tick(2);
+            } else {
             const float c1v = sBias[D + col];
             const float c2v = sBias[2 * D + col] * c2scale;
             // phase B: self1 = (E[x1] + q) W1 + b1 ; Z = self1 + (S' + (sum p / K) q) W2 + (sum p / K) b2   (model.py:277-283)
@@ -693,7 +721,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                     }
                 }
             }
-            f32x4 accN0 = (f32x4){0.f, 0.f, 0.f, 0.f}, accN1 = accN0;
 #pragma unroll
             for (int m = 0; m < G::RT; ++m) {
                 if (m == 0 || two) {
@@ -707,11 +734,6 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                         } else {
                             s1v = tA[row * LDA + col];
                             zv = tA[row * LDA + D + col];
-                            if constexpr (PRJ) {        // (E.W1)[x1] + u1 ;  sum_k w_k (E.W2)[y_k] + (sum p / K) u2
-                                const float* up = sUw + ((i0t - ucount + sgi[m][r]) & (kPackUR - 1)) * 32 + l16;
-                                s1v += up[0];
-                                zv = fmaf(c2scale, up[16], zv);
-                            }
                             zv += s1v;
                         }
                         // nagg0[segment] += w0[row] self1[row]: contraction over this accumulator register's four rows
@@ -760,6 +782,7 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
                         accN1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1[m][r], o, accN1, 0, 0, 0);
                     }
                 }
+            }
             }
             // accN0 / accN1 register i = segment 4 q16 + i, column col
 #pragma unroll
@@ -994,6 +1017,45 @@ static hipError_t launch_packed(const FusedL2Args& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- projected-tables form: the per-call parameter block behind the three tables (see the PRJ comment at the kernel) ----
+//   Wstack [3][D][D] = W1 | W1.A0 | W2.A0   (the B operands of the table build: mvin_linear_fwd, nz = 3)
+//   Wv [D][D] = (W1 + c W2).A0 ;  b1c [D] = b1 ;  bv [D] = (b1 + c b2).A0 + a0
+__global__ void prj_prepare_kernel(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ b1,
+                                   const float* __restrict__ b2, const float* __restrict__ A0, const float* __restrict__ a0, float c, int D,
+                                   float* __restrict__ blk) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    float* Wstack = blk;
+    float* Wv = blk + (size_t)3 * D * D;
+    float* b1c = Wv + (size_t)D * D;
+    float* bv = b1c + D;
+    if (j >= D) return;
+    if (i < D) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float av = A0[(size_t)k * D + j];
+            s1 = fmaf(W1[(size_t)i * D + k], av, s1);
+            s2 = fmaf(W2[(size_t)i * D + k], av, s2);
+        }
+        Wstack[(size_t)i * D + j] = W1[(size_t)i * D + j];
+        Wstack[(size_t)D * D + (size_t)i * D + j] = s1;
+        Wstack[(size_t)2 * D * D + (size_t)i * D + j] = s2;
+        Wv[(size_t)i * D + j] = fmaf(c, s2, s1);
+    } else {
+        float s = a0 ? a0[j] : 0.f;
+        if (b1) {
+            for (int k = 0; k < D; ++k) s = fmaf(fmaf(c, b2[k], b1[k]), A0[(size_t)k * D + j], s);
+        }
+        b1c[j] = b1 ? b1[j] : 0.f;
+        bv[j] = s;
+    }
+}
+
+hipError_t launch_prj_prepare(const float* W1, const float* W2, const float* b1, const float* b2, const float* A0, const float* a0,
+                              float c, int D, float* blk, hipStream_t st) {
+    prj_prepare_kernel<<<D + 1, D < 64 ? 64 : D, 0, st>>>(W1, W2, b1, b2, A0, a0, c, D, blk);
+    return hipGetLastError();
+}
+
 bool fused_packed_supported(int D, int K) {
     return (D == 32 || D == 64 || D == 128) && (K == 16 || K == 32 || K == 64 || K == 128);
 }
@@ -1002,7 +1064,7 @@ bool fused_packed_supported(int D, int K) {
 // 32-bit byte offsets, output rows indexable with an int
 bool fused_packed_applies(const FusedL2Args& a, int D) {
     return fused_packed_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_r && a.adj_bytes > 0 &&
-           a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31) && a.table_bytes < (a.prj ? (1ull << 31) : (1ull << 32)) &&
+           a.adj_bytes < (1ull << 31) && (uint64_t)a.P * D * 4 < (1ull << 31) && a.table_bytes < (a.prj ? (1ull << 30) : (1ull << 32)) &&
            a.max_id < (1u << 24) &&
            (uint64_t)a.P / (uint64_t)a.parents_per_pair * D * 4 < (a.prj ? (1ull << 30) : (1ull << 31));
 }

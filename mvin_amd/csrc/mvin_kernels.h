@@ -179,8 +179,9 @@ struct FusedL2Args {
     int pid_stride;              // 1: parent_ids is int32 [P]; 2: the low words of an int64 [P] array (little endian)
     unsigned max_id;             // n_entity - 1: parent ids are clamped (a fault would kill the process)
     int dbg;                     // timing experiments only (MVIN_SPLIT_DBG): 1 = skip the MFMAs, 2 = skip the row loads
-    int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [2][nE][D] fp32
-                                 // (E.W1 | E.W2); W1 / W2 / b1 / b2 / q project the PARENTS' queries only
+    int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [3][nE][D] fp32
+                                 // (E.W1 | E.W1.A0 | E.W2.A0); W1 / b1 and W2 / b2 (= the combined (W1 + c W2).A0 and its bias)
+                                 // project the PARENTS' queries only; A0 / a0 unused
 };
 
 __device__ __forceinline__ int fused_parent_id(const FusedL2Args& a, int64_t i) {
@@ -360,7 +361,9 @@ hipError_t launch_gather_attn_l2_d16(const FusedL2Args& a, int table_bf16, hipSt
 bool fused_l2_split_in_use();                   // false under MVIN_L2_SPLIT=0
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 hipError_t split_read_trace(long long* host_dst, size_t n);
-bool fused_packed_supported(int D, int K);     // packed-tile variant over the duplicate-slot encoding (mvin_fused_packed.hip)
+bool fused_packed_supported(int D, int K);
+hipError_t launch_prj_prepare(const float* W1, const float* W2, const float* b1, const float* b2, const float* A0, const float* a0,
+                              float c, int D, float* blk, hipStream_t st);     // packed-tile variant over the duplicate-slot encoding (mvin_fused_packed.hip)
 bool fused_packed_applies(const FusedL2Args& a, int D);
 hipError_t pack_read_prof(long long* host_dst, size_t n);
 hipError_t launch_gather_attn_l2_packed(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);

@@ -261,7 +261,7 @@ class MVIN(object):
         self._native_l2_ws = {}
         # projected-tables form of the fused two-level pass inside mvin_score_l2_fwd (_prj_for_l2): None = by batch size
         self.prj = {"0": False, "1": True}.get(os.environ.get("MVIN_PRJ", ""), None)
-        self._prj_tables = {}                # per stream: [2, n_entity, D] workspace, rewritten by every call
+        self._prj_tables = {}                # per stream: workspace of mvin_project_tables_elems floats, rewritten by every call
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
         # up to this many pairs the whole pass is ONE kernel launch (mvin_score_small_fwd: the reference's own batch sizes,
@@ -626,9 +626,10 @@ class MVIN(object):
             enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
             tabs = None
             if enc is not None and self._prj_for_l2(B, B * K ** (L - 2)):
-                # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W2 from the current parameters, per call
+                # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 from the current parameters, per call
                 Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
-                tabs = ops.project_rows(self.entity_emb_matrix, Wp[L - 1], Wp[L])
+                tabs = ops.project_tables(self.entity_emb_matrix, Wp[L - 1], Wp[L], bp[L - 1], bp[L], a0.weights, a0.bias, K,
+                                          a0.User_orient_rela)
             if self._profile is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -638,7 +639,8 @@ class MVIN(object):
                        self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
                        q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
             if tabs is not None:
-                n0, n1 = ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
+                n0, n1 = ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
+                                                K ** (L - 2), K, D, self.n_relation, self.n_entity)
                 pp = pc = None
             elif enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
@@ -839,11 +841,13 @@ class MVIN(object):
         """Projected-tables form of the fused two-level pass for a batch of B pairs (``n_parents`` level-(L-2) nodes)?
         ``self.prj``: None = automatic (MVIN_PRJ=0 / 1 overrides), True / False."""
         if not (self.args.User_orient and self.entity_emb_matrix.dtype == torch.float32
-                and self.entity_emb_matrix.numel() * 4 < (1 << 31) and B * self.dim * 4 < (1 << 30)):
+                and self.entity_emb_matrix.numel() * 4 < (1 << 30) and B * self.dim * 4 < (1 << 30)):
             return False
         want = self.prj
-        if want is None:      # (D = 128: that instance of the kernel spills registers -- on request only)
-            want = self.dim <= 64 and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
+        if want is None:
+            # D <= 64, K <= 32: the other instances of the kernel are at their register budget already (K = 64: the second self row
+            # costs 18 spilled registers in the front role's id pipeline) and measured no faster (C4) -- on request only
+            want = self.dim <= 64 and self.n_neighbor <= 32 and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
         return bool(want)
 
     def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):
@@ -894,14 +898,15 @@ class MVIN(object):
         st["live"] = (self.entity_emb_matrix, t0, t1, enc, rec)
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
-        # projected-tables form of the two deepest levels (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W2 is rebuilt by every call
+        # projected-tables form of the two deepest levels (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 is rebuilt by every call
         # from the current parameters -- worth it when the batch's distinct children outnumber the entities (the per-entity
         # products cost ~n_entity rows of work, the per-child products they replace ~B K / 4)
         prj = enc is not None and self._prj_for_l2(B)
         if prj:
             pt = self._prj_tables.get(stream.cuda_stream)
-            if pt is None or pt.shape[1] != self.n_entity:
-                pt = self._prj_tables[stream.cuda_stream] = torch.empty((2, self.n_entity, D), dtype=torch.float32, device=self.device)
+            n_ws = _lib.load().mvin_project_tables_elems(self.n_entity, D)
+            if pt is None or pt.numel() != n_ws:
+                pt = self._prj_tables[stream.cuda_stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
             s.prj_tables = pt.data_ptr()
         else:
             s.prj_tables = None

@@ -313,24 +313,39 @@ def project_rows(src, W1, W2, b1=None, b2=None):
     return out
 
 
-def gather_attn_l2_prj(tables, enc_entity, enc_relation, parent_ids, t0, t1, W1, W2, b1, b2, q, A0, a0, B, parents_per_pair, K, D, nR):
-    """mvin_gather_attn_l2_prj_fwd: gather_attn_l2_enc over projected tables (``project_rows`` of the entity table); the
-    parents' queries are projected inside the kernel.  Returns (nagg0 [P,D], nagg1 [P,D])."""
+def project_tables(entity_emb, W1, W2, b1, b2, A0, a0, K, attention, out=None):
+    """mvin_project_tables: the workspace of the projected-tables form -- E.W1 | E.W1.A0 | E.W2.A0 and the per-call parameter
+    block -- from the CURRENT parameters.  ``attention``: whether the relation logits t0 will be given to the gather."""
     lib = _lib.load()
-    for t, dt, nm in ((tables, F32, "tables"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
+    for t, nm in ((entity_emb, "entity_emb"), (W1, "W1"), (W2, "W2"), (b1, "b1"), (b2, "b2"), (A0, "A0"), (a0, "a0")):
+        _chk(t, F32, nm)
+    nE, D = entity_emb.shape
+    n = lib.mvin_project_tables_elems(nE, D)
+    if out is None:
+        out = torch.empty((n,), dtype=F32, device=entity_emb.device)
+    elif out.numel() != n or out.dtype != F32 or not out.is_contiguous():
+        raise ValueError("project_tables: workspace of mvin_project_tables_elems floats expected")
+    _lib.check(lib.mvin_project_tables(_p(entity_emb), _p(W1), _p(W2), _p(b1), _p(b2), _p(A0), _p(a0), 1 if attention else 0, K, nE, D,
+                                       _p(out), _stream()), "mvin_project_tables")
+    return out
+
+
+def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity):
+    """mvin_gather_attn_l2_prj_fwd: gather_attn_l2_enc over the workspace of ``project_tables`` (built with attention =
+    (t0 is not None)).  Returns (nagg0 [P,D], nagg1 [P,D])."""
+    lib = _lib.load()
+    for t, dt, nm in ((ws, F32, "ws"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
                       (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"),
-                      (t1, F32, "t1"), (W1, F32, "W1"), (W2, F32, "W2"), (b1, F32, "b1"), (b2, F32, "b2"), (q, F32, "q"),
-                      (A0, F32, "A0"), (a0, F32, "a0")):
+                      (t1, F32, "t1"), (q, F32, "q")):
         _chk(t, dt, nm)
-    if tables.dim() != 3 or tables.shape[0] != 2 or tables.shape[2] != D or q is None or tuple(q.shape) != (B, D):
-        raise ValueError("gather_attn_l2_prj: tables [2, n_entity, D] and q [B, D] expected")
+    if ws.numel() != lib.mvin_project_tables_elems(n_entity, D) or q is None or tuple(q.shape) != (B, D):
+        raise ValueError("gather_attn_l2_prj: the workspace of project_tables(n_entity, D) and q [B, D] expected")
     P = B * parents_per_pair
-    nagg0 = torch.empty((P, D), dtype=F32, device=tables.device)
-    nagg1 = torch.empty((P, D), dtype=F32, device=tables.device)
-    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(tables), _p(enc_entity), _p(enc_relation), _p(parent_ids),
-                                               int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(W1), _p(W2), _p(b1),
-                                               _p(b2), _p(q), _p(A0), _p(a0), B, parents_per_pair, K, D, tables.shape[1], nR,
-                                               _p(nagg0), _p(nagg1), _stream()), "mvin_gather_attn_l2_prj_fwd")
+    nagg0 = torch.empty((P, D), dtype=F32, device=ws.device)
+    nagg1 = torch.empty((P, D), dtype=F32, device=ws.device)
+    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(ws), _p(enc_entity), _p(enc_relation), _p(parent_ids),
+                                               int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(q), B, parents_per_pair, K, D,
+                                               n_entity, nR, _p(nagg0), _p(nagg1), _stream()), "mvin_gather_attn_l2_prj_fwd")
     return nagg0, nagg1
 
 

@@ -25,7 +25,7 @@ c = torch.rand((B, D), device=dev, generator=g); bias = torch.zeros(D, device=de
 args = (table, enc_e, enc_r, parents, t0, t0, W, W, bias, bias, c, W, bias, B, 1, K, D, 9)
 run = ops.gather_attn_l2_enc
 if "--prj" in sys.argv:                      # the projected-tables form of the same pass
-    args = (ops.project_rows(table, W, W),) + args[1:]
+    args = (ops.project_tables(table, W, W, bias, bias, W, bias, K, True), enc_e, enc_r, parents, t0, t0, c, B, 1, K, D, 9, nE)
     run = ops.gather_attn_l2_prj
 buf = np.zeros(16, dtype=np.int64)
 lib = _lib.load()

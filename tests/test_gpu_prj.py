@@ -3,7 +3,8 @@
 The user-oriented projection (reference model.py:270-283) is linear and the attention weights are scalars, so
 (sum_k w_k E[y_k] + c q) W2 + c b2 = sum_k w_k (E W2)[y_k] + c (q W2 + b2): the packed-tile kernel gathers rows of E.W1 /
 E.W2 (built once per call, per ENTITY) and adds q.W1 + b1 / q.W2 + b2 (once per PARENT, inside the kernel) instead of
-multiplying every distinct child by W1 and W2.  Same ids, same rows per pair; results equal to fp32 round-off -- checked here against the
+multiplying every distinct child by W1 and W2; round 5's final form folds the aggregator's matrix A0 in as well (E.W1 | E.W1.A0 | E.W2.A0:
+mvin_project_tables), so no product per distinct child is left.  Same ids, same rows per pair; results equal to fp32 round-off -- checked here against the
 faithful encoded kernel, the fp32 mirror of the reference graph and the float64 equations."""
 import numpy as np
 import pytest
@@ -85,13 +86,13 @@ def test_projected_kernel_matches_faithful_kernel(dk, kind, ppp, att, hip_lib):
     t1 = f(7) if att in ("both", "t1") else None
     W1, W2, b1, b2, q, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
     want0, want1 = ops.gather_attn_l2_enc(E, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
-    tabs = ops.project_rows(E, W1, W2)
-    got0, got1 = ops.gather_attn_l2_prj(tabs, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, t0 is not None)
+    got0, got1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t1, q, B, ppp, K, D, 7, case.n_entity)
     torch.cuda.synchronize()
     assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0", rtol=3e-5, atol=6e-6)       # two fp32 programs, sums of up to 128 x 128 terms
     assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1", rtol=3e-5, atol=6e-6)
     # int64 parent ids read in place, and the launch is deterministic
-    again0, again1 = ops.gather_attn_l2_prj(tabs, enc_e, enc_r, parents.long(), t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    again0, again1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents.long(), t0, t1, q, B, ppp, K, D, 7, case.n_entity)
     assert torch.equal(again0, got0) and torch.equal(again1, got1)
 
 
@@ -173,15 +174,35 @@ def test_auto_rule_and_refusals(hip_lib):
                 params=init_params(a2, case.n_user, case.n_entity, case.n_relation, seed=6), device="cuda:0")
     nouo.prj = True
     assert not nouo._prj_for_l2(1 << 20)
-    from mvin_amd._lib import MvinHipError
-    tabs = torch.zeros(2, 500, 64, device="cuda:0")
     enc = model.encoded_adjacency()
-    ids, W, q = torch.zeros(4, dtype=torch.int32, device="cuda:0"), model._agg[(0, 0)].weights, torch.zeros(4, 64, device="cuda:0")
+    E, W = model.entity_emb_matrix, model._agg[(0, 0)].weights
+    ws = ops.project_tables(E, W, W, None, None, W, None, 32, True)
+    ids = torch.zeros(4, dtype=torch.int32, device="cuda:0")
     with pytest.raises(ValueError):                          # queries of another batch size
-        ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ids, None, None, W, W, None, None, torch.zeros(5, 64, device="cuda:0"), W, None,
-                               4, 1, 32, 64, 6)
-    with pytest.raises(MvinHipError):                        # no projection matrices: nothing to project the queries with
-        ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ids, None, None, None, None, None, None, q, W, None, 4, 1, 32, 64, 6)
+        ops.gather_attn_l2_prj(ws, enc[0], enc[1], ids, None, None, torch.zeros(5, 64, device="cuda:0"), 4, 1, 32, 64, 6, 500)
+    with pytest.raises(ValueError):                          # a workspace built for another table
+        ops.gather_attn_l2_prj(ws[:-64].contiguous(), enc[0], enc[1], ids, None, None, torch.zeros(4, 64, device="cuda:0"), 4, 1, 32, 64, 6, 500)
+
+
+def test_project_tables_holds_the_three_products(hip_lib):
+    """The workspace: E.W1 | E.W1.A0 | E.W2.A0, then W1 | W1.A0 | W2.A0, (W1 + c W2).A0, b1, (b1 + c b2).A0 + a0."""
+    rng = np.random.default_rng(5)
+    nE, D, K = 777, 64, 32
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).cuda()
+    E, W1, W2, b1, b2, A0, a0 = f(nE, D), f(D, D), f(D, D), f(D), f(D), f(D, D), f(D)
+    for att in (True, False):
+        c = 1.0 / K if att else 1.0
+        ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, att).double().cpu()
+        d = lambda t: t.double().cpu()
+        tabs = ws[:3 * nE * D].view(3, nE, D)
+        want = torch.stack([d(E) @ d(W1), d(E) @ d(W1) @ d(A0), d(E) @ d(W2) @ d(A0)])
+        assert_close(tabs.numpy(), want.numpy(), "tables", rtol=2e-5, atol=2e-6)
+        blk = ws[3 * nE * D:]
+        assert_close(blk[:3 * D * D].view(3, D, D).numpy(), torch.stack([d(W1), d(W1) @ d(A0), d(W2) @ d(A0)]).numpy(), "Wstack",
+                     rtol=1e-5, atol=1e-6)
+        assert_close(blk[3 * D * D:4 * D * D].view(D, D).numpy(), ((d(W1) + c * d(W2)) @ d(A0)).numpy(), "Wv", rtol=1e-5, atol=1e-6)
+        assert_close(blk[4 * D * D:4 * D * D + D].numpy(), d(b1).numpy(), "b1", rtol=0, atol=0)
+        assert_close(blk[4 * D * D + D:].numpy(), ((d(b1) + c * d(b2)) @ d(A0) + d(a0)).numpy(), "bv", rtol=1e-5, atol=1e-6)
 
 
 def test_parameters_changed_between_calls_are_seen(hip_lib):
