@@ -822,8 +822,8 @@ def main():
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
                  else "gather_attn_l2_packed_kernel<..., PRJ> (mvin_gather_attn_l2_prj_fwd: duplicate-slot encoding of the adjacency, rows "
-                      "gathered from the projected tables E.W1 | E.W2 that mvin_project_rows rebuilds every step -- same ids, rows and "
-                      "bytes per pair as mvin_gather_attn_l2_enc_fwd, no W1 / W2 product per distinct child)"
+                      "gathered from the projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step -- same ids "
+                      "and grandchild rows per pair as mvin_gather_attn_l2_enc_fwd, no W1 / W2 / A0 product per distinct child)"
                  if prj_now
                  else "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd: duplicate-slot encoding of the adjacency)"
                  if enc is not None
@@ -923,7 +923,7 @@ def main():
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "ablation": a.ablation, "hipgraph_replay": bool(scorer), "streams": nstreams,
-                       "two_level_form": ("projected tables (E.W1 | E.W2 rebuilt inside every timed step: mvin_project_rows + "
+                       "two_level_form": ("projected tables (E.W1 | E.W1.A0 | E.W2.A0 rebuilt inside every timed step: mvin_project_tables + "
                                           "mvin_gather_attn_l2_prj_fwd)" if prj_now else
                                           "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
