@@ -857,6 +857,8 @@ def main():
             ch = (enc_e[it] & 0xFFFFFF).long()
             real = ((enc_r[it] >> 16) & 0xFF) > 0
             rows_loaded = float((1 + cnt[it].double() + (cnt[ch].double() * real).sum(1)).mean())
+            if prj_now:       # the projected-tables form reads TWO self rows per distinct child (T1[x] and TA1[x])
+                rows_loaded += float(cnt[it].double().mean())
             K_ = a.fanout
             # encoded adjacency rows read per pair: the item's and its distinct children's, K words of ids + K of relations each
             adj_rows = float((1 + cnt[it].double()).mean())
