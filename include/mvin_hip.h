@@ -299,6 +299,22 @@ MVIN_API int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const f
                                         const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
                                         const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
                                         int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream);
+/* The same pass with the users' U rows GATHERED.  U_m = R_KGE[r_m] . E[h_m] (model.py:214-220 re-associated) depends on the
+ * (relation, entity) pair alone: mvin_project_relations writes it for every pair -- ws = [nR, nE, D] fp32, then E[e] . w (the
+ * h-set read's logits) and scratch; mvin_project_relations_elems floats; from the CURRENT parameters, to be called again whenever
+ * E, R_KGE or w changed (mvin_score_l2_fwd and mvin_amd.MVIN call it in every pass) -- and the kernel over the user records
+ * loads a user's rows from there instead of multiplying them (half of the records kernel's matrix work).  D = 64, fp32 table,
+ * shapes of mvin_user_records_supported, at most 64 memories per hop when w is given, nR * n_entity < 2^31
+ * (mvin_key_addressing_grouped_er_supported). */
+MVIN_API size_t mvin_project_relations_elems(int n_entity, int nR, int D);
+MVIN_API int mvin_project_relations(const float* entity_emb, const float* relation_kge, const float* w, int n_entity, int nR, int D,
+                                    float* ws, void* stream);
+MVIN_API int mvin_key_addressing_grouped_er_supported(int D, int P, int Nm, int nR, int n_entity, int has_set);
+MVIN_API int mvin_key_addressing_grouped_er_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                       const int32_t* uts, const int32_t* user_records, const float* er_ws, const int32_t* seg_user,
+                                       const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                       const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                       int nR, int n_entity, int n_user, float* out, int64_t ldo, void* stream);
 /* The batch in user order for mvin_key_addressing_grouped_fwd, built on the device (counting sort by user id, int
  * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
  * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair
@@ -405,6 +421,9 @@ typedef struct {
                                       fp32 table, the encoded adjacency and the projection on (W1), the two deepest levels run in their
                                       PROJECTED-TABLES form: mvin_project_tables -> mvin_gather_attn_l2_prj_fwd.  Rewritten by every
                                       call (nothing cached) */
+    float* ka_er;                  /* mvin_score_l2_fwd only, or NULL: workspace of mvin_project_relations_elems(nE, nR, D) floats -- with
+                                      user_records and an fp32 table the grouped key addressing runs in its GATHERED form:
+                                      mvin_project_relations -> mvin_key_addressing_grouped_er_fwd.  Rewritten by every call */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

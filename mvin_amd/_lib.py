@@ -69,7 +69,7 @@ class ScoreL2Args(C.Structure):
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
         ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p),
-        ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p)]
+        ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p), ("ka_er", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -93,6 +93,10 @@ SIGNATURES = {
     "mvin_shard_space_ids": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_key_addressing_grouped_fwd": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "mvin_key_addressing_grouped_rec_fwd": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "mvin_project_relations_elems": (C.c_size_t, [C.c_int] * 3),
+    "mvin_project_relations": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2),
+    "mvin_key_addressing_grouped_er_supported": (C.c_int, [C.c_int] * 6),
+    "mvin_key_addressing_grouped_er_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "mvin_user_records_len": (C.c_int, [C.c_int] * 3),
     "mvin_user_records_supported": (C.c_int, [C.c_int] * 5),
     "mvin_build_user_records": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

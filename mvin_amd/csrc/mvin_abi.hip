@@ -587,6 +587,16 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         int32_t* pair_index = nseg + 1;
         rc = mvin_group_pairs_by_user(a->users, nullptr, a->B, a->n_user, ws, seg_user, seg_ptr, nseg, pair_index, stream);
         if (rc) return rc;
+        if (a->ka_er && a->user_records && !a->table_bf16 &&
+            mvin_key_addressing_grouped_er_supported(D, a->P, a->Nm, nR, a->n_entity, a->h_set_w != nullptr)) {
+            // gathered form of the U rows: R_KGE[r] . E[e] for every (relation, entity) from the CURRENT parameters, per call
+            rc = mvin_project_relations(reinterpret_cast<const float*>(a->entity_emb), a->relation_kge, a->h_set_w, a->n_entity, nR, D,
+                                        a->ka_er, stream);
+            if (rc) return rc;
+            rc = mvin_key_addressing_grouped_er_fwd(a->entity_emb, a->relation_kge, a->h_set_w, a->uts, a->user_records, a->ka_er, seg_user,
+                                                    seg_ptr, nseg, pair_index, a->items, nullptr, (int)a->B, (int)a->B, a->P, a->Nm, D, nR,
+                                                    a->n_entity, a->n_user, a->o_cat, (int64_t)n_o * D, stream);
+        } else
         rc = mvin_key_addressing_grouped_rec_fwd(a->entity_emb, a->relation_kge, a->h_set_w, a->uts, a->user_records, seg_user, seg_ptr,
                                                  nseg, pair_index, a->items, nullptr, (int)a->B, (int)a->B, a->P, a->Nm, D, nR,
                                                  a->n_entity, a->n_user, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
@@ -754,11 +764,76 @@ int mvin_key_addressing_grouped_fwd(const void* entity_emb, const float* relatio
                                                items_i32, nseg, B, P, Nm, D, nR, n_entity, n_user, out, ldo, table_bf16, stream);
 }
 
+size_t mvin_project_relations_elems(int n_entity, int nR, int D) {
+    if (n_entity <= 0 || nR <= 0 || D <= 0) return 0;
+    return (size_t)nR * n_entity * D + (size_t)((n_entity + 3) & ~3) + (size_t)nR * D * D;
+}
+
+int mvin_project_relations(const float* entity_emb, const float* relation_kge, const float* w, int n_entity, int nR, int D, float* ws,
+                           void* stream) {
+    const char* who = "mvin_project_relations";
+    if (!entity_emb || !relation_kge || !ws) return fail(-1, "%s: null pointer", who);
+    if (n_entity <= 0 || nR <= 0 || (D != 16 && D != 32 && D != 64 && D != 128)) return fail(-2, "%s: n_entity=%d nR=%d D=%d", who, n_entity, nR, D);
+    float* hs = ws + (size_t)nR * n_entity * D;
+    float* RT = hs + (size_t)((n_entity + 3) & ~3);
+    if (int rc = hip_result(mvin::launch_transpose_blocks(relation_kge, nR, D, RT, (hipStream_t)stream), who)) return rc;
+    mvin_linear_args l{};                     // ER[r][e][n] = sum_k E[e][k] R_KGE[r][n][k]  (= R_KGE[r] . E[e], model.py:214-220)
+    l.src[0] = entity_emb;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = n_entity;
+    l.rows_per_group = 1;
+    l.W = RT;
+    l.w_zstride = (int64_t)D * D;
+    l.out = ws;
+    l.ldo = D;
+    l.nz = nR;
+    l.out_zstride = (int64_t)n_entity * D;
+    if (int rc = mvin_linear_fwd(&l, stream)) return rc;
+    if (w) return hip_result(mvin::launch_entity_dot(entity_emb, w, n_entity, D, hs, (hipStream_t)stream), who);
+    return 0;
+}
+
+static int key_addressing_grouped_impl(const void* entity_emb, const float* relation_kge, const float* w,
+                                        const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
+                                        const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                        const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                        int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream,
+                                        const float* er_ws);
+
 int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
                                         const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
                                         const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
                                         const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
                                         int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream) {
+    return key_addressing_grouped_impl(entity_emb, relation_kge, w, uts, user_records, seg_user, seg_ptr, nseg_dev, pair_index, items_i64,
+                                       items_i32, nseg, B, P, Nm, D, nR, n_entity, n_user, out, ldo, table_bf16, stream, nullptr);
+}
+
+int mvin_key_addressing_grouped_er_supported(int D, int P, int Nm, int nR, int n_entity, int has_set) {
+    return (D == 64 && mvin::key_addr_static_er_ok(P, Nm, nR, n_entity, has_set != 0)) ? 1 : 0;
+}
+
+int mvin_key_addressing_grouped_er_fwd(const void* entity_emb, const float* relation_kge, const float* w,
+                                       const int32_t* uts, const int32_t* user_records, const float* er_ws, const int32_t* seg_user,
+                                       const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                       const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                       int nR, int n_entity, int n_user, float* out, int64_t ldo, void* stream) {
+    const char* who = "mvin_key_addressing_grouped_er_fwd";
+    if (!user_records || !er_ws) return fail(-1, "%s: the gathered form needs the user records and the workspace of mvin_project_relations", who);
+    if (!mvin_key_addressing_grouped_er_supported(D, P, Nm, nR, n_entity, w != nullptr))
+        return fail(-3, "%s: unsupported shape D=%d P=%d Nm=%d nR=%d n_entity=%d", who, D, P, Nm, nR, n_entity);
+    return key_addressing_grouped_impl(entity_emb, relation_kge, w, uts, user_records, seg_user, seg_ptr, nseg_dev, pair_index, items_i64,
+                                       items_i32, nseg, B, P, Nm, D, nR, n_entity, n_user, out, ldo, 0, stream, er_ws);
+}
+
+static int key_addressing_grouped_impl(const void* entity_emb, const float* relation_kge, const float* w,
+                                        const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
+                                        const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                        const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
+                                        int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream,
+                                        const float* er_ws) {
     const char* who = "mvin_key_addressing_grouped_fwd";
     if (!entity_emb || !uts || !seg_user || !seg_ptr || !pair_index || !out) return fail(-1, "%s: null pointer", who);
     if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
@@ -792,6 +867,10 @@ int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* rel
     k.nR = nR;
     k.n_entity = n_entity;
     k.records = user_records;
+    if (er_ws) {
+        k.ER = er_ws;
+        k.hs = er_ws + (size_t)nR * n_entity * D;
+    }
     return hip_result(mvin::launch_key_addr_grouped(k, table_bf16, (hipStream_t)stream), who);
 }
 

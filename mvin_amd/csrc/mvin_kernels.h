@@ -111,11 +111,14 @@ struct KeyAddrGroupedArgs {
     int n_entity;              // rows of E: the wave-per-user kernel clamps item ids into the table
     int dbg;                   // wave-per-user kernel, measurement only (MVIN_KA_WAVE_DBG)
     const int32_t* records;    // [nU, ka_rec_layout(P, Nm, nR).len] static per-user records (mvin_keyaddr_static.hip) or NULL
+    const float* ER;           // [nR, nE, D] R_KGE[r] . E[e] for every (relation, entity) (mvin_project_relations) or NULL: with the
+                               // records, a user's U rows are GATHERED from it instead of multiplied (key_addr_static_kernel<..., ER>)
+    const float* hs;           // [nE] E[e] . w (same call) -- the h-set read's logits; required with ER when w is given
 };
 
 // the static record of one user: offsets in int32 words (mvin_keyaddr_static.hip); len == 0: shape outside the record form
 struct KaRecLayout {
-    int NmP, rows, maxtiles, o_cnt, o_off, o_trel, o_bidx, o_head, o_tail, len;
+    int NmP, rows, maxtiles, o_cnt, o_off, o_trel, o_bidx, o_head, o_tail, o_hr, len;
 };
 
 struct TailArgs {
@@ -362,6 +365,9 @@ bool fused_l2_split_in_use();                   // false under MVIN_L2_SPLIT=0
 hipError_t launch_gather_attn_l2_split(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 hipError_t split_read_trace(long long* host_dst, size_t n);
 bool fused_packed_supported(int D, int K);
+bool key_addr_static_er_ok(int P, int Nm, int nR, int n_entity, bool has_set);
+hipError_t launch_transpose_blocks(const float* R, int nR, int D, float* RT, hipStream_t st);
+hipError_t launch_entity_dot(const float* E, const float* w, int n, int D, float* out, hipStream_t st);
 hipError_t launch_prj_prepare(const float* W1, const float* W2, const float* b1, const float* b2, const float* A0, const float* a0,
                               float c, int D, float* blk, hipStream_t st);     // packed-tile variant over the duplicate-slot encoding (mvin_fused_packed.hip)
 bool fused_packed_applies(const FusedL2Args& a, int D);

@@ -62,7 +62,8 @@ __host__ __device__ constexpr KaRecLayout ka_rec_layout_c(int P, int Nm, int nR)
     R.o_bidx = R.o_trel + kas_pad4(R.maxtiles);
     R.o_head = R.o_bidx + R.maxtiles * 16;
     R.o_tail = R.o_head + R.rows;
-    R.len = (R.o_tail + R.rows + 63) & ~63;
+    R.o_hr = R.o_tail + R.rows;                            // row of [nR, nE, D] (mvin_project_relations): relation * n_entity + head
+    R.len = (R.o_hr + R.rows + 63) & ~63;
     return R;
 }
 KaRecLayout ka_rec_layout(int P, int Nm, int nR) { return ka_rec_layout_c(P, Nm, nR); }
@@ -129,8 +130,11 @@ __global__ __launch_bounds__(64) void user_records_kernel(const int32_t* __restr
             const int at = sCnt[r] + before;
             rec[RL.o_bidx + sOff[r] + at] = i;
             const int hop = i / RL.NmP, m = i - hop * RL.NmP;
-            rec[RL.o_head + i] = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);
+            const int hd = (int)min((unsigned)ub[(hop * 3 + 0) * Nm + m], emax);
+            rec[RL.o_head + i] = hd;
             rec[RL.o_tail + i] = (int)min((unsigned)ub[(hop * 3 + 2) * Nm + m], emax);
+            const long long hr = (long long)r * n_entity + hd;
+            rec[RL.o_hr + i] = hr < (1ll << 31) ? (int)hr : 0;       // (tables that large never take the gathered form)
         }
         __syncthreads();
         if (r >= 0 && last) sCnt[r] += before + 1;
@@ -185,7 +189,11 @@ __device__ __forceinline__ void kas_dma_lines(const char* p, int lane4, unsigned
 // CP > 0: an instance for ONE shape (P = CP hops of Nm = CNM memories, CNR relations): every offset of the record and of the LDS
 // layout, every row stride and trip count is a constant -- the generic instance keeps ~60 of them in scalar registers, 130-180
 // scalar registers spilled to vector lanes, a v_readlane in front of most address computations
-template <bool TRACE, int CP, int CNM, int CNR>
+// ER: the U rows are GATHERED -- U_m = R_KGE[r_m] . E[h_m] depends on (entity, relation) alone, and mvin_project_relations
+// has written it for every such pair ([nR, nE, D], once per call) -- and the h-set read takes its logits E[h] . w from a per-entity
+// table of the same call: no U tiles, no resident R_KGE fragments, the h-set read is a softmax over Nm table values + one weighted
+// sum of the head rows at hand.
+template <bool TRACE, int CP, int CNM, int CNR, bool ER = false>
 __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGroupedArgs a_, KaRecLayout RL_, KaStaticLds L_) {
     const KaRecLayout RL = CP > 0 ? ka_rec_layout_c(CP, CNM, CNR) : RL_;
     const KaStaticLds L = CP > 0 ? ka_static_layout(CP, ka_rec_layout_c(CP > 0 ? CP : 1, CNM > 0 ? CNM : 16, CNR > 0 ? CNR : 1)) : L_;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
     //      spent ~0.6 k cycles on those reads and its loop per 512 of MFMA issue).  Contraction index permuted so that a lane's
     //      values are contiguous. ----
     constexpr int RES = 4;
-    const bool resident = a.nR * NT <= RES * (kSW - 1);
+    const bool resident = !ER && a.nR * NT <= RES * (kSW - 1);
     float rb[RES][KS];
     auto load_bfrag = [&](int r, int nt, float (&bf)[KS]) {
         const float* Rr = a.R + (size_t)r * D * D + (size_t)(16 * nt + KAS_L16) * D + KS * KAS_Q16;   // R[r][n][k]
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
     //        head rows of s+1 : the side waves, 2 x 16 rows each, under tile 0's logits -> softmax and softmax -> reads phases.
     //      (the registers are local to a piece: one array at function scope was live across the whole segment loop) ----
     const int sj = wave_u - (kSW - kSSide);                  // side wave number (< 0: not a side wave)
-    auto stage_issue = [&](auto& stg, const int* ids, int base) {   // rows base + 4 b + (lane >> 4); ids: clamped row ids in LDS (-1: padding)
+    auto stage_issue = [&](auto& stg, const int* ids, int base, const float* tab = nullptr) {   // rows base + 4 b + (lane >> 4); ids: clamped row ids in LDS (-1: padding); tab: the table (default E)
         constexpr int N = sizeof(stg) / sizeof(float4);
         const int g_ = KAS_Q16, c_ = KAS_L16;
         // all ids, then all loads, no branch in between: one LDS and one memory latency per piece (a padding row or a row past PN
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         for (int b = 0; b < N; ++b) idr[b] = ids[min(base + 4 * b + g_, PN - 1)];
 #pragma unroll
         for (int b = 0; b < N; ++b)
-            stg[b] = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.E) + (size_t)(unsigned)max(idr[b], 0) * D)[c_];
+            stg[b] = reinterpret_cast<const float4*>((tab ? tab : reinterpret_cast<const float*>(a.E)) + (size_t)(unsigned)max(idr[b], 0) * D)[c_];
     };
     // sH rows are padded (LDH = D + 4).  sT rows are not: the 16-byte chunk c of row m sits at position c ^ ((m & 3) << 2), which
     // puts the four rows of a reads-phase B operand (m = q16 + 4 j) into four different 16-bank groups
@@ -450,6 +458,10 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
         float4 tl[3];
         const bool has_tl = wave_u * 12 < PN;               // (128 rows: waves 0 .. 10; wave 11, the U phase's longest, loads none)
         if (has_tl) stage_issue(tl, rec + RL.o_tail, wave_u * 12);
+        float4 ul[3];                                        // ER: this segment's U rows, 12 per wave like the tail rows
+        if constexpr (ER) {
+            if (has_tl) stage_issue(ul, rec + RL.o_hr, wave_u * 12, a.ER);
+        }
         // fire and forget: the record of the next segment (waited for behind this wave's h-set read)
         if (wave_u == kSW - 1 && has_next) dma_record(u1, par ^ 1);
         // the descriptor of the segment after the next: read by wave 11 only (three registers held across the U tiles by every
@@ -480,6 +492,23 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             // exponentials are independent, the running maximum is touched once per step
             int d_u, d_p0, d_p1;
             desc_load(d_u, d_p0, d_p1);
+            if constexpr (ER) {
+                // logits from the per-entity table (one memory per lane: NmP <= 64), softmax across the wave, then ONE weighted
+                // sum of the head rows at hand, four rows per step
+                const int hid = lane < NmP ? rec[RL.o_head + lane] : -1;
+                const float v = (lane < Nm && hid >= 0) ? a.hs[hid] : -INFINITY;
+                const float M = wave_max(v);
+                const float e = lane < Nm ? kas_exp(v - M) : 0.f;
+                const float p = e / wave_sum(e);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int j = 0; j < NmP / RPW; ++j) {
+                    const int m = RPW * j + KAS_Q16;
+                    const float pm = __shfl(p, m, 64);
+                    acc = f4_fma(pm, *reinterpret_cast<const float4*>(sH + (size_t)m * LDH + 4 * KAS_L16), acc);
+                }
+                acc = group_xor_sum(acc, LPR);
+                if (KAS_Q16 == 0) *reinterpret_cast<float4*>(sHset + 4 * KAS_L16) = acc;
+            } else {
             const float4 w4 = reinterpret_cast<const float4*>(a.w)[KAS_L16];
             constexpr int HB = 4;
             float mx = -INFINITY, z = 0.f;
@@ -524,8 +553,9 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             z = group_xor_sum(make_float4(z, 0.f, 0.f, 0.f), LPR).x;
             const float inv = 1.f / z;
             if (KAS_Q16 == 0) *reinterpret_cast<float4*>(sHset + 4 * KAS_L16) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+            }
             desc_put(d_u, d_p0, d_p1);
-        } else {
+        } else if constexpr (!ER) {
             if (resident) {
                 if (wave < kSW - 1) {
                     // wave-uniform task table first (scalars)
@@ -573,6 +603,9 @@ __global__ __launch_bounds__(kSW * 64, 1) void key_addr_static_kernel(KeyAddrGro
             desc_put(d_u, d_p0, d_p1);
         }
         if (has_tl) stage_write(tl, rec + RL.o_tail, wave_u * 12, sT, LDT, true);
+        if constexpr (ER) {
+            if (has_tl) stage_write(ul, rec + RL.o_hr, wave_u * 12, sU, LDH, false);     // (padding rows: zeros)
+        }
         // wave 11: the next segment's record has landed before the tiles' first barrier
         if (wave_u == kSW - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // behind the phase's barrier: the descriptors move up by one
@@ -788,6 +821,42 @@ bool key_addr_static_applies(const KeyAddrGroupedArgs& a, int table_bf16) {
            (int64_t)a.nseg * a.ldo < (int64_t(1) << 31);       // (nseg = the batch size: the bound the caller gives for the segments)
 }
 
+// the gathered form (KeyAddrGroupedArgs::ER): one memory per lane in the h-set read, 32-bit row numbers in the records
+bool key_addr_static_er_ok(int P, int Nm, int nR, int n_entity, bool has_set) {
+    const KaRecLayout RL = ka_rec_layout(P, Nm, nR);
+    return RL.len != 0 && (!has_set || RL.NmP <= 64) && (long long)nR * n_entity < (1ll << 31);
+}
+
+// s[e] = E[e] . w for every entity (the h-set read's logits), one wave per 4 rows
+__global__ __launch_bounds__(256) void entity_dot_kernel(const float* __restrict__ E, const float* __restrict__ w, int n, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + g;
+    float s = 0.f;
+    if (row < n)
+        for (int d = 4 * c; d < D; d += 64) {
+            const float4 e4 = *reinterpret_cast<const float4*>(E + row * D + d), w4 = *reinterpret_cast<const float4*>(w + d);
+            s = fmaf(e4.x, w4.x, fmaf(e4.y, w4.y, fmaf(e4.z, w4.z, fmaf(e4.w, w4.w, s))));
+        }
+    s = group_sum(s, 4);
+    if (row < n && c == 0) out[row] = s;
+}
+
+// RT[r][k][n] = R[r][n][k]: the B operand of the table build (mvin_linear_fwd multiplies rows by W[k][n])
+__global__ void transpose_blocks_kernel(const float* __restrict__ R, int D, float* __restrict__ RT) {
+    const int r = blockIdx.x / D, k = blockIdx.x % D, n = threadIdx.x;
+    if (n < D) RT[((size_t)r * D + k) * D + n] = R[((size_t)r * D + n) * D + k];
+}
+
+hipError_t launch_transpose_blocks(const float* R, int nR, int D, float* RT, hipStream_t st) {
+    transpose_blocks_kernel<<<nR * D, D < 64 ? 64 : D, 0, st>>>(R, D, RT);
+    return hipGetLastError();
+}
+
+hipError_t launch_entity_dot(const float* E, const float* w, int n, int D, float* out, hipStream_t st) {
+    entity_dot_kernel<<<(n + 15) / 16, 256, 0, st>>>(E, w, n, D, out);
+    return hipGetLastError();
+}
+
 hipError_t kas_read_trace(long long* host_dst, size_t n) {
     const size_t have = sizeof(g_kas_trace) / sizeof(long long);
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_kas_trace), (n < have ? n : have) * sizeof(long long));
@@ -799,8 +868,11 @@ hipError_t launch_key_addr_static(const KeyAddrGroupedArgs& a, hipStream_t st) {
     static const bool trace = getenv("MVIN_KA_TRACE") != nullptr;
     // BASELINE.json's metric config (last-fm: 2 hops of 64 memories, 9 relations) has its own instance
     const bool c3 = a.P == 2 && a.Nm == 64 && a.nR == 9 && !(getenv("MVIN_KAS_GENERIC") && atoi(getenv("MVIN_KAS_GENERIC")));
-    auto k = c3 ? (trace ? key_addr_static_kernel<true, 2, 64, 9> : key_addr_static_kernel<false, 2, 64, 9>)
-                : (trace ? key_addr_static_kernel<true, 0, 0, 0> : key_addr_static_kernel<false, 0, 0, 0>);
+    const bool er = a.ER != nullptr;
+    auto k = er ? (c3 ? (trace ? key_addr_static_kernel<true, 2, 64, 9, true> : key_addr_static_kernel<false, 2, 64, 9, true>)
+                      : key_addr_static_kernel<false, 0, 0, 0, true>)
+                : c3 ? (trace ? key_addr_static_kernel<true, 2, 64, 9> : key_addr_static_kernel<false, 2, 64, 9>)
+                     : (trace ? key_addr_static_kernel<true, 0, 0, 0> : key_addr_static_kernel<false, 0, 0, 0>);
     hipError_t e = hipSuccess;
     if (L.total > 64 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
     if (e != hipSuccess) return e;

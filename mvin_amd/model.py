@@ -262,6 +262,9 @@ class MVIN(object):
         # projected-tables form of the fused two-level pass inside mvin_score_l2_fwd (_prj_for_l2): None = by batch size
         self.prj = {"0": False, "1": True}.get(os.environ.get("MVIN_PRJ", ""), None)
         self._prj_tables = {}                # per stream: workspace of mvin_project_tables_elems floats, rewritten by every call
+        # gathered form of the grouped key addressing (mvin_key_addressing_grouped_er_fwd, _ka_er_for): on request only
+        self.ka_er = os.environ.get("MVIN_KA_ER", "0") == "1"
+        self._ka_er_ws = {}                  # per stream: workspace of mvin_project_relations_elems floats, rewritten by every call
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
         # up to this many pairs the whole pass is ONE kernel launch (mvin_score_small_fwd: the reference's own batch sizes,
@@ -837,6 +840,17 @@ class MVIN(object):
             _lib.check(rc, "mvin_score_small_fwd")
         return _SmallOut(out, B, D)
 
+    def _ka_er_for(self, uts, records):
+        """Gathered form of the grouped key addressing for this call?  OFF unless asked for (``self.ka_er = True`` / MVIN_KA_ER=1):
+        measured at C3 the kernel over the records goes 0.94 -> 0.74 ms, the table R_KGE[r] . E[e] (245 MB, rebuilt per call) costs
+        0.11 ms, and with two scoring streams its writes compete with the other stream's kernels -- 2.74 -> 2.67 ms per step on
+        one stream, 197.0 -> 197.6 M pairs/s on two."""
+        a = self.args
+        if not self.ka_er or records is None or self.entity_emb_matrix.dtype != torch.float32 or self.p_hop < 1:
+            return False
+        return bool(ops.key_addressing_grouped_er_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, self.n_entity,
+                                                            bool(a.PS_O_ft)))
+
     def _prj_for_l2(self, B, n_parents=None):
         """Projected-tables form of the fused two-level pass for a batch of B pairs (``n_parents`` level-(L-2) nodes)?
         ``self.prj``: None = automatic (MVIN_PRJ=0 / 1 overrides), True / False."""
@@ -896,6 +910,14 @@ class MVIN(object):
         rec = self.user_records(uts) if grouped else None
         s.user_records = ptr(rec)
         st["live"] = (self.entity_emb_matrix, t0, t1, enc, rec)
+        s.ka_er = None
+        if grouped and self._ka_er_for(uts, rec):          # gathered U rows: the table is rebuilt by every call
+            cs = torch.cuda.current_stream().cuda_stream
+            n_ws = _lib.load().mvin_project_relations_elems(self.n_entity, self.n_relation, D)
+            ew = self._ka_er_ws.get(cs)
+            if ew is None or ew.numel() != n_ws:
+                ew = self._ka_er_ws[cs] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+            s.ka_er = ew.data_ptr()
         n_o = P + (1 if a.PS_O_ft else 0)
         stream = torch.cuda.current_stream()
         # projected-tables form of the two deepest levels (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 is rebuilt by every call
@@ -946,8 +968,10 @@ class MVIN(object):
         o_cat = torch.empty((item.shape[0], n_o * D), dtype=torch.float32, device=self.device)
         w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
         groups = ops.group_pairs_by_user(user, n_user=uts.shape[0])
+        rec = self.user_records(uts)
+        er = ops.project_relations(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h) if self._ka_er_for(uts, rec) else None
         ops.key_addressing_grouped(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, uts, groups, item, P,
-                                   o_cat, n_o * D, self.n_relation, records=self.user_records(uts))
+                                   o_cat, n_o * D, self.n_relation, records=rec, er=er)
         return ops.linear([o_cat], self.user_mlp_matrix, D, bias=self.user_mlp_bias)
 
     def _forward_small(self, users, items, mem_h, mem_r, mem_t, uts):

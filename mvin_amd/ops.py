@@ -561,10 +561,31 @@ def build_user_records(uts, P, nR, n_entity):
     return rec
 
 
-def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, out, ldo, nR, records=None):
+def key_addressing_grouped_er_supported(D, P, Nm, nR, n_entity, has_set):
+    return bool(_lib.load().mvin_key_addressing_grouped_er_supported(D, P, Nm, nR, n_entity, 1 if has_set else 0))
+
+
+def project_relations(entity_emb, relation_kge, w=None, out=None):
+    """mvin_project_relations: the workspace of the gathered key addressing -- R_KGE[r] . E[e] for every (relation, entity)
+    and E[e] . w -- from the CURRENT parameters."""
+    lib = _lib.load()
+    _chk(entity_emb, F32, "entity_emb"), _chk(relation_kge, F32, "relation_kge"), _chk(w, F32, "w")
+    nE, D = entity_emb.shape
+    nR = relation_kge.shape[0]
+    n = lib.mvin_project_relations_elems(nE, nR, D)
+    if out is None:
+        out = torch.empty((n,), dtype=F32, device=entity_emb.device)
+    elif out.numel() != n or out.dtype != F32 or not out.is_contiguous():
+        raise ValueError("project_relations: workspace of mvin_project_relations_elems floats expected")
+    _lib.check(lib.mvin_project_relations(_p(entity_emb), _p(relation_kge), _p(w), nE, nR, D, _p(out), _stream()), "mvin_project_relations")
+    return out
+
+
+def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, out, ldo, nR, records=None, er=None):
     """mvin_key_addressing_grouped_fwd: the attention reads of a batch whose pairs are grouped by user
     (``groups`` = group_pairs_by_user(users)); fills ``out`` [B, ldo] with [o_hset | o_hop0 | ...].
-    ``records`` = build_user_records(uts, ...): the same results from the kernel over static per-user records."""
+    ``records`` = build_user_records(uts, ...): the same results from the kernel over static per-user records;
+    ``er`` = project_relations(...): that kernel with the users' U rows gathered (mvin_key_addressing_grouped_er_fwd)."""
     lib = _lib.load()
     bf = _chk_table(entity_emb, "entity_emb")
     _chk(relation_kge, F32, "relation_kge"), _chk(w, F32, "w"), _chk(out, F32, "out"), _chk(uts, I32, "uts")
@@ -580,6 +601,15 @@ def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, o
         _chk(records, I32, "records")
         if tuple(records.shape) != (n_user, user_records_len(P, Nm, nR)):
             raise ValueError(f"records shape {tuple(records.shape)} is not that of build_user_records(uts, {P}, {nR}, ...)")
+    if er is not None:
+        _chk(er, F32, "er")
+        if records is None or er.numel() != lib.mvin_project_relations_elems(entity_emb.shape[0], nR, D):
+            raise ValueError("key_addressing_grouped: er = project_relations(entity_emb, relation_kge, w) goes with the user records")
+        _lib.check(lib.mvin_key_addressing_grouped_er_fwd(_p(entity_emb), _p(relation_kge), _p(w), _p(uts), _p(records), _p(er),
+                                                          _p(seg_user), _p(seg_ptr), _p(nseg), _p(perm), _p(i64), _p(i32), B, B, P, Nm, D,
+                                                          nR, entity_emb.shape[0], n_user, _p(out), ldo, _stream()),
+                   "mvin_key_addressing_grouped_er_fwd")
+        return out
     _lib.check(lib.mvin_key_addressing_grouped_rec_fwd(_p(entity_emb), _p(relation_kge), _p(w), _p(uts), _p(records), _p(seg_user),
                                                        _p(seg_ptr), _p(nseg), _p(perm), _p(i64), _p(i32), B, B, P, Nm, D, nR,
                                                        entity_emb.shape[0], n_user, _p(out), ldo, bf, _stream()),

@@ -157,8 +157,9 @@ def user_records_layout(P, Nm, nR):
     o_bidx = o_trel + pad4(maxtiles)
     o_head = o_bidx + maxtiles * 16
     o_tail = o_head + rows
+    o_hr = o_tail + rows
     return dict(NmP=NmP, rows=rows, maxtiles=maxtiles, o_cnt=o_cnt, o_off=o_off, o_trel=o_trel, o_bidx=o_bidx, o_head=o_head,
-                o_tail=o_tail, len=(o_tail + rows + 63) & ~63)
+                o_tail=o_tail, o_hr=o_hr, len=(o_hr + rows + 63) & ~63)
 
 
 def user_records(uts, nR, n_entity):
@@ -167,7 +168,8 @@ def user_records(uts, nR, n_entity):
     model.py:66-76 / data_loader_user_set.py), one record per user:
       [0] tiles, [1..3] 0 | members per relation | first bucket row per relation | relation of each tile |
       bucket slots -> row hop * NmP + m (rows of a relation -- they share R_KGE[r], model.py:214-216 -- in row order, every
-      bucket padded to whole 16-row tiles) | head id per row | tail id per row; ids clamped into the tables, all other words -1.
+      bucket padded to whole 16-row tiles) | head id per row | tail id per row | relation * n_entity + head per row (the row of
+      mvin_project_relations' [nR, nE, D] table; 0 where that does not fit 31 bits); ids clamped into the tables, all other words -1.
     Pure integer work: bit-exact."""
     uts = np.asarray(uts, dtype=np.int64)
     n_user, P, three, Nm = uts.shape
@@ -181,8 +183,11 @@ def user_records(uts, nR, n_entity):
         for hop in range(P):
             for m in range(Nm):
                 i = hop * L["NmP"] + m
-                members[min(int(uts[u, hop, 1, m]) & 0xFFFFFFFF, nR - 1)].append(i)      # clamped as unsigned words, like every device id
+                rel = min(int(uts[u, hop, 1, m]) & 0xFFFFFFFF, nR - 1)
+                members[rel].append(i)                                                    # clamped as unsigned words, like every device id
                 r_[L["o_head"] + i] = min(int(uts[u, hop, 0, m]) & 0xFFFFFFFF, n_entity - 1)
+                hr = rel * n_entity + int(r_[L["o_head"] + i])
+                r_[L["o_hr"] + i] = hr if hr < (1 << 31) else 0
                 r_[L["o_tail"] + i] = min(int(uts[u, hop, 2, m]) & 0xFFFFFFFF, n_entity - 1)
         tile = 0
         for r in range(nR):

@@ -18,6 +18,9 @@ items = torch.randint(0, d["n_entity"], (B,), device=dev, generator=g)
 out = torch.empty((B, 3 * D), device=dev)
 groups = ops.group_pairs_by_user(users)
 rec = ops.build_user_records(uts, P, nR, d["n_entity"]) if STATIC else None
+er = ops.project_relations(E, R, w) if (STATIC and "--er" in sys.argv) else None      # the gathered form of the U rows
+_kag = ops.key_addressing_grouped
+ops.key_addressing_grouped = lambda *a_, **k_: _kag(*a_, er=er, **k_)
 for _ in range(3):
     ops.key_addressing_grouped(E, R, w, uts, groups, items, P, out, 3 * D, nR, records=rec)
 torch.cuda.synchronize()

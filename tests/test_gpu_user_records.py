@@ -235,3 +235,111 @@ def test_fuzz_kernel_over_records(i, hip_lib):
         want.append((p[:, :, None] * E64[t]).sum(1))
     want = torch.cat(want, dim=1)
     assert_close(b[pick].double().cpu().numpy(), want.cpu().numpy(), "records kernel vs float64 equations", rtol=1e-5, atol=2e-6)
+
+
+# ---- the gathered form: U rows from mvin_project_relations' table (mvin_key_addressing_grouped_er_fwd) ----
+def test_project_relations_holds_the_products(hip_lib):
+    from mvin_amd import ops
+    rng = np.random.default_rng(3)
+    nE, nR, D = 333, 7, 64
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).cuda()
+    E, R, w = f(nE, D), f(nR, D, D), f(D)
+    ws = ops.project_relations(E, R, w).double().cpu()
+    want = torch.einsum("rnk,ek->ren", R.double().cpu(), E.double().cpu())         # R_KGE[r] . E[e]
+    assert_close(ws[:nR * nE * D].view(nR, nE, D).numpy(), want.numpy(), "R_KGE[r] . E[e]", rtol=2e-5, atol=2e-6)
+    assert_close(ws[nR * nE * D:nR * nE * D + nE].numpy(), (E.double().cpu() @ w.double().cpu()).numpy(), "E[e] . w", rtol=1e-5, atol=1e-6)
+
+
+ER_SHAPES = [s for s in SHAPES if s[1] <= 64 or not s[5]]
+
+
+@pytest.mark.parametrize("shape", ER_SHAPES, ids=lambda s: "P%dNm%dnR%d_u%d_B%d%s" % (s[0], s[1], s[2], s[3], s[4], "" if s[5] else "_noset"))
+def test_gathered_form_equals_the_kernel_over_records(shape, hip_lib):
+    from mvin_amd import ops
+    P, Nm, nR, n_user, B, has_set, idt = shape
+    D, n_entity = 64, 5000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(B + Nm)
+    E = torch.rand((n_entity, D), device=dev, generator=g) - 0.5
+    R = torch.rand((nR, D, D), device=dev, generator=g) - 0.5
+    w = (torch.rand(D, device=dev, generator=g) - 0.5) if has_set else None
+    uts_np = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=B)
+    uts_np[0, 0, 0, 0] = n_entity + 5                        # out-of-range ids: clamped by the records
+    uts_np[0, P - 1, 1, Nm - 1] = nR + 3
+    uts = torch.from_numpy(uts_np).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g).to(idt)
+    assert ops.key_addressing_grouped_er_supported(D, P, Nm, nR, n_entity, has_set)
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    er = ops.project_relations(E, R, w)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    n_o = P + (1 if has_set else 0)
+    a = torch.full((B, n_o * D), float("nan"), device=dev)
+    b = torch.full((B, n_o * D), float("nan"), device=dev)
+    ops.key_addressing_grouped(E, R, w, uts, groups, items, P, a, n_o * D, nR, records=rec)
+    first = None
+    for _ in range(2):
+        b.fill_(float("nan"))
+        ops.key_addressing_grouped(E, R, w, uts, groups, items, P, b, n_o * D, nR, records=rec, er=er)
+        torch.cuda.synchronize()
+        assert torch.isfinite(b).all()
+        assert_close(b.cpu().numpy(), a.cpu().numpy(), "gathered form vs kernel over records", rtol=1e-5, atol=1e-6)
+        if first is None:
+            first = b.clone()
+        assert torch.equal(first, b)
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["one_native_call", "python_schedule"])
+@pytest.mark.parametrize("case", [c for c in CASES if c[4] <= 64], ids=lambda c: "P%dNm%dnR%d_%s" % (c[3], c[4], c[5], c[8]))
+def test_forward_users_gathered_form_against_the_oracle(case, native, hip_lib):
+    from mvin_amd.model import MVIN
+    from oracle import mirror_fp32
+    D, K, H, P, Nm, nR, n_user, B, abl = case
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    n_entity = 500
+    rng = np.random.default_rng(D + Nm + B)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=3)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0")
+    model.group_min_pairs_per_user = 0
+    model.ka_er = True
+    if not native:
+        model._profile = []
+    dev = model.device
+    u_d, i_d, uts_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev), torch.from_numpy(uts).to(dev)
+    got = model.forward_users(u_d, i_d, uts_d)
+    assert model._ka_er_for(uts_d, model.user_records(uts_d)), "the gathered form was not taken"
+    model.ka_er = False
+    plain = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert_close(got.user_o.cpu().numpy(), plain.user_o.cpu().numpy(), "user_o gathered form vs kernel over records")
+    mh, mr, mt = synth.memories_for(uts, users)
+    ref = mirror_fp32.forward(args, params, adj_e, adj_r, users, items, mh, mr, mt)
+    assert_close(got.user_o.cpu().numpy(), ref.user_o.numpy(), "user_o vs fp32 mirror")
+    assert_close(got.scores.cpu().numpy(), ref.scores.numpy(), "scores vs fp32 mirror")
+    # nothing of the table is kept between calls: an in-place change of R_KGE shows in the next call
+    model.ka_er = True
+    with torch.no_grad():
+        model.relation_emb_KGE_matrix.mul_(1.5)
+    changed = model.forward_users(u_d, i_d, uts_d)
+    model.ka_er = False
+    want = model.forward_users(u_d, i_d, uts_d)
+    assert not torch.allclose(changed.user_o, got.user_o)
+    assert_close(changed.user_o.cpu().numpy(), want.user_o.cpu().numpy(), "user_o after an in-place change of R_KGE")
+
+
+def test_gathered_form_is_on_request_only(hip_lib):
+    from mvin_amd.model import MVIN
+    args = make_args(dim=64, neighbor_sample_size=4, h_hop=2, n_mix_hop=1, p_hop=2, n_memory=64, batch_size=64)
+    n_user, n_entity, nR = 40, 300, 6
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, 4, seed=1)
+    uts_d = torch.from_numpy(synth.ripple_sets(n_user, n_entity, nR, 2, 64, seed=2)).cuda()
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, device="cuda:0", seed=3)
+    rec = model.user_records(uts_d)
+    assert not model._ka_er_for(uts_d, rec)                  # measured neutral on the default (two-stream) line: opt-in
+    model.ka_er = True
+    assert model._ka_er_for(uts_d, rec) and not model._ka_er_for(uts_d, None)
