@@ -154,3 +154,31 @@ def test_synthetic_kg_reproduces_both_notebook_statistics(name):
         assert abs(deg.mean() - d["mean_degree"]) < 0.01
         assert abs((deg >= 20).mean() - d["share_ge20"]) < 0.03, (name, seed, (deg >= 20).mean())
         assert kg[:, 1].min() >= 0 and kg[:, 1].max() < d["n_relation"]
+
+
+def test_projected_tables_identity_in_float64():
+    """everything the two deepest levels apply to a gathered row before the ReLU is linear, so the
+    matrices can be applied to the TABLE (model.py:270-283, aggregators.py:108-116 re-associated).  Checked here in float64,
+    independent of any kernel: per-child self1 and out1, and the per-parent sums, in both forms."""
+    rng = np.random.default_rng(11)
+    nE, D, K, B = 200, 16, 8, 5
+    E, W1, W2, A0 = (rng.normal(size=s) for s in ((nE, D), (D, D), (D, D), (D, D)))
+    b1, b2, a0 = (rng.normal(size=D) for _ in range(3))
+    q = rng.normal(size=(B, D))
+    x1 = rng.integers(0, nE, size=(B, K))                       # children of the pair's item
+    y = rng.integers(0, nE, size=(B, K, K))                     # grandchildren
+    w = rng.random(size=(B, K, K))
+    w /= w.sum(-1, keepdims=True) * K                           # attention weights p_k / K: c = sum_k w_k = 1 / K
+    c = 1.0 / K
+    # the reference's order: project every gathered row, then the weighted sum, then the aggregator
+    self1 = (E[x1] + q[:, None, :]) @ W1 + b1
+    neigh = ((E[y] + q[:, None, None, :]) @ W2 + b2) * w[..., None]
+    out1 = np.maximum((self1 + neigh.sum(2)) @ A0 + a0, 0.0)
+    # the projected-tables form: T1 = E W1, TA1 = E W1 A0, TA2 = E W2 A0 per entity; u1, v per pair
+    T1, TA1, TA2 = E @ W1, E @ W1 @ A0, E @ W2 @ A0
+    u1 = q @ W1 + b1
+    v = q @ ((W1 + c * W2) @ A0) + (b1 + c * b2) @ A0 + a0
+    self1_p = T1[x1] + u1[:, None, :]
+    out1_p = np.maximum(TA1[x1] + (TA2[y] * w[..., None]).sum(2) + v[:, None, :], 0.0)
+    np.testing.assert_allclose(self1_p, self1, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(out1_p, out1, rtol=1e-11, atol=1e-11)
