@@ -6,9 +6,29 @@ kernels: launch latency, not the GPU, sets the step time.  ``GraphedScorer`` cap
 ctypes launches into libmvin_hip.so are recorded like any other kernel on the capture stream) and
 replays it per batch: one graph launch instead of ~10 kernel launches plus Python glue.
 """
+import contextlib
+import gc
+
 import torch
 
 _STREAMS = {}
+
+
+@contextlib.contextmanager
+def capture_without_gc():
+    """Around a hipGraph capture: collect first, then keep the cyclic collector OFF until the capture ends.  A capture runs
+    plain Python (hundreds of short-lived objects per step); a collection that starts inside it may free device tensors other
+    streams still hold (``record_stream``: the allocator records events on those streams) or destroy stream / event objects
+    -- none of which is allowed while a stream captures: the process aborts (seen once in a full test run, in the garbage
+    collector under ``torch.cuda.current_stream()``)."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def scoring_streams(device, n=2):
@@ -40,7 +60,7 @@ class GraphedScorer(object):
                 model.forward_device(self.users, self.items, self.mh, self.mr, self.mt)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture_without_gc(), torch.cuda.graph(self.graph):
             self.out = model.forward_device(self.users, self.items, self.mh, self.mr, self.mt)
         # the graph reads derived tables (relation logits, hoisted entity tables) that an optimizer step,
         # set_adjacency or restore_pretrain_emb replaces: such a graph must be captured again

@@ -584,7 +584,8 @@ class GraphedTrainer(object):
         torch.cuda.current_stream().wait_stream(side)
         m.invalidate()                           # the derived tables are to be rebuilt INSIDE the graph
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from .graph import capture_without_gc
+        with capture_without_gc(), torch.cuda.graph(self.graph):
             self.loss = trainer.enqueue(*feed, apply=True, lr_dev=self.lr_dev)
         m.invalidate()                           # nothing ran during capture: no derived table is valid yet
         self._captured = self._storage_key()
