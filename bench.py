@@ -750,7 +750,7 @@ def main():
         single_stream = (time.perf_counter() - t1) / a.steps
     faithful = None
     if scorer is None and not rowshard and model.prj is None and model._prj_for_l2(Bl, Bl * a.fanout ** (a.hop * a.mix - 2)) \
-            and model._enc_for_l2(n_parents=Bl * a.fanout ** (a.hop * a.mix - 2)) is not None:
+            and (model._enc_for_l2(n_parents=Bl * a.fanout ** (a.hop * a.mix - 2)) is not None or model._prj_plain_ok()):
         # the same K steps with the two deepest levels in their round-4 form (W1 / W2 products per distinct child), one stream
         model.prj = False
         for _ in range(3):
@@ -818,12 +818,16 @@ def main():
         table_bytes = case.n_entity * a.dim * s_
         cache_resident = table_bytes <= 256 * 2 ** 20        # Infinity Cache (MI355X_MICROARCH.md)
         enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
-        prj_now = enc is not None and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2))
+        prj_now = (used_l2 and not hoisted and (enc is not None or model._prj_plain_ok())
+                   and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2)))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
                  else "gather_attn_l2_packed_kernel<..., PRJ> (mvin_gather_attn_l2_prj_fwd: duplicate-slot encoding of the adjacency, rows "
                       "gathered from the projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step -- same ids "
                       "and grandchild rows per pair as mvin_gather_attn_l2_enc_fwd, no W1 / W2 / A0 product per distinct child)"
+                 if (prj_now and enc is not None)
+                 else "gather_attn_l2_d32_kernel<..., PRJ> (mvin_gather_attn_l2_prj_fwd over the plain adjacency: rows gathered from the "
+                      "projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step)"
                  if prj_now
                  else "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd: duplicate-slot encoding of the adjacency)"
                  if enc is not None
@@ -925,8 +929,8 @@ def main():
                                    f"full get_scores path",
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "ablation": a.ablation, "hipgraph_replay": bool(scorer), "streams": nstreams,
-                       "two_level_form": ("projected tables (E.W1 | E.W1.A0 | E.W2.A0 rebuilt inside every timed step: mvin_project_tables + "
-                                          "mvin_gather_attn_l2_prj_fwd)" if prj_now else
+                       "two_level_form": (("projected tables (E.W1 | E.W1.A0 | E.W2.A0 rebuilt inside every timed step: mvin_project_tables + "
+                                           "mvin_gather_attn_l2_prj_fwd" + (")" if enc is not None else " over the plain adjacency)")) if prj_now else
                                           "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",

@@ -183,7 +183,8 @@ MVIN_API int mvin_gather_attn_l2_enc_supported(int D, int K);
  * (mvin_project_tables_elems floats; fp32 entity table; `attention` = whether t0 will be given: it fixes c = 1/K or 1) and
  * must be called again whenever E, W1, W2, b1, b2, A0 or a0 changed -- mvin_score_l2_fwd and mvin_amd.MVIN call it in
  * every pass.  mvin_gather_attn_l2_prj_fwd: as mvin_gather_attn_l2_enc_fwd with `ws` in place of the table and the weights;
- * D in {32, 64, 128}, tables below 1 GiB each.  mvin_project_rows is the plain two-matrix form (out[0] = src W1 (+ b1),
+ * D in {32, 64, 128}, tables below 1 GiB each.  adjacency_encoded = 0: enc_entity / enc_relation are the PLAIN adjacency
+ * (D = 32, K in {8, 16} only: the wave-per-parent kernel, BASELINE config C2's, reads either form).  mvin_project_rows is the plain two-matrix form (out[0] = src W1 (+ b1),
  * out[1] = src W2 (+ b2)). */
 MVIN_API int mvin_project_rows(const float* src, int64_t rows, int D, const float* W1, const float* W2, const float* b1,
                                const float* b2, float* out, void* stream);
@@ -191,7 +192,7 @@ MVIN_API size_t mvin_project_tables_elems(int n_entity, int D);
 MVIN_API int mvin_project_tables(const float* entity_emb, const float* W1, const float* W2, const float* b1, const float* b2,
                                  const float* A0, const float* a0, int attention, int K, int n_entity, int D, float* ws,
                                  void* stream);
-MVIN_API int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation,
+MVIN_API int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
                                 void* stream);

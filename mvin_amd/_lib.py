@@ -86,7 +86,7 @@ SIGNATURES = {
     "mvin_project_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int] + [C.c_void_p] * 6),
     "mvin_project_tables_elems": (C.c_size_t, [C.c_int, C.c_int]),
     "mvin_project_tables": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_void_p] * 2),
-    "mvin_gather_attn_l2_prj_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p] * 3),
+    "mvin_gather_attn_l2_prj_fwd": (C.c_int, [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_void_p] * 3),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_linear_wgrad_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

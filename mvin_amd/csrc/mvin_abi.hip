@@ -195,8 +195,8 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
                                float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false) {
     const char* who = prj ? "mvin_gather_attn_l2_prj_fwd" : encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
-    if (prj && (!encoded || table_bf16 || !W1 || !W2 || !q))
-        return fail(-1, "%s: projected tables are fp32 and go with the encoded adjacency and the queries", who);
+    if (prj && (table_bf16 || !W1 || !W2 || !q))
+        return fail(-1, "%s: projected tables are fp32 and go with the queries", who);
     if (encoded && !mvin::fused_packed_supported(D, K))
         return fail(-3, "%s: unsupported shape D=%d K=%d (D in {32,64,128}, K in {16,32,64,128})", who, D, K);
     if (!mvin::fused_l2_supported(D, K))
@@ -244,13 +244,17 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
         static const char* dbg = getenv("MVIN_SPLIT_DBG");
         f.dbg = dbg ? atoi(dbg) : 0;
     }
+    if (prj && !encoded) {       // plain adjacency: only the wave-per-parent kernel (D = 32, K <= 16) has a projected-tables form
+        if (!mvin::fused_d32_applies(f, D)) return fail(-3, "%s: the projected-tables form over a plain adjacency exists for D = 32, K in {8, 16}", who);
+        return hip_result(mvin::launch_gather_attn_l2_d32(f, 0, (hipStream_t)stream, false), who);
+    }
     if (encoded) {
         if (!adj_relation) return fail(-1, "%s: null enc_relation", who);
         if (!mvin::fused_packed_applies(f, D))
             return fail(-3, "%s: tables too large (n_entity <= 2^24, table < 4 GiB, adjacency and outputs < 2 GiB)", who);
         // D = 32, K <= 16 (BASELINE C2): the wave-per-parent kernel reads the encoding too (MVIN_L2_D32ENC=0: the packed-tile kernel, A/B)
         static const bool d32enc_off = getenv("MVIN_L2_D32ENC") && atoi(getenv("MVIN_L2_D32ENC")) == 0;
-        if (!prj && !d32enc_off && mvin::fused_d32_applies(f, D))
+        if (!d32enc_off && mvin::fused_d32_applies(f, D))
             return hip_result(mvin::launch_gather_attn_l2_d32(f, table_bf16, (hipStream_t)stream, true), who);
         return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
     }
@@ -330,7 +334,7 @@ int mvin_project_tables(const float* entity_emb, const float* W1, const float* W
     return mvin_linear_fwd(&l, stream);
 }
 
-int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation,
+int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
                                 void* stream) {
@@ -341,7 +345,7 @@ int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, cons
     // (W1, b1) and (the combined matrix, its bias) project the parents' queries; A0 / a0 are inside the tables and the bias
     return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
                                parent_ids_i64 ? 2 : 1, t0, t1, blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K,
-                               D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, true, true);
+                               D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, adjacency_encoded != 0, true);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -628,14 +632,15 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
-    if (enc && a->prj_tables && a->W1 && !a->table_bf16) {
+    const bool d32 = mvin::fused_d32_supported(D, a->K);       // the wave-per-parent kernel: projected tables over either adjacency
+    if ((enc || d32) && a->prj_tables && a->W1 && !a->table_bf16) {
         // projected-tables form: E.W1 | E.W1.A0 | E.W2.A0 once per entity from the CURRENT parameters (nothing is kept between
         // calls), then the packed kernel without any product per distinct child
         rc = mvin_project_tables(reinterpret_cast<const float*>(a->entity_emb), a->W1, a->W2, a->b1, a->b2, a->A0, a->a0,
                                  a->t0 != nullptr, a->K, a->n_entity, D, a->prj_tables, stream);
         if (rc) return rc;
-        rc = mvin_gather_attn_l2_prj_fwd(a->prj_tables, a->enc_entity, a->enc_relation, a->items, 1, a->t0, a->t1, a->user_o, (int)a->B, 1,
-                                         a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, stream);
+        rc = mvin_gather_attn_l2_prj_fwd(a->prj_tables, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation, enc ? 1 : 0,
+                                         a->items, 1, a->t0, a->t1, a->user_o, (int)a->B, 1, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, stream);
     } else
     rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                              reinterpret_cast<const int32_t*>(a->items), 2,

@@ -30,7 +30,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kD32 = 32;
 constexpr int kD32Ld = 36;                                   // LDS row stride (floats): 16-byte aligned rows, 16 rows -> 16 bank groups
 constexpr int kD32Waves = 4;
-constexpr int d32_wave_words(int K) { return 2 * 16 * kD32Ld + 32 + 2 * 16 * K; }      // sA1 | sA2 (= sZ) | sP0 | sP1 | sY | sWt
+constexpr int d32_wave_words(int K) { return 2 * 16 * kD32Ld + 32 + 2 * 16 * K + 96; }      // sA1 | sA2 (= sZ) | sP0 | sP1 | sY | sWt | sQ | sUV (PRJ)
 constexpr int kD32WeightWords = 3 * kD32 * kD32;             // W1 | W2 | A0, shared by the workgroup
 
 size_t fused_d32_lds_bytes(int nR, int K) {
@@ -50,8 +50,13 @@ __device__ __forceinline__ float d32_exp(float x) {
 // relation | multiplicity << 16 | cnt << 24, padding = slot 0 with multiplicity 0).  A slot then weighs multiplicity x exp(logit), and a
 // padding slot is never fetched: its row id becomes an offset beyond the table, which a buffer load answers with zeros without
 // touching memory -- no branch, no predicate.  A C2 pair loads ~93 rows instead of 273.
-template <int K, bool BF, bool ENC>
+// PRJ: the projected-tables form (mvin_gather_attn_l2_prj_fwd; see mvin_fused_packed.hip): a.table = [E.W1 ; E.W1.A0 ; E.W2.A0],
+// a.W1 / a.b1 and a.W2 / a.b2 = the matrices and biases of the PARENT's two query terms u1 = q.W1 + b1, v = q.Wv + bv (64 dot
+// products of length 32: one per lane, plain FMAs out of the workgroup's LDS copy of the two blocks).  A child's tile row is
+// {T1[x1] + u1 | TA1[x1] + sum_k w_k TA2[y_k] + v}; out1 = relu of the second half: no MFMA left in the kernel.
+template <int K, bool BF, bool ENC, bool PRJ = false>
 __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(FusedL2Args a) {
+    static_assert(!(PRJ && BF), "projected tables are fp32");
     constexpr int D = kD32, LD = kD32Ld;
     constexpr int NCH = K / 8;               // children per lane
     constexpr int KE = K / 8;                // grandchild slots per child whose ids / logits this lane computes
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
     float* sP1 = sP0 + 16;                               // [16]
     int* sY = reinterpret_cast<int*>(sP1 + 16);          // [16][K] grandchild ids
     float* sWt = reinterpret_cast<float*>(sY + 16 * K);  // [16][K] their weights p_k / K
-    const bool has_proj = a.W1 != nullptr;
+    float* sQ = sWt + 16 * K;                            // [32]  PRJ: the parent's query row
+    float* sUV = sQ + 32;                                // [64]  PRJ: u1 | v of the parent
+    const bool has_proj = PRJ ? false : a.W1 != nullptr;
     const bool has_att0 = a.t0 != nullptr, has_att1 = a.t1 != nullptr;
     const float invK = 1.f / (float)K;
     const float c2scale = has_att0 ? invK : 1.f;         // sum_k of the grandchild weights
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
         sT1[i] = has_att1 ? a.t1[i] : 0.f;
     }
     for (int i = tid; i < D * D; i += kD32Waves * 64) {
-        sWts[i] = has_proj ? a.W1[i] : 0.f;
-        sWts[D * D + i] = has_proj ? a.W2[i] : 0.f;
-        sWts[2 * D * D + i] = a.A0[i];
+        sWts[i] = (has_proj || PRJ) ? a.W1[i] : 0.f;
+        sWts[D * D + i] = (has_proj || PRJ) ? a.W2[i] : 0.f;
+        sWts[2 * D * D + i] = PRJ ? 0.f : a.A0[i];
     }
     for (int i = lane; i < WW; i += 64) wbase[i] = 0.f;  // tile rows >= K stay zero (weights 0)
     __syncthreads();                                     // the only workgroup barrier: the shared tables
@@ -108,20 +115,24 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
     }
 
     // 32-bit offsets through buffer descriptors (the launcher guarantees every range < 2^31 / 2^32 bytes)
-    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.table), 0, (int)a.table_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.table), 0, (int)(PRJ ? 3 * a.table_bytes : a.table_bytes), 0x00020000);
+    const unsigned tb1 = PRJ ? (unsigned)a.table_bytes : 0u, tb2 = 2u * tb1;     // PRJ: byte offsets of TA1 / TA2
+    const float ubias = PRJ ? (lane < 32 ? (a.b1 ? a.b1[lane] : 0.f) : (a.b2 ? a.b2[lane - 32] : 0.f)) : 0.f;
     const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, a.adj_r ? (int)a.adj_bytes : 0,
                                                                            0x00020000);      // none: relation ids read as 0
     const __amdgpu_buffer_rsrc_t qsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.q), 0, has_proj ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
+        const_cast<float*>(a.q), 0, (has_proj || PRJ) ? (int)((a.P / a.parents_per_pair) * D * 4) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t out0 = __builtin_amdgcn_make_buffer_rsrc(a.nagg0, 0, (int)(a.P * D * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t out1 = __builtin_amdgcn_make_buffer_rsrc(a.nagg1, 0, (int)(a.P * D * 4), 0x00020000);
-    auto row4 = [&](int id) -> float4 {                 // chunk c of table row `id`
+    constexpr unsigned kNoRowAll = 0xFFFFFFFFu / (unsigned)(BF ? 64 : 128);
+    auto row4 = [&](int id, unsigned toff = 0u) -> float4 {                 // chunk c of table row `id` (PRJ: of the table at byte offset toff)
+        if constexpr (PRJ) toff = (unsigned)id == kNoRowAll ? 0u : toff;   // (a padding slot stays beyond the buffer: reads zeros)
         if constexpr (BF) {
             const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 8u, 0, 0);
             return bf16x4_to_f32(make_uint2(r[0], r[1]));
         } else {
-            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 16u, 0, 0);
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, (unsigned)id * (unsigned)RB + (unsigned)c * 16u + toff, 0, 0);
             return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
         }
     };
@@ -208,9 +219,37 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
             }
         }
         // ---- the children's own rows land under the rest ----
-        float4 sv[NCH];
+        float4 sv[NCH], sa[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) sv[i] = row4(ENC && mu1[i] == 0.f ? (int)kNoRow : x1[i]);
+        for (int i = 0; i < NCH; ++i) {
+            sv[i] = row4(ENC && mu1[i] == 0.f ? (int)kNoRow : x1[i]);
+            sa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PRJ) sa[i] = row4(ENC && mu1[i] == 0.f ? (int)kNoRow : x1[i], tb1);
+        }
+        float4 u1c = make_float4(0.f, 0.f, 0.f, 0.f), vc = u1c;
+        if constexpr (PRJ) {
+            // the parent's two query terms: output j = lane (u1: 0..31, v: 32..63), 32 FMAs each
+            if (g == 0) *reinterpret_cast<float4*>(sQ + 4 * c) = qv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            const float* wj = sWts + (lane >> 5) * D * D + (lane & 31);
+            float uacc = ubias;
+#pragma unroll
+            for (int k4 = 0; k4 < D / 4; ++k4) {
+                const float4 q4 = *reinterpret_cast<const float4*>(sQ + 4 * k4);
+                uacc = fmaf(q4.x, wj[(4 * k4) * D], uacc);
+                uacc = fmaf(q4.y, wj[(4 * k4 + 1) * D], uacc);
+                uacc = fmaf(q4.z, wj[(4 * k4 + 2) * D], uacc);
+                uacc = fmaf(q4.w, wj[(4 * k4 + 3) * D], uacc);
+            }
+            sUV[lane] = uacc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+            u1c = *reinterpret_cast<const float4*>(sUV + 4 * c);
+            vc = *reinterpret_cast<const float4*>(sUV + 32 + 4 * c);
+        }
         // ---- attention over the parent's K children: aggregator (0,.) -> p0, aggregator (1,.) -> p1 ----
         float p0[NCH], p1[NCH];
         {
@@ -268,14 +307,14 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 const float4 wa = *reinterpret_cast<const float4*>(sWt + n * K + k0);
                 const float4 wb = *reinterpret_cast<const float4*>(sWt + n * K + k0 + 4);
                 float4 rows[8];
-                rows[0] = row4(ya.x);
-                rows[1] = row4(ya.y);
-                rows[2] = row4(ya.z);
-                rows[3] = row4(ya.w);
-                rows[4] = row4(yb.x);
-                rows[5] = row4(yb.y);
-                rows[6] = row4(yb.z);
-                rows[7] = row4(yb.w);
+                rows[0] = row4(ya.x, tb2);
+                rows[1] = row4(ya.y, tb2);
+                rows[2] = row4(ya.z, tb2);
+                rows[3] = row4(ya.w, tb2);
+                rows[4] = row4(yb.x, tb2);
+                rows[5] = row4(yb.y, tb2);
+                rows[6] = row4(yb.z, tb2);
+                rows[7] = row4(yb.w, tb2);
                 acc = f4_fma(wa.x, rows[0], acc);
                 acc = f4_fma(wa.y, rows[1], acc);
                 acc = f4_fma(wa.z, rows[2], acc);
@@ -286,8 +325,13 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
                 acc = f4_fma(wb.w, rows[7], acc);
             }
             // ---- the K children as rows of a 16-row tile: {E[x1] + q | S' + (sum p / K) q} (model.py:277) ----
+            if constexpr (PRJ) {
+                *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv[i].x + u1c.x, sv[i].y + u1c.y, sv[i].z + u1c.z, sv[i].w + u1c.w);
+                *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = make_float4(sa[i].x + acc.x + vc.x, sa[i].y + acc.y + vc.y, sa[i].z + acc.z + vc.z, sa[i].w + acc.w + vc.w);
+            } else {
             *reinterpret_cast<float4*>(sA1 + n * LD + 4 * c) = make_float4(sv[i].x + qv.x, sv[i].y + qv.y, sv[i].z + qv.z, sv[i].w + qv.w);
             *reinterpret_cast<float4*>(sA2 + n * LD + 4 * c) = f4_fma(c2scale, qv, acc);
+            }
             if (c == 0) {
                 sP0[n] = pvalid ? p0[i] : 0.f;
                 sP1[n] = pvalid ? p1[i] : 0.f;
@@ -328,8 +372,31 @@ __global__ __launch_bounds__(kD32Waves * 64, 4) void gather_attn_l2_d32_kernel(F
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     s1v[cc][r] = sA1[(4 * q16 + r) * LD + 16 * cc + l16];
-                    zv[cc][r] = s1v[cc][r] + sA2[(4 * q16 + r) * LD + 16 * cc + l16];
+                    zv[cc][r] = (PRJ ? 0.f : s1v[cc][r]) + sA2[(4 * q16 + r) * LD + 16 * cc + l16];      // PRJ: already Z A0 + a0
                 }
+        }
+        if constexpr (PRJ) {
+            // out1 = relu(row) ; both per-parent sums straight from the tile
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                float part0 = 0.f, part1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    part0 = fmaf(sP0[4 * q16 + r], s1v[cc][r], part0);
+                    part1 = fmaf(sP1[4 * q16 + r], fmaxf(zv[cc][r], 0.f), part1);
+                }
+                const float n0 = PPW == 2 ? xor16_sum(part0) : rows_combine_sum(part0);
+                const float n1 = PPW == 2 ? xor16_sum(part1) : rows_combine_sum(part1);
+                const int64_t po = pp + (PPW == 2 ? (q16 >> 1) : 0);
+                if ((PPW == 2 ? (q16 & 1) == 0 : q16 == 0) && po < a.P) {
+                    const unsigned off = ((unsigned)po * D + 16u * cc + (unsigned)l16) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(n0 * invK), out0, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(n1 * invK), out1, off, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         // Z overwrites S' in place: every lane's reads of sA2 (above) are ahead of these writes in the wave's LDS queue
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -388,29 +455,34 @@ bool fused_d32_applies(const FusedL2Args& a, int D) {
     static const char* e = getenv("MVIN_L2_D32");
     if (e && e[0] == '0') return false;                  // A/B: the role-split / symmetric kernel
     return fused_d32_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_bytes > 0 && a.adj_bytes < (1ull << 31) &&
-           a.table_bytes > 0 && a.table_bytes < (1ull << 32) - 4096 && (uint64_t)a.P * D * 4 < (1ull << 31) &&
+           a.table_bytes > 0 && a.table_bytes < (a.prj ? (1ull << 30) : (1ull << 32) - 4096) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
            fused_d32_lds_bytes(a.nR, a.K) <= 64 * 1024;     // (default dynamic-LDS limit; larger relation tables keep the pipeline)
 }
 
-template <int K, bool BF, bool ENC>
+template <int K, bool BF, bool ENC, bool PRJ = false>
 static hipError_t launch_d32(const FusedL2Args& a, hipStream_t st) {
     const size_t lds = fused_d32_lds_bytes(a.nR, K);
     const int64_t wgs = (a.P + kD32Waves - 1) / kD32Waves;
     static thread_local int per_cu = 0;
     if (per_cu == 0) {
         int v = 3;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(gather_attn_l2_d32_kernel<K, BF, ENC>), kD32Waves * 64, lds) !=
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(gather_attn_l2_d32_kernel<K, BF, ENC, PRJ>), kD32Waves * 64, lds) !=
                 hipSuccess || v < 1)
             v = 3;
         per_cu = v;
     }
     const int64_t cap = 256 * (int64_t)per_cu;           // persistent grid
     const int grid = (int)(wgs < cap ? wgs : cap);
-    gather_attn_l2_d32_kernel<K, BF, ENC><<<grid, kD32Waves * 64, lds, st>>>(a);
+    gather_attn_l2_d32_kernel<K, BF, ENC, PRJ><<<grid, kD32Waves * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
 hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded) {
+    if (a.prj) {
+        if (table_bf16) return hipErrorInvalidValue;
+        if (encoded) return a.K == 8 ? launch_d32<8, false, true, true>(a, st) : launch_d32<16, false, true, true>(a, st);
+        return a.K == 8 ? launch_d32<8, false, false, true>(a, st) : launch_d32<16, false, false, true>(a, st);
+    }
     if (encoded) {
         switch (a.K) {
             case 8: return table_bf16 ? launch_d32<8, true, true>(a, st) : launch_d32<8, false, true>(a, st);

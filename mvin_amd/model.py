@@ -628,7 +628,7 @@ class MVIN(object):
             uo = self.args.User_orient
             enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
             tabs = None
-            if enc is not None and self._prj_for_l2(B, B * K ** (L - 2)):
+            if (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B, B * K ** (L - 2)):
                 # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 from the current parameters, per call
                 Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
                 tabs = ops.project_tables(self.entity_emb_matrix, Wp[L - 1], Wp[L], bp[L - 1], bp[L], a0.weights, a0.bias, K,
@@ -642,8 +642,9 @@ class MVIN(object):
                        self.transfer_matrix_bias[L - 1] if uo else None, self.transfer_matrix_bias[L] if uo else None,
                        q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
             if tabs is not None:
-                n0, n1 = ops.gather_attn_l2_prj(tabs, enc[0], enc[1], ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
-                                                K ** (L - 2), K, D, self.n_relation, self.n_entity)
+                ae, ar = (enc[0], enc[1]) if enc is not None else (self.adj_entity, self.adj_relation)
+                n0, n1 = ops.gather_attn_l2_prj(tabs, ae, ar, ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
+                                                K ** (L - 2), K, D, self.n_relation, self.n_entity, encoded=enc is not None)
                 pp = pc = None
             elif enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
@@ -851,6 +852,10 @@ class MVIN(object):
         return bool(ops.key_addressing_grouped_er_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, self.n_entity,
                                                             bool(a.PS_O_ft)))
 
+    def _prj_plain_ok(self):
+        """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2)."""
+        return self.dim == 32 and self.n_neighbor in (8, 16) and self.fused is not False
+
     def _prj_for_l2(self, B, n_parents=None):
         """Projected-tables form of the fused two-level pass for a batch of B pairs (``n_parents`` level-(L-2) nodes)?
         ``self.prj``: None = automatic (MVIN_PRJ=0 / 1 overrides), True / False."""
@@ -923,7 +928,7 @@ class MVIN(object):
         # projected-tables form of the two deepest levels (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 is rebuilt by every call
         # from the current parameters -- worth it when the batch's distinct children outnumber the entities (the per-entity
         # products cost ~n_entity rows of work, the per-child products they replace ~B K / 4)
-        prj = enc is not None and self._prj_for_l2(B)
+        prj = (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B)
         if prj:
             pt = self._prj_tables.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_project_tables_elems(self.n_entity, D)

@@ -330,9 +330,10 @@ def project_tables(entity_emb, W1, W2, b1, b2, A0, a0, K, attention, out=None):
     return out
 
 
-def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity):
+def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity, encoded=True):
     """mvin_gather_attn_l2_prj_fwd: gather_attn_l2_enc over the workspace of ``project_tables`` (built with attention =
-    (t0 is not None)).  Returns (nagg0 [P,D], nagg1 [P,D])."""
+    (t0 is not None)).  ``encoded=False``: the two adjacency arrays are the plain adjacency (D = 32, K in {8, 16}).
+    Returns (nagg0 [P,D], nagg1 [P,D])."""
     lib = _lib.load()
     for t, dt, nm in ((ws, F32, "ws"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
                       (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"),
@@ -343,7 +344,7 @@ def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, p
     P = B * parents_per_pair
     nagg0 = torch.empty((P, D), dtype=F32, device=ws.device)
     nagg1 = torch.empty((P, D), dtype=F32, device=ws.device)
-    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(ws), _p(enc_entity), _p(enc_relation), _p(parent_ids),
+    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(ws), _p(enc_entity), _p(enc_relation), 1 if encoded else 0, _p(parent_ids),
                                                int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(q), B, parents_per_pair, K, D,
                                                n_entity, nR, _p(nagg0), _p(nagg1), _stream()), "mvin_gather_attn_l2_prj_fwd")
     return nagg0, nagg1

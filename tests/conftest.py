@@ -32,4 +32,8 @@ def _pin_kernel_under_test(request, monkeypatch):
     mod = request.module.__name__.rsplit(".", 1)[-1]
     if mod.startswith("test_gpu") and mod not in SMALL_KERNEL_MODULES:
         monkeypatch.setenv("MVIN_SMALL", "0")
+        # ... and the form of the two deepest levels they pin: the projected-tables form (taken by batch size: B K >= 16 n_entity)
+        # has its own module; an explicit MVIN_PRJ in the environment (a forced run of the whole suite) is respected
+        if mod != "test_gpu_prj" and "MVIN_PRJ" not in os.environ:
+            monkeypatch.setenv("MVIN_PRJ", "0")
     yield

@@ -221,3 +221,71 @@ def test_parameters_changed_between_calls_are_seen(hip_lib):
     want = _pairs(model, case).scores
     assert not torch.allclose(before, after)
     assert_close(after.cpu().numpy(), want.cpu().numpy(), "scores after an in-place parameter change", rtol=1e-5, atol=1e-6)
+
+
+# ---- D = 32, K in {8, 16}: the wave-per-parent kernel (BASELINE C2) reads projected tables over EITHER adjacency form ----
+@pytest.mark.parametrize("encoded", [False, True], ids=["plain", "encoded"])
+@pytest.mark.parametrize("att", ["both", "none"])
+@pytest.mark.parametrize("ppp", [1, "K"])
+@pytest.mark.parametrize("K", [8, 16])
+def test_projected_wave_per_parent_kernel_matches_faithful(K, ppp, att, encoded, hip_lib):
+    D = 32
+    if encoded and K == 8:
+        pytest.skip("the encoded entry points start at K = 16")
+    ppp = K if ppp == "K" else 1
+    B = 23 if ppp == 1 else 5
+    args = make_args(**_shape(D, K, B=B))
+    case = synth.small_case(args, n_user=8, n_entity=900, n_relation=7, seed=31 + K, zero_rows=4, repeats=True)
+    rng = np.random.default_rng(K * 7 + ppp)
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)
+    E = f(case.n_entity, D)
+    ae = torch.from_numpy(case.adj_entity.astype(np.int32)).to(dev)
+    ar = torch.from_numpy(case.adj_relation.astype(np.int32)).to(dev)
+    parents = torch.from_numpy(rng.integers(0, case.n_entity, size=B * ppp).astype(np.int32)).to(dev)
+    parents[0] = int(np.flatnonzero((case.adj_entity == 0).all(1))[0])
+    t0 = f(7) if att == "both" else None
+    t1 = f(7) if att == "both" else None
+    W1, W2, b1, b2, q, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
+    want0, want1, _, _ = ops.gather_attn_l2(E, ae, ar, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, ppp, K, D, 7)
+    ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, t0 is not None)
+    if encoded:
+        ee, er, _ = ops.encode_adjacency(ae, ar)
+    else:
+        ee, er = ae, ar
+    got0, got1 = ops.gather_attn_l2_prj(ws, ee, er, parents, t0, t1, q, B, ppp, K, D, 7, case.n_entity, encoded=encoded)
+    torch.cuda.synchronize()
+    assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0", rtol=3e-5, atol=6e-6)
+    assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1", rtol=3e-5, atol=6e-6)
+
+
+@pytest.mark.parametrize("feed", ["pairs", "python-schedule"])
+@pytest.mark.parametrize("K", [8, 16])
+def test_c2_shaped_model_with_projected_tables_vs_oracles(K, feed, hip_lib):
+    """dim 32, fan-out 8 / 16 with the PLAIN adjacency (what MVIN takes at BASELINE C2's shape) and the projected tables."""
+    args = make_args(**_shape(32, K, B=29))
+    case = synth.small_case(args, n_user=16, n_entity=900, n_relation=7, seed=77 + K, zero_rows=4, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=43, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
+    model.prj = True
+    assert model._enc_for_l2(n_parents=29) is None and model._prj_plain_ok()
+    if feed == "python-schedule":
+        model.native_l2_max_batch = 0
+    out = _pairs(model, case)
+    m, e = run_oracles(args, case, params)
+    assert_close(out.scores.cpu().numpy(), m.scores.numpy(), "scores vs fp32 mirror", rtol=1e-5, atol=1e-6)
+    model.prj = False
+    ref = _pairs(model, case)
+    assert_close(out.scores.cpu().numpy(), ref.scores.cpu().numpy(), "projected vs faithful", rtol=1e-5, atol=1e-6)
+
+
+def test_plain_adjacency_form_exists_only_for_the_wave_per_parent_kernel(hip_lib):
+    from mvin_amd._lib import MvinHipError
+    dev = "cuda:0"
+    E = torch.zeros(300, 64, device=dev)
+    W = torch.zeros(64, 64, device=dev)
+    ws = ops.project_tables(E, W, W, None, None, W, None, 32, True)
+    adj = torch.zeros((300, 32), dtype=torch.int32, device=dev)
+    with pytest.raises(MvinHipError):
+        ops.gather_attn_l2_prj(ws, adj, adj, torch.zeros(4, dtype=torch.int32, device=dev), None, None, torch.zeros(4, 64, device=dev),
+                               4, 1, 32, 64, 6, 300, encoded=False)
