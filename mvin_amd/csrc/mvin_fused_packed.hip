@@ -276,7 +276,9 @@ __global__ __launch_bounds__((NG + D / 16) * 64, pack_minw(D, NG)) void gather_a
     // rewrites them for the next tile while the dense wave may still walk them. ----
     constexpr int NRND = G::NRND, NS = TM / NRND;
     constexpr bool HELP = pack_help(D, KT, BF, NG);      // (NRND == 2, not the 8-per-lane bf16 form, K <= 32: measured C4 (K = 64)
-                                                          //  1.10 -> 1.15 ms, C5 (bf16, K = 128) 1.72 -> 2.53 ms with it)
+                                                          //  1.10 -> 1.15 ms (round 4), 1.107 -> 1.107 (round 5: the dense waves idle 25 k
+                                                          //  of a tile's 32 k cycles there and helping still moves nothing -- the row rate,
+                                                          //  not the front's issue, bounds that shape), C5 (bf16, K = 128) 1.72 -> 2.53 ms)
     static_assert(!HELP || NRND == 2, "HELP needs two gather rounds");
     constexpr int SH = KT >= 32 ? (KT == 32 ? 2 : KT == 64 ? 3 : 4) : 1;
     auto rank_of = [&](int gwx, int h, int grp) -> int {    // rank of the h-th row of lane group grp of front wave gwx
@@ -1112,7 +1114,11 @@ static hipError_t launch_packed_k(const FusedL2Args& a, hipStream_t st) {
                 if (a.dbg & 8) return launch_packed<D, 32, BF, 4, true>(a, st);      // MVIN_SPLIT_DBG=8: profiled build
             }
             return launch_packed<D, 32, BF, 4>(a, st);
-        case 64: return launch_packed<D, 64, BF, 4>(a, st);
+        case 64:
+            if constexpr (D == 64 && !BF) {
+                if (a.dbg & 8) return launch_packed<D, 64, BF, 4, true>(a, st);      // MVIN_SPLIT_DBG=8: profiled build
+            }
+            return launch_packed<D, 64, BF, 4>(a, st);
         case 128: return launch_packed<D, 128, BF, 4>(a, st);
         default: return hipErrorInvalidValue;
     }

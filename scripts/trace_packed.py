@@ -10,8 +10,8 @@ os.environ["MVIN_PACK_TRACE"] = "1"
 from mvin_amd import _lib, ops, synth
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(0)
-D, K, B = 64, 32, int(os.environ.get("B", 524288))
-case = synth.dataset_case("last-fm_50core", K=K, B=B, seed=0, uniform_adj="--uniform" in sys.argv)
+D, K, B = 64, int(os.environ.get("K", 32)), int(os.environ.get("B", 524288))
+case = synth.dataset_case(os.environ.get("DATASET", "last-fm_50core"), K=K, B=B, seed=0, uniform_adj="--uniform" in sys.argv)
 nE = case.n_entity
 table = torch.rand((nE, D), device=dev, generator=g) - 0.5
 adj_e = torch.from_numpy(case.adj_entity.astype(np.int32)).to(dev)
