@@ -41,6 +41,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 L2_PEAK_GBS = 34500.0  # aggregate L2 bandwidth (8 XCDs x 4 MiB), same guide, "L2 (per XCD)"
 HBM_LEG_ROWS = 16_000_000   # x 64 x 4 B = 4.1 GB: 16x the Infinity Cache, < 4 GiB (32-bit buffer offsets)
 HBM_LEG_PAIRS = 32768
+# projected-tables form: three tables of 4 M x 64 x 4 B = 1.02 GB each (below the kernel's 1 GiB-per-table limit), 3.07 GB = 12x the
+# Infinity Cache
+HBM_LEG_PRJ_ROWS = 4_000_000
+
+
+def prj_bytes_per_pair(D, K, s=4):
+    """What mvin_gather_attn_l2_prj_fwd must read per pair of a depth-2 tree: SURVEY.md 8(d)'s figure with TWO self rows per child
+    (T1[x], TA1[x]) instead of one -- (1 + 2K + K^2) rows, the adjacency rows of the item and its K children, the query row, the score."""
+    return (1 + 2 * K + K * K) * D * s + (1 + K) * K * 2 * 4 + D * s + 4
 
 
 def algorithmic_bytes_per_pair(D, K, L, s=4):
@@ -88,6 +97,9 @@ def parse():
     ap.add_argument("--hbm-leg-only", action="store_true",
                     help="run ONLY the 4 GB-table leg and print its record (the command profiles/r2/*hbm_leg* were "
                          "collected with: one kernel name, one regime per rocprofv3 run)")
+    ap.add_argument("--hbm-leg-form", choices=["enc", "plain", "prj"], default="enc",
+                    help="with --hbm-leg-only: enc = mvin_gather_attn_l2_enc_fwd (16 M-row table), plain = mvin_gather_attn_l2_fwd, "
+                         "prj = mvin_gather_attn_l2_prj_fwd (projected tables of a 4 M-row table: the instance the default line times)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep")
     ap.add_argument("--feed", choices=["pairs", "users"], default="users",
                     help="pairs: per-pair ripple-set arrays [B, n_memory] resident in HBM (the reference's feed_dict "
@@ -214,14 +226,18 @@ def check_l2_launch(out, table, adj_e, adj_r, parents, t0, t1, W1, W2, b1, b2, q
     return max_abs, worst, worst <= 1.0
 
 
-def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0, encoded=False):
+def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=None, pairs=HBM_LEG_PAIRS, n_rel=9, seed=0, encoded=False, prj=False):
     """The dominant kernel in its HBM-bound regime: the SAME kernel as in the timed steps (same D, K, table dtype,
     projection + attention on) -- mvin_gather_attn_l2_fwd (role-split kernel), or with ``encoded`` mvin_gather_attn_l2_enc_fwd
     (packed-tile kernel over the duplicate-slot encoding of the same adjacency) -- on a ``n_rows`` x D table far larger than the
     Infinity Cache, uniform adjacency (no repeated slots: every one of the K + K^2 rows per pair is loaded), ``pairs`` parents
-    per launch.  Each launch is bracketed by HIP events on the stream it is launched on (torch's current stream)."""
+    per launch.  ``prj``: the PROJECTED-TABLES instance (mvin_gather_attn_l2_prj_fwd over E.W1 | E.W1.A0 | E.W2.A0, built once
+    before the launches by mvin_project_tables; 4 M rows: 3 x 1.02 GB of tables), priced on ITS bytes (prj_bytes_per_pair).
+    Each launch is bracketed by HIP events on the stream it is launched on (torch's current stream)."""
     import torch
     from mvin_amd import ops
+    if n_rows is None:
+        n_rows = HBM_LEG_PRJ_ROWS if prj else HBM_LEG_ROWS
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     dt = torch.bfloat16 if table_dtype == "bf16" else torch.float32
@@ -234,10 +250,25 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     q = torch.rand((pairs, D), device=dev, generator=g)
     bias = torch.zeros(D, device=dev)
     args = (table, adj_e, adj_r, parents, t0, t0, W[0], W[1], bias, bias, q, W[2], bias, pairs, 1, K, D, n_rel)
-    if encoded:
+    if prj:
+        if table_dtype != "f32":
+            raise ValueError("projected tables are fp32")
+        encoded = ops.gather_attn_l2_prj_supported(D, K, True, n_rows, n_rel)
+        if not encoded and not ops.gather_attn_l2_prj_supported(D, K, False, n_rows, n_rel):
+            raise ValueError(f"no projected-tables kernel for D={D} K={K}")
+        ws = ops.project_tables(table, W[0], W[1], bias, bias, W[2], bias, K, True)
+        if encoded:
+            enc_e, enc_r, cnt = ops.encode_adjacency(adj_e, adj_r)
+            launch = lambda: ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t0, q, pairs, 1, K, D, n_rel, n_rows, encoded=True)   # noqa: E731
+            kernel = f"gather_attn_l2_packed_kernel<{D}, {K}, false, 4, false, true> (mvin_gather_attn_l2_prj_fwd)"
+        else:
+            launch = lambda: ops.gather_attn_l2_prj(ws, adj_e, adj_r, parents, t0, t0, q, pairs, 1, K, D, n_rel, n_rows, encoded=False)  # noqa: E731
+            kernel = f"gather_attn_l2_d32_kernel<{K}, false, false, true> (mvin_gather_attn_l2_prj_fwd, plain adjacency)"
+    elif encoded:
         enc_e, enc_r, cnt = ops.encode_adjacency(adj_e, adj_r)
         launch = lambda: ops.gather_attn_l2_enc(table, enc_e, enc_r, *args[3:])       # noqa: E731
-        kernel = "gather_attn_l2_packed_kernel (mvin_gather_attn_l2_enc_fwd)"
+        kernel = (f"gather_attn_l2_packed_kernel<{D}, {K}, {'true' if table_dtype == 'bf16' else 'false'}, 4, false, false> "
+                  "(mvin_gather_attn_l2_enc_fwd)")
     else:
         launch = lambda: ops.gather_attn_l2(*args)[:2]                                # noqa: E731
         kernel = "gather_attn_l2_split_kernel (mvin_gather_attn_l2_fwd)"
@@ -256,13 +287,19 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=HBM_LEG_ROWS, pai
     max_abs, worst, ok = check_l2_launch(out, *args[:13], K)
     ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     s_ = 2 if table_dtype == "bf16" else 4
-    bpp = algorithmic_bytes_per_pair(D, K, 2, s=s_)
+    bpp = prj_bytes_per_pair(D, K, s=s_) if prj else algorithmic_bytes_per_pair(D, K, 2, s=s_)
     del table, adj_e, adj_r
     if encoded:
         del enc_e, enc_r, cnt
+    if prj:
+        del ws
     torch.cuda.empty_cache()
-    return {"kernel": kernel, "avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
-            "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows, "table_bytes": n_rows * D * s_,
+    return {"kernel": kernel, "form": "prj" if prj else "enc" if encoded else "plain",
+            "avg_launch_ms": ms, "pairs_per_launch": pairs, "bytes_per_pair": bpp,
+            "bytes_per_pair_formula": ("(1 + 2K + K^2) rows (two self rows per child: T1[x], TA1[x]) + (1 + K) K 8 B of adjacency + query + score"
+                                       if prj else "SURVEY.md 8(d): (1 + K + K^2) rows + (1 + K) K 8 B of adjacency + query + score"),
+            "achieved": bpp * pairs / (ms * 1e-3) / 1e9, "table_rows": n_rows,
+            "table_bytes": (3 if prj else 1) * n_rows * D * s_,
             "launches": iters, "outputs_finite": finite, "max_abs_err": max_abs, "worst_err_over_bound": worst,
             "verified": bool(ok and finite),
             "verified_how": "nagg0 / nagg1 of 256 parents sampled across the launch vs a torch float64 evaluation on the GPU, "
@@ -598,7 +635,7 @@ def main():
 
     if a.hbm_leg_only:
         leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, iters=max(a.steps, 1), warmup=a.warmup,
-                      encoded=os.environ.get("MVIN_L2_ENC", "auto") != "0")
+                      encoded=a.hbm_leg_form != "plain" and os.environ.get("MVIN_L2_ENC", "auto") != "0", prj=a.hbm_leg_form == "prj")
         leg.update(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", frac=leg["achieved"] / HBM_PEAK_GBS)
         print(json.dumps({"hbm_leg_only": leg}), flush=True)
         return
@@ -890,32 +927,53 @@ def main():
             timed["gather_only_probe"] = gp
         roofline = timed
         if not a.no_hbm_leg and used_l2 and not hoisted and cache_resident and L == 2:
-            # the genuinely HBM-bound measurement of the SAME kernel instance, live, after the timed region
-            leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=enc is not None)
-            pl = pmc_record("pmc_hbm_leg.json")
-            leg_traffic = None
-            if pl and all(pl.get(k) == v for k, v in (("dim", a.dim), ("fanout", a.fanout), ("table_rows", leg["table_rows"]),
-                                                      ("pairs_per_launch", leg["pairs_per_launch"]),
-                                                      ("table_dtype", a.table_dtype))) \
-                    and leg["kernel"].split(" ")[0] in pl.get("kernel", leg["kernel"]):     # the PMC passes timed the same kernel
-                leg_traffic = pl["traffic_bytes_per_launch"]
-            other = None
-            if enc is not None:      # the plain-adjacency kernel on the same table, for comparison (round 3's roofline kernel)
-                o = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=False)
-                other = {k: o[k] for k in ("kernel", "avg_launch_ms", "achieved", "max_abs_err", "verified")}
-                other["frac"] = o["achieved"] / HBM_PEAK_GBS
+            # the genuinely HBM-bound measurement of the kernel INSTANCE the timed steps run, live, after the timed region: the
+            # projected-tables instance when that is what they take (its own leg: 4 M-row table, 3 x 1.02 GB of projected tables, its
+            # own bytes per pair), the unprojected instance otherwise; the sibling instances are reported next to it
+            def leg_brief(o):
+                b = {k: o[k] for k in ("kernel", "form", "avg_launch_ms", "achieved", "bytes_per_pair", "pairs_per_launch", "table_rows",
+                                       "table_bytes", "max_abs_err", "verified")}
+                b["frac"] = o["achieved"] / HBM_PEAK_GBS
+                return b
+
+            def leg_traffic_of(leg, fname):
+                pl = pmc_record(fname)
+                if pl and all(pl.get(k) == v for k, v in (("dim", a.dim), ("fanout", a.fanout), ("table_rows", leg["table_rows"]),
+                                                          ("pairs_per_launch", leg["pairs_per_launch"]),
+                                                          ("table_dtype", a.table_dtype))) \
+                        and leg["kernel"].split(" ")[0].split("<")[0] in pl.get("kernel", leg["kernel"]):     # the PMC passes timed the same kernel
+                    return pl["traffic_bytes_per_launch"]
+                return None
+            prj_leg = bool(prj_now and a.table_dtype == "f32")
+            leg = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=enc is not None, prj=prj_leg)
+            leg_traffic = leg_traffic_of(leg, "pmc_hbm_leg_prj.json" if prj_leg else "pmc_hbm_leg.json")
+            siblings = {}
+            if prj_leg and enc is not None:      # the unprojected packed-tile instance on the 16 M-row table (rounds 4-5's roofline leg)
+                o = hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=True)
+                siblings["unprojected_kernel"] = leg_brief(o)
+                siblings["unprojected_kernel"]["traffic"] = leg_traffic_of(o, "pmc_hbm_leg.json")
+            if enc is not None or prj_leg:       # the plain-adjacency kernel on the same 16 M-row table (round 3's roofline kernel)
+                siblings["plain_adjacency_kernel"] = leg_brief(hbm_leg(dev, a.dim, a.fanout, a.table_dtype, encoded=False))
             roofline = {"bound": "hbm", "kernel": leg["kernel"], "achieved": leg["achieved"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": leg["achieved"] / HBM_PEAK_GBS, "traffic": leg_traffic,
-                        "bytes_per_pair": leg["bytes_per_pair"], "pairs_per_launch": leg["pairs_per_launch"],
+                        "bytes_per_pair": leg["bytes_per_pair"], "bytes_per_pair_formula": leg["bytes_per_pair_formula"],
+                        "pairs_per_launch": leg["pairs_per_launch"],
                         "avg_launch_ms": leg["avg_launch_ms"], "table_bytes": leg["table_bytes"],
                         "table_rows": leg["table_rows"], "launches": leg["launches"],
                         "max_abs_err": leg["max_abs_err"], "verified": leg["verified"], "verified_how": leg["verified_how"],
-                        "plain_adjacency_kernel": other,
-                        "workload": "the timed region's kernel (same instance: D, K, dtype, projection + attention on) on a "
-                                    "16 M-row synthetic entity table with uniform adjacency (no repeated slots: all K + K^2 "
-                                    "rows per pair are loaded): 16x the Infinity Cache, so every gathered row comes from HBM; measured after the timed region with HIP events "
-                                    "around each launch; `traffic` = 2*FETCH_SIZE + WRITE_SIZE per launch from "
-                                    "profiles/pmc_hbm_leg.json (rocprofv3 --pmc passes over `bench.py --hbm-leg-only`)",
+                        "instance_is_the_timed_regions": bool(prj_leg == bool(prj_now)),
+                        **siblings,
+                        "workload": ("%s -- %s -- on a %.1f M-row synthetic entity table (%.2f GB of tables: %.0fx the Infinity Cache) with uniform "
+                                     "adjacency (no repeated slots: every row of every slot is loaded), so every gathered row comes from HBM; "
+                                     "measured after the timed region with HIP events around each launch on the launch stream; `traffic` = "
+                                     "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (rocprofv3 --pmc passes over `bench.py "
+                                     "--hbm-leg-only%s`)"
+                                     % (leg["kernel"],
+                                        "the template instance the timed steps launch" if prj_leg == bool(prj_now) else
+                                        "NOT the timed region's instance (that one reads projected tables; see `timed_region.kernel`)",
+                                        leg["table_rows"] / 1e6, leg["table_bytes"] / 1e9, leg["table_bytes"] / (256 * 2 ** 20),
+                                        "pmc_hbm_leg_prj.json" if prj_leg else "pmc_hbm_leg.json",
+                                        " --hbm-leg-form prj" if prj_leg else "")),
                         "timed_region": timed}
         rec = {
             "metric": "(user,item) pairs scored/sec @ dim=%d hop=%d fan-out=%d; %% HBM roofline"

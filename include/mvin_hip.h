@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 10
+#define MVIN_ABI_VERSION 11
 /* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
 #define MVIN_API __attribute__((visibility("default")))
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
@@ -186,6 +186,7 @@ MVIN_API int mvin_gather_attn_l2_enc_supported(int D, int K);
  * D in {32, 64, 128}, tables below 1 GiB each.  adjacency_encoded = 0: enc_entity / enc_relation are the PLAIN adjacency
  * (D = 32, K in {8, 16} only: the wave-per-parent kernel, BASELINE config C2's, reads either form).  mvin_project_rows is the plain two-matrix form (out[0] = src W1 (+ b1),
  * out[1] = src W2 (+ b2)). */
+MVIN_API int mvin_gather_attn_l2_prj_supported(int D, int K, int adjacency_encoded, int n_entity, int nR);   /* 1: _prj_fwd takes these tables */
 MVIN_API int mvin_project_rows(const float* src, int64_t rows, int D, const float* W1, const float* W2, const float* b1,
                                const float* b2, float* out, void* stream);
 MVIN_API size_t mvin_project_tables_elems(int n_entity, int D);

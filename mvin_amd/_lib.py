@@ -9,6 +9,7 @@ import os
 from . import build as _build
 
 MAX_SRC = 8
+ABI_VERSION = 11          # include/mvin_hip.h: MVIN_ABI_VERSION
 
 _c_f32p = C.c_void_p
 _c_i32p = C.c_void_p
@@ -123,6 +124,7 @@ SIGNATURES = {
                                               _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.c_int, _c_f32p, _c_f32p, C.c_int, C.c_void_p]),
     "mvin_gather_attn_l2_enc_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mvin_gather_attn_l2_prj_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "mvin_encode_adjacency": (C.c_int, [_c_i32p, _c_i32p, C.c_int, C.c_int, _c_i32p, _c_i32p, _c_i32p, C.c_void_p]),
     "mvin_gather_attn_l2_variant": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int]),
     "mvin_gather_attn_l2_variant_ex": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int]),
@@ -217,8 +219,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.mvin_abi_version()
-    if ver != 10:
-        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected 10")
+    if ver != ABI_VERSION:
+        raise MvinHipError(f"libmvin_hip.so ABI version {ver}, expected {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -334,6 +334,29 @@ int mvin_project_tables(const float* entity_emb, const float* W1, const float* W
     return mvin_linear_fwd(&l, stream);
 }
 
+// does mvin_gather_attn_l2_prj_fwd run for these tables?  (the plain-adjacency form exists in the wave-per-parent kernel only)
+static bool prj_applies(int D, int K, bool encoded, int n_entity, int nR, int64_t n_parents) {
+    if (n_entity <= 0 || nR <= 0 || nR > 4096 || !mvin::fused_l2_supported(D, K)) return false;
+    mvin::FusedL2Args f{};
+    f.K = K;
+    f.nR = nR;
+    f.P = n_parents > 0 ? n_parents : 1;
+    f.prj = 1;
+    f.parents_per_pair = 1;
+    f.max_id = (unsigned)(n_entity - 1);
+    static const int32_t present = 0;
+    f.adj_r = &present;                       // (only tested for presence)
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    if (f.table_bytes >= (1ull << 30)) return false;
+    if (encoded) return mvin::fused_packed_supported(D, K) && mvin::fused_packed_applies(f, D);
+    return mvin::fused_d32_applies(f, D);
+}
+
+int mvin_gather_attn_l2_prj_supported(int D, int K, int adjacency_encoded, int n_entity, int nR) {
+    return prj_applies(D, K, adjacency_encoded != 0, n_entity, nR, 1) ? 1 : 0;
+}
+
 int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
@@ -633,7 +656,8 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
     const bool d32 = mvin::fused_d32_supported(D, a->K);       // the wave-per-parent kernel: projected tables over either adjacency
-    if ((enc || d32) && a->prj_tables && a->W1 && !a->table_bf16) {
+    // (asked for on a shape / table size the projected-tables kernels do not take: the unprojected form, not an error)
+    if ((enc || d32) && a->prj_tables && a->W1 && !a->table_bf16 && prj_applies(D, a->K, enc, a->n_entity, nR, a->B)) {
         // projected-tables form: E.W1 | E.W1.A0 | E.W2.A0 once per entity from the CURRENT parameters (nothing is kept between
         // calls), then the packed kernel without any product per distinct child
         rc = mvin_project_tables(reinterpret_cast<const float*>(a->entity_emb), a->W1, a->W2, a->b1, a->b2, a->A0, a->a0,

@@ -202,6 +202,11 @@ def ctr_eval_device(feeder, data, batch_size, streams=2, window=16):
     from .graph import scoring_streams
     lanes = scoring_streams(dev, streams) if streams > 1 else None
     if lanes:
+        # everything the forward builds lazily and CACHES (relation-logit tables dropped by invalidate() after a training epoch,
+        # the adjacency encoding, the one-time id check and the static per-user records of user_triplet_set) is built here, on
+        # the current stream, before the lanes start: a table built by the first batch on lane 0 would be read by the second
+        # batch on lane 1 with nothing ordering the two
+        feeder.model.prepare(getattr(feeder, "uts", None))
         for ln in lanes:
             ln.wait_stream(torch.cuda.current_stream(dev))
     pending = []

@@ -320,7 +320,8 @@ class MVIN(object):
         aggregators and -- given a device-resident ``user_triplet_set`` -- its one-time id check and static per-user records
         (an allocation of up to USER_RECORDS_MAX_BYTES + a kernel).  Called by __init__ and set_adjacency for the encoding;
         call it yourself before capturing a forward in a hipGraph or running it on a side stream."""
-        if self.fused is not False:
+        mode = os.environ.get("MVIN_L2_ENC", "auto") if self.dedup is None else ("1" if self.dedup else "0")
+        if self.fused is not False and mode != "0":      # (forbidden encoding: nothing to build -- 2 launches, a sync, 2 n_entity K words)
             self.encoded_adjacency()
         for agg in self.aggregators:
             if agg.User_orient_rela:
@@ -628,7 +629,8 @@ class MVIN(object):
             uo = self.args.User_orient
             enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
             tabs = None
-            if (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B, B * K ** (L - 2)):
+            # (the projected-tables kernels write no attention outputs: a want_probs pass keeps the form that does)
+            if not want_probs and (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B, B * K ** (L - 2)):
                 # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 from the current parameters, per call
                 Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
                 tabs = ops.project_tables(self.entity_emb_matrix, Wp[L - 1], Wp[L], bp[L - 1], bp[L], a0.weights, a0.bias, K,
@@ -853,8 +855,18 @@ class MVIN(object):
                                                             bool(a.PS_O_ft)))
 
     def _prj_plain_ok(self):
-        """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2)."""
-        return self.dim == 32 and self.n_neighbor in (8, 16) and self.fused is not False
+        """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
+        where the library takes THAT kernel for this model's tables (mvin_gather_attn_l2_prj_supported: its LDS copy of the
+        relation logits fits, the adjacency is below 2 GiB, MVIN_L2_D32 does not forbid it); otherwise the unprojected form stays."""
+        if not (self.dim == 32 and self.n_neighbor in (8, 16) and self.fused is not False):
+            return False
+        key = (self.n_entity, self.n_relation, self.entity_emb_matrix.dtype)
+        c = getattr(self, "_prj_plain_cache", None)
+        if c is None or c[0] != key:
+            ok = (self.entity_emb_matrix.dtype == torch.float32
+                  and ops.gather_attn_l2_prj_supported(self.dim, self.n_neighbor, False, self.n_entity, self.n_relation))
+            c = self._prj_plain_cache = (key, ok)
+        return c[1]
 
     def _prj_for_l2(self, B, n_parents=None):
         """Projected-tables form of the fused two-level pass for a batch of B pairs (``n_parents`` level-(L-2) nodes)?
@@ -1169,14 +1181,21 @@ class MVIN(object):
         if (os.environ.get("MVIN_TRAIN_GRAPH", "1") != "0" and self.trainer.world == 1 and B <= self.train_graph_max_batch):
             from .training import GraphedTrainer
             g = self._train_graphs.get(B)
-            if g is not None and g._storage_key() != g._captured:
+            if g is False:
+                g = None
+            elif g is not None and g._storage_key() != g._captured:
                 g = None                                   # adjacency / a parameter tensor replaced: capture again
-            if g is None and self._train_seen == B:
-                g = self._train_graphs[B] = GraphedTrainer(self.trainer, B, ids_dtype=item.dtype, warmup=0)
+            if g is None and self._train_seen == B and self._train_graphs.get(B) is not False:
+                try:
+                    g = self._train_graphs[B] = GraphedTrainer(self.trainer, B, ids_dtype=item.dtype, warmup=0)
+                except RuntimeError:
+                    # a step that cannot be captured (a kernel or allocation that refuses to run under capture) still runs
+                    # eagerly: remember the failure for this batch size and fall through (train_epoch_device does the same)
+                    g, self._train_graphs[B] = None, False
                 if len(self._train_graphs) > 4:
                     self._train_graphs.pop(next(iter(self._train_graphs)))
             self._train_seen = B
-            if g is not None:
+            if g:
                 return None, float(g.step(user, item, labels, mh, mr, mt).item())
         return None, self.trainer.step(user, item, labels, mh, mr, mt)
 

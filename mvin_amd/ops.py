@@ -232,6 +232,11 @@ def probe_gather_l2(table, child_ids, grandchild_ids, K, sums=None):
     return sums
 
 
+def gather_attn_l2_prj_supported(D, K, encoded, n_entity, n_relation):
+    """Does mvin_gather_attn_l2_prj_fwd take these tables (encoded: the packed-tile kernel; plain: D = 32, K in {8, 16})?"""
+    return bool(_lib.load().mvin_gather_attn_l2_prj_supported(D, K, int(bool(encoded)), n_entity, n_relation))
+
+
 def gather_attn_l2_variant(D, K, n_parents, n_entity, want_probs=False, table_bf16=False):
     """0 = unsupported, 1 = symmetric fused kernel, 2 = role-split pipeline, 3 / 4 = wave-per-parent kernels (include/mvin_hip.h)."""
     return int(_lib.load().mvin_gather_attn_l2_variant_ex(D, K, n_parents, n_entity, int(bool(want_probs)), int(bool(table_bf16))))

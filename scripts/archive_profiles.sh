@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build container: copy the summaries scripts/collect_all.sh <tag> left under gpurun_out/ into profiles/<round>/<prefix>_*
-# (gpurun_out/ is scratch; profiles/ is what is committed and judged).  usage: archive_profiles.sh <tag> <prefix> [round=r3]
-tag=$1; p=$2; round=${3:-r3}
+# (gpurun_out/ is scratch; profiles/ is what is committed and judged).  usage: archive_profiles.sh <tag> <prefix> [round=r6]
+tag=$1; p=$2; round=${3:-r6}
 root=$(cd "$(dirname "$0")/.." && pwd); cd "$root"
 g=gpurun_out; d=profiles/$round; mkdir -p $d
 cp $g/prof_$tag/kernel_stats.csv $d/${p}_c3_B524288_kernel_stats.csv
@@ -10,6 +10,10 @@ cp $g/prof_$tag/pmc.json $d/${p}_c3_B524288_pmc.json
 cp $g/prof_$tag/hbm_leg_kernel_stats.csv $d/${p}_hbm_leg_kernel_stats.csv
 cp $g/prof_$tag/hbm_leg_bench.json $d/${p}_hbm_leg_bench.json
 cp $g/prof_$tag/pmc_hbm_leg.json $d/${p}_hbm_leg_pmc.json
+cp $g/prof_$tag/hbm_leg_prj_kernel_stats.csv $d/${p}_hbm_leg_prj_kernel_stats.csv
+cp $g/prof_$tag/hbm_leg_prj_bench.json $d/${p}_hbm_leg_prj_bench.json
+cp $g/prof_$tag/pmc_hbm_leg_prj.json $d/${p}_hbm_leg_prj_pmc.json
+cp $g/prof_$tag/pmc_hbm_leg_prj.json profiles/pmc_hbm_leg_prj.json
 cp $g/prof_$tag/pmc.json profiles/pmc_latest.json
 cp $g/prof_$tag/pmc_hbm_leg.json profiles/pmc_hbm_leg.json
 cp $g/pmc_$tag/counters.json $d/${p}_c3_sq_tcp_tcc_counters.json

@@ -28,8 +28,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hbm_stats" -- pyth
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/hbm_pmc_$c" -- python "$root/bench.py" $hargs > "$out/bench_hbm_pmc_$c.log" 2>&1
 done
+# B'. the same for the PROJECTED-TABLES instance (the one the default line's timed steps launch): 4 M-row table, 3 x 1.02 GB of tables
+pargs="--hbm-leg-only --hbm-leg-form prj --steps 10 --warmup 3 $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/hbm_prj_stats" -- python "$root/bench.py" $pargs > "$out/bench_hbm_prj_stats.log" 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out/hbm_prj_pmc_$c" -- python "$root/bench.py" $pargs > "$out/bench_hbm_prj_pmc_$c.log" 2>&1
+done
 cd "$root"
 python scripts/summarize_pmc.py "$out" $bargs
+python scripts/summarize_pmc.py --hbm-leg --prj "$out" $pargs
+f=$(ls "$out"/hbm_prj_stats/*/*kernel_stats.csv | head -1); cp "$f" "$out/hbm_leg_prj_kernel_stats.csv"
+grep '^{' "$out/bench_hbm_prj_stats.log" | tail -1 > "$out/hbm_leg_prj_bench.json"
 python scripts/summarize_pmc.py --hbm-leg "$out" $hargs
 f=$(ls "$out"/stats/*/*kernel_stats.csv | head -1); cp "$f" "$out/kernel_stats.csv"
 f=$(ls "$out"/hbm_stats/*/*kernel_stats.csv | head -1); cp "$f" "$out/hbm_leg_kernel_stats.csv"
@@ -37,3 +46,4 @@ grep '^{' "$out/bench_stats.log" | tail -1 > "$out/bench.json"
 grep '^{' "$out/bench_hbm_stats.log" | tail -1 > "$out/hbm_leg_bench.json"
 head -8 "$out/kernel_stats.csv" | cut -c1-160
 head -4 "$out/hbm_leg_kernel_stats.csv" | cut -c1-160
+head -4 "$out/hbm_leg_prj_kernel_stats.csv" | cut -c1-160

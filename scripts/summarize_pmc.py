@@ -16,6 +16,9 @@ def main():
     hbm = "--hbm-leg" in sys.argv
     if hbm:
         sys.argv.remove("--hbm-leg")
+    prj = "--prj" in sys.argv      # the projected-tables leg (bench.py --hbm-leg-only --hbm-leg-form prj): hbm_prj_pmc_* -> pmc_hbm_leg_prj.json
+    if prj:
+        sys.argv.remove("--prj")
     out = sys.argv[1]
     saved = sys.argv
     sys.argv = ["bench.py"] + saved[2:]
@@ -23,7 +26,7 @@ def main():
     a = bench.parse()
     sys.argv = saved
     kernels = {}
-    prefix = "hbm_pmc_" if hbm else "pmc_"
+    prefix = ("hbm_prj_pmc_" if prj else "hbm_pmc_") if hbm else "pmc_"
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for path in glob.glob(os.path.join(out, f"{prefix}{c}", "*", "*counter_collection.csv")):
             with open(path) as f:
@@ -45,16 +48,17 @@ def main():
         k = summ[fused[0]]
         rec = {"command": "rocprofv3 --kernel-trace --pmc <COUNTER> --output-format csv -- python bench.py "
                           + " ".join(saved[2:]) + " (separate passes: FETCH_SIZE, WRITE_SIZE)",
-               "dim": a.dim, "fanout": a.fanout, "table_dtype": a.table_dtype, "table_rows": bench.HBM_LEG_ROWS,
+               "dim": a.dim, "fanout": a.fanout, "table_dtype": a.table_dtype,
+               "table_rows": bench.HBM_LEG_PRJ_ROWS if prj else bench.HBM_LEG_ROWS,
                "pairs_per_launch": bench.HBM_LEG_PAIRS,
-               "algorithmic_bytes_per_launch": bench.algorithmic_bytes_per_pair(
-                   a.dim, a.fanout, 2, 2 if a.table_dtype == "bf16" else 4) * bench.HBM_LEG_PAIRS,
+               "algorithmic_bytes_per_launch": (bench.prj_bytes_per_pair(a.dim, a.fanout) if prj else bench.algorithmic_bytes_per_pair(
+                   a.dim, a.fanout, 2, 2 if a.table_dtype == "bf16" else 4)) * bench.HBM_LEG_PAIRS,
                "units": "FETCH_SIZE/WRITE_SIZE in KiB as reported; gfx950 correction: read bytes = 2*FETCH_SIZE*1024 "
                         "(MI355X_MICROARCH.md, HBM section)",
                "kernel": fused[0], "counters": k,
                "traffic_bytes_per_launch": (2 * k["FETCH_SIZE"]["mean_per_launch"]
                                             + k["WRITE_SIZE"]["mean_per_launch"]) * 1024}
-        with open(os.path.join(out, "pmc_hbm_leg.json"), "w") as f:
+        with open(os.path.join(out, "pmc_hbm_leg_prj.json" if prj else "pmc_hbm_leg.json"), "w") as f:
             json.dump(rec, f, indent=1)
         print(json.dumps({k: rec[k] for k in ("traffic_bytes_per_launch", "algorithmic_bytes_per_launch")}))
         return

@@ -20,8 +20,8 @@ def hip_lib():
     return _lib.load()
 
 
-# The whole-pass single-launch kernel (mvin_score_small_fwd) is the product's default for batches of at most 16 384
-# pairs.  Most GPU test modules exist to pin ONE of the other kernels (packed / split / wave-per-parent fused kernels,
+# The whole-pass single-launch kernel (mvin_score_small_fwd) is the product's default for batches of at most 1 024
+# pairs (MVIN.small_max_batch; the entry point itself takes any batch and tests drive it to 16 384).  Most GPU test modules exist to pin ONE of the other kernels (packed / split / wave-per-parent fused kernels,
 # the key-addressing family, the tail, the native multi-launch schedule) through small MVIN forwards: those keep their
 # kernels (MVIN_SMALL=0, read when a model is built).  The modules below run the product default.
 SMALL_KERNEL_MODULES = {"test_gpu_small", "test_gpu_ref_pins", "test_gpu_api", "test_gpu_properties", "test_gpu_dist"}
@@ -34,6 +34,7 @@ def _pin_kernel_under_test(request, monkeypatch):
         monkeypatch.setenv("MVIN_SMALL", "0")
         # ... and the form of the two deepest levels they pin: the projected-tables form (taken by batch size: B K >= 16 n_entity)
         # has its own module; an explicit MVIN_PRJ in the environment (a forced run of the whole suite) is respected
-        if mod != "test_gpu_prj" and "MVIN_PRJ" not in os.environ:
+        # -- and so does test_gpu_bench_scale, which must run what bench.py times: the AUTOMATIC rule
+        if mod not in ("test_gpu_prj", "test_gpu_bench_scale") and "MVIN_PRJ" not in os.environ:
             monkeypatch.setenv("MVIN_PRJ", "0")
     yield

@@ -1,6 +1,7 @@
-"""-m gpu: parity AT THE SIZES bench.py TIMES -- the default metric workload (C3: 524 288 last-fm-shaped pairs, users
-feed, KG adjacency with repeats -> packed-tile kernel over the encoded adjacency, grouped key addressing in its LDS-DMA
-form with several user segments per workgroup) and the C2 / C4 bench sizes:
+"""-m gpu: parity AT THE SIZES bench.py TIMES, IN THE FORM bench.py TIMES (the automatic rules: no kernel pinned by this
+module) -- the default metric workload (C3: 524 288 last-fm-shaped pairs, users feed, KG adjacency with repeats ->
+PROJECTED-TABLES form of the packed-tile kernel over the encoded adjacency (B K >= 16 n_entity), grouped key addressing over
+the static per-user records) and the C2 (projected tables, wave-per-parent kernel) / C4 (K = 64: unprojected) bench sizes:
   * a sample of pairs drawn across the WHOLE batch against the fp32 mirror of the reference graph (oracle/mirror_fp32.py),
   * the users feed (grouped key addressing) against the per-pair feed (the reference's feed_dict contents) over the
     whole batch,
@@ -25,8 +26,15 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
     dev = model.device
     users, items = torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev)
     uts = torch.from_numpy(case.user_triplet_set).to(dev)
+    assert model.prj is None and model.dedup is None, "this module runs the automatic rules (tests/conftest.py must not pin a form)"
+    took_prj = (model._enc_for_l2(n_parents=B) is not None or model._prj_plain_ok()) and model._prj_for_l2(B)
+    assert took_prj == (name in ("C3", "C2")), f"{name}: projected-tables form taken = {took_prj}"
     got = model.forward_users(users, items, uts)
     torch.cuda.synchronize()
+    if took_prj:          # the workspace mvin_score_l2_fwd wrote the three projected tables into exists: the form really ran
+        assert any(t is not None for t in model._prj_tables.values()), "mvin_project_tables was not called"
+    if name in ("C3", "C2"):
+        assert model._uts_records is not None or name == "C2", "the records kernel was expected at C3"
     s_users = got.scores.cpu().numpy()
     assert np.isfinite(s_users).all()
     # (a) sample across the batch vs the mirror
@@ -54,3 +62,18 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
     torch.cuda.synchronize()
     if model._enc_for_l2(n_parents=B) is not None or took_enc:
         assert_close(s_users, other.scores.cpu().numpy(), f"{name}: encoded vs plain adjacency over {B} pairs")
+    model.dedup = None
+    if took_prj:
+        # (d) the projected-tables form against the unprojected form of the same two levels, whole batch
+        model.prj = False
+        other = model.forward_users(users, items, uts)
+        torch.cuda.synchronize()
+        assert_close(s_users, other.scores.cpu().numpy(), f"{name}: projected tables vs per-row projection over {B} pairs")
+        model.prj = None
+    if name == "C3":
+        # (e) the gathered form of the grouped key addressing (R_KGE[r] . E[h] per (relation, entity), rebuilt per call), whole batch
+        model.ka_er = not model.ka_er
+        other = model.forward_users(users, items, uts)
+        torch.cuda.synchronize()
+        assert_close(s_users, other.scores.cpu().numpy(), f"{name}: gathered vs multiplied U rows over {B} pairs")
+        assert_close(other.user_o[torch.from_numpy(idx).to(dev)].cpu().numpy(), ref.user_o.numpy(), f"{name}: user_o sample, other key-addressing form")

@@ -289,3 +289,47 @@ def test_plain_adjacency_form_exists_only_for_the_wave_per_parent_kernel(hip_lib
     with pytest.raises(MvinHipError):
         ops.gather_attn_l2_prj(ws, adj, adj, torch.zeros(4, dtype=torch.int32, device=dev), None, None, torch.zeros(4, 64, device=dev),
                                4, 1, 32, 64, 6, 300, encoded=False)
+
+
+@pytest.mark.parametrize("K", [8, 16])
+def test_attention_outputs_keep_the_unprojected_form(K, hip_lib):
+    """the projected-tables kernels write no attention outputs, so a want_probs pass (eval_case_study,
+    model.py:428-441) must not take them even when the form is forced: importance_list == the reference graph's
+    probs_normalized, not [None, None]."""
+    args = make_args(**_shape(32, K, B=13))
+    case = synth.small_case(args, n_user=16, n_entity=900, n_relation=7, seed=177 + K, zero_rows=4, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=44, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
+    model.prj = True
+    model.native_l2_max_batch = 0
+    assert model._prj_plain_ok() and model._prj_for_l2(13)
+    dev = model.device
+    out = model.forward_device(torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev),
+                               [torch.from_numpy(m).to(dev) for m in case.memories_h], [torch.from_numpy(m).to(dev) for m in case.memories_r],
+                               [torch.from_numpy(m).to(dev) for m in case.memories_t], want_probs=True)
+    m, _ = run_oracles(args, case, params)
+    assert len(out.importance_list) == 2 and all(p is not None for p in out.importance_list)
+    for got, want in zip(out.importance_list, m.importance_list):
+        assert_close(got.cpu().numpy(), want.numpy().reshape(got.shape), "importance_list", rtol=1e-5, atol=1e-7)
+    assert_close(out.scores.cpu().numpy(), m.scores.numpy(), "scores vs fp32 mirror", rtol=1e-5, atol=1e-6)
+
+
+def test_forced_projection_falls_back_where_no_kernel_takes_it(hip_lib):
+    """D = 32, K = 16 over the plain adjacency with a relation table too large for the wave-per-parent kernel's LDS
+    (fused_d32_applies false): a forced / automatic projected-tables form must fall back to the unprojected kernels, not raise."""
+    nR = 4000
+    args = make_args(**_shape(32, 16, B=21))
+    case = synth.small_case(args, n_user=16, n_entity=900, n_relation=nR, seed=99, zero_rows=4, repeats=False)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=45, random_agg_bias=True)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
+    assert not ops.gather_attn_l2_prj_supported(32, 16, False, case.n_entity, nR)
+    assert ops.gather_attn_l2_prj_supported(32, 16, False, case.n_entity, 7) and ops.gather_attn_l2_prj_supported(64, 32, True, case.n_entity, nR)
+    assert not ops.gather_attn_l2_prj_supported(64, 32, False, case.n_entity, 7)
+    model.prj = True
+    model.dedup = False
+    assert not model._prj_plain_ok()
+    m, _ = run_oracles(args, case, params)
+    for native in (65536, 0):
+        model.native_l2_max_batch = native
+        out = _pairs(model, case)
+        assert_close(out.scores.cpu().numpy(), m.scores.numpy(), f"scores vs fp32 mirror (native_l2_max_batch={native})", rtol=1e-5, atol=1e-6)

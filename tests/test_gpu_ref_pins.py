@@ -113,6 +113,26 @@ def test_hot_kernels_match_reference_graph(path, hip_lib):
         check(m.forward_device(users, items, *mem), f"python schedule, dedup={dedup}")
     assert taken == {"enc", "plain"}
     check(model(fused=False).forward_device(users, items, *mem), "per-level kernels")
+    # the forms the headline runs (VERDICT r5 #1b): projected tables (E.W1 | E.W1.A0 | E.W2.A0 per call; packed-tile kernel over the
+    # encoding, or the wave-per-parent kernel of D = 32 over either adjacency) and the gathered form of the grouped key addressing
+    # (R_KGE[r] . E[h] per (relation, entity) per call) -- forced here, since the fixtures' batches are below the automatic rule
+    if args.User_orient and D <= 64:
+        for dedup in ((True, False) if (D == 32 and K <= 16) else (True,)):
+            for ka_er in (False, True):
+                m = model()
+                m.small_max_batch = 0
+                m.dedup, m.prj, m.ka_er = dedup, True, ka_er
+                if not (m._enc_for_l2(n_parents=items.shape[0]) is not None or m._prj_plain_ok()):
+                    continue
+                assert m._prj_for_l2(items.shape[0])
+                what = f"projected tables, dedup={dedup}, ka_er={ka_er}"
+                check(m.forward_device(users, items, *mem), f"{what}: per-pair feed")
+                check(m.forward_users(users, items, uts_d), f"{what}: users feed")
+                assert any(t is not None for t in m._prj_tables.values()), "mvin_project_tables was not called"
+                if ka_er and m._ka_er_for(uts_d, m._uts_records):
+                    assert any(t is not None for t in m._ka_er_ws.values()), "mvin_project_relations was not called"
+                m.native_l2_max_batch = 0
+                check(m.forward_device(users, items, *mem), f"{what}: python schedule")
 
 
 def _harness_model():
