@@ -317,6 +317,29 @@ MVIN_API int mvin_key_addressing_grouped_er_fwd(const void* entity_emb, const fl
                                        const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
                                        const int64_t* items_i64, const int32_t* items_i32, int nseg, int B, int P, int Nm, int D,
                                        int nR, int n_entity, int n_user, float* out, int64_t ldo, void* stream);
+/* MVIN._key_addressing (model.py:161-240) AND the user MLP behind it (model.py:232-236) for pairs grouped by user, as ONE
+ * barrier-free kernel: every wave walks tiles of up to 32 pairs of one user on its own -- logits, softmax and reads of each hop
+ * as TRANSPOSED products on the matrix cores, the accumulator of the first the B operand of the second, every gathered row
+ * loaded straight into its operand layout once per tile, nothing staged in LDS (mvin_keyaddr_flash.hip).  Two exact
+ * re-associations move the per-row matrix products to per-call TABLES: U_m = R_KGE[r_m] . E[h_m] depends on (relation, entity)
+ * alone, and the user MLP is linear in the tail rows,
+ *     user_o = bias + sum_m p_hset[m] TW_0[h_m] + sum_hop sum_m p_hop[m] TW_{1+hop}[t_m],   TW_j = E . user_mlp_W[D j : D j + D, :].
+ * mvin_key_addressing_flash_prepare writes them from the CURRENT parameters into `ws` (mvin_key_addressing_flash_tables_elems
+ * floats: [nR, nE, D] R_KGE[r] . E[e] | E[e] . w | scratch | [P + has_set][nE, D] TW); it must be called again whenever E, R_KGE,
+ * w or user_mlp_W changed (mvin_score_l2_fwd and mvin_amd.MVIN call it in every pass).  w != NULL: the h-set read
+ * (model.py:162-197) is part of the pass (has_set).  user_records: mvin_build_user_records.  sched_ws:
+ * mvin_key_addressing_flash_ws_elems(B, n_user) int32 words of scheduling scratch, rewritten by every call.  D = 64, fp32
+ * tables, 1 <= P <= 8, Nm <= 64, nR * n_entity < 2^31 (mvin_key_addressing_flash_supported; -3 otherwise). */
+MVIN_API int mvin_key_addressing_flash_supported(int D, int P, int Nm, int nR, int n_entity);
+MVIN_API size_t mvin_key_addressing_flash_tables_elems(int n_entity, int nR, int D, int P, int has_set);
+MVIN_API int mvin_key_addressing_flash_prepare(const float* entity_emb, const float* relation_kge, const float* w,
+                                      const float* user_mlp_W, int n_entity, int nR, int D, int P, float* ws, void* stream);
+MVIN_API size_t mvin_key_addressing_flash_ws_elems(int64_t B, int n_user);
+MVIN_API int mvin_key_addressing_flash_fwd(const float* entity_emb, const float* ws, const int32_t* user_records,
+                                  const int32_t* seg_user, const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,
+                                  const int64_t* items_i64, const int32_t* items_i32, int64_t B, int P, int Nm, int D, int nR,
+                                  int n_entity, int n_user, int has_set, const float* user_mlp_b, float* user_o,
+                                  int32_t* sched_ws, void* stream);
 /* The batch in user order for mvin_key_addressing_grouped_fwd, built on the device (counting sort by user id, int
  * atomics; no host sync): seg_user [>= min(B, n_user)] = the users that occur, increasing; seg_ptr [>= min(B, n_user) + 1]
  * = first position of each user's pairs (+ the total at [nseg]); nseg [1]; pair_index [B] = original index of the pair

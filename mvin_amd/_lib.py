@@ -97,6 +97,11 @@ SIGNATURES = {
     "mvin_project_relations_elems": (C.c_size_t, [C.c_int] * 3),
     "mvin_project_relations": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2),
     "mvin_key_addressing_grouped_er_supported": (C.c_int, [C.c_int] * 6),
+    "mvin_key_addressing_flash_supported": (C.c_int, [C.c_int] * 5),
+    "mvin_key_addressing_flash_tables_elems": (C.c_size_t, [C.c_int] * 5),
+    "mvin_key_addressing_flash_prepare": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p] * 2),
+    "mvin_key_addressing_flash_ws_elems": (C.c_size_t, [C.c_int64, C.c_int]),
+    "mvin_key_addressing_flash_fwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64] + [C.c_int] * 7 + [C.c_void_p] * 4),
     "mvin_key_addressing_grouped_er_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int] * 8 + [C.c_void_p, C.c_int64, C.c_void_p]),
     "mvin_user_records_len": (C.c_int, [C.c_int] * 3),
     "mvin_user_records_supported": (C.c_int, [C.c_int] * 5),

@@ -831,6 +831,79 @@ static int key_addressing_grouped_impl(const void* entity_emb, const float* rela
                                         int nR, int n_entity, int n_user, float* out, int64_t ldo, int table_bf16, void* stream,
                                         const float* er_ws);
 
+int mvin_key_addressing_flash_supported(int D, int P, int Nm, int nR, int n_entity) {
+    return mvin::key_addr_flash_supported(D, P, Nm, nR, n_entity) ? 1 : 0;
+}
+
+static int flash_nseg_bound(int64_t B, int n_user) { return (int)(B < (int64_t)n_user ? B : (int64_t)n_user); }
+
+size_t mvin_key_addressing_flash_ws_elems(int64_t B, int n_user) {
+    if (B <= 0 || n_user <= 0) return 0;
+    return mvin::key_addr_flash_ws_elems(B, flash_nseg_bound(B, n_user));
+}
+
+size_t mvin_key_addressing_flash_tables_elems(int n_entity, int nR, int D, int P, int has_set) {
+    if (n_entity <= 0 || nR <= 0 || D <= 0 || P < 0) return 0;
+    return mvin_project_relations_elems(n_entity, nR, D) + (size_t)(P + (has_set ? 1 : 0)) * n_entity * D;
+}
+
+int mvin_key_addressing_flash_prepare(const float* entity_emb, const float* relation_kge, const float* w, const float* user_mlp_W,
+                                      int n_entity, int nR, int D, int P, float* ws, void* stream) {
+    const char* who = "mvin_key_addressing_flash_prepare";
+    if (!entity_emb || !relation_kge || !user_mlp_W || !ws) return fail(-1, "%s: null pointer", who);
+    if (n_entity <= 0 || nR <= 0 || D != 64 || P < 1 || P > 8) return fail(-2, "%s: n_entity=%d nR=%d D=%d P=%d", who, n_entity, nR, D, P);
+    if (int rc = mvin_project_relations(entity_emb, relation_kge, w, n_entity, nR, D, ws, stream)) return rc;
+    mvin_linear_args l{};                     // TW[j][e][n] = sum_k E[e][k] Wmlp[D j + k][n]  (model.py:232-236 taken per entity)
+    l.src[0] = entity_emb;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = n_entity;
+    l.rows_per_group = 1;
+    l.W = user_mlp_W;
+    l.w_zstride = (int64_t)D * D;
+    l.out = ws + mvin_project_relations_elems(n_entity, nR, D);
+    l.ldo = D;
+    l.nz = P + (w ? 1 : 0);
+    l.out_zstride = (int64_t)n_entity * D;
+    return mvin_linear_fwd(&l, stream);
+}
+
+int mvin_key_addressing_flash_fwd(const float* entity_emb, const float* ws, const int32_t* user_records, const int32_t* seg_user,
+                                  const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index, const int64_t* items_i64,
+                                  const int32_t* items_i32, int64_t B, int P, int Nm, int D, int nR, int n_entity, int n_user, int has_set,
+                                  const float* user_mlp_b, float* user_o, int32_t* sched_ws, void* stream) {
+    const char* who = "mvin_key_addressing_flash_fwd";
+    if (!entity_emb || !ws || !user_records || !seg_user || !seg_ptr || !pair_index || !user_o || !sched_ws)
+        return fail(-1, "%s: null pointer", who);
+    if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
+    if (B <= 0 || B >= (int64_t(1) << 31) || n_user <= 0 || n_entity <= 0 || nR <= 0)
+        return fail(-2, "%s: bad sizes B=%lld n_user=%d n_entity=%d nR=%d", who, (long long)B, n_user, n_entity, nR);
+    if (!mvin::key_addr_flash_supported(D, P, Nm, nR, n_entity))
+        return fail(-3, "%s: unsupported shape D=%d P=%d Nm=%d nR=%d n_entity=%d (D = 64, 1 <= P <= 8, Nm <= 64, nR * n_entity < 2^31)", who,
+                    D, P, Nm, nR, n_entity);
+    mvin::KaFlashArgs k{};
+    k.E = entity_emb;
+    k.ER = ws;                                                          // (the layout of mvin_project_relations' workspace, then TW)
+    k.hs = has_set ? ws + (size_t)nR * n_entity * D : nullptr;
+    k.TW = ws + mvin_project_relations_elems(n_entity, nR, D);
+    k.records = user_records;
+    k.seg_user = seg_user;
+    k.seg_ptr = seg_ptr;
+    k.nseg_dev = nseg_dev;
+    k.pair_index = pair_index;
+    k.items64 = items_i64;
+    k.items32 = items_i32;
+    k.bmlp = user_mlp_b;
+    k.user_o = user_o;
+    k.P = P;
+    k.Nm = Nm;
+    k.nR = nR;
+    k.n_entity = n_entity;
+    k.B = B;
+    return hip_result(mvin::launch_key_addr_flash(k, flash_nseg_bound(B, n_user), has_set != 0, sched_ws, (hipStream_t)stream), who);
+}
+
 int mvin_key_addressing_grouped_rec_fwd(const void* entity_emb, const float* relation_kge, const float* w,
                                         const int32_t* uts, const int32_t* user_records, const int32_t* seg_user,
                                         const int32_t* seg_ptr, const int32_t* nseg_dev, const int32_t* pair_index,

@@ -116,6 +116,28 @@ struct KeyAddrGroupedArgs {
     const float* hs;           // [nE] E[e] . w (same call) -- the h-set read's logits; required with ER when w is given
 };
 
+// the barrier-free ("flash") form of the grouped key addressing + user MLP (mvin_keyaddr_flash.hip)
+struct KaFlashArgs {
+    const float* E;            // [nE, 64] fp32
+    const float* ER;           // [nR, nE, 64] R_KGE[r] . E[e] (mvin_project_relations)
+    const float* hs;           // [nE] E[e] . w (same call) or NULL (no h-set read)
+    const int32_t* records;    // static per-user records
+    const int32_t* seg_user;
+    const int32_t* seg_ptr;
+    const int32_t* nseg_dev;
+    const int32_t* pair_index;
+    const int64_t* items64;
+    const int32_t* items32;
+    const float* TW;           // [P + has_set][nE, 64] E . user_mlp_matrix[64 j : 64 j + 64, :] (mvin_key_addressing_flash_prepare)
+    const float* bmlp;         // [64] or NULL
+    float* user_o;             // [B, 64]
+    int32_t* slot_seg;         // scheduling (set by the launcher)
+    int32_t* counter;
+    int nslots;
+    int P, Nm, nR, n_entity;
+    int64_t B;
+};
+
 // the static record of one user: offsets in int32 words (mvin_keyaddr_static.hip); len == 0: shape outside the record form
 struct KaRecLayout {
     int NmP, rows, maxtiles, o_cnt, o_off, o_trel, o_bidx, o_head, o_tail, o_hr, len;
@@ -297,6 +319,9 @@ hipError_t launch_user_records(const int32_t* uts, int n_user, int P, int Nm, in
 bool key_addr_static_supported(int D, int P, int Nm, int nR);
 bool key_addr_static_applies(const KeyAddrGroupedArgs& a, int table_bf16);
 hipError_t launch_key_addr_static(const KeyAddrGroupedArgs& a, hipStream_t st);
+bool key_addr_flash_supported(int D, int P, int Nm, int nR, int n_entity);
+size_t key_addr_flash_ws_elems(int64_t B, int nseg_bound);
+hipError_t launch_key_addr_flash(const KaFlashArgs& a, int nseg_bound, bool has_set, int32_t* sched_ws, hipStream_t st);
 hipError_t kas_read_trace(long long* host_dst, size_t n);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 bool key_addr_stream_supported(const KeyAddrArgs& a, int table_bf16);       // LDS-DMA streaming variant, mvin_keyaddr_stream.hip

@@ -623,6 +623,63 @@ def key_addressing_grouped(entity_emb, relation_kge, w, uts, groups, items, P, o
     return out
 
 
+def key_addressing_flash_supported(D, P, Nm, nR, n_entity):
+    return bool(_lib.load().mvin_key_addressing_flash_supported(D, P, Nm, nR, n_entity))
+
+
+def key_addressing_flash_prepare(entity_emb, relation_kge, w, user_mlp_W, P, out=None):
+    """mvin_key_addressing_flash_prepare: the per-call tables of the flash form -- R_KGE[r] . E[e] for every (relation, entity),
+    E[e] . w (``w`` None: no h-set read) and E . user_mlp_W[D j : D j + D] per block of o_list -- from the CURRENT parameters."""
+    lib = _lib.load()
+    for t, nm in ((entity_emb, "entity_emb"), (relation_kge, "relation_kge"), (w, "w"), (user_mlp_W, "user_mlp_W")):
+        _chk(t, F32, nm)
+    nE, D = entity_emb.shape
+    nR = relation_kge.shape[0]
+    has_set = w is not None
+    if tuple(user_mlp_W.shape) != ((P + (1 if has_set else 0)) * D, D):
+        raise ValueError("key_addressing_flash_prepare: user_mlp_W [(P + has_set) D, D] expected")
+    n = lib.mvin_key_addressing_flash_tables_elems(nE, nR, D, P, 1 if has_set else 0)
+    if out is None:
+        out = torch.empty((n,), dtype=F32, device=entity_emb.device)
+    elif out.numel() != n or out.dtype != F32 or not out.is_contiguous():
+        raise ValueError("key_addressing_flash_prepare: workspace of mvin_key_addressing_flash_tables_elems floats expected")
+    _lib.check(lib.mvin_key_addressing_flash_prepare(_p(entity_emb), _p(relation_kge), _p(w), _p(user_mlp_W), nE, nR, D, P, _p(out), _stream()),
+               "mvin_key_addressing_flash_prepare")
+    return out
+
+
+def key_addressing_flash(entity_emb, tables, records, groups, items, P, Nm, nR, has_set, user_mlp_b, n_user, sched_ws=None, out=None):
+    """mvin_key_addressing_flash_fwd: MVIN._key_addressing + the user MLP for a batch grouped by user (``groups`` =
+    group_pairs_by_user(users)) in one barrier-free kernel over the static per-user ``records`` and ``tables`` =
+    key_addressing_flash_prepare(entity_emb, relation_kge, w if has_set else None, user_mlp_W, P).  Returns user_o [B, D]."""
+    lib = _lib.load()
+    for t, dt, nm in ((entity_emb, F32, "entity_emb"), (tables, F32, "tables"), (records, I32, "records"), (user_mlp_b, F32, "user_mlp_b")):
+        _chk(t, dt, nm)
+    seg_user, seg_ptr, nseg, perm = groups
+    B = items.shape[0]
+    nE, D = entity_emb.shape
+    i64 = items if items.dtype == torch.int64 else None
+    i32 = items if items.dtype == I32 else None
+    if i64 is None and i32 is None:
+        raise TypeError("items must be int64 or int32")
+    if tables.numel() != lib.mvin_key_addressing_flash_tables_elems(nE, nR, D, P, 1 if has_set else 0):
+        raise ValueError("key_addressing_flash: tables = key_addressing_flash_prepare(entity_emb, relation_kge, w, user_mlp_W, P) expected")
+    if tuple(records.shape) != (n_user, user_records_len(P, Nm, nR)):
+        raise ValueError(f"records shape {tuple(records.shape)} is not that of build_user_records(uts, {P}, {nR}, ...)")
+    n_ws = lib.mvin_key_addressing_flash_ws_elems(B, n_user)
+    if sched_ws is None:
+        sched_ws = torch.empty((n_ws,), dtype=I32, device=entity_emb.device)
+    elif sched_ws.numel() < n_ws or sched_ws.dtype != I32:
+        raise ValueError("key_addressing_flash: sched_ws of mvin_key_addressing_flash_ws_elems int32 words expected")
+    user_o = out if out is not None else torch.empty((B, D), dtype=F32, device=entity_emb.device)
+    _chk(user_o, F32, "out")
+    _lib.check(lib.mvin_key_addressing_flash_fwd(_p(entity_emb), _p(tables), _p(records), _p(seg_user), _p(seg_ptr), _p(nseg), _p(perm),
+                                                 _p(i64), _p(i32), B, P, Nm, D, nR, nE, n_user, 1 if has_set else 0,
+                                                 _p(user_mlp_b), _p(user_o), _p(sched_ws), _stream()),
+               "mvin_key_addressing_flash_fwd")
+    return user_o
+
+
 # ------------------------------------------------------------------------------- training ops
 def _fill_linear_args(a, srcs, ids, Dout, rows, nz, sum_sources):
     nsrc = len(srcs)

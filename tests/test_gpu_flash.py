@@ -1,0 +1,129 @@
+"""-m gpu: the barrier-free ("flash") form of the grouped key addressing + user MLP (mvin_key_addressing_flash_fwd,
+mvin_keyaddr_flash.hip) -- MVIN._key_addressing (model.py:161-240) with the user MLP of :232-236 folded in, every wave walking
+tiles of 16 pairs of one user on its own over the static per-user records and the per-call table R_KGE[r] . E[e]
+(mvin_project_relations).  Checked against a float64 evaluation of the reference's formulas pair by pair, against the kernel
+that buckets every segment's ids itself (mvin_key_addressing_grouped_fwd) + mvin_linear_fwd, and -- through MVIN.forward_users
+-- against the fp32 mirror of the reference graph."""
+import numpy as np
+import pytest
+import torch
+
+from mvin_amd import ops, synth
+from mvin_amd.config import make_args
+from mvin_amd.params import init_params
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # (P, Nm, nR, n_user, B, with h-set, item dtype)
+    (2, 64, 9, 40, 700, True, torch.int64),            # BASELINE C3's key-addressing shape; ~17 pairs per user: two tiles per slot
+    (2, 64, 9, 2000, 9000, True, torch.int64),
+    (2, 64, 9, 300, 1300, True, torch.int32),
+    (2, 64, 9, 3000, 3500, True, torch.int64),         # most users appear once: one partly filled tile per slot
+    (1, 64, 9, 500, 4000, True, torch.int64),          # one hop
+    (1, 16, 39, 800, 5000, True, torch.int64),         # amazon-book's shape (BASELINE C4): one memory tile
+    (2, 40, 9, 1500, 6000, True, torch.int64),         # padding memories (Nm = 40 -> 48 per hop)
+    (3, 32, 9, 700, 3000, False, torch.int64),         # three hops, no h-set
+    (4, 32, 7, 600, 5000, True, torch.int64),
+    (8, 8, 5, 100, 900, True, torch.int64),            # eight hops of half a tile
+    (2, 64, 25, 500, 4000, True, torch.int64),
+    (2, 33, 70, 400, 3000, False, torch.int64),        # three memory tiles, more relations than a hop has memories
+    (2, 56, 9, 600, 2500, True, torch.int64),
+    (2, 64, 9, 5, 3000, True, torch.int64),            # 600 pairs per user: ten slots per segment
+    (2, 64, 9, 7, 1, True, torch.int64),               # one pair
+    (2, 1, 1, 3, 50, True, torch.int64),               # one memory, one relation
+]
+IDS = lambda s: "P%dNm%dnR%d_u%d_B%d%s" % (s[0], s[1], s[2], s[3], s[4], "" if s[5] else "_noset")      # noqa: E731
+
+
+def reference_f64(E, R, w, W, b, uts, users, items, P, Nm, has_set, idx):
+    """model.py:161-240 for the pairs ``idx``, float64, written from the reference's formulas: o_hset = softmax_m([h; user] . w_h) h
+    (the user term and bias are constant over m: softmax shift invariance), per hop Rh_m = R_KGE[r_m] h_m, p = softmax_m(Rh_m . item),
+    o = sum_m p_m t_m, user_o = concat(o_list) . user_mlp_matrix + bias."""
+    Ed, Rd = E.double(), R.double()
+    u = users[idx].long()
+    v = Ed[items[idx].long()]                                   # [n, D]
+    outs = []
+    if has_set:
+        h = Ed[uts[u, 0, 0].long()]                             # [n, Nm, D]
+        p = torch.softmax(h @ w.double(), dim=-1)
+        outs.append((p[..., None] * h).sum(1))
+    for hop in range(P):
+        h = Ed[uts[u, hop, 0].long()]
+        t = Ed[uts[u, hop, 2].long()]
+        Rm = Rd[uts[u, hop, 1].long()]                          # [n, Nm, D, D]
+        Rh = torch.einsum("bmnk,bmk->bmn", Rm, h)
+        p = torch.softmax(torch.einsum("bmn,bn->bm", Rh, v), dim=-1)
+        outs.append((p[..., None] * t).sum(1))
+    o_cat = torch.cat(outs, dim=1)
+    return o_cat, o_cat @ W.double() + b.double()
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=IDS)
+def test_flash_kernel_against_float64_and_the_bucketing_kernel(shape, hip_lib):
+    P, Nm, nR, n_user, B, has_set, idt = shape
+    D, n_entity = 64, 5000
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(B + Nm)
+    rnd = lambda *s: torch.rand(s, device=dev, generator=g) - 0.5     # noqa: E731
+    E, R = rnd(n_entity, D), rnd(nR, D, D) * 0.5
+    w = rnd(D) if has_set else None
+    n_o = P + (1 if has_set else 0)
+    W, b = rnd(n_o * D, D) * 0.3, rnd(D)
+    uts = torch.from_numpy(synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=B)).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g).to(idt)
+    assert ops.key_addressing_flash_supported(D, P, Nm, nR, n_entity)
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    tabs = ops.key_addressing_flash_prepare(E, R, w, W, P)
+    first = None
+    for _ in range(2):                                        # twice: the scheduling scratch of a launch must not leak into the next
+        user_o = torch.full((B, D), float("nan"), device=dev)
+        ops.key_addressing_flash(E, tabs, rec, groups, items, P, Nm, nR, has_set, b, n_user, out=user_o)
+        torch.cuda.synchronize()
+        assert torch.isfinite(user_o).all()                   # every pair's row written, whatever its slot
+        if first is None:
+            first = user_o.clone()
+        assert torch.equal(first, user_o)                     # same bits whoever draws which slot
+    # float64, pair by pair, on a sample across the batch
+    idx = torch.from_numpy(np.unique(np.random.default_rng(B).integers(0, B, 300))).to(dev)
+    ref_cat, ref_uo = reference_f64(E, R, w, W, b, uts, users, items, P, Nm, has_set, idx)
+    assert_close(user_o[idx].cpu().numpy(), ref_uo.cpu().numpy(), "user_o vs float64", rtol=1e-5, atol=2e-6)
+    # the bucketing kernel + the MFMA linear kernel on the same inputs (other summation orders)
+    a = torch.full((B, n_o * D), float("nan"), device=dev)
+    if ops.key_addressing_grouped_supported(D, P, Nm, nR):
+        ops.key_addressing_grouped(E, R, w, uts, groups, items, P, a, n_o * D, nR)
+        assert_close(user_o.cpu().numpy(), ops.linear([a], W, D, bias=b).cpu().numpy(), "flash user_o vs linear kernel", rtol=1e-5, atol=2e-6)
+
+
+def test_unsupported_shapes_are_refused(hip_lib):
+    assert not ops.key_addressing_flash_supported(32, 2, 64, 9, 1000)          # D != 64
+    assert not ops.key_addressing_flash_supported(64, 0, 64, 9, 1000)          # no hop
+    assert not ops.key_addressing_flash_supported(64, 2, 65, 9, 1000)          # more than four memory tiles
+    assert not ops.key_addressing_flash_supported(64, 2, 64, 4096, 1 << 20)    # row numbers beyond 31 bits
+    assert ops.key_addressing_flash_supported(64, 2, 64, 9, 106389) and ops.key_addressing_flash_supported(64, 1, 16, 39, 113487)
+
+
+def test_out_of_range_item_ids_are_clamped(hip_lib):
+    """Device-resident ids are never validated per launch: an item id outside the table reads the last row (like every other kernel)."""
+    dev = torch.device("cuda:0")
+    P, Nm, nR, n_user, B, D, n_entity = 2, 64, 9, 10, 200, 64, 300
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    rnd = lambda *s: torch.rand(s, device=dev, generator=g) - 0.5     # noqa: E731
+    E, R, w, W, b = rnd(n_entity, D), rnd(nR, D, D), rnd(D), rnd(3 * D, D), rnd(D)
+    uts = torch.from_numpy(synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=3)).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g)
+    bad = items.clone()
+    bad[::7] = n_entity + 12345
+    items[::7] = n_entity - 1
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    tabs = ops.key_addressing_flash_prepare(E, R, w, W, P)
+    x = ops.key_addressing_flash(E, tabs, rec, groups, items, P, Nm, nR, True, b, n_user)
+    y = ops.key_addressing_flash(E, tabs, rec, groups, bad, P, Nm, nR, True, b, n_user)
+    assert torch.equal(x, y)
