@@ -995,7 +995,11 @@ def main():
                        "key_addressing_variant": (
                            "pairs (mvin_key_addressing_fwd: 2*P*Nm rows gathered per pair)"
                            if (a.feed == "pairs" or scorer is not None) else
-                           ("grouped over static per-user records (mvin_key_addressing_grouped_rec_fwd: relation buckets, tile table "
+                           ("grouped, flash form (mvin_key_addressing_flash_prepare + mvin_key_addressing_flash_fwd: the per-call tables R_KGE[r] . E[e] "
+                            "and E . user_mlp blocks are rebuilt inside every timed step; attention reads AND the user MLP in one barrier-free kernel "
+                            "over the static per-user records, each wave walking tiles of 32 pairs of one user on transposed MFMA products)"
+                            if (getattr(model, "_uts_records", None) is not None and by_user and model._ka_flash_for(uts_d, model._uts_records[3], Bl)) else
+                            "grouped over static per-user records (mvin_key_addressing_grouped_rec_fwd: relation buckets, tile table "
                             "and clamped ids of every user's ripple sets built once by mvin_build_user_records; a user's rows staged once "
                             "per user segment)" if getattr(model, "_uts_records", None) is not None else
                             "grouped (mvin_key_addressing_grouped_fwd: a user's rows staged once per user segment)")

@@ -449,6 +449,12 @@ typedef struct {
     float* ka_er;                  /* mvin_score_l2_fwd only, or NULL: workspace of mvin_project_relations_elems(nE, nR, D) floats -- with
                                       user_records and an fp32 table the grouped key addressing runs in its GATHERED form:
                                       mvin_project_relations -> mvin_key_addressing_grouped_er_fwd.  Rewritten by every call */
+    float* ka_flash;               /* mvin_score_l2_fwd only, or NULL: workspace of mvin_key_addressing_flash_tables_elems(nE, nR, D, P,
+                                      h_set_w != NULL) floats -- with user_records, group_ws and an fp32 table of a shape
+                                      mvin_key_addressing_flash_supported takes, key addressing AND the user MLP run as
+                                      mvin_key_addressing_flash_prepare -> mvin_key_addressing_flash_fwd (o_cat is then not written; the
+                                      scheduling scratch is the part of group_ws the grouping leaves behind).  Takes precedence over
+                                      ka_er.  Rewritten by every call */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

@@ -70,7 +70,8 @@ class ScoreL2Args(C.Structure):
         "uts", "users", "V", "o_cat", "parents", "nagg0", "nagg1", "user_o", "item_emb", "scores", "sig")] + [
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
         ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p),
-        ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p), ("ka_er", C.c_void_p)]
+        ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p), ("ka_er", C.c_void_p),
+        ("ka_flash", C.c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.

@@ -49,6 +49,7 @@ int mvin_debug_read_trace(long long* host_dst, size_t n) {
     static const bool ka = getenv("MVIN_KA_TRACE") != nullptr;     // which kernel's stamps
     static const bool pk = getenv("MVIN_PACK_TRACE") != nullptr;
     if (getenv("MVIN_SMALL_TRACE")) return (int)mvin::small_read_trace(host_dst, n);
+    if (getenv("MVIN_KAF_TRACE")) return (int)mvin::kaf_read_trace(host_dst, n);
     if (pk) return (int)mvin::pack_read_prof(host_dst, n);
     if (ka && getenv("MVIN_KA_TRACE")[0] == '2') return (int)mvin::kas_read_trace(host_dst, n);     // the kernel over static records
     return (int)(ka ? mvin::ka_read_trace(host_dst, n) : mvin::split_read_trace(host_dst, n));
@@ -605,6 +606,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     l.w_zstride = (int64_t)D * D;
     l.out_zstride = D;
     int rc = 0;
+    bool flash = false;
     if (grouped) {
         // the batch in user order (device-side counting sort, no host sync), then a user's rows staged once per segment
         int32_t* ws = a->group_ws;
@@ -614,7 +616,20 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         int32_t* pair_index = nseg + 1;
         rc = mvin_group_pairs_by_user(a->users, nullptr, a->B, a->n_user, ws, seg_user, seg_ptr, nseg, pair_index, stream);
         if (rc) return rc;
-        if (a->ka_er && a->user_records && !a->table_bf16 &&
+        if (a->ka_flash && a->user_records && !a->table_bf16 && mvin::key_addr_flash_supported(D, a->P, a->Nm, nR, a->n_entity)) {
+            // flash form: per-call tables (R_KGE[r] . E[e], E . Wmlp blocks) from the CURRENT parameters, then ONE barrier-free kernel
+            // for the attention reads and the user MLP.  Its scheduling scratch: the counters / offsets / ranks of the counting sort
+            // (2 n_user + B words at the head of group_ws), dead once the batch is grouped
+            rc = mvin_key_addressing_flash_prepare(reinterpret_cast<const float*>(a->entity_emb), a->relation_kge, a->h_set_w, a->user_mlp_W,
+                                                   a->n_entity, nR, D, a->P, a->ka_flash, stream);
+            if (rc) return rc;
+            if (mvin_key_addressing_flash_ws_elems(a->B, a->n_user) > (size_t)2 * a->n_user + (size_t)a->B)
+                return fail(-2, "%s: group_ws too small for the flash form's scheduling scratch", who);
+            rc = mvin_key_addressing_flash_fwd(reinterpret_cast<const float*>(a->entity_emb), a->ka_flash, a->user_records, seg_user, seg_ptr,
+                                               nseg, pair_index, a->items, nullptr, a->B, a->P, a->Nm, D, nR, a->n_entity, a->n_user,
+                                               a->h_set_w != nullptr, a->user_mlp_b, a->user_o, ws, stream);
+            flash = true;
+        } else if (a->ka_er && a->user_records && !a->table_bf16 &&
             mvin_key_addressing_grouped_er_supported(D, a->P, a->Nm, nR, a->n_entity, a->h_set_w != nullptr)) {
             // gathered form of the U rows: R_KGE[r] . E[e] for every (relation, entity) from the CURRENT parameters, per call
             rc = mvin_project_relations(reinterpret_cast<const float*>(a->entity_emb), a->relation_kge, a->h_set_w, a->n_entity, nR, D,
@@ -639,6 +654,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         rc = mvin_key_addressing_fwd(a->entity_emb, a->V, a->h_set_w, a->mem_h, a->mem_r, a->mem_t, a->P, (int)a->B, a->Nm, D,
                                      nR, a->n_entity, a->o_cat, (int64_t)n_o * D, a->table_bf16, stream);
     if (rc) return rc;
+    if (!flash) {
     mvin_linear_args u{};                     // user_o = o_cat . user_mlp + bias (model.py:232-236)
     u.src[0] = a->o_cat;
     u.nsrc = 1;
@@ -653,6 +669,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     u.nz = 1;
     rc = mvin_linear_fwd(&u, stream);
     if (rc) return rc;
+    }
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
     const bool d32 = mvin::fused_d32_supported(D, a->K);       // the wave-per-parent kernel: projected tables over either adjacency

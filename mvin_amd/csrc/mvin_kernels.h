@@ -323,6 +323,7 @@ bool key_addr_flash_supported(int D, int P, int Nm, int nR, int n_entity);
 size_t key_addr_flash_ws_elems(int64_t B, int nseg_bound);
 hipError_t launch_key_addr_flash(const KaFlashArgs& a, int nseg_bound, bool has_set, int32_t* sched_ws, hipStream_t st);
 hipError_t kas_read_trace(long long* host_dst, size_t n);
+hipError_t kaf_read_trace(long long* host_dst, size_t n);
 hipError_t launch_key_addr(const KeyAddrArgs& a, int table_bf16, hipStream_t st);
 bool key_addr_stream_supported(const KeyAddrArgs& a, int table_bf16);       // LDS-DMA streaming variant, mvin_keyaddr_stream.hip
 hipError_t launch_key_addr_stream(const KeyAddrArgs& a, int table_bf16, hipStream_t st);

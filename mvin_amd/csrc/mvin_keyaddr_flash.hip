@@ -27,6 +27,7 @@
 // p0 / 64 + s ... (disjoint by construction, holes = -1), one slot = up to 64 pairs = two tiles -- and ONE atomic counter the
 // persistent waves draw slots from (results do not depend on who draws what).  D = 64, fp32 tables, Nm <= 64, P >= 1.
 #include <cstdlib>
+#include <type_traits>
 
 #include "mvin_kernels.h"
 
@@ -51,7 +52,9 @@ __global__ void ka_flash_slots_kernel(const int32_t* __restrict__ seg_ptr, const
 
 #define KAF_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int NMT, bool HAS_SET>
+__device__ long long g_kaf_trace[64 * 16];    // MVIN_KAF_TRACE=1: wave 0 of workgroup 0 stamps its stage boundaries (scripts/trace_flash.py)
+
+template <int NMT, bool HAS_SET, bool TRACE = false>
 __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaFlashArgs a, KaRecLayout RL) {
     constexpr int D = 64;
     // the slot's constant part of user_o (bias + h-set block), parked per wave between the tiles of a slot: 16 registers more in
@@ -69,9 +72,13 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
     };
     // U rows of one hop: memory tile mt, lane (q16, l16) -> row hr[mt] (of memory 16 mt + l16), bytes [64 nt + 16 q16, + 16)
     auto issue_u = [&](int mt, const int (&hr)[NMT], Rows& R) {
-        const float4* src = reinterpret_cast<const float4*>(a.ER + (size_t)(unsigned)max(hr[mt], 0) * D) + q16;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.ER + (size_t)(unsigned)max(hr[mt], 0) * D) + q16;
+        // (a row of the 245 MB table is used once per slot: streamed past the caches that hold the entity-sized tables)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) R.v[mt][nt] = src[4 * nt];
+        for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 v = __builtin_nontemporal_load(src + 4 * nt);
+            R.v[mt][nt] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     };
     // projected tail rows: step (mt, i) <-> memory 16 mt + 4 q16 + i, lane (q16, l16) -> columns [4 l16, + 4) of that row
     auto issue_t = [&](int mt, const float* __restrict__ tab, const int4 (&ids)[NMT], Rows& R) {
@@ -81,15 +88,24 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
             R.v[mt][i] = reinterpret_cast<const float4*>(tab + (size_t)(unsigned)max(id[i], 0) * D)[l16];
     };
     // uo^T += rows^T p for one memory tile (both column tiles of pairs share the A operand)
-    auto reads_tile = [&](int mt, const Rows& R, const f32x4 (&p0)[NMT], const f32x4 (&p1)[NMT], bool two, f32x4 (&u0)[4], f32x4 (&u1)[4]) {
+    auto reads_tile = [&](bool two, int mt, const Rows& R, const f32x4 (&p0)[NMT], const f32x4 (&p1)[NMT], f32x4 (&u0)[4], f32x4 (&u1)[4]) {
+        // (the flag is tested ONCE per memory tile: under a test per product every MFMA of the second column tile sat in a branch of
+        //  its own, with the loads in flight waited for inside)
+        if (two) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float t[4] = {R.v[mt][i].x, R.v[mt][i].y, R.v[mt][i].z, R.v[mt][i].w};
+            for (int i = 0; i < 4; ++i) {
+                const float t[4] = {R.v[mt][i].x, R.v[mt][i].y, R.v[mt][i].z, R.v[mt][i].w};
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) u0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[nt], p0[mt][i], u0[nt], 0, 0, 0);
-            if (two) {
+                for (int nt = 0; nt < 4; ++nt) u0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[nt], p0[mt][i], u0[nt], 0, 0, 0);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) u1[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[nt], p1[mt][i], u1[nt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t[4] = {R.v[mt][i].x, R.v[mt][i].y, R.v[mt][i].z, R.v[mt][i].w};
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) u0[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(t[nt], p0[mt][i], u0[nt], 0, 0, 0);
             }
         }
     };
@@ -126,7 +142,14 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
         }
     };
 
-    for (;;) {
+    int iter = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 0 && threadIdx.x == 0 && iter >= 2 && iter < 66) g_kaf_trace[(iter - 2) * 16 + slot] = __builtin_readcyclecounter();
+        }
+    };
+    for (;; ++iter) {
+        stamp(0);
         int k = 0;
         if (lane == 0) k = atomicAdd(a.counter, 1) + 1;       // (the launcher's memset leaves -1)
         k = __builtin_amdgcn_readfirstlane(k);
@@ -138,6 +161,7 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
         const int cbeg = p0 + (k - (p0 / kFlashChunk + s)) * kFlashChunk;
         const int cend = min(p1, cbeg + kFlashChunk);
         const int32_t* __restrict__ rec = a.records + (size_t)u * RL.len;
+        stamp(1);
         auto load_hr = [&](int hop, int (&hr)[NMT]) {
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) hr[mt] = rec[RL.o_hr + hop * NmP + 16 * mt + l16];
@@ -195,6 +219,8 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
             for (int mt = 0; mt < NMT; ++mt) hid[mt] = *reinterpret_cast<const int4*>(rec + RL.o_head + 16 * mt + 4 * q16);
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) issue_t(mt, a.TW, hid, R);
+            KAF_FENCE();
+            stamp(11);
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
                 const int id[4] = {hid[mt].x, hid[mt].y, hid[mt].z, hid[mt].w};
@@ -203,15 +229,19 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
             }
             load_item(orig, item);
             KAF_FENCE();
+            stamp(12);
             softmax(ph, hid);
+            KAF_FENCE();
+            stamp(13);
             f32x4 unused[4];
 #pragma unroll
             for (int mt = 0; mt < NMT; ++mt) {
-                reads_tile(mt, R, ph, ph, false, uo0, unused);
+                reads_tile(false, mt, R, ph, ph, uo0, unused);
                 KAF_FENCE();
                 issue_u(mt, hrC, R);
                 KAF_FENCE();
             }
+            stamp(14);
         } else {
             load_item(orig, item);
 #pragma unroll
@@ -221,12 +251,12 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) myUo0[nt][lane] = uo0[nt];      // (read back by this lane only)
         KAF_FENCE();
+        stamp(2);
 
         const int ntile = (cend - cbeg + 31) >> 5;
         int t0 = cbeg;
-        for (int tile = 0; tile < ntile; ++tile, t0 += 32) {
-            const bool two = cend - t0 > 16;
-            const bool more = tile + 1 < ntile;
+        // one tile of up to 16 (two false) or up to 32 pairs
+        auto run_tile = [&](const bool two, const bool more) {
             f32x4 uo[2][4];
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -242,21 +272,32 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
                 const float* __restrict__ tw = a.TW + (size_t)(hop + (HAS_SET ? 1 : 0)) * tw_stride;
                 if (next_stage) load_hr(hopN, hrN);
                 KAF_FENCE();
+                if (t0 == cbeg && hop < 3) stamp(3 + 4 * hop);
                 // logits^T, one memory tile after the other; the registers of a tile's U rows take its projected tail rows at once
                 f32x4 lg[2][NMT];
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
                     lg[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     lg[1][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (two) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        const float av[4] = {R.v[mt][nt].x, R.v[mt][nt].y, R.v[mt][nt].z, R.v[mt][nt].w};
-                        const float e0[4] = {bE[0][nt].x, bE[0][nt].y, bE[0][nt].z, bE[0][nt].w};
-                        const float e1[4] = {bE[1][nt].x, bE[1][nt].y, bE[1][nt].z, bE[1][nt].w};
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const float av[4] = {R.v[mt][nt].x, R.v[mt][nt].y, R.v[mt][nt].z, R.v[mt][nt].w};
+                            const float e0[4] = {bE[0][nt].x, bE[0][nt].y, bE[0][nt].z, bE[0][nt].w};
+                            const float e1[4] = {bE[1][nt].x, bE[1][nt].y, bE[1][nt].z, bE[1][nt].w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            lg[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], e0[i], lg[0][mt], 0, 0, 0);
-                            if (two) lg[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], e1[i], lg[1][mt], 0, 0, 0);
+                            for (int i = 0; i < 4; ++i) {
+                                lg[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], e0[i], lg[0][mt], 0, 0, 0);
+                                lg[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], e1[i], lg[1][mt], 0, 0, 0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const float av[4] = {R.v[mt][nt].x, R.v[mt][nt].y, R.v[mt][nt].z, R.v[mt][nt].w};
+                            const float e0[4] = {bE[0][nt].x, bE[0][nt].y, bE[0][nt].z, bE[0][nt].w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) lg[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], e0[i], lg[0][mt], 0, 0, 0);
                         }
                     }
                     KAF_FENCE();
@@ -266,17 +307,20 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
                 // the item rows are done with after the tile's last logits: the next tile's take their registers
                 if (last_hop && more) load_be(itemN, bE);
                 KAF_FENCE();
+                if (t0 == cbeg && hop < 3) stamp(4 + 4 * hop);
                 softmax(lg[0], tidC);
                 if (two) softmax(lg[1], tidC);
                 KAF_FENCE();
+                if (t0 == cbeg && hop < 3) stamp(5 + 4 * hop);
 #pragma unroll
                 for (int mt = 0; mt < NMT; ++mt) {
-                    reads_tile(mt, R, lg[0], lg[1], two, uo[0], uo[1]);
+                    reads_tile(two, mt, R, lg[0], lg[1], uo[0], uo[1]);
                     KAF_FENCE();
                     if (next_stage) issue_u(mt, hrN, R);
                     KAF_FENCE();
                 }
                 if (next_stage) load_tid(hopN, tidC);
+                if (t0 == cbeg && hop < 3) stamp(6 + 4 * hop);
             }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -287,10 +331,20 @@ __global__ __launch_bounds__(kFlashWaves * 64, 2) void key_addr_flash_kernel(KaF
                             make_float4(uo[rt][0][r], uo[rt][1][r], uo[rt][2][r], uo[rt][3][r]);
                 }
             }
+        };
+        for (int tile = 0; tile < ntile; ++tile, t0 += 32) {
+            const bool more = tile + 1 < ntile;
+            run_tile(cend - t0 > 16, more);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) orig[rt] = origN[rt], valid[rt] = validN[rt];
         }
+        stamp(15);
     }
+}
+
+hipError_t kaf_read_trace(long long* host_dst, size_t n) {
+    const size_t have = sizeof(g_kaf_trace) / sizeof(long long);
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_kaf_trace), (n < have ? n : have) * sizeof(long long));
 }
 #undef KAF_FENCE
 
@@ -307,6 +361,10 @@ size_t key_addr_flash_ws_elems(int64_t B, int nseg_bound) { return (size_t)(B / 
 template <int NMT>
 static hipError_t launch_flash_n(const KaFlashArgs& a, const KaRecLayout& RL, bool has_set, hipStream_t st) {
     auto k = has_set ? key_addr_flash_kernel<NMT, true> : key_addr_flash_kernel<NMT, false>;
+    if constexpr (NMT == 4) {
+        static const bool trace = getenv("MVIN_KAF_TRACE") != nullptr;
+        if (trace && has_set) k = key_addr_flash_kernel<4, true, true>;
+    }
     static thread_local int per_cu[2] = {0, 0};
     int& pc = per_cu[has_set ? 1 : 0];
     if (pc == 0) {

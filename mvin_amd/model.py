@@ -76,6 +76,11 @@ class _SmallOut(object):
         return self._buf[n:n + self._B]
 
 
+def _lib_flash_elems(m):
+    from . import _lib
+    return _lib.load().mvin_key_addressing_flash_tables_elems(m.n_entity, m.n_relation, m.dim, m.p_hop, 1 if m.args.PS_O_ft else 0)
+
+
 class MVIN(object):
     def __init__(self, args, n_user, n_entity, n_relation, adj_entity, adj_relation,
                  params=None, device=None, seed=0, fused=None, table_dtype="f32", hoist=False):
@@ -265,6 +270,11 @@ class MVIN(object):
         # gathered form of the grouped key addressing (mvin_key_addressing_grouped_er_fwd, _ka_er_for): on request only
         self.ka_er = os.environ.get("MVIN_KA_ER", "0") == "1"
         self._ka_er_ws = {}                  # per stream: workspace of mvin_project_relations_elems floats, rewritten by every call
+        # flash form of the grouped key addressing + user MLP (mvin_key_addressing_flash_fwd, _ka_flash_for): None = automatic
+        # (MVIN_KA_FLASH=0 / 1 overrides), True / False
+        self.ka_flash = {"0": False, "1": True}.get(os.environ.get("MVIN_KA_FLASH", ""), None)
+        self._ka_flash_ws = {}               # per stream: workspace of mvin_key_addressing_flash_tables_elems floats, rewritten by every call
+        self._distinct_hint = None           # forward_device's distinct_users of the call at hand
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
         # up to this many pairs the whole pass is ONE kernel launch (mvin_score_small_fwd: the reference's own batch sizes,
@@ -297,7 +307,8 @@ class MVIN(object):
         if not (uts.is_cuda and uts.dtype == torch.int32 and uts.is_contiguous()):
             return None
         bf = self.entity_emb_matrix.dtype == torch.bfloat16
-        if not ops.user_records_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, bf):
+        if not (ops.user_records_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, bf)
+                or (not bf and ops.key_addressing_flash_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, self.n_entity))):
             return None
         c = self._uts_records
         if c is not None and c[0]() is uts and c[1] == uts._version and c[2] == (self.n_entity, self.n_relation):
@@ -854,6 +865,27 @@ class MVIN(object):
         return bool(ops.key_addressing_grouped_er_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, self.n_entity,
                                                             bool(a.PS_O_ft)))
 
+    def _ka_flash_for(self, uts, records, B):
+        """Flash form of the grouped key addressing + user MLP (mvin_key_addressing_flash_fwd) for a batch of B pairs?  Its per-call
+        tables cost ~(nR + P + 1) n_entity rows of work whatever the batch (0.15 ms at BASELINE C3, where the kernel then takes 0.52
+        ms against 0.89 + 0.15 for the kernel over the records + the MLP launch; amazon-book's 39 relations make it a 1.1 GB table):
+        automatic when the users the batch can hold reference at least as many ripple rows as the table has -- users x P x Nm >=
+        nR x n_entity.  ``self.ka_flash`` True / False (MVIN_KA_FLASH=1 / 0) forces it."""
+        if (records is None or self.ka_flash is False or self.entity_emb_matrix.dtype != torch.float32 or self.p_hop < 1
+                or not ops.key_addressing_flash_supported(self.dim, self.p_hop, self.n_memory, self.n_relation, self.n_entity)):
+            return False
+        if self.ka_flash:
+            return True
+        users = min(int(B), int(uts.shape[0]), int(self._distinct_hint or uts.shape[0]))
+        return users * self.p_hop * self.n_memory >= self.n_relation * self.n_entity
+
+    def _ka_flash_tables(self, stream):
+        n_ws = _lib_flash_elems(self)
+        ws = self._ka_flash_ws.get(stream)
+        if ws is None or ws.numel() != n_ws:
+            ws = self._ka_flash_ws[stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+        return ws
+
     def _prj_plain_ok(self):
         """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
         where the library takes THAT kernel for this model's tables (mvin_gather_attn_l2_prj_supported: its LDS copy of the
@@ -927,8 +959,10 @@ class MVIN(object):
         rec = self.user_records(uts) if grouped else None
         s.user_records = ptr(rec)
         st["live"] = (self.entity_emb_matrix, t0, t1, enc, rec)
-        s.ka_er = None
-        if grouped and self._ka_er_for(uts, rec):          # gathered U rows: the table is rebuilt by every call
+        s.ka_er = s.ka_flash = None
+        if grouped and self._ka_flash_for(uts, rec, B):    # flash form: its tables are rebuilt by every call
+            s.ka_flash = self._ka_flash_tables(torch.cuda.current_stream().cuda_stream).data_ptr()
+        elif grouped and self._ka_er_for(uts, rec):        # gathered U rows: the table is rebuilt by every call
             cs = torch.cuda.current_stream().cuda_stream
             n_ws = _lib.load().mvin_project_relations_elems(self.n_entity, self.n_relation, D)
             ew = self._ka_er_ws.get(cs)
@@ -986,6 +1020,13 @@ class MVIN(object):
         w_h = self.h_emb_item_mlp_matrix.view(-1) if a.PS_O_ft else None
         groups = ops.group_pairs_by_user(user, n_user=uts.shape[0])
         rec = self.user_records(uts)
+        if self._ka_flash_for(uts, rec, item.shape[0]):
+            tabs = ops.key_addressing_flash_prepare(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, self.user_mlp_matrix, P,
+                                                    out=self._ka_flash_tables(torch.cuda.current_stream().cuda_stream))
+            return ops.key_addressing_flash(self.entity_emb_matrix, tabs, rec, groups, item, P, self.n_memory, self.n_relation,
+                                            w_h is not None, self.user_mlp_bias, uts.shape[0])
+        if not ops.user_records_supported(self.dim, P, self.n_memory, self.n_relation, self.entity_emb_matrix.dtype == torch.bfloat16):
+            rec = None                                   # (records built for the flash form's sake on a shape the records kernel does not take)
         er = ops.project_relations(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h) if self._ka_er_for(uts, rec) else None
         ops.key_addressing_grouped(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, uts, groups, item, P,
                                    o_cat, n_o * D, self.n_relation, records=rec, er=er)
@@ -1027,6 +1068,7 @@ class MVIN(object):
             out = self._forward_small(user_indices, item_indices, memories_h, memories_r, memories_t, uts)
             if out is not None:
                 return out
+        self._distinct_hint = distinct_users
         item32 = item_indices.contiguous()   # int64 (reference dtype) or int32: kernels take both
         user32 = user_indices.contiguous()
         need_ps = a.PS_only or (not a.HO_only) or a.User_orient_kg_eh

@@ -1,7 +1,7 @@
 """-m gpu: parity AT THE SIZES bench.py TIMES, IN THE FORM bench.py TIMES (the automatic rules: no kernel pinned by this
 module) -- the default metric workload (C3: 524 288 last-fm-shaped pairs, users feed, KG adjacency with repeats ->
-PROJECTED-TABLES form of the packed-tile kernel over the encoded adjacency (B K >= 16 n_entity), grouped key addressing over
-the static per-user records) and the C2 (projected tables, wave-per-parent kernel) / C4 (K = 64: unprojected) bench sizes:
+PROJECTED-TABLES form of the packed-tile kernel over the encoded adjacency (B K >= 16 n_entity), grouped key addressing + user
+MLP in their FLASH form over the static per-user records (users x P x Nm >= nR x n_entity)) and the C2 (projected tables, wave-per-parent kernel) / C4 (K = 64: unprojected) bench sizes:
   * a sample of pairs drawn across the WHOLE batch against the fp32 mirror of the reference graph (oracle/mirror_fp32.py),
   * the users feed (grouped key addressing) against the per-pair feed (the reference's feed_dict contents) over the
     whole batch,
@@ -33,8 +33,10 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
     torch.cuda.synchronize()
     if took_prj:          # the workspace mvin_score_l2_fwd wrote the three projected tables into exists: the form really ran
         assert any(t is not None for t in model._prj_tables.values()), "mvin_project_tables was not called"
-    if name in ("C3", "C2"):
-        assert model._uts_records is not None or name == "C2", "the records kernel was expected at C3"
+    if name == "C3":
+        assert model._uts_records is not None, "static per-user records were expected at C3"
+        assert model._ka_flash_for(uts, model._uts_records[3], B) and any(t is not None for t in model._ka_flash_ws.values()), \
+            "the flash form of key addressing (mvin_key_addressing_flash_fwd) was expected at C3"
     s_users = got.scores.cpu().numpy()
     assert np.isfinite(s_users).all()
     # (a) sample across the batch vs the mirror
@@ -71,9 +73,12 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
         assert_close(s_users, other.scores.cpu().numpy(), f"{name}: projected tables vs per-row projection over {B} pairs")
         model.prj = None
     if name == "C3":
-        # (e) the gathered form of the grouped key addressing (R_KGE[r] . E[h] per (relation, entity), rebuilt per call), whole batch
-        model.ka_er = not model.ka_er
-        other = model.forward_users(users, items, uts)
-        torch.cuda.synchronize()
-        assert_close(s_users, other.scores.cpu().numpy(), f"{name}: gathered vs multiplied U rows over {B} pairs")
-        assert_close(other.user_o[torch.from_numpy(idx).to(dev)].cpu().numpy(), ref.user_o.numpy(), f"{name}: user_o sample, other key-addressing form")
+        # (e) the other forms of the grouped key addressing, whole batch: the kernel over the static records + the MLP launch, and its
+        #     gathered form (R_KGE[r] . E[h] per (relation, entity), rebuilt per call) -- against the flash form the automatic rule took
+        for ka_er in (False, True):
+            model.ka_flash, model.ka_er = False, ka_er
+            other = model.forward_users(users, items, uts)
+            torch.cuda.synchronize()
+            assert_close(s_users, other.scores.cpu().numpy(), f"{name}: flash form vs records kernel (gathered U rows: {ka_er}) over {B} pairs")
+            assert_close(other.user_o[torch.from_numpy(idx).to(dev)].cpu().numpy(), ref.user_o.numpy(), f"{name}: user_o sample, records kernel, ka_er={ka_er}")
+        model.ka_flash, model.ka_er = None, False

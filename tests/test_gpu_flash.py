@@ -127,3 +127,70 @@ def test_out_of_range_item_ids_are_clamped(hip_lib):
     x = ops.key_addressing_flash(E, tabs, rec, groups, items, P, Nm, nR, True, b, n_user)
     y = ops.key_addressing_flash(E, tabs, rec, groups, bad, P, Nm, nR, True, b, n_user)
     assert torch.equal(x, y)
+
+
+CASES = [
+    # (dim, K, H, P, Nm, nR, n_user, B, ablation)
+    (64, 4, 2, 2, 64, 9, 40, 700, "all"),
+    (64, 4, 2, 2, 40, 9, 1500, 6000, "all"),
+    (64, 4, 2, 3, 32, 9, 700, 3000, "no_ps_o_ft"),
+    (64, 4, 2, 1, 16, 39, 300, 1300, "all"),              # amazon-book's key-addressing shape: no records kernel, flash form only
+    (64, 32, 2, 2, 64, 9, 60, 1500, "all"),               # the metric config's shapes (packed-tile kernel below)
+]
+
+
+@pytest.mark.parametrize("native", [True, False], ids=["one_native_call", "python_schedule"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "K%dP%dNm%dnR%d_%s" % (c[1], c[3], c[4], c[5], c[8]))
+def test_forward_users_in_flash_form_against_the_oracle(case, native, hip_lib):
+    """MVIN.forward_users with the flash form forced (both schedules: mvin_score_l2_fwd with ka_flash; op by op) against the fp32
+    mirror of the reference's graph and against the form it replaces; the automatic rule by table size."""
+    from mvin_amd.model import MVIN
+    from oracle import mirror_fp32
+    D, K, H, P, Nm, nR, n_user, B, abl = case
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=H, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    n_entity = 500
+    rng = np.random.default_rng(D + Nm + B)
+    adj_e, adj_r = synth.uniform_adjacency(n_entity, nR, K, seed=3)
+    uts = synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=4)
+    users = rng.integers(0, n_user, B, dtype=np.int64)
+    items = rng.integers(0, n_entity, B, dtype=np.int64)
+    params = init_params(args, n_user, n_entity, nR, seed=5, random_agg_bias=True)
+    model = MVIN(args, n_user, n_entity, nR, adj_e, adj_r, params=params, device="cuda:0")
+    model.group_min_pairs_per_user = 0
+    model.small_max_batch = 0
+    if not native:
+        model.native_l2_max_batch = 0
+        model._profile = []                                  # event hooks requested: the Python schedule
+    dev = model.device
+    u_d, i_d, uts_d = torch.from_numpy(users).to(dev), torch.from_numpy(items).to(dev), torch.from_numpy(uts).to(dev)
+    # automatic rule: users x P x Nm >= nR x n_entity
+    model.ka_flash = None
+    model.user_records(uts_d)
+    rec = model._uts_records[3]
+    assert model._ka_flash_for(uts_d, rec, B) == (min(B, n_user) * P * Nm >= nR * n_entity)
+    assert not model._ka_flash_for(uts_d, rec, 1)
+    model.ka_flash = True
+    got = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert any(t is not None for t in model._ka_flash_ws.values()), "mvin_key_addressing_flash_prepare was not called"
+    model.ka_flash = False
+    plain = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert_close(got.user_o.cpu().numpy(), plain.user_o.cpu().numpy(), "user_o flash form vs the form it replaces", rtol=1e-5, atol=2e-6)
+    mh, mr, mt = synth.memories_for(uts, users)
+    ref = mirror_fp32.forward(args, params, adj_e, adj_r, users, items, mh, mr, mt)
+    assert_close(got.user_o.cpu().numpy(), ref.user_o.numpy(), "user_o vs fp32 mirror")
+    assert_close(got.scores.cpu().numpy(), ref.scores.numpy(), "scores vs fp32 mirror")
+    # parameters changed in place between calls are seen (nothing of the tables is kept)
+    model.ka_flash = True
+    with torch.no_grad():
+        model.entity_emb_matrix.mul_(1.1)
+        model.user_mlp_matrix.add_(0.01)
+        model.relation_emb_KGE_matrix.mul_(0.9)
+    model.invalidate()
+    after = model.forward_users(u_d, i_d, uts_d)
+    model.ka_flash = False
+    want = model.forward_users(u_d, i_d, uts_d)
+    torch.cuda.synchronize()
+    assert not torch.allclose(after.user_o, got.user_o)
+    assert_close(after.user_o.cpu().numpy(), want.user_o.cpu().numpy(), "user_o after an in-place parameter change", rtol=1e-5, atol=2e-6)

@@ -118,19 +118,24 @@ def test_hot_kernels_match_reference_graph(path, hip_lib):
     # (R_KGE[r] . E[h] per (relation, entity) per call) -- forced here, since the fixtures' batches are below the automatic rule
     if args.User_orient and D <= 64:
         for dedup in ((True, False) if (D == 32 and K <= 16) else (True,)):
-            for ka_er in (False, True):
+            for ka_er, ka_flash in ((False, False), (True, False), (False, True)):
                 m = model()
                 m.small_max_batch = 0
-                m.dedup, m.prj, m.ka_er = dedup, True, ka_er
+                m.dedup, m.prj, m.ka_er, m.ka_flash = dedup, True, ka_er, ka_flash
                 if not (m._enc_for_l2(n_parents=items.shape[0]) is not None or m._prj_plain_ok()):
                     continue
                 assert m._prj_for_l2(items.shape[0])
-                what = f"projected tables, dedup={dedup}, ka_er={ka_er}"
+                what = f"projected tables, dedup={dedup}, ka_er={ka_er}, ka_flash={ka_flash}"
                 check(m.forward_device(users, items, *mem), f"{what}: per-pair feed")
                 check(m.forward_users(users, items, uts_d), f"{what}: users feed")
                 assert any(t is not None for t in m._prj_tables.values()), "mvin_project_tables was not called"
-                if ka_er and m._ka_er_for(uts_d, m._uts_records):
+                if ka_er and m._ka_er_for(uts_d, m._uts_records[3] if m._uts_records else None):
                     assert any(t is not None for t in m._ka_er_ws.values()), "mvin_project_relations was not called"
+                if ka_flash and ops.key_addressing_flash_supported(D, args.p_hop, args.n_memory, case.n_relation, case.n_entity):
+                    assert any(t is not None for t in m._ka_flash_ws.values()), "mvin_key_addressing_flash_prepare was not called"
+                    m.native_l2_max_batch = 0              # the Python schedule of the users feed takes the flash form too
+                    check(m.forward_users(users, items, uts_d), f"{what}: users feed, python schedule")
+                    m.native_l2_max_batch = 65536
                 m.native_l2_max_batch = 0
                 check(m.forward_device(users, items, *mem), f"{what}: python schedule")
 
