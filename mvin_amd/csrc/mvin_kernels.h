@@ -165,6 +165,7 @@ struct TailArgs {
     int64_t B;
     int table_bf16;
     int n_entity;              // rows of E: item ids are clamped to [0, n_entity)
+    int dbg;                   // MVIN_TAIL_DBG (measurement only; results wrong): 1 no nagg / user_o loads, 2 one LDS read per product, 4 no stores
 };
 
 struct GatherMixArgs {
@@ -372,6 +373,8 @@ hipError_t small_read_trace(long long* host_dst, size_t n);
 
 bool l2_tail_supported(int D);
 hipError_t launch_l2_tail(const TailArgs& a, int D, hipStream_t st);
+bool l2_tail_flash_applies(const TailArgs& a, int D);
+hipError_t launch_l2_tail_flash(const TailArgs& a, hipStream_t st);
 bool fused_l2_supported(int D, int K);
 hipError_t launch_gather_attn_l2(const FusedL2Args& a, int D, int table_bf16, hipStream_t st);
 bool fused_split_supported(int D, int K);      // role-split variant (mvin_fused_split.hip)

@@ -233,6 +233,7 @@ static hipError_t launch_tail_d(const TailArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_l2_tail(const TailArgs& a, int D, hipStream_t st) {
+    if (l2_tail_flash_applies(a, D)) return launch_l2_tail_flash(a, st);      // dim 64, fp32 table, projection on: mvin_tail_flash.hip
     switch (D) {
         case 16: return launch_tail_d<16>(a, st);
         case 32: return launch_tail_d<32>(a, st);

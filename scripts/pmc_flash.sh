@@ -14,11 +14,11 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_
            "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$out/g$i" -- python "$root/scripts/bench_ka_flash.py" "$@" > "$out/g$i.log" 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$out/g$i" -- python "$root/scripts/${SCRIPT:-bench_ka_flash.py}" "$@" > "$out/g$i.log" 2>&1
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/scripts/bench_ka_flash.py" "$@" > "$out/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python "$root/scripts/${SCRIPT:-bench_ka_flash.py}" "$@" > "$out/stats.log" 2>&1
 cd "$root"
-python - "$out" <<'PY'
+KERNEL=${KERNEL:-key_addr_flash} python - "$out" <<'PY'
 import csv, glob, sys, collections, json
 out = sys.argv[1]
 d = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -29,7 +29,7 @@ for path in glob.glob(out + "/g*/*/*counter_collection.csv"):
 res = {k: {c: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]) for c, v in cs.items()} for k, cs in d.items()}
 json.dump(res, open(out + "/counters.json", "w"), indent=1)
 for k, cs in res.items():
-    if "key_addr_flash" in k:
+    if __import__("os").environ["KERNEL"] in k:
         print(k)
         for c, v in sorted(cs.items()):
             print("   %-34s %.4g" % (c, v))
