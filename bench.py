@@ -806,11 +806,14 @@ def main():
         model.prj = None
     if one_call:
         model._profile = []
+        model._ka_profile = []
         for _ in range(a.steps):
             step()
         barrier()
     prof = model._profile
+    ka_prof = getattr(model, "_ka_profile", None) or []
     model._profile = None
+    model._ka_profile = None
     ranks_counted = 1
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -919,6 +922,35 @@ def main():
                                         "loads (distinct entity rows + the encoded adjacency rows + query + score); "
                                         "`faithful_bytes_rate_gbs` = SURVEY 8(d)'s bytes per pair (every slot's row) over the same time is "
                                         "informational and can exceed any peak -- it is a rate of work done, not of bytes moved"})
+        if ka_prof and by_user:
+            # the flash form of key addressing + user MLP inside the same (single-stream, instrumented) repeat of the timed steps:
+            # a kernel that IS bound by bytes from beyond the L2 -- every user's ripple rows come from a 245 MB per-call table
+            # (R_KGE[r] . E[e]) and three entity-sized ones, once per user and 32-pair tile
+            prep_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ka_prof]))
+            kern2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ka_prof]))
+            P_, Nm_, D_ = d["p_hop"], d["n_memory"], a.dim
+            NmP = (Nm_ + 15) // 16 * 16
+            ucount = torch.bincount(users, minlength=case.n_user)
+            n_users_now = int((ucount > 0).sum().item())
+            tiles32 = int(((ucount + 31) // 32).sum().item())
+            slots64 = int(((ucount + 63) // 64).sum().item())
+            row_b = D_ * 4
+            # per 32-pair tile: P NmP rows of R_KGE.E + P NmP rows of E.Wmlp blocks; per 64-pair slot: NmP h-set rows + the record's three
+            # id sections; per pair: the item row, its id, its index in user order, the user_o row written
+            bytes_step = (tiles32 * 2 * P_ * NmP * row_b + slots64 * (NmP * row_b + (NmP + 2 * P_ * NmP) * 4)
+                          + Bl * (row_b + 8 + 4 + row_b))
+            tab_bytes = (case.n_relation + P_ + 1) * case.n_entity * row_b
+            timed["key_addressing_kernel"] = {
+                "kernel": "key_addr_flash_kernel (mvin_key_addressing_flash_fwd: attention reads + user MLP of model.py:161-240 in one barrier-free "
+                          "kernel over per-call tables)",
+                "avg_launch_ms": kern2_ms, "tables_build_ms": prep_ms, "tables_bytes_written_per_step": tab_bytes,
+                "users_in_batch": n_users_now, "tiles_of_32_pairs": tiles32,
+                "bytes_loaded_per_step": bytes_step, "bound": "hbm", "achieved": bytes_step / (kern2_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": bytes_step / (kern2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "bytes the kernel must load per step (every row counted once per tile that needs it; the 245 MB R_KGE.E table and the "
+                        "82 MB of E.Wmlp blocks are far beyond the 8 x 4 MB of L2, the ripple sets are uniform random: SURVEY 8(d)) over its "
+                        "HIP-event time in the instrumented single-stream repeat; rocprofv3 counters of the same kernel under profiles/r6/ "
+                        "(TCC_EA0_RDREQ: ~1.2x these bytes leave the L2)"}
         if used_l2 and not hoisted and L == 2 and world == 1 and not a.no_probe and kern_avg_ms:
             gp = gather_probe(model, items, a.fanout, a.dim, s_)
             rows_gbs = gp["row_bytes_per_pair"] * Bl / (kern_avg_ms * 1e-3) / 1e9     # the fused kernel, rows only

@@ -1021,10 +1021,20 @@ class MVIN(object):
         groups = ops.group_pairs_by_user(user, n_user=uts.shape[0])
         rec = self.user_records(uts)
         if self._ka_flash_for(uts, rec, item.shape[0]):
+            kp = getattr(self, "_ka_profile", None)      # bench.py: HIP events around the table build and the kernel
+            if kp is not None:
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                evs[0].record()
             tabs = ops.key_addressing_flash_prepare(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h, self.user_mlp_matrix, P,
                                                     out=self._ka_flash_tables(torch.cuda.current_stream().cuda_stream))
-            return ops.key_addressing_flash(self.entity_emb_matrix, tabs, rec, groups, item, P, self.n_memory, self.n_relation,
-                                            w_h is not None, self.user_mlp_bias, uts.shape[0])
+            if kp is not None:
+                evs[1].record()
+            uo = ops.key_addressing_flash(self.entity_emb_matrix, tabs, rec, groups, item, P, self.n_memory, self.n_relation,
+                                          w_h is not None, self.user_mlp_bias, uts.shape[0])
+            if kp is not None:
+                evs[2].record()
+                kp.append(evs)
+            return uo
         if not ops.user_records_supported(self.dim, P, self.n_memory, self.n_relation, self.entity_emb_matrix.dtype == torch.bfloat16):
             rec = None                                   # (records built for the flash form's sake on a shape the records kernel does not take)
         er = ops.project_relations(self.entity_emb_matrix, self.relation_emb_KGE_matrix, w_h) if self._ka_er_for(uts, rec) else None

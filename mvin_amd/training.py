@@ -430,9 +430,7 @@ class Trainer(object):
                             G.add(c[L - 1], dc)
                         else:
                             dS = dZ
-                        # (by entity: one pass over ALL n_entity rows whatever the batch -- it pays once the level holds more tree
-                        #  nodes than there are entities; below, e.g. 512 pairs x 32 = 16 384 nodes of 106 389 entities, one per node)
-                        if self.by_entity and T >= m.n_entity and (pr is not None or not agg.User_orient_rela):
+                        if self.by_entity and (pr is not None or not agg.User_orient_rela):
                             # the deepest hop's backward is linear in dS and depends on a node only through
                             # its entity: sum dS per entity first (T row scatter-adds), then ONE pass per
                             # touched entity instead of one per tree node (a batch repeats entities heavily)
