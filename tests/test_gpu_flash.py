@@ -194,3 +194,47 @@ def test_forward_users_in_flash_form_against_the_oracle(case, native, hip_lib):
     torch.cuda.synchronize()
     assert not torch.allclose(after.user_o, got.user_o)
     assert_close(after.user_o.cpu().numpy(), want.user_o.cpu().numpy(), "user_o after an in-place parameter change", rtol=1e-5, atol=2e-6)
+
+
+N_FUZZ = int(__import__("os").environ.get("MVIN_FUZZ_CASES", "24"))      # a longer campaign: MVIN_FUZZ_CASES=400 pytest tests/test_gpu_flash.py -k fuzz
+
+
+@pytest.mark.parametrize("i", range(N_FUZZ))
+def test_fuzz_flash_kernel(i, hip_lib):
+    """Random shapes inside the flash form's range (D = 64, fp32, 1 <= P <= 8, Nm <= 64) -- batch sizes from one pair to 30 000, one to
+    3 000 users (one pair per user up to thousands), tables from 50 to 200 000 entities, with and without the h-set read, both id
+    widths -- pair by pair on a sample against a float64 evaluation of MVIN._key_addressing + the user MLP (model.py:161-240)."""
+    rng = np.random.default_rng(91000 + i)
+    D = 64
+    P = int(rng.choice([1, 1, 2, 2, 3, 4, 8]))
+    Nm = int(rng.choice([1, 5, 8, 15, 16, 17, 31, 32, 40, 48, 63, 64]))
+    nR = int(rng.choice([1, 2, 5, 9, 9, 12, 39]))
+    n_user = int(rng.choice([1, 7, 100, 300, 700, 3000]))
+    B = int(rng.choice([1, 17, 64, 65, 300, 2000, 9000, 30000]))
+    n_entity = int(rng.choice([50, 5000, 200000]))
+    has_set = bool(rng.random() < 0.8)
+    idt = torch.int32 if rng.random() < 0.3 else torch.int64
+    if not ops.key_addressing_flash_supported(D, P, Nm, nR, n_entity):
+        pytest.skip("outside the flash form")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + i)
+    rnd = lambda *s: torch.rand(s, device=dev, generator=g) - 0.5     # noqa: E731
+    E, R = rnd(n_entity, D), rnd(nR, D, D) * 0.5
+    w = rnd(D) if has_set else None
+    n_o = P + (1 if has_set else 0)
+    W, b = rnd(n_o * D, D) * 0.3, rnd(D)
+    uts = torch.from_numpy(synth.ripple_sets(n_user, n_entity, nR, P, Nm, seed=i)).to(dev)
+    users = torch.randint(0, n_user, (B,), device=dev, generator=g)
+    items = torch.randint(0, n_entity, (B,), device=dev, generator=g).to(idt)
+    rec = ops.build_user_records(uts, P, nR, n_entity)
+    groups = ops.group_pairs_by_user(users, n_user=n_user)
+    tabs = ops.key_addressing_flash_prepare(E, R, w, W, P)
+    user_o = torch.full((B, D), float("nan"), device=dev)
+    ops.key_addressing_flash(E, tabs, rec, groups, items, P, Nm, nR, has_set, b, n_user, out=user_o)
+    torch.cuda.synchronize()
+    assert torch.isfinite(user_o).all(), f"case {i}: P={P} Nm={Nm} nR={nR} n_user={n_user} B={B} n_entity={n_entity} set={has_set}"
+    idx = torch.from_numpy(np.unique(rng.integers(0, B, 200))).to(dev)
+    _, ref_uo = reference_f64(E, R, w, W, b if b is not None else torch.zeros(D, device=dev), uts, users, items, P, Nm, has_set, idx)
+    assert_close(user_o[idx].cpu().numpy(), ref_uo.cpu().numpy(),
+                 f"case {i}: P={P} Nm={Nm} nR={nR} n_user={n_user} B={B} n_entity={n_entity} set={has_set}", rtol=1e-5, atol=2e-6)
