@@ -298,6 +298,7 @@ class MVIN(object):
         self._uts_records = None
 
     USER_RECORDS_MAX_BYTES = 8 << 30
+    FLASH_TABLES_MAX_BYTES = 4 << 30
 
     def user_records(self, uts):
         """The static per-user records of a device-resident user_triplet_set, or None when the shape / table type has no
@@ -877,6 +878,10 @@ class MVIN(object):
         if self.ka_flash:
             return True
         users = min(int(B), int(uts.shape[0]), int(self._distinct_hint or uts.shape[0]))
+        # (and never a workspace beyond FLASH_TABLES_MAX_BYTES per stream on its own initiative: nR = 100 relations over 10^6
+        #  entities would be a 27 GB table)
+        if _lib_flash_elems(self) * 4 > self.FLASH_TABLES_MAX_BYTES:
+            return False
         return users * self.p_hop * self.n_memory >= self.n_relation * self.n_entity
 
     def _ka_flash_tables(self, stream):
