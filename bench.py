@@ -260,7 +260,9 @@ def hbm_leg(dev, D, K, table_dtype, iters=10, warmup=3, n_rows=None, pairs=HBM_L
         if encoded:
             enc_e, enc_r, cnt = ops.encode_adjacency(adj_e, adj_r)
             launch = lambda: ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t0, q, pairs, 1, K, D, n_rel, n_rows, encoded=True)   # noqa: E731
-            kernel = f"gather_attn_l2_packed_kernel<{D}, {K}, false, 4, false, true> (mvin_gather_attn_l2_prj_fwd)"
+            kernel = (f"gather_attn_l2_wpp_kernel<{K}> (mvin_gather_attn_l2_prj_fwd: wave-per-parent kernel over projected tables)"
+                      if ops.gather_attn_l2_wpp_supported(D, K) else
+                      f"gather_attn_l2_packed_kernel<{D}, {K}, false, 4, false, true> (mvin_gather_attn_l2_prj_fwd)")
         else:
             launch = lambda: ops.gather_attn_l2_prj(ws, adj_e, adj_r, parents, t0, t0, q, pairs, 1, K, D, n_rel, n_rows, encoded=False)  # noqa: E731
             kernel = f"gather_attn_l2_d32_kernel<{K}, false, false, true> (mvin_gather_attn_l2_prj_fwd, plain adjacency)"
@@ -867,6 +869,11 @@ def main():
                    and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2)))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "gather_attn_l2_wpp_kernel<%d> (mvin_gather_attn_l2_prj_ordered_fwd: wave-per-parent kernel over the duplicate-slot encoding of the "
+                      "adjacency, rows gathered from the projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step "
+                      "-- same ids and grandchild rows per pair as mvin_gather_attn_l2_enc_fwd, no product per distinct child; parents taken in "
+                      "item order: %s)" % (a.fanout, bool(model._item_order_for(Bl)))
+                 if (prj_now and enc is not None and _ops.gather_attn_l2_wpp_supported(a.dim, a.fanout))
                  else "gather_attn_l2_packed_kernel<..., PRJ> (mvin_gather_attn_l2_prj_fwd: duplicate-slot encoding of the adjacency, rows "
                       "gathered from the projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step -- same ids "
                       "and grandchild rows per pair as mvin_gather_attn_l2_enc_fwd, no W1 / W2 / A0 product per distinct child)"
@@ -1025,7 +1032,9 @@ def main():
                        "pairs_per_step_total": a.batch, "pairs_per_gpu_per_step": Bl,
                        "adjacency": a.adj, "items": a.items, "ablation": a.ablation, "hipgraph_replay": bool(scorer), "streams": nstreams,
                        "two_level_form": (("projected tables (E.W1 | E.W1.A0 | E.W2.A0 rebuilt inside every timed step: mvin_project_tables + "
-                                           "mvin_gather_attn_l2_prj_fwd" + (")" if enc is not None else " over the plain adjacency)")) if prj_now else
+                                           "mvin_gather_attn_l2_prj_fwd" + (("; parents in item order, mvin_order_by_key inside every step)"
+                                                                             if model._item_order_for(Bl) else ")") if enc is not None
+                                                                            else " over the plain adjacency)")) if prj_now else
                                           "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",

@@ -197,6 +197,21 @@ MVIN_API int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_ent
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
                                 void* stream);
+/* order [B] int32 = a permutation of 0 .. B-1 in which equal keys are neighbours (a partition by the key's low 14 bits, any order
+ * inside a bucket: NOT a sort, and the order inside a bucket may differ from run to run).  keys: int64 [B] (low words read) or
+ * int32 [B]; workspace: mvin_order_by_key_ws_elems(B) int32, rewritten by every call.  Three small launches (LDS histograms per
+ * chunk, one scan, scatter), ~30 us per 524 288 keys whatever their skew. */
+MVIN_API size_t mvin_order_by_key_ws_elems(int64_t B);
+MVIN_API int mvin_order_by_key(const int64_t* keys_i64, const int32_t* keys_i32, int64_t B, int32_t* workspace, int32_t* order, void* stream);
+/* The same launch with its parents taken in the order `order` (int32 [B], a permutation of the launch's parents; NULL = as given):
+ * slot i works on parent order[i] -- its id, its query row, its rows of nagg0 / nagg1 -- so the results do not depend on it.
+ * Pairs that share an item gather the same rows; next to each other (mvin_order_by_key over the item ids) their loads are cache
+ * hits instead of trips past the L2.  Taken by the wave-per-parent kernel only: encoded adjacency, D = 64, K <= 32,
+ * parents_per_pair = 1 (-3 otherwise). */
+MVIN_API int mvin_gather_attn_l2_prj_ordered_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
+                                const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
+                                const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
+                                float* nagg1, void* stream);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
@@ -455,6 +470,10 @@ typedef struct {
                                       mvin_key_addressing_flash_prepare -> mvin_key_addressing_flash_fwd (o_cat is then not written; the
                                       scheduling scratch is the part of group_ws the grouping leaves behind).  Takes precedence over
                                       ka_er.  Rewritten by every call */
+    int32_t* item_order_ws;        /* mvin_score_l2_fwd only, or NULL: mvin_order_by_key_ws_elems(B) + B int32 -- when the two deepest levels
+                                      run as the wave-per-parent kernel over projected tables (D = 64, K <= 32, encoded adjacency), its
+                                      parents are taken in ITEM order (mvin_order_by_key -> mvin_gather_attn_l2_prj_ordered_fwd): pairs of
+                                      the same item back to back, their identical rows cache hits.  Results do not depend on it */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

@@ -194,7 +194,8 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                const float* W1, const float* W2, const float* b1, const float* b2, const float* q,
                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D,
                                int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
-                               float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false) {
+                               float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false,
+                               const int32_t* order = nullptr) {
     const char* who = prj ? "mvin_gather_attn_l2_prj_fwd" : encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
     if (prj && (table_bf16 || !W1 || !W2 || !q))
         return fail(-1, "%s: projected tables are fp32 and go with the queries", who);
@@ -239,6 +240,12 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
     f.max_id = (unsigned)(n_entity - 1);
     f.prj = prj ? 1 : 0;
     int l = 0;
+    if (order) {
+        f.order = order;
+        if (!(prj && encoded && parents_per_pair == 1 && mvin::fused_wpp_applies(f, D)))
+            return fail(-3, "%s: a parent order is taken by the wave-per-parent kernel only (projected tables, encoded adjacency, D = 64, K <= 32, "
+                            "one parent per pair)", who);
+    }
     while ((4 << l) < K) ++l;
     f.lpn_log2 = l;
     {
@@ -257,6 +264,8 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
         static const bool d32enc_off = getenv("MVIN_L2_D32ENC") && atoi(getenv("MVIN_L2_D32ENC")) == 0;
         if (!d32enc_off && mvin::fused_d32_applies(f, D))
             return hip_result(mvin::launch_gather_attn_l2_d32(f, table_bf16, (hipStream_t)stream, true), who);
+        // dim 64 over projected tables: the wave-per-parent kernel (MVIN_L2_WPP=0: the packed-tile kernel, A/B)
+        if (prj && mvin::fused_wpp_applies(f, D)) return hip_result(mvin::launch_gather_attn_l2_wpp(f, (hipStream_t)stream), who);
         return hip_result(mvin::launch_gather_attn_l2_packed(f, D, table_bf16, (hipStream_t)stream), who);
     }
     return hip_result(mvin::launch_gather_attn_l2(f, D, table_bf16, (hipStream_t)stream), who);
@@ -362,6 +371,24 @@ int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, cons
                                 const void* parent_ids, int parent_ids_i64, const float* t0, const float* t1, const float* q,
                                 int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0, float* nagg1,
                                 void* stream) {
+    return mvin_gather_attn_l2_prj_ordered_fwd(ws, enc_entity, enc_relation, adjacency_encoded, parent_ids, parent_ids_i64, nullptr, t0, t1, q,
+                                               B, parents_per_pair, K, D, n_entity, nR, nagg0, nagg1, stream);
+}
+
+size_t mvin_order_by_key_ws_elems(int64_t B) { return B > 0 ? mvin::order_ws_elems(B) : 0; }
+
+int mvin_order_by_key(const int64_t* keys_i64, const int32_t* keys_i32, int64_t B, int32_t* workspace, int32_t* order, void* stream) {
+    const char* who = "mvin_order_by_key";
+    if ((keys_i64 == nullptr) == (keys_i32 == nullptr)) return fail(-1, "%s: exactly one of keys_i64 / keys_i32", who);
+    if (!workspace || !order) return fail(-1, "%s: null pointer", who);
+    if (B <= 0 || B >= (int64_t(1) << 31)) return fail(-2, "%s: B=%lld", who, (long long)B);
+    return hip_result(mvin::launch_order_by_key(keys_i64, keys_i32, B, workspace, order, (hipStream_t)stream), who);
+}
+
+int mvin_gather_attn_l2_prj_ordered_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
+                                        const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
+                                        const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
+                                        float* nagg1, void* stream) {
     if (!ws || n_entity <= 0 || D <= 0) return fail(-1, "mvin_gather_attn_l2_prj_fwd: null workspace / bad sizes");
     const float* blk = ws + (size_t)3 * n_entity * D;
     const float* Wv = blk + (size_t)3 * D * D;
@@ -369,7 +396,7 @@ int mvin_gather_attn_l2_prj_fwd(const float* ws, const int32_t* enc_entity, cons
     // (W1, b1) and (the combined matrix, its bias) project the parents' queries; A0 / a0 are inside the tables and the bias
     return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
                                parent_ids_i64 ? 2 : 1, t0, t1, blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K,
-                               D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, adjacency_encoded != 0, true);
+                               D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, adjacency_encoded != 0, true, order);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -680,8 +707,23 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         rc = mvin_project_tables(reinterpret_cast<const float*>(a->entity_emb), a->W1, a->W2, a->b1, a->b2, a->A0, a->a0,
                                  a->t0 != nullptr, a->K, a->n_entity, D, a->prj_tables, stream);
         if (rc) return rc;
-        rc = mvin_gather_attn_l2_prj_fwd(a->prj_tables, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation, enc ? 1 : 0,
-                                         a->items, 1, a->t0, a->t1, a->user_o, (int)a->B, 1, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, stream);
+        const int32_t* order = nullptr;
+        if (enc && a->item_order_ws && mvin::fused_wpp_supported(D, a->K) && nR <= 4096) {
+            // item order for the wave-per-parent kernel (it takes the launch when fused_wpp_applies; otherwise the order is not passed on)
+            mvin::FusedL2Args f{};
+            f.prj = 1, f.K = a->K, f.nR = nR, f.P = a->B, f.parents_per_pair = 1, f.max_id = (unsigned)(a->n_entity - 1);
+            f.table_bytes = (uint64_t)a->n_entity * D * 4, f.adj_bytes = (uint64_t)a->n_entity * a->K * 4;
+            f.adj_r = a->enc_relation, f.W1 = a->W1, f.W2 = a->W2, f.q = a->user_o;
+            if (mvin::fused_wpp_applies(f, D)) {
+                int32_t* ord = a->item_order_ws + mvin::order_ws_elems(a->B);
+                rc = mvin_order_by_key(a->items, nullptr, a->B, a->item_order_ws, ord, stream);
+                if (rc) return rc;
+                order = ord;
+            }
+        }
+        rc = mvin_gather_attn_l2_prj_ordered_fwd(a->prj_tables, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
+                                                 enc ? 1 : 0, a->items, 1, order, a->t0, a->t1, a->user_o, (int)a->B, 1, a->K, D, a->n_entity, nR,
+                                                 a->nagg0, a->nagg1, stream);
     } else
     rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                              reinterpret_cast<const int32_t*>(a->items), 2,

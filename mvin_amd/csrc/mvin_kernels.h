@@ -205,6 +205,9 @@ struct FusedL2Args {
     int pid_stride;              // 1: parent_ids is int32 [P]; 2: the low words of an int64 [P] array (little endian)
     unsigned max_id;             // n_entity - 1: parent ids are clamped (a fault would kill the process)
     int dbg;                     // timing experiments only (MVIN_SPLIT_DBG): 1 = skip the MFMAs, 2 = skip the row loads
+    const int32_t* order;        // wave-per-parent kernel (mvin_fused_wpp.hip), parents_per_pair == 1 only, or NULL: slot i of the launch
+                                 // works on parent order[i] (its id, its query row, its output rows) -- a permutation that puts parents
+                                 // with the same entity next to each other, so that their (identical) rows are cache hits
     int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [3][nE][D] fp32
                                  // (E.W1 | E.W1.A0 | E.W2.A0); W1 / b1 and W2 / b2 (= the combined (W1 + c W2).A0 and its bias)
                                  // project the PARENTS' queries only; A0 / a0 unused
@@ -386,6 +389,11 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
 hipError_t launch_count_ids(const int32_t* ids, int64_t n, int nbins, float* out, hipStream_t st);   // mvin_bwd.hip
 bool fused_d32_supported(int D, int K);        // wave-per-parent variant for D = 32, K in {8, 16} (mvin_fused_d32.hip)
 bool fused_d32_applies(const FusedL2Args& a, int D);
+size_t order_ws_elems(int64_t B);                             // pairs in key order (mvin_order.hip)
+hipError_t launch_order_by_key(const int64_t* k64, const int32_t* k32, int64_t B, int32_t* ws, int32_t* order, hipStream_t st);
+bool fused_wpp_supported(int D, int K);                       // wave-per-parent kernel over projected tables, dim 64 (mvin_fused_wpp.hip)
+bool fused_wpp_applies(const FusedL2Args& a, int D);
+hipError_t launch_gather_attn_l2_wpp(const FusedL2Args& a, hipStream_t st);
 hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded = false);   // encoded: adj_e / adj_r = the duplicate-slot encoding
 bool fused_d16_supported(int D, int K);        // wave-per-parent variant for D = 16, K <= 16 (mvin_fused_d16.hip)
 bool fused_d16_applies(const FusedL2Args& a, int D);

@@ -274,6 +274,8 @@ class MVIN(object):
         # (MVIN_KA_FLASH=0 / 1 overrides), True / False
         self.ka_flash = {"0": False, "1": True}.get(os.environ.get("MVIN_KA_FLASH", ""), None)
         self._ka_flash_ws = {}               # per stream: workspace of mvin_key_addressing_flash_tables_elems floats, rewritten by every call
+        # parents of the projected-tables launch in item order (_item_order_for): None = by batch size (MVIN_ITEM_ORDER=0 / 1 overrides)
+        self.item_order = {"0": False, "1": True}.get(os.environ.get("MVIN_ITEM_ORDER", ""), None)
         self._distinct_hint = None           # forward_device's distinct_users of the call at hand
         self.group_min_pairs_per_user = 4    # forward_users: batch size / n_user above which pairs are grouped by user
         self.native_l2_max_batch = 65536     # above this the pass is kernel-bound: the Python schedule costs nothing
@@ -657,8 +659,11 @@ class MVIN(object):
                        q if uo else None, a0.weights, a0.bias, B, K ** (L - 2), K, D, self.n_relation)
             if tabs is not None:
                 ae, ar = (enc[0], enc[1]) if enc is not None else (self.adj_entity, self.adj_relation)
+                order = None
+                if enc is not None and L == 2 and self._item_order_for(B) and ops.gather_attn_l2_wpp_supported(D, K):
+                    order = ops.order_by_key(ents[0].view(-1))
                 n0, n1 = ops.gather_attn_l2_prj(tabs, ae, ar, ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
-                                                K ** (L - 2), K, D, self.n_relation, self.n_entity, encoded=enc is not None)
+                                                K ** (L - 2), K, D, self.n_relation, self.n_entity, encoded=enc is not None, order=order)
                 pp = pc = None
             elif enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
@@ -891,6 +896,20 @@ class MVIN(object):
             ws = self._ka_flash_ws[stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
         return ws
 
+    ITEM_ORDER_MIN_BATCH = 32768
+
+    def _item_order_for(self, B):
+        """Parents of the projected-tables launch in ITEM order (mvin_order_by_key, ~36 us per 524 288 pairs)?  Pairs of the same item
+        gather the same rows; back to back they are cache hits -- the launch's requests past the L2 halve at BASELINE C3 (7.5 -> 3.6 GB),
+        and those bytes are what bounds the step.  For the wave-per-parent kernel (dim 64, fan-out <= 32, depth-2 trees: the parents
+        are the pairs) and batches large enough to hold repeated items; ``self.item_order`` True / False (MVIN_ITEM_ORDER=1 / 0) forces it."""
+        if self.dim != 64 or self.n_neighbor > 32 or self.n_mix_hop * self.h_hop != 2 or os.environ.get("MVIN_L2_WPP", "1") == "0":
+            return False
+        want = self.item_order
+        if want is None:
+            want = B >= self.ITEM_ORDER_MIN_BATCH
+        return bool(want)
+
     def _prj_plain_ok(self):
         """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
         where the library takes THAT kernel for this model's tables (mvin_gather_attn_l2_prj_supported: its LDS copy of the
@@ -994,8 +1013,9 @@ class MVIN(object):
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
             # grouped key addressing needs no [B, nR, D] item projection; its sort workspace instead
             gws = torch.empty(2 * uts.shape[0] + 4 * B + 3, dtype=torch.int32, device=self.device) if grouped else None
+            ows = None                    # (the item-order workspace: allocated when first wanted, below)
             ws = self._native_l2_ws[wkey] = (None if grouped else f(B, self.n_relation, D), f(B, n_o * D),
-                                             torch.empty(B, dtype=torch.int32, device=self.device), f(B, D), f(B, D), gws)
+                                             torch.empty(B, dtype=torch.int32, device=self.device), f(B, D), f(B, D), gws, ows)
             if len(self._native_l2_ws) > 8:
                 self._native_l2_ws.pop(next(iter(self._native_l2_ws)))
         user_o = torch.empty((B, D), dtype=torch.float32, device=self.device)
@@ -1010,7 +1030,13 @@ class MVIN(object):
             ph, pr, pt = (st["arr"](*[t.data_ptr() for t in lst[:P]]) for lst in (mem_h, mem_r, mem_t))
             s.uts = s.users = None
             s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
-        s.V, s.o_cat, s.parents, s.nagg0, s.nagg1, s.group_ws = (w.data_ptr() if w is not None else None for w in ws)
+        s.V, s.o_cat, s.parents, s.nagg0, s.nagg1, s.group_ws = (w.data_ptr() if w is not None else None for w in ws[:6])
+        s.item_order_ws = None
+        if prj and enc is not None and self._item_order_for(B):
+            if ws[6] is None:
+                ws = self._native_l2_ws[wkey] = ws[:6] + (torch.empty(_lib.load().mvin_order_by_key_ws_elems(B) + B, dtype=torch.int32,
+                                                                      device=self.device),)
+            s.item_order_ws = ws[6].data_ptr()
         s.user_o, s.item_emb, s.scores, s.sig = user_o.data_ptr(), item_emb.data_ptr(), scores.data_ptr(), sig.data_ptr()
         s.B = B
         _lib.check(_lib.load().mvin_score_l2_fwd(C.byref(s), C.c_void_p(stream.cuda_stream)), "mvin_score_l2_fwd")

@@ -5,6 +5,7 @@ path runs in libmvin_hip.so.  Every op requires CUDA(ROCm) tensors and raises ot
 there is no CPU / eager fallback.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -335,7 +336,28 @@ def project_tables(entity_emb, W1, W2, b1, b2, A0, a0, K, attention, out=None):
     return out
 
 
-def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity, encoded=True):
+def gather_attn_l2_wpp_supported(D, K):
+    """The shapes the wave-per-parent kernel over projected tables takes (it is the one that honours ``order``)."""
+    return D == 64 and K in (16, 32) and os.environ.get("MVIN_L2_WPP", "1") != "0"
+
+
+def order_by_key(keys, ws=None, out=None):
+    """mvin_order_by_key: a permutation of 0 .. B-1 (int32) in which equal keys (int64 / int32 ids) are neighbours -- a partition by
+    the key's low bits, not a sort; the order inside a bucket is unspecified."""
+    lib = _lib.load()
+    B = keys.shape[0]
+    _chk(keys, torch.int64 if keys.dtype == torch.int64 else I32, "keys")
+    n = lib.mvin_order_by_key_ws_elems(B)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty((n,), dtype=I32, device=keys.device)
+    if out is None:
+        out = torch.empty((B,), dtype=I32, device=keys.device)
+    k64, k32 = (_p(keys), None) if keys.dtype == torch.int64 else (None, _p(keys))
+    _lib.check(lib.mvin_order_by_key(k64, k32, B, _p(ws), _p(out), _stream()), "mvin_order_by_key")
+    return out
+
+
+def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity, encoded=True, order=None):
     """mvin_gather_attn_l2_prj_fwd: gather_attn_l2_enc over the workspace of ``project_tables`` (built with attention =
     (t0 is not None)).  ``encoded=False``: the two adjacency arrays are the plain adjacency (D = 32, K in {8, 16}).
     Returns (nagg0 [P,D], nagg1 [P,D])."""
@@ -349,9 +371,13 @@ def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, p
     P = B * parents_per_pair
     nagg0 = torch.empty((P, D), dtype=F32, device=ws.device)
     nagg1 = torch.empty((P, D), dtype=F32, device=ws.device)
-    _lib.check(lib.mvin_gather_attn_l2_prj_fwd(_p(ws), _p(enc_entity), _p(enc_relation), 1 if encoded else 0, _p(parent_ids),
-                                               int(parent_ids.dtype == torch.int64), _p(t0), _p(t1), _p(q), B, parents_per_pair, K, D,
-                                               n_entity, nR, _p(nagg0), _p(nagg1), _stream()), "mvin_gather_attn_l2_prj_fwd")
+    _chk(order, I32, "order")
+    if order is not None and order.numel() != P:
+        raise ValueError("gather_attn_l2_prj: order must be a permutation of the launch's parents")
+    _lib.check(lib.mvin_gather_attn_l2_prj_ordered_fwd(_p(ws), _p(enc_entity), _p(enc_relation), 1 if encoded else 0, _p(parent_ids),
+                                                       int(parent_ids.dtype == torch.int64), _p(order), _p(t0), _p(t1), _p(q), B,
+                                                       parents_per_pair, K, D, n_entity, nR, _p(nagg0), _p(nagg1), _stream()),
+               "mvin_gather_attn_l2_prj_fwd")
     return nagg0, nagg1
 
 

@@ -333,3 +333,65 @@ def test_forced_projection_falls_back_where_no_kernel_takes_it(hip_lib):
         model.native_l2_max_batch = native
         out = _pairs(model, case)
         assert_close(out.scores.cpu().numpy(), m.scores.numpy(), f"scores vs fp32 mirror (native_l2_max_batch={native})", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_wave_per_parent_kernel_every_distinct_count(K, hip_lib):
+    """The wave-per-parent kernel of dim 64 (mvin_fused_wpp.hip) walks a parent's distinct children four at a time, one per 16-lane group:
+    every distinct-children count 1 .. K as parent AND as child (partly filled last passes; a last pass whose only valid group reads the
+    parent's slot word from a lane of an invalid group -- a dropped 17th child was the first bug of that kernel), with and without
+    attention, in item order and as given, against the float64 evaluation of the unprojected formulas on the PLAIN adjacency."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    D, nR, n_entity = 64, 7, 600
+    rng = np.random.default_rng(K)
+    adj_e = np.zeros((n_entity, K), dtype=np.int64)
+    adj_r = np.zeros((n_entity, K), dtype=np.int64)
+    for x in range(n_entity):
+        nd = x % K + 1                                        # distinct (neighbour, relation) slots of this row
+        ne = rng.choice(n_entity, nd, replace=False)
+        nr = rng.integers(0, nR, nd)
+        pick = np.concatenate([np.arange(nd), rng.integers(0, nd, K - nd)])      # every distinct slot at least once, the rest repeats
+        rng.shuffle(pick)
+        adj_e[x], adj_r[x] = ne[pick], nr[pick]
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    E = f(n_entity, D)
+    ae, ar = torch.from_numpy(adj_e.astype(np.int32)).to(dev), torch.from_numpy(adj_r.astype(np.int32)).to(dev)
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    assert sorted(set(cnt.cpu().tolist())) == list(range(1, K + 1))
+    B = 4 * K + 37
+    parents = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64)).to(dev)          # every count 1 .. K several times
+    W1, W2, b1, b2, q, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
+    for att in (True, False):
+        t0 = f(nR) if att else None
+        t1 = f(nR) if att else None
+        ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, att)
+        for order in (None, ops.order_by_key(parents), torch.flip(torch.arange(B, dtype=torch.int32, device=dev), dims=[0])):
+            got0, got1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t1, q, B, 1, K, D, nR, n_entity, order=order)
+            torch.cuda.synchronize()
+            if att:
+                r0, r1 = bench.l2_reference_f64(E, ae, ar, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, K)
+                assert_close(got0.cpu().numpy(), r0.cpu().numpy(), "nagg0 vs float64", rtol=1e-5, atol=2e-6)
+                assert_close(got1.cpu().numpy(), r1.cpu().numpy(), "nagg1 vs float64", rtol=1e-5, atol=2e-6)
+            want0, want1 = ops.gather_attn_l2_enc(E, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, 1, K, D, nR)
+            assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0 vs the packed-tile kernel", rtol=3e-5, atol=6e-6)
+            assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1 vs the packed-tile kernel", rtol=3e-5, atol=6e-6)
+
+
+def test_order_by_key_is_a_bucket_partition(hip_lib):
+    """mvin_order_by_key: a permutation in which the keys' buckets (low 14 bits) are contiguous and ascending; any key skew, both widths."""
+    dev = "cuda:0"
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    for B, hi, dt in ((1, 10, torch.int64), (1000, 5, torch.int32), (70000, 48091, torch.int64), (300000, 1 << 20, torch.int64)):
+        keys = torch.randint(0, hi, (B,), device=dev, generator=g).to(dt)
+        if B > 1000:
+            keys[: B // 3] = 7                               # one key holds a third of the batch (Zipf's head)
+        order = ops.order_by_key(keys)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.sort(order.long()).values, torch.arange(B, device=dev))
+        kb = keys[order.long()].long() & 16383
+        assert bool((kb[1:] >= kb[:-1]).all())
