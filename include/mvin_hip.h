@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MVIN_ABI_VERSION 11
+#define MVIN_ABI_VERSION 12
 /* The library is built with -fvisibility=hidden: the entry points below are its whole dynamic symbol table. */
 #define MVIN_API __attribute__((visibility("default")))
 #define MVIN_MAX_DIM 256      /* D % 4 == 0, 4 <= D <= 256 */
@@ -209,6 +209,26 @@ MVIN_API int mvin_order_by_key(const int64_t* keys_i64, const int32_t* keys_i32,
  * hits instead of trips past the L2.  Taken by the wave-per-parent kernel only: encoded adjacency, D = 64, K <= 32,
  * parents_per_pair = 1 (-3 otherwise). */
 MVIN_API int mvin_gather_attn_l2_prj_ordered_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, int adjacency_encoded,
+                                const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
+                                const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
+                                float* nagg1, void* stream);
+/* PER-ENTITY AGGREGATES of the projected tables (D = 64, K in {16, 32}, encoded adjacency).  With one logit per relation
+ * (aggregators.py:118-146: User_orient_rela scores a relation, not a user) the softmax weights w(e)_k of entity e's slots under
+ * aggregator (0,.) belong to the ENTITY, and so does everything of the formulas above that does not carry the query:
+ *     G[e]  = TA1[e] + sum_k w(e)_k TA2[y_ek]          S0[e] = sum_k w(e)_k T1[y_ek]            (once per ENTITY and call)
+ *     nagg0 = S0[x] + c0 u1                            nagg1 = sum_c (p1_c / K) relu(G[x_c] + v)  (per parent x with children x_c)
+ * -- the same sums in another association (the order of the additions differs: results agree to rounding, not bit for bit).  A
+ * parent gathers its distinct children's G rows and one S0 row instead of its grandchildren's rows of three tables: ~12 rows
+ * instead of ~120 at BASELINE C3.  mvin_entity_aggregates writes S0 | G ([2][n_entity][D] fp32, mvin_entity_aggregates_elems
+ * floats) from `ws` (mvin_project_tables' output, the CURRENT call's), the encoded adjacency and t0 (NULL: plain mean); it costs
+ * ~17 gathered rows per entity and must follow every mvin_project_tables.  mvin_gather_attn_l2_agg_fwd: as
+ * mvin_gather_attn_l2_prj_ordered_fwd (same arguments and outputs; t0 is only tested for presence) with `agg` beside `ws`.
+ * MVIN_L2_AGG=0 in the environment makes _supported answer 0 (A/B against the kernels over the tables themselves). */
+MVIN_API int mvin_gather_attn_l2_agg_supported(int D, int K, int n_entity, int nR);
+MVIN_API size_t mvin_entity_aggregates_elems(int n_entity, int D);
+MVIN_API int mvin_entity_aggregates(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, int K, int D,
+                                    int n_entity, int nR, float* agg, void* stream);
+MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, const int32_t* enc_entity, const int32_t* enc_relation,
                                 const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
                                 const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
                                 float* nagg1, void* stream);
@@ -474,6 +494,10 @@ typedef struct {
                                       run as the wave-per-parent kernel over projected tables (D = 64, K <= 32, encoded adjacency), its
                                       parents are taken in ITEM order (mvin_order_by_key -> mvin_gather_attn_l2_prj_ordered_fwd): pairs of
                                       the same item back to back, their identical rows cache hits.  Results do not depend on it */
+    float* agg_tables;             /* mvin_score_l2_fwd only, or NULL: workspace of mvin_entity_aggregates_elems(nE, D) floats -- with
+                                      prj_tables, the encoded adjacency and a shape mvin_gather_attn_l2_agg_supported takes, the two deepest
+                                      levels run as mvin_project_tables -> mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd (in item
+                                      order when item_order_ws is given).  Rewritten by every call */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

@@ -195,7 +195,7 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
                                const float* A0, const float* a0, int B, int parents_per_pair, int K, int D,
                                int n_entity, int nR, float* nagg0, float* nagg1, float* probs_parent,
                                float* probs_child, int table_bf16, void* stream, bool encoded = false, bool prj = false,
-                               const int32_t* order = nullptr) {
+                               const int32_t* order = nullptr, const float* agg = nullptr) {
     const char* who = prj ? "mvin_gather_attn_l2_prj_fwd" : encoded ? "mvin_gather_attn_l2_enc_fwd" : "mvin_gather_attn_l2_fwd";
     if (prj && (table_bf16 || !W1 || !W2 || !q))
         return fail(-1, "%s: projected tables are fp32 and go with the queries", who);
@@ -240,6 +240,14 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
     f.max_id = (unsigned)(n_entity - 1);
     f.prj = prj ? 1 : 0;
     int l = 0;
+    if (agg) {                   // per-entity aggregates in place of the tables (mvin_gather_attn_l2_agg_fwd)
+        f.agg = const_cast<float*>(agg);
+        f.order = order;
+        if (!(prj && encoded && mvin::fused_agg_applies(f, D) && (!order || parents_per_pair == 1)))
+            return fail(-3, "mvin_gather_attn_l2_agg_fwd: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency and outputs < 2 GiB "
+                            "(a parent order: one parent per pair)");
+        return hip_result(mvin::launch_gather_attn_l2_agg(f, (hipStream_t)stream), "mvin_gather_attn_l2_agg_fwd");
+    }
     if (order) {
         f.order = order;
         if (!(prj && encoded && parents_per_pair == 1 && mvin::fused_wpp_applies(f, D)))
@@ -397,6 +405,64 @@ int mvin_gather_attn_l2_prj_ordered_fwd(const float* ws, const int32_t* enc_enti
     return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids),
                                parent_ids_i64 ? 2 : 1, t0, t1, blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K,
                                D, n_entity, nR, nagg0, nagg1, nullptr, nullptr, 0, stream, adjacency_encoded != 0, true, order);
+}
+
+// does the per-entity aggregates form run for these tables?
+static bool agg_applies(int D, int K, int n_entity, int nR, int64_t n_parents) {
+    if (n_entity <= 0 || nR <= 0 || nR > 4096 || !mvin::fused_agg_supported(D, K)) return false;
+    static const char* e = getenv("MVIN_L2_AGG");
+    if (e && e[0] == '0') return false;                   // A/B: the kernels over the projected tables themselves
+    mvin::FusedL2Args f{};
+    f.K = K;
+    f.nR = nR;
+    f.P = n_parents > 0 ? n_parents : 1;
+    f.prj = 1;
+    f.parents_per_pair = 1;
+    f.max_id = (unsigned)(n_entity - 1);
+    static const int32_t present = 0;
+    f.adj_r = &present;                       // (only tested for presence)
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    return mvin::fused_agg_applies(f, D);
+}
+
+int mvin_gather_attn_l2_agg_supported(int D, int K, int n_entity, int nR) { return agg_applies(D, K, n_entity, nR, 1) ? 1 : 0; }
+
+size_t mvin_entity_aggregates_elems(int n_entity, int D) { return n_entity > 0 && D > 0 ? (size_t)2 * n_entity * D : 0; }
+
+int mvin_entity_aggregates(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, int K, int D,
+                           int n_entity, int nR, float* agg, void* stream) {
+    const char* who = "mvin_entity_aggregates";
+    if (!ws || !enc_entity || !enc_relation || !agg) return fail(-1, "%s: null pointer", who);
+    if (!agg_applies(D, K, n_entity, nR, 1))
+        return fail(-3, "%s: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
+                    who, D, K, n_entity, nR);
+    mvin::FusedL2Args f{};
+    f.table = ws;
+    f.adj_e = enc_entity;
+    f.adj_r = enc_relation;
+    f.t0 = t0;
+    f.agg = agg;
+    f.K = K;
+    f.nR = nR;
+    f.max_id = (unsigned)(n_entity - 1);
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    f.prj = 1;
+    return hip_result(mvin::launch_entity_aggregates(f, (hipStream_t)stream), who);
+}
+
+int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, const int32_t* enc_entity, const int32_t* enc_relation,
+                                const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
+                                const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
+                                float* nagg1, void* stream) {
+    if (!ws || !agg || n_entity <= 0 || D <= 0) return fail(-1, "mvin_gather_attn_l2_agg_fwd: null workspace / bad sizes");
+    const float* blk = ws + (size_t)3 * n_entity * D;
+    const float* Wv = blk + (size_t)3 * D * D;
+    const float* b1c = Wv + (size_t)D * D;
+    return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids), parent_ids_i64 ? 2 : 1, t0, t1,
+                               blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K, D, n_entity, nR, nagg0, nagg1, nullptr,
+                               nullptr, 0, stream, true, true, order, agg);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -708,6 +774,19 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
                                  a->t0 != nullptr, a->K, a->n_entity, D, a->prj_tables, stream);
         if (rc) return rc;
         const int32_t* order = nullptr;
+        if (enc && a->agg_tables && agg_applies(D, a->K, a->n_entity, nR, a->B)) {
+            // per-entity aggregates form: S0 | G once per entity from the tables just built, then ~cnt rows per pair instead of ~cnt^2
+            rc = mvin_entity_aggregates(a->prj_tables, a->enc_entity, a->enc_relation, a->t0, a->K, D, a->n_entity, nR, a->agg_tables, stream);
+            if (rc) return rc;
+            if (a->item_order_ws) {
+                int32_t* ord = a->item_order_ws + mvin::order_ws_elems(a->B);
+                rc = mvin_order_by_key(a->items, nullptr, a->B, a->item_order_ws, ord, stream);
+                if (rc) return rc;
+                order = ord;
+            }
+            rc = mvin_gather_attn_l2_agg_fwd(a->prj_tables, a->agg_tables, a->enc_entity, a->enc_relation, a->items, 1, order, a->t0, a->t1,
+                                             a->user_o, (int)a->B, 1, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, stream);
+        } else {
         if (enc && a->item_order_ws && mvin::fused_wpp_supported(D, a->K) && nR <= 4096) {
             // item order for the wave-per-parent kernel (it takes the launch when fused_wpp_applies; otherwise the order is not passed on)
             mvin::FusedL2Args f{};
@@ -724,6 +803,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
         rc = mvin_gather_attn_l2_prj_ordered_fwd(a->prj_tables, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                                                  enc ? 1 : 0, a->items, 1, order, a->t0, a->t1, a->user_o, (int)a->B, 1, a->K, D, a->n_entity, nR,
                                                  a->nagg0, a->nagg1, stream);
+        }
     } else
     rc = gather_attn_l2_impl(a->entity_emb, enc ? a->enc_entity : a->adj_entity, enc ? a->enc_relation : a->adj_relation,
                              reinterpret_cast<const int32_t*>(a->items), 2,

@@ -208,6 +208,9 @@ struct FusedL2Args {
     const int32_t* order;        // wave-per-parent kernel (mvin_fused_wpp.hip), parents_per_pair == 1 only, or NULL: slot i of the launch
                                  // works on parent order[i] (its id, its query row, its output rows) -- a permutation that puts parents
                                  // with the same entity next to each other, so that their (identical) rows are cache hits
+    float* agg;                  // per-entity aggregates form (mvin_fused_agg.hip), or NULL: [2][nE][64] fp32, S0 | G -- written by
+                                 // entity_aggregates_kernel from the projected tables (`table`) and the adjacency, read by
+                                 // gather_attn_l2_agg_kernel in place of the tables
     int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [3][nE][D] fp32
                                  // (E.W1 | E.W1.A0 | E.W2.A0); W1 / b1 and W2 / b2 (= the combined (W1 + c W2).A0 and its bias)
                                  // project the PARENTS' queries only; A0 / a0 unused
@@ -394,6 +397,10 @@ hipError_t launch_order_by_key(const int64_t* k64, const int32_t* k32, int64_t B
 bool fused_wpp_supported(int D, int K);                       // wave-per-parent kernel over projected tables, dim 64 (mvin_fused_wpp.hip)
 bool fused_wpp_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_wpp(const FusedL2Args& a, hipStream_t st);
+bool fused_agg_supported(int D, int K);                       // per-entity aggregates S0 | G of the projected tables, dim 64 (mvin_fused_agg.hip)
+bool fused_agg_applies(const FusedL2Args& a, int D);
+hipError_t launch_entity_aggregates(const FusedL2Args& a, hipStream_t st);      // a.table (T1 | TA1 | TA2), a.adj_e / adj_r (encoding), a.t0 -> a.agg
+hipError_t launch_gather_attn_l2_agg(const FusedL2Args& a, hipStream_t st);     // a.agg, the encoding, a.t1, the query terms -> nagg0 / nagg1
 hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded = false);   // encoded: adj_e / adj_r = the duplicate-slot encoding
 bool fused_d16_supported(int D, int K);        // wave-per-parent variant for D = 16, K <= 16 (mvin_fused_d16.hip)
 bool fused_d16_applies(const FusedL2Args& a, int D);

@@ -267,6 +267,10 @@ class MVIN(object):
         # projected-tables form of the fused two-level pass inside mvin_score_l2_fwd (_prj_for_l2): None = by batch size
         self.prj = {"0": False, "1": True}.get(os.environ.get("MVIN_PRJ", ""), None)
         self._prj_tables = {}                # per stream: workspace of mvin_project_tables_elems floats, rewritten by every call
+        # per-entity aggregates S0 | G of those tables (_agg_for): None = whenever the projected-tables form is taken on a shape the
+        # kernels take (MVIN_L2_AGG=0 / 1 overrides: 0 answers through the library too)
+        self.agg = {"0": False, "1": True}.get(os.environ.get("MVIN_L2_AGG", ""), None)
+        self._agg_tables = {}                # per stream: workspace of mvin_entity_aggregates_elems floats, rewritten by every call
         # gathered form of the grouped key addressing (mvin_key_addressing_grouped_er_fwd, _ka_er_for): on request only
         self.ka_er = os.environ.get("MVIN_KA_ER", "0") == "1"
         self._ka_er_ws = {}                  # per stream: workspace of mvin_project_relations_elems floats, rewritten by every call
@@ -660,10 +664,21 @@ class MVIN(object):
             if tabs is not None:
                 ae, ar = (enc[0], enc[1]) if enc is not None else (self.adj_entity, self.adj_relation)
                 order = None
-                if enc is not None and L == 2 and self._item_order_for(B) and ops.gather_attn_l2_wpp_supported(D, K):
-                    order = ops.order_by_key(ents[0].view(-1))
-                n0, n1 = ops.gather_attn_l2_prj(tabs, ae, ar, ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
-                                                K ** (L - 2), K, D, self.n_relation, self.n_entity, encoded=enc is not None, order=order)
+                if self._agg_for(enc):
+                    # per-entity aggregates S0 | G of the tables just built: ~cnt rows per parent instead of ~cnt^2
+                    cs = torch.cuda.current_stream().cuda_stream
+                    n_ws = ops._lib.load().mvin_entity_aggregates_elems(self.n_entity, D)
+                    at = self._agg_tables.get(cs)
+                    if at is None or at.numel() != n_ws:
+                        at = self._agg_tables[cs] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+                    ops.entity_aggregates(tabs, ae, ar, l2_args[0], K, D, self.n_relation, self.n_entity, out=at)
+                    n0, n1 = ops.gather_attn_l2_agg(tabs, at, ae, ar, ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
+                                                    K ** (L - 2), K, D, self.n_relation, self.n_entity)
+                else:
+                    if enc is not None and L == 2 and self._item_order_for(B) and ops.gather_attn_l2_wpp_supported(D, K):
+                        order = ops.order_by_key(ents[0].view(-1))
+                    n0, n1 = ops.gather_attn_l2_prj(tabs, ae, ar, ents[L - 2].view(-1), l2_args[0], l2_args[1], q, B,
+                                                    K ** (L - 2), K, D, self.n_relation, self.n_entity, encoded=enc is not None, order=order)
                 pp = pc = None
             elif enc is not None:
                 n0, n1 = ops.gather_attn_l2_enc(self.entity_emb_matrix, enc[0], enc[1], ents[L - 2].view(-1), *l2_args)
@@ -910,6 +925,20 @@ class MVIN(object):
             want = B >= self.ITEM_ORDER_MIN_BATCH
         return bool(want)
 
+    def _agg_for(self, enc):
+        """Per-entity aggregates form of the two deepest levels (mvin_project_tables -> mvin_entity_aggregates ->
+        mvin_gather_attn_l2_agg_fwd) for a call that takes the projected-tables form?  The aggregates cost ~17 gathered rows per
+        entity and save a parent ~100 of its ~120 (C3): whenever the tables themselves pay (_prj_for_l2's rule is the stricter one),
+        on the shapes the kernels take (D = 64, K in {16, 32}, encoded adjacency).  ``self.agg`` False (MVIN_L2_AGG=0) keeps the kernels
+        over the tables."""
+        if enc is None or self.agg is False:
+            return False
+        key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
+        c = getattr(self, "_agg_ok_cache", None)
+        if c is None or c[0] != key:
+            c = self._agg_ok_cache = (key, ops.gather_attn_l2_agg_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation))
+        return c[1]
+
     def _prj_plain_ok(self):
         """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
         where the library takes THAT kernel for this model's tables (mvin_gather_attn_l2_prj_supported: its LDS copy of the
@@ -1007,6 +1036,13 @@ class MVIN(object):
             s.prj_tables = pt.data_ptr()
         else:
             s.prj_tables = None
+        s.agg_tables = None
+        if prj and self._agg_for(enc):
+            at = self._agg_tables.get(stream.cuda_stream)
+            n_ws = _lib.load().mvin_entity_aggregates_elems(self.n_entity, D)
+            if at is None or at.numel() != n_ws:
+                at = self._agg_tables[stream.cuda_stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+            s.agg_tables = at.data_ptr()
         wkey = (B, n_o, stream.cuda_stream, bool(grouped), uts.shape[0] if grouped else 0)
         ws = self._native_l2_ws.get(wkey)
         if ws is None:        # reused across calls of the same batch size ON THE SAME STREAM (which orders the reuse)
@@ -1032,7 +1068,8 @@ class MVIN(object):
             s.mem_h, s.mem_r, s.mem_t = C.addressof(ph), C.addressof(pr), C.addressof(pt)
         s.V, s.o_cat, s.parents, s.nagg0, s.nagg1, s.group_ws = (w.data_ptr() if w is not None else None for w in ws[:6])
         s.item_order_ws = None
-        if prj and enc is not None and self._item_order_for(B):
+        # (the aggregates form gathers ~12 rows of a 27 MB table per pair: item order buys it nothing -- measured 235 vs 252 us at C3)
+        if prj and enc is not None and s.agg_tables is None and self._item_order_for(B):
             if ws[6] is None:
                 ws = self._native_l2_ws[wkey] = ws[:6] + (torch.empty(_lib.load().mvin_order_by_key_ws_elems(B) + B, dtype=torch.int32,
                                                                       device=self.device),)

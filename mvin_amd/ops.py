@@ -381,6 +381,52 @@ def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, p
     return nagg0, nagg1
 
 
+def gather_attn_l2_agg_supported(D, K, n_entity, nR):
+    """mvin_gather_attn_l2_agg_supported: does the per-entity aggregates form take these tables?  (D = 64, K in {16, 32}.)"""
+    return bool(_lib.load().mvin_gather_attn_l2_agg_supported(D, K, n_entity, nR))
+
+
+def entity_aggregates(ws, enc_entity, enc_relation, t0, K, D, nR, n_entity, out=None):
+    """mvin_entity_aggregates: S0 | G ([2, n_entity, D] fp32) from the workspace of ``project_tables`` (the CURRENT call's), the
+    encoded adjacency and the relation logits t0 of aggregator (0,.) (None: plain mean)."""
+    lib = _lib.load()
+    for t, dt, nm in ((ws, F32, "ws"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"), (t0, F32, "t0")):
+        _chk(t, dt, nm)
+    if ws.numel() != lib.mvin_project_tables_elems(n_entity, D):
+        raise ValueError("entity_aggregates: the workspace of project_tables(n_entity, D) expected")
+    n = lib.mvin_entity_aggregates_elems(n_entity, D)
+    if out is None:
+        out = torch.empty((n,), dtype=F32, device=ws.device)
+    elif out.numel() != n or out.dtype != F32 or not out.is_contiguous():
+        raise ValueError("entity_aggregates: workspace of mvin_entity_aggregates_elems floats expected")
+    _lib.check(lib.mvin_entity_aggregates(_p(ws), _p(enc_entity), _p(enc_relation), _p(t0), K, D, n_entity, nR, _p(out), _stream()),
+               "mvin_entity_aggregates")
+    return out
+
+
+def gather_attn_l2_agg(ws, agg, enc_entity, enc_relation, parent_ids, t0, t1, q, B, parents_per_pair, K, D, nR, n_entity, order=None):
+    """mvin_gather_attn_l2_agg_fwd: gather_attn_l2_prj with the per-entity aggregates of ``entity_aggregates`` beside the
+    workspace.  Returns (nagg0 [P,D], nagg1 [P,D])."""
+    lib = _lib.load()
+    for t, dt, nm in ((ws, F32, "ws"), (agg, F32, "agg"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
+                      (parent_ids, torch.int64 if parent_ids.dtype == torch.int64 else I32, "parent_ids"), (t0, F32, "t0"),
+                      (t1, F32, "t1"), (q, F32, "q"), (order, I32, "order")):
+        _chk(t, dt, nm)
+    if (ws.numel() != lib.mvin_project_tables_elems(n_entity, D) or agg.numel() != lib.mvin_entity_aggregates_elems(n_entity, D)
+            or q is None or tuple(q.shape) != (B, D)):
+        raise ValueError("gather_attn_l2_agg: the workspaces of project_tables / entity_aggregates (n_entity, D) and q [B, D] expected")
+    P = B * parents_per_pair
+    if order is not None and order.numel() != P:
+        raise ValueError("gather_attn_l2_agg: order must be a permutation of the launch's parents")
+    nagg0 = torch.empty((P, D), dtype=F32, device=ws.device)
+    nagg1 = torch.empty((P, D), dtype=F32, device=ws.device)
+    _lib.check(lib.mvin_gather_attn_l2_agg_fwd(_p(ws), _p(agg), _p(enc_entity), _p(enc_relation), _p(parent_ids),
+                                               int(parent_ids.dtype == torch.int64), _p(order), _p(t0), _p(t1), _p(q), B,
+                                               parents_per_pair, K, D, n_entity, nR, _p(nagg0), _p(nagg1), _stream()),
+               "mvin_gather_attn_l2_agg_fwd")
+    return nagg0, nagg1
+
+
 def gather_mix(table, adj_entity, adj_relation, node_ids, rel_score_t, rowbias, nodes, nodes_per_group, K, nR,
                relu=False):
     """mvin_gather_mix_fwd: out[i] = (1/K) sum_k w_k f(table[adj_entity[x_i,k]] + rowbias[i // npg]) ->

@@ -365,10 +365,14 @@ def test_wave_per_parent_kernel_every_distinct_count(K, hip_lib):
     B = 4 * K + 37
     parents = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64)).to(dev)          # every count 1 .. K several times
     W1, W2, b1, b2, q, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(B, D), f(D, D), f(D)
-    for att in (True, False):
-        t0 = f(nR) if att else None
-        t1 = f(nR) if att else None
-        ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, att)
+    # (att = the relation logits' scale: 1 -> softmaxes over the exp tables; 130 -> a spread above the kernel's threshold of 60, the
+    #  per-row-maximum form: rows whose logits all lie far below the global maximum must keep their weights)
+    for att in (1.0, 130.0, False):
+        t0 = f(nR) * att if att else None
+        t1 = f(nR) * att if att else None
+        if att and att > 1:
+            assert float(t0.max() - t0.min()) > 60 and float(t1.max() - t1.min()) > 60
+        ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, bool(att))
         for order in (None, ops.order_by_key(parents), torch.flip(torch.arange(B, dtype=torch.int32, device=dev), dims=[0])):
             got0, got1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t1, q, B, 1, K, D, nR, n_entity, order=order)
             torch.cuda.synchronize()
@@ -379,6 +383,75 @@ def test_wave_per_parent_kernel_every_distinct_count(K, hip_lib):
             want0, want1 = ops.gather_attn_l2_enc(E, enc_e, enc_r, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, B, 1, K, D, nR)
             assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0 vs the packed-tile kernel", rtol=3e-5, atol=6e-6)
             assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1 vs the packed-tile kernel", rtol=3e-5, atol=6e-6)
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_entity_aggregates_form_every_distinct_count(K, hip_lib):
+    """The per-entity aggregates form (mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd, mvin_fused_agg.hip): S0 | G against their
+    float64 definitions over the projected tables, then the launch -- every distinct-children count 1 .. K as parent and as child,
+    ragged last batches and quads, both softmax forms, with and without attention, parents as given / in key order / reversed -- against
+    the float64 evaluation of the UNPROJECTED formulas on the plain adjacency and against the wave-per-parent kernel over the tables."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    D, nR, n_entity = 64, 7, 603
+    rng = np.random.default_rng(K + 100)
+    adj_e = np.zeros((n_entity, K), dtype=np.int64)
+    adj_r = np.zeros((n_entity, K), dtype=np.int64)
+    for x in range(n_entity):
+        nd = x % K + 1
+        ne = rng.choice(n_entity, nd, replace=False)
+        nr = rng.integers(0, nR, nd)
+        pick = np.concatenate([np.arange(nd), rng.integers(0, nd, K - nd)])
+        rng.shuffle(pick)
+        adj_e[x], adj_r[x] = ne[pick], nr[pick]
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    E = f(n_entity, D)
+    ae, ar = torch.from_numpy(adj_e.astype(np.int32)).to(dev), torch.from_numpy(adj_r.astype(np.int32)).to(dev)
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    assert ops.gather_attn_l2_agg_supported(D, K, n_entity, nR)
+    W1, W2, b1, b2, A0, a0 = f(D, D), f(D, D), f(D), f(D), f(D, D), f(D)
+    for B in (4 * K + 37, 1, 18):
+        parents = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64)).to(dev)
+        q = f(B, D)
+        for att in (1.0, 130.0, False):
+            t0 = f(nR) * att if att else None
+            t1 = f(nR) * att if att else None
+            ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, bool(att))
+            agg = ops.entity_aggregates(ws, enc_e, enc_r, t0, K, D, nR, n_entity)
+            if B > 18:
+                # S0 | G from their definitions: w(e) = softmax over the K slots of t0[relation] (plain mean without), over K
+                T = ws[: 3 * n_entity * D].view(3, n_entity, D).double()
+                lg = t0.double()[ar.long()] if att else torch.zeros((n_entity, K), dtype=torch.float64, device=dev)
+                w = torch.softmax(lg, dim=1) / K if att else torch.full_like(lg, 1.0 / K)
+                S0 = (w[:, :, None] * T[0][ae.long()]).sum(1)
+                G = T[1] + (w[:, :, None] * T[2][ae.long()]).sum(1)
+                got = agg.view(2, n_entity, D)
+                assert_close(got[0].cpu().numpy(), S0.cpu().numpy(), "S0", rtol=1e-5, atol=2e-6)
+                assert_close(got[1].cpu().numpy(), G.cpu().numpy(), "G", rtol=1e-5, atol=2e-6)
+            orders = (None,) if B == 1 else (None, ops.order_by_key(parents), torch.flip(torch.arange(B, dtype=torch.int32, device=dev), dims=[0]))
+            for order in orders:
+                got0, got1 = ops.gather_attn_l2_agg(ws, agg, enc_e, enc_r, parents, t0, t1, q, B, 1, K, D, nR, n_entity, order=order)
+                torch.cuda.synchronize()
+                if att:
+                    r0, r1 = bench.l2_reference_f64(E, ae, ar, parents, t0, t1, W1, W2, b1, b2, q, A0, a0, K)
+                    assert_close(got0.cpu().numpy(), r0.cpu().numpy(), "nagg0 vs float64", rtol=1e-5, atol=2e-6)
+                    assert_close(got1.cpu().numpy(), r1.cpu().numpy(), "nagg1 vs float64", rtol=1e-5, atol=2e-6)
+                want0, want1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t1, q, B, 1, K, D, nR, n_entity)
+                assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0 vs the kernel over the tables", rtol=3e-5, atol=6e-6)
+                assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1 vs the kernel over the tables", rtol=3e-5, atol=6e-6)
+    # several parents per pair (deeper trees: the level-(L-2) nodes of a pair share its query row)
+    B, ppp = 9, K
+    parents = torch.from_numpy(rng.integers(0, n_entity, B * ppp).astype(np.int32)).to(dev)
+    q, t0, t1 = f(B, D), f(nR), f(nR)
+    ws = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, True)
+    agg = ops.entity_aggregates(ws, enc_e, enc_r, t0, K, D, nR, n_entity)
+    got0, got1 = ops.gather_attn_l2_agg(ws, agg, enc_e, enc_r, parents, t0, t1, q, B, ppp, K, D, nR, n_entity)
+    want0, want1 = ops.gather_attn_l2_prj(ws, enc_e, enc_r, parents, t0, t1, q, B, ppp, K, D, nR, n_entity)
+    assert_close(got0.cpu().numpy(), want0.cpu().numpy(), "nagg0, K parents per pair", rtol=3e-5, atol=6e-6)
+    assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1, K parents per pair", rtol=3e-5, atol=6e-6)
 
 
 def test_order_by_key_is_a_bucket_partition(hip_lib):
