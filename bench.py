@@ -867,8 +867,13 @@ def main():
         enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
         prj_now = (used_l2 and not hoisted and (enc is not None or model._prj_plain_ok())
                    and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2)))
+        agg_now = bool(prj_now and model._agg_for(enc))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "entity_aggregates_kernel<%d> + gather_attn_l2_agg_kernel<%d> (mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd: per-entity "
+                      "aggregates S0 | G of the projected tables E.W1 | E.W1.A0 | E.W2.A0, all rebuilt inside every step from the current parameters; a "
+                      "pair then gathers its distinct children's G rows and one S0 row -- the same sums in another association)" % (a.fanout, a.fanout)
+                 if agg_now
                  else "gather_attn_l2_wpp_kernel<%d> (mvin_gather_attn_l2_prj_ordered_fwd: wave-per-parent kernel over the duplicate-slot encoding of the "
                       "adjacency, rows gathered from the projected tables E.W1 | E.W1.A0 | E.W2.A0 that mvin_project_tables rebuilds every step "
                       "-- same ids and grandchild rows per pair as mvin_gather_attn_l2_enc_fwd, no product per distinct child; parents taken in "
@@ -918,12 +923,26 @@ def main():
             K_ = a.fanout
             # encoded adjacency rows read per pair: the item's and its distinct children's, K words of ids + K of relations each
             adj_rows = float((1 + cnt[it].double()).mean())
-            loaded_bpp = rows_loaded * a.dim * s_ + adj_rows * K_ * 8 + a.dim * 4 + 4
+            if agg_now:
+                # the aggregates form: per pair its S0 row and its distinct children's G rows, its own adjacency row, the query row and
+                # the two output rows; per ENTITY and step (entity_aggregates_kernel) its adjacency row, TA1[e], T1 and TA2 of its
+                # distinct slots, S0[e] and G[e] written -- shared out over the step's pairs
+                rows_loaded = float((1 + cnt[it].double()).mean())
+                adj_rows = 1.0
+                per_entity = float(((2 * cnt.double() + 1) * a.dim * 4 + K_ * 8 + 2 * a.dim * 4).sum()) / Bl
+                loaded_bpp = rows_loaded * a.dim * 4 + K_ * 8 + 3 * a.dim * 4 + per_entity
+                timed["aggregates_build_bytes_per_step"] = per_entity * Bl
+            else:
+                loaded_bpp = rows_loaded * a.dim * s_ + adj_rows * K_ * 8 + a.dim * 4 + 4
             loaded_gbs = loaded_bpp * Bl / (kern_avg_ms * 1e-3) / 1e9
             timed.update({"achieved": loaded_gbs, "frac": loaded_gbs / peak, "bytes_per_pair": loaded_bpp,
                           "rows_per_pair_faithful": 1 + K_ + K_ * K_, "rows_per_pair_loaded": rows_loaded,
                           "adjacency_rows_per_pair_loaded": adj_rows,
                           "distinct_slots_per_adjacency_row": frac_distinct * K_,
+                          "aggregates_note": ("aggregates form: `avg_launch_ms` covers BOTH launches (aggregates over all %d entities + the per-pair "
+                                              "gather); a pair's rows come from the 27 MB G table, not from its grandchildren's rows of three tables "
+                                              "(rows_per_pair_loaded ~ 1 + its distinct children; the wave-per-parent kernel over the tables loaded "
+                                              "~120); MVIN_L2_AGG=0 times that kernel instead" % case.n_entity) if agg_now else None,
                           "dedup_note": "the reference's sampler repeats slots whenever deg < K (data_loader_user_set.py:383-384) and the "
                                         "packed kernel fetches every DISTINCT row once: `achieved` / `frac` / `bytes_per_pair` price what it "
                                         "loads (distinct entity rows + the encoded adjacency rows + query + score); "
@@ -1005,7 +1024,12 @@ def main():
                         "avg_launch_ms": leg["avg_launch_ms"], "table_bytes": leg["table_bytes"],
                         "table_rows": leg["table_rows"], "launches": leg["launches"],
                         "max_abs_err": leg["max_abs_err"], "verified": leg["verified"], "verified_how": leg["verified_how"],
-                        "instance_is_the_timed_regions": bool(prj_leg == bool(prj_now)),
+                        "instance_is_the_timed_regions": bool(prj_leg == bool(prj_now)) and not agg_now,
+                        "instance_note": ("the timed steps take the per-entity aggregates form (timed_region.kernel): it exists where the batch holds "
+                                          "more parents than ~n_entity / 6 -- on this leg's 4 M-row table the aggregates alone would cost 4 M x 65 "
+                                          "rows per launch, so the gather kernel over the projected tables stays the kernel of this regime (and of "
+                                          "MVIN_L2_AGG=0) and keeps the leg; the aggregates kernels' own bytes and time are under timed_region"
+                                          if agg_now else None),
                         **siblings,
                         "workload": ("%s -- %s -- on a %.1f M-row synthetic entity table (%.2f GB of tables: %.0fx the Infinity Cache) with uniform "
                                      "adjacency (no repeated slots: every row of every slot is loaded), so every gathered row comes from HBM; "
@@ -1013,6 +1037,8 @@ def main():
                                      "2*FETCH_SIZE + WRITE_SIZE per launch from profiles/%s (rocprofv3 --pmc passes over `bench.py "
                                      "--hbm-leg-only%s`)"
                                      % (leg["kernel"],
+                                        "the gather kernel over the projected tables (the timed steps' tables; they then read per-entity aggregates of them)"
+                                        if agg_now else
                                         "the template instance the timed steps launch" if prj_leg == bool(prj_now) else
                                         "NOT the timed region's instance (that one reads projected tables; see `timed_region.kernel`)",
                                         leg["table_rows"] / 1e6, leg["table_bytes"] / 1e9, leg["table_bytes"] / (256 * 2 ** 20),
@@ -1033,8 +1059,10 @@ def main():
                        "adjacency": a.adj, "items": a.items, "ablation": a.ablation, "hipgraph_replay": bool(scorer), "streams": nstreams,
                        "two_level_form": (("projected tables (E.W1 | E.W1.A0 | E.W2.A0 rebuilt inside every timed step: mvin_project_tables + "
                                            "mvin_gather_attn_l2_prj_fwd" + (("; parents in item order, mvin_order_by_key inside every step)"
-                                                                             if model._item_order_for(Bl) else ")") if enc is not None
-                                                                            else " over the plain adjacency)")) if prj_now else
+                                                                             if (model._item_order_for(Bl) and not agg_now) else ")") if enc is not None
+                                                                            else " over the plain adjacency)")
+                                           + ("; per-entity aggregates S0 | G of those tables rebuilt inside every timed step too: mvin_entity_aggregates + "
+                                              "mvin_gather_attn_l2_agg_fwd in place of mvin_gather_attn_l2_prj_fwd" if agg_now else "")) if prj_now else
                                           "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",

@@ -232,6 +232,29 @@ MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, cons
                                 const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
                                 const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
                                 float* nagg1, void* stream);
+/* FOLDED-TAIL form of everything above key addressing for n_mix_hop = 1, h_hop = 2, User_orient on (mvin_l2_tail_fwd's formulas
+ * over the aggregates above; D = 64, K in {16, 32}).  nagg0 only ever enters through (ev0 + nagg0) A0 + a0, and ev0 through that and
+ * the combiner, so with c = the sum of a row's slot weights over K (1/K with attention, 1 without):
+ *     (ev0 + nagg0) A0 + a0 = H0[x] + q Wq + bq        H0[e] = E[e] W0 A0 + sum_k w(e)_k TA1[y_ek],  Wq = (W0 + c W1) A0,
+ *                                                       bq = (b0 + c b1) A0 + a0                      (S0[e] A0 = sum_k w(e)_k TA1[y_ek])
+ *     ev0 Wm0               = M0[x] + q Wqm + b0 Wm0    M0 = E W0 Wm0,  Wqm = W0 Wm0   (Wm0 | Wm1 | Wm2 = the row blocks of Wmix)
+ * mvin_fold_tables builds, per call and from the current parameters, TA1 | TA2 | T0A = E W0 A0 | M0 (one four-matrix table build),
+ * H0 | G (mvin_entity_aggregates' kernel) and the parameter block into `ws` (mvin_fold_tables_elems floats).
+ * mvin_score_l2_folded_fwd then scores B pairs in two launches:
+ *     out0 = relu(H0[x] + q Wq + bq) ;  Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + q Wv + bv)            (the pair kernel; out0, z2 [B, D] scratch)
+ *     out2 = relu(Z2 A1 + a1) ;  item_emb = M0[x] + q Wqm + out0 Wm1 + out2 Wm2 + bmix + b0 Wm0 ;  scores = <user_o, item_emb>
+ * -- six D x D products per pair instead of eight, the same sums in another association (agreement to rounding).  item_emb / sig may
+ * be NULL.  _supported: as mvin_gather_attn_l2_agg_supported. */
+MVIN_API int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR);
+MVIN_API size_t mvin_fold_tables_elems(int n_entity, int D);
+MVIN_API int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
+                              const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
+                              const float* a0, const float* Wmix, const float* bmix, const float* A1, int K, int D, int n_entity, int nR,
+                              float* ws, void* stream);
+MVIN_API int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const int64_t* items_i64,
+                                      const int32_t* items_i32, const float* t0, const float* t1, const float* q, const float* user_o,
+                                      const float* A1, const float* a1, const float* Wmix, int64_t B, int K, int D, int n_entity, int nR,
+                                      float* out0, float* z2, float* item_emb, float* scores, float* sig, void* stream);
 /* Which kernel mvin_gather_attn_l2_fwd takes for a call of this shape: 0 = none (returns -3), 1 = the symmetric
  * fused kernel (every wave gathers and multiplies; the only one that writes probs_parent / probs_child),
  * 2 = the role-split pipeline (gather waves + MFMA waves; D in {32,64,128}, K in {16 (D=32), 32, 64, 128}, no
@@ -498,6 +521,10 @@ typedef struct {
                                       prj_tables, the encoded adjacency and a shape mvin_gather_attn_l2_agg_supported takes, the two deepest
                                       levels run as mvin_project_tables -> mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd (in item
                                       order when item_order_ws is given).  Rewritten by every call */
+    float* fold_ws;                /* mvin_score_l2_fwd only, or NULL: workspace of mvin_fold_tables_elems(nE, D) floats -- with the encoded
+                                      adjacency, User_orient on, an fp32 table and a shape mvin_score_l2_folded_supported takes, everything
+                                      above key addressing runs as mvin_fold_tables -> mvin_score_l2_folded_fwd (nagg0 / nagg1 are its
+                                      scratch rows); takes precedence over prj_tables / agg_tables.  Rewritten by every call */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

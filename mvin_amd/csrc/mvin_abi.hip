@@ -437,18 +437,21 @@ int mvin_entity_aggregates(const float* ws, const int32_t* enc_entity, const int
     if (!agg_applies(D, K, n_entity, nR, 1))
         return fail(-3, "%s: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
                     who, D, K, n_entity, nR);
-    mvin::FusedL2Args f{};
-    f.table = ws;
+    mvin::EntityAggArgs f{};
+    const size_t tab = (size_t)n_entity * D;
+    f.tabS = ws;                              // T1
+    f.selfG = ws + tab;                       // TA1
+    f.tabG = ws + 2 * tab;                    // TA2
     f.adj_e = enc_entity;
     f.adj_r = enc_relation;
     f.t0 = t0;
-    f.agg = agg;
+    f.outS = agg;
+    f.outG = agg + tab;
+    f.n_entity = n_entity;
     f.K = K;
     f.nR = nR;
-    f.max_id = (unsigned)(n_entity - 1);
     f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 4;
     f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
-    f.prj = 1;
     return hip_result(mvin::launch_entity_aggregates(f, (hipStream_t)stream), who);
 }
 
@@ -463,6 +466,134 @@ int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, const int32_t
     return gather_attn_l2_impl(ws, enc_entity, enc_relation, reinterpret_cast<const int32_t*>(parent_ids), parent_ids_i64 ? 2 : 1, t0, t1,
                                blk, Wv, b1c, b1c + D, q, blk, nullptr, B, parents_per_pair, K, D, n_entity, nR, nagg0, nagg1, nullptr,
                                nullptr, 0, stream, true, true, order, agg);
+}
+
+// ---- folded-tail form: tables TA1 | TA2 | T0A | M0, aggregates H0 | G, parameter block ----
+static size_t fold_blk_elems(int D) { return (size_t)12 * D * D + (size_t)3 * D; }      // Wstack[4] | Wv | Wq | bv | bq | bm | Wperm[6]
+
+size_t mvin_fold_tables_elems(int n_entity, int D) {
+    return n_entity > 0 && D > 0 ? (size_t)6 * n_entity * D + fold_blk_elems(D) : 0;
+}
+
+int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR) { return agg_applies(D, K, n_entity, nR, 1) ? 1 : 0; }
+
+int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
+                     const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0, const float* a0,
+                     const float* Wmix, const float* bmix, const float* A1, int K, int D, int n_entity, int nR, float* ws, void* stream) {
+    const char* who = "mvin_fold_tables";
+    if (!entity_emb || !enc_entity || !enc_relation || !W0 || !W1 || !W2 || !A0 || !Wmix || !A1 || !ws) return fail(-1, "%s: null pointer", who);
+    if (!agg_applies(D, K, n_entity, nR, 1))
+        return fail(-3, "%s: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
+                    who, D, K, n_entity, nR);
+    const size_t tab = (size_t)n_entity * D;
+    float* blk = ws + 6 * tab;
+    const float c = t0 ? 1.f / (float)K : 1.f;            // sum of a row's slot weights over K  (aggregators.py:139-152)
+    if (int rc = hip_result(mvin::launch_fold_prepare(W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, c, D, blk, (hipStream_t)stream), who)) return rc;
+    mvin_linear_args l{};
+    l.src[0] = entity_emb;
+    l.nsrc = 1;
+    l.Dsrc = D;
+    l.Dout = D;
+    l.rows = n_entity;
+    l.rows_per_group = 1;
+    l.W = blk;                                // W1.A0 | W2.A0 | W0.A0 | W0.Wm0
+    l.w_zstride = (int64_t)D * D;
+    l.out = ws;                               // TA1 | TA2 | T0A | M0
+    l.ldo = D;
+    l.nz = 4;
+    l.out_zstride = (int64_t)n_entity * D;
+    if (int rc = mvin_linear_fwd(&l, stream)) return rc;
+    mvin::EntityAggArgs f{};
+    f.tabS = ws;                              // H0[e] = T0A[e] + sum_k w_k TA1[y_k]
+    f.selfS = ws + 2 * tab;
+    f.tabG = ws + tab;                        // G[e]  = TA1[e] + sum_k w_k TA2[y_k]
+    f.selfG = ws;
+    f.adj_e = enc_entity;
+    f.adj_r = enc_relation;
+    f.t0 = t0;
+    f.outS = ws + 4 * tab;
+    f.outG = ws + 5 * tab;
+    f.n_entity = n_entity;
+    f.K = K;
+    f.nR = nR;
+    f.table_bytes = (uint64_t)tab * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    return hip_result(mvin::launch_entity_aggregates(f, (hipStream_t)stream), who);
+}
+
+int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const int64_t* items_i64,
+                             const int32_t* items_i32, const float* t0, const float* t1, const float* q, const float* user_o, const float* A1,
+                             const float* a1, const float* Wmix, int64_t B, int K, int D, int n_entity, int nR, float* out0, float* z2,
+                             float* item_emb, float* scores, float* sig, void* stream) {
+    const char* who = "mvin_score_l2_folded_fwd";
+    if (!ws || !enc_entity || !enc_relation || !q || !user_o || !A1 || !Wmix || !out0 || !z2 || !scores) return fail(-1, "%s: null pointer", who);
+    if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
+    if (B <= 0 || B >= (int64_t(1) << 31)) return fail(-2, "%s: B=%lld", who, (long long)B);
+    if (!agg_applies(D, K, n_entity, nR, B)) return fail(-3, "%s: unsupported shape / sizes D=%d K=%d n_entity=%d nR=%d B=%lld", who, D, K, n_entity, nR, (long long)B);
+    const size_t tab = (size_t)n_entity * D;
+    const float* blk = ws + 6 * tab;
+    const float* Wv = blk + (size_t)4 * D * D;
+    const float* Wq = Wv + (size_t)D * D;
+    const float* bv = Wq + (size_t)D * D;
+    const float* bq = bv + D;
+    const float* bm = bq + D;
+    static const bool two = getenv("MVIN_L2_FOLD_TWO") && atoi(getenv("MVIN_L2_FOLD_TWO")) != 0;
+    if (!two)                                 // ONE launch: pair kernel and tail on the same batches of 16 pairs (out0 / z2 stay unused)
+    {       // (the regrouped copies Wperm of the six blocks -- of the CURRENT A1 / Wmix too: mvin_fold_tables wrote them)
+        const float* Wp = bm + D;
+        const size_t DD = (size_t)D * D;
+        return hip_result(mvin::launch_score_l2_folded(ws + 4 * tab, ws + 3 * tab, enc_entity, enc_relation,
+                                                       items_i64 ? reinterpret_cast<const int32_t*>(items_i64) : items_i32, items_i64 ? 2 : 1, t1, q,
+                                                       user_o, Wp, bq, Wp + DD, bv, Wp + 2 * DD, Wp + 3 * DD, a1, Wp + 4 * DD, Wp + 5 * DD, bm,
+                                                       item_emb, scores, sig, B, K, nR, n_entity, (hipStream_t)stream),
+                          who);
+    }
+    // MVIN_L2_FOLD_TWO=1 (A/B): the pair kernel writes out0 and Z2, the tile kernel of mvin_tail.hip takes them from there
+    mvin::FusedL2Args f{};
+    f.table = ws;
+    f.agg = const_cast<float*>(ws + 4 * tab);     // H0 | G
+    f.adj_e = enc_entity;
+    f.adj_r = enc_relation;
+    f.parent_ids = items_i64 ? reinterpret_cast<const int32_t*>(items_i64) : items_i32;
+    f.pid_stride = items_i64 ? 2 : 1;
+    f.t0 = t0;
+    f.t1 = t1;
+    f.W1 = Wq;
+    f.b1 = bq;
+    f.W2 = Wv;
+    f.b2 = bv;
+    f.q = q;
+    f.nagg0 = out0;
+    f.nagg1 = z2;
+    f.P = B;
+    f.table_bytes = (uint64_t)tab * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    f.parents_per_pair = 1;
+    f.K = K;
+    f.nR = nR;
+    f.max_id = (unsigned)(n_entity - 1);
+    f.prj = 1;
+    f.fold = 1;
+    if (int rc = hip_result(mvin::launch_gather_attn_l2_agg(f, (hipStream_t)stream), who)) return rc;
+    mvin::TailFoldArgs t{};
+    t.M0 = ws + 3 * tab;
+    t.items64 = items_i64;
+    t.items32 = items_i32;
+    t.q = q;
+    t.user_o = user_o;
+    t.out0 = out0;
+    t.z2 = z2;
+    t.Wqm = blk + (size_t)3 * D * D;
+    t.A1 = A1;
+    t.a1 = a1;
+    t.Wmix = Wmix;
+    t.bm = bm;
+    t.item_emb = item_emb;
+    t.scores = scores;
+    t.sig = sig;
+    t.B = B;
+    t.n_entity = n_entity;
+    return hip_result(mvin::launch_l2_tail_fold(t, (hipStream_t)stream), who);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -764,6 +895,15 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     }
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
+    if (a->fold_ws && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 && agg_applies(D, a->K, a->n_entity, nR, a->B)) {
+        // folded-tail form: four per-entity tables + the aggregates H0 | G from the CURRENT parameters, then two launches per batch
+        rc = mvin_fold_tables(reinterpret_cast<const float*>(a->entity_emb), a->enc_entity, a->enc_relation, a->t0, a->W0, a->b0, a->W1, a->b1,
+                              a->W2, a->b2, a->A0, a->a0, a->Wmix, a->bmix, a->A1, a->K, D, a->n_entity, nR, a->fold_ws, stream);
+        if (rc) return rc;
+        return mvin_score_l2_folded_fwd(a->fold_ws, a->enc_entity, a->enc_relation, a->items, nullptr, a->t0, a->t1, a->user_o, a->user_o, a->A1,
+                                        a->a1, a->Wmix, a->B, a->K, D, a->n_entity, nR, a->nagg0, a->nagg1, a->item_emb, a->scores, a->sig,
+                                        stream);
+    }
     const bool enc = a->enc_entity && a->enc_relation && mvin::fused_packed_supported(D, a->K);
     const bool d32 = mvin::fused_d32_supported(D, a->K);       // the wave-per-parent kernel: projected tables over either adjacency
     // (asked for on a shape / table size the projected-tables kernels do not take: the unprojected form, not an error)

@@ -37,6 +37,7 @@ constexpr int kAggPad = 4;            // list entries of padding behind a group'
 constexpr unsigned kAggOob = 0xFFFFFFF0u;       // a byte offset beyond every buffer: the load returns zeros, no memory access
 constexpr unsigned kAggPadRow = 0xFFFFFE00u;    // ... that stays beyond them (and below 2^32) with a lane's column offset added
 constexpr int agg_list_words(int K) { return 4 * 2 * (K + kAggPad); }      // per wave: 4 groups x (K + padding) x (offset, weight)
+size_t fused_agg_lds_bytes(int nR, int K);
 
 __device__ __forceinline__ int agg_xor16_imax(int v) {
     const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
@@ -129,9 +130,10 @@ __device__ __forceinline__ float4 agg_row4(__amdgpu_buffer_rsrc_t tab, unsigned 
     return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
 }
 
-// ---- S0 | G over all entities: a.table = T1 | TA1 | TA2, a.agg = S0 | G ([2][nE][64]); four entities per wave and step ----
+// ---- outS | outG over all entities (four entities per wave and step): the aggregates form S0 | G (tabS = T1, no selfS), the
+//      folded-tail form H0 | G (tabS = TA1, selfS = T0A) ----
 template <int K>
-__global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(FusedL2Args a) {
+__global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(EntityAggArgs a) {
     constexpr int D = 64, SPL = K / 16;
     static_assert(K == 16 || K == 32, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -146,17 +148,17 @@ __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(Fused
     const bool fast = agg_logit_table(a.t0, a.nR, sT, tid, lane);
     __syncthreads();
 
-    const unsigned tbytes = (unsigned)a.table_bytes;
-    const char* tb = reinterpret_cast<const char*>(a.table);
-    const __amdgpu_buffer_rsrc_t tabT1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb), 0, (int)tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t tabTA1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb + a.table_bytes), 0, (int)tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t tabTA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb + 2 * a.table_bytes), 0, (int)tbytes, 0x00020000);
+    const int tbytes = (int)a.table_bytes;
+    const __amdgpu_buffer_rsrc_t tabS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.tabS), 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tabG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.tabG), 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t selfS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.selfS), 0, a.selfS ? tbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t selfG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.selfG), 0, tbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, (int)a.adj_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t outS = __builtin_amdgcn_make_buffer_rsrc(a.agg, 0, (int)tbytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t outG = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.agg) + a.table_bytes, 0, (int)tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t outS = __builtin_amdgcn_make_buffer_rsrc(a.outS, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t outG = __builtin_amdgcn_make_buffer_rsrc(a.outG, 0, tbytes, 0x00020000);
     const unsigned c16 = (unsigned)c * 16u;
-    const unsigned n_entity = a.max_id + 1u;
+    const unsigned n_entity = (unsigned)a.n_entity;
     const unsigned nquad = (n_entity + 3u) >> 2;
 
     auto run = [&](auto fast_tag) {
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(Fused
             const bool valid = e < n_entity;
             unsigned ce[SPL], cr[SPL];
             agg_load_slots<SPL>(adjE, adjR, valid ? (e * (unsigned)K + (unsigned)(SPL * c)) * 4u : kAggOob, ce, cr);
-            const float4 ta1 = agg_row4(tabTA1, valid ? e * (unsigned)(D * 4) + c16 : kAggPadRow);
+            const unsigned so = valid ? e * (unsigned)(D * 4) + c16 : kAggPadRow;
+            const float4 sg = agg_row4(selfG, so);
+            const float4 ss = agg_row4(selfS, so);       // (no selfS: an empty buffer, zeros)
             float wk[SPL];
             agg_row_weights<SPL, FAST>(cr, att, sT, invK, wk);
             int cc = (int)(cr[0] >> 24);                 // the row's distinct-slot count (in every slot word)
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(Fused
                 float4 r1[4], r2[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    r1[t] = agg_row4(tabT1, off[t] + c16);
-                    r2[t] = agg_row4(tabTA2, off[t] + c16);
+                    r1[t] = agg_row4(tabS, off[t] + c16);
+                    r2[t] = agg_row4(tabG, off[t] + c16);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -204,9 +208,10 @@ __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(Fused
                 }
             }
             const unsigned oo = valid ? e * (unsigned)(D * 4) + c16 : kAggOob;      // (a store beyond the buffer is dropped)
-            const u32x4 vs = {__float_as_uint(s01[0]), __float_as_uint(s01[1]), __float_as_uint(s23[0]), __float_as_uint(s23[1])};
-            const u32x4 vg = {__float_as_uint(g01[0] + ta1.x), __float_as_uint(g01[1] + ta1.y), __float_as_uint(g23[0] + ta1.z),
-                              __float_as_uint(g23[1] + ta1.w)};
+            const u32x4 vs = {__float_as_uint(s01[0] + ss.x), __float_as_uint(s01[1] + ss.y), __float_as_uint(s23[0] + ss.z),
+                              __float_as_uint(s23[1] + ss.w)};
+            const u32x4 vg = {__float_as_uint(g01[0] + sg.x), __float_as_uint(g01[1] + sg.y), __float_as_uint(g23[0] + sg.z),
+                              __float_as_uint(g23[1] + sg.w)};
             __builtin_amdgcn_raw_buffer_store_b128(vs, outS, oo, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(vg, outG, oo, 0, 0);
         }
@@ -231,7 +236,8 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(F
     float* sLw = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(sUV + 16 * kAggUvLd) + 4 * (K + kAggPad)) + g * (K + kAggPad);
     const bool att1 = a.t1 != nullptr;
     const float invK = 1.f / (float)K;
-    const float c0 = a.t0 != nullptr ? invK : 1.f;       // sum of the parent's slot weights under aggregator (0,.), over K
+    const bool fold = a.fold != 0;
+    const float c0 = fold ? 1.f : a.t0 != nullptr ? invK : 1.f;      // sum of the parent's slot weights under aggregator (0,.), over K (folded: inside Wq)
     const bool fast = agg_logit_table(a.t1, a.nR, sT, tid, lane);
     __syncthreads();                                     // the only workgroup barrier
 
@@ -258,9 +264,12 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(F
             //      matrix cores (A = the two 64 x 64 blocks straight from L2; B = the parents' query rows, lane (g, c = parent): 4 x 16
             //      bytes of its row; accumulator register r of column tile ntp <-> n = 16 ntp + 4 g + r).  Every address = a uniform
             //      base + ONE 32-bit lane offset + a constant ----
+            // (parent c of the batch in every group: its slot of the launch and its entity id, known before the products -- the four
+            //  steps below take theirs by a lane exchange, and each step's adjacency row is requested one step early)
+            int64_t pr = min(p_base + c, a.P - 1);
+            if (a.order) pr = a.order[pr];
+            const int x0c = fused_parent_id(a, pr);
             {
-                int64_t pr = min(p_base + c, a.P - 1);
-                if (a.order) pr = a.order[pr];
                 const unsigned qoff = (unsigned)(pr / a.parents_per_pair) * (unsigned)(D * 4) + (unsigned)g * 16u;
                 const char* qbase = reinterpret_cast<const char*>(a.q);
                 float4 qb[4];
@@ -301,15 +310,30 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(F
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             const int nquad = (int)((min((int64_t)16, a.P - p_base) + 3) >> 2);
+            struct Quad {
+                unsigned p;
+                unsigned ce[SPL], cr[SPL];
+                float4 s0;
+            };
+            auto quad_load = [&](int it) -> Quad {       // group g's parent of step `it`: j = 4 it + g
+                Quad qd;
+                const int src = ((lane & 48) + 4 * it + g) << 2;
+                qd.p = (unsigned)__builtin_amdgcn_ds_bpermute(src, (int)pr);
+                const unsigned x0 = (unsigned)__builtin_amdgcn_ds_bpermute(src, x0c);
+                agg_load_slots<SPL>(adjE, adjR, (x0 * (unsigned)K + (unsigned)(SPL * c)) * 4u, qd.ce, qd.cr);
+                qd.s0 = agg_row4(aggS, x0 * (unsigned)(D * 4) + c16);
+                return qd;
+            };
+            Quad nx = quad_load(0);
             for (int it = 0; it < nquad; ++it) {
                 const int j = 4 * it + g;                // this group's parent of the batch
                 const bool pvalid = p_base + j < a.P;
-                int64_t p = min(p_base + j, a.P - 1);
-                if (a.order) p = a.order[p];
-                const unsigned x0 = (unsigned)fused_parent_id(a, p);
-                unsigned ce[SPL], cr[SPL];
-                agg_load_slots<SPL>(adjE, adjR, (x0 * (unsigned)K + (unsigned)(SPL * c)) * 4u, ce, cr);
-                const float4 s0 = agg_row4(aggS, x0 * (unsigned)(D * 4) + c16);
+                const Quad qd = nx;
+                if (it + 1 < nquad) nx = quad_load(it + 1);
+                const unsigned p = qd.p;
+                const unsigned (&ce)[SPL] = qd.ce;
+                const unsigned (&cr)[SPL] = qd.cr;
+                const float4 s0 = qd.s0;
                 const float4 u1 = *reinterpret_cast<const float4*>(sUV + j * kAggUvLd + 4 * c);
                 const float4 vv = *reinterpret_cast<const float4*>(sUV + j * kAggUvLd + D + 4 * c);
                 float wk[SPL];
@@ -360,10 +384,15 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(F
                     sum4(rb, wb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const unsigned oo = pvalid ? (unsigned)p * (unsigned)(D * 4) + c16 : kAggOob;      // (a store beyond the buffer is dropped)
-                const u32x4 o0 = {__float_as_uint(fmaf(c0, u1.x, s0.x)), __float_as_uint(fmaf(c0, u1.y, s0.y)),
-                                  __float_as_uint(fmaf(c0, u1.z, s0.z)), __float_as_uint(fmaf(c0, u1.w, s0.w))};
-                const u32x4 o1 = {__float_as_uint(a01[0]), __float_as_uint(a01[1]), __float_as_uint(a23[0]), __float_as_uint(a23[1])};
+                const unsigned oo = pvalid ? p * (unsigned)(D * 4) + c16 : kAggOob;      // (a store beyond the buffer is dropped)
+                float4 r0 = make_float4(fmaf(c0, u1.x, s0.x), fmaf(c0, u1.y, s0.y), fmaf(c0, u1.z, s0.z), fmaf(c0, u1.w, s0.w));
+                float4 r1 = make_float4(a01[0], a01[1], a23[0], a23[1]);
+                if (fold) {      // folded-tail form: out0 = relu(H0[x] + q Wq + bq) and Z2 = out0 + nagg1 leave the kernel
+                    r0 = make_float4(fmaxf(r0.x, 0.f), fmaxf(r0.y, 0.f), fmaxf(r0.z, 0.f), fmaxf(r0.w, 0.f));
+                    r1 = make_float4(r1.x + r0.x, r1.y + r0.y, r1.z + r0.z, r1.w + r0.w);
+                }
+                const u32x4 o0 = {__float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z), __float_as_uint(r0.w)};
+                const u32x4 o1 = {__float_as_uint(r1.x), __float_as_uint(r1.y), __float_as_uint(r1.z), __float_as_uint(r1.w)};
                 __builtin_amdgcn_raw_buffer_store_b128(o0, out0, oo, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(o1, out1, oo, 0, 0);
             }
@@ -374,6 +403,293 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(F
     };
     if (fast) run(std::true_type{});
     else run(std::false_type{});
+}
+
+// ---- folded-tail form in ONE launch (mvin_score_l2_folded_fwd): everything above key addressing for a pair, from its item id and
+//      query row to its score.  The pair kernel above with the tail's products on its own matrix-core scheme: a batch of 16 pairs per
+//      wave, every product TRANSPOSED -- (X W)^T[n, pair] = sum_k W[k][n] X[pair][k], A = the 64 x 64 block straight from L2, B = the
+//      pairs' rows, lane (g, c = pair) holding floats [16 nt + 4 g, + 4) of its row -- so an accumulator (lane (g, c): n = 16 ntp + 4 g + r)
+//      IS the next product's B operand, and the rows a group leaves in LDS (out0, Z2: row-major per pair) are read back as B operands
+//      by one 16-byte read per k tile.  Nothing of a pair but its score (and item embedding) is written:
+//        t = q Wq + bq ; v = q Wv + bv ; m = q Wqm                                        (matrix cores; t, v -> LDS, m stays in registers)
+//        out0 = relu(H0[x] + t) ; Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + v)           (four pairs at a time, one per 16-lane group)
+//        out2 = relu(Z2 A1 + a1) ; item = M0[x] + m + out0 Wm1 + out2 Wm2 + bm ; score = <user_o, item>       (matrix cores)
+struct FoldArgs {
+    const float* agg;            // [2][nE][64] H0 | G
+    const float* M0;             // [nE][64]
+    const int32_t* adj_e;        // duplicate-slot encoding
+    const int32_t* adj_r;
+    const int32_t* items;        // [B] (stride pid_stride words)
+    const float* t1;             // [nR] relation logits of aggregator (1,.) or NULL
+    const float* q;              // [B][64]
+    const float* user_o;         // [B][64]
+    const float *Wq, *bq, *Wv, *bv, *Wqm, *A1, *a1, *Wm1, *Wm2, *bm;
+    float* item_emb;             // [B][64] or NULL
+    float* scores;
+    float* sig;                  // or NULL
+    int64_t B;
+    uint64_t table_bytes, adj_bytes;
+    int K, nR, pid_stride;
+    unsigned max_id;
+    int dbg;                     // MVIN_FOLD_DBG (measurement only; results wrong): 1 no G rows, 2 no products behind the gather, 4 none before it
+};
+
+template <int K>
+__global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(FoldArgs a) {
+    constexpr int D = 64, SPL = K / 16;
+    static_assert(K == 16 || K == 32, "K");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nRp = (a.nR + 3) & ~3;
+    float* sT = smem;                                    // [nRp] relation logits of aggregator (1,.), or exp(logit - max) of them
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    float* sUV = sT + nRp + wave * (16 * kAggUvLd + agg_list_words(K));      // this wave's [16 pairs][t -> out0 (64) | v -> Z2 (64) | pad]
+    unsigned* sLo = reinterpret_cast<unsigned*>(sUV + 16 * kAggUvLd) + g * (K + kAggPad);
+    float* sLw = reinterpret_cast<float*>(reinterpret_cast<unsigned*>(sUV + 16 * kAggUvLd) + 4 * (K + kAggPad)) + g * (K + kAggPad);
+    const bool att1 = a.t1 != nullptr;
+    const float invK = 1.f / (float)K;
+    const bool fast = agg_logit_table(a.t1, a.nR, sT, tid, lane);
+    __syncthreads();                                     // the only workgroup barrier
+
+    const int tbytes = (int)a.table_bytes;
+    const __amdgpu_buffer_rsrc_t aggS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.agg), 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t aggG = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<float*>(a.agg)) + a.table_bytes, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjE = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_e), 0, (int)a.adj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t adjR = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.adj_r), 0, (int)a.adj_bytes, 0x00020000);
+    const unsigned c16 = (unsigned)c * 16u;
+    if (c < kAggPad) {                                   // the padding behind a group's K slots: beyond the buffer, no weight
+        sLo[K + c] = kAggPadRow;
+        sLw[K + c] = 0.f;
+    }
+
+    const int64_t nbatch = (a.B + 15) >> 4;
+    const int64_t nwaves = (int64_t)gridDim.x * kAggWaves;
+    auto run = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        for (int64_t batch = (int64_t)blockIdx.x * kAggWaves + wave; batch < nbatch; batch += nwaves) {
+            const int64_t p_base = batch << 4;
+            // pair c of the batch in every group: its row of the launch and its entity id
+            const int64_t pr = min(p_base + c, a.B - 1);
+            const bool cvalid = p_base + c < a.B;
+            unsigned x0u = (unsigned)a.items[pr * a.pid_stride];
+            x0u = x0u < a.max_id ? x0u : a.max_id;
+            const int x0c = (int)x0u;
+            unsigned woff = ((unsigned)(4 * g) * (unsigned)D + (unsigned)c * 4u) * 4u;      // Wperm[4 g][c][0]
+            unsigned boff = (unsigned)g * 16u;
+            unsigned roff = (unsigned)pr * (unsigned)(D * 4) + (unsigned)g * 16u;     // floats [4 g, 4 g + 4) of row `pr` of a [B][64] array
+            asm volatile("" : "+v"(woff), "+v"(boff));   // (loop-invariant loads are not to be hoisted out of the batch loop)
+            // acc[ntp] (+)= sum over the k tiles of W[k][16 ntp + c] b[nt] -- 64 MFMAs.  A from the regrouped copy of the block (Wperm: the
+            // four tiles' values of a lane's k in one 16-byte load -- buffer loads, so that they are known not to alias the LDS traffic
+            // around them), the loads of k tile nt + 1 in flight under the MFMAs of tile nt
+            auto prod = [&](const float* Wp, const f32x4 (&b)[4], f32x4 (&acc)[4]) {
+                asm volatile("" : "+s"(Wp));             // (the descriptor is not to be kept in SGPRs across the batch loop: six of them and their k-tile bases were 1100 spills)
+                const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, D * D * 4, 0x00020000);
+                f32x4 wa[4], wb[4];
+                auto stage = [&](int nt, f32x4 (&w)[4]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (unsigned)(r * D * 4), nt * 16 * D * 4, 0);
+                        w[r] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+                    }
+                };
+                auto mm = [&](int nt, const f32x4 (&w)[4]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int ntp = 0; ntp < 4; ++ntp) acc[ntp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][ntp], b[nt][r], acc[ntp], 0, 0, 0);
+                    }
+                };
+                stage(0, wa);
+                stage(1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(0, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                stage(2, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(1, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                stage(3, wb);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2, wa);
+                mm(3, wb);
+            };
+            auto bias4 = [&](const float* bp, f32x4 (&acc)[4]) {
+                const char* bias = reinterpret_cast<const char*>(bp);
+#pragma unroll
+                for (int ntp = 0; ntp < 4; ++ntp)
+                    acc[ntp] = bias ? *reinterpret_cast<const f32x4*>(bias + 64 * ntp + (size_t)boff) : f32x4{0.f, 0.f, 0.f, 0.f};
+            };
+            f32x4 qm[4];
+            {
+                f32x4 qb[4];
+                const char* qbase = reinterpret_cast<const char*>(a.q);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) qb[nt] = *reinterpret_cast<const f32x4*>(qbase + 64 * nt + (size_t)roff);
+#pragma unroll
+                for (int mat = 0; mat < 2; ++mat) {
+                    f32x4 acc[4];
+                    bias4(mat == 0 ? a.bq : a.bv, acc);
+                    if (!(a.dbg & 4)) prod(mat == 0 ? a.Wq : a.Wv, qb, acc);
+#pragma unroll
+                    for (int ntp = 0; ntp < 4; ++ntp) *reinterpret_cast<f32x4*>(sUV + c * kAggUvLd + mat * D + 16 * ntp + 4 * g) = acc[ntp];
+                }
+                bias4(a.bm, qm);
+                if (!(a.dbg & 4)) prod(a.Wqm, qb, qm);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            const int nquad = (int)((min((int64_t)16, a.B - p_base) + 3) >> 2);
+            struct Quad {
+                unsigned ce[SPL], cr[SPL];
+                float4 s0;
+            };
+            auto quad_load = [&](int it) -> Quad {       // group g's pair of step `it`: j = 4 it + g
+                Quad qd;
+                const unsigned x0 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane & 48) + 4 * it + g) << 2, x0c);
+                agg_load_slots<SPL>(adjE, adjR, (x0 * (unsigned)K + (unsigned)(SPL * c)) * 4u, qd.ce, qd.cr);
+                qd.s0 = agg_row4(aggS, x0 * (unsigned)(D * 4) + c16);
+                return qd;
+            };
+            Quad nx = quad_load(0);
+            for (int it = 0; it < nquad; ++it) {
+                const int j = 4 * it + g;                // this group's pair of the batch
+                const bool pvalid = p_base + j < a.B;
+                const Quad qd = nx;
+                if (it + 1 < nquad) nx = quad_load(it + 1);
+                const unsigned (&ce)[SPL] = qd.ce;
+                const unsigned (&cr)[SPL] = qd.cr;
+                float* rowT = sUV + j * kAggUvLd + 4 * c;
+                const float4 tt = *reinterpret_cast<const float4*>(rowT);
+                const float4 vv = *reinterpret_cast<const float4*>(rowT + D);
+                float wk[SPL];
+                agg_row_weights<SPL, FAST>(cr, att1, sT, invK, wk);
+                int cc = (int)(cr[0] >> 24);
+                cc = pvalid ? (cc < 1 ? 1 : (cc > K ? K : cc)) : 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (the previous step's reads of the lists are done)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < SPL; ++i) {
+                    sLo[SPL * c + i] = ((cr[i] >> 16) & 0xFFu) ? (ce[i] & 0xFFFFFFu) * (unsigned)(D * 4) : kAggPadRow;
+                    sLw[SPL * c + i] = wk[i];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int kmax = (a.dbg & 1) ? 0 : __builtin_amdgcn_readfirstlane(agg_xor32_imax(agg_xor16_imax(cc)));
+                const f32x2 v01 = {vv.x, vv.y}, v23 = {vv.z, vv.w};
+                f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+                float4 ra[4], rb[4];
+                float4 wa, wb;
+                auto issue = [&](int k, float4 (&r)[4], float4& w) {
+                    const uint4 o4 = *reinterpret_cast<const uint4*>(sLo + k);
+                    w = *reinterpret_cast<const float4*>(sLw + k);
+                    r[0] = agg_row4(aggG, o4.x + c16), r[1] = agg_row4(aggG, o4.y + c16);
+                    r[2] = agg_row4(aggG, o4.z + c16), r[3] = agg_row4(aggG, o4.w + c16);
+                };
+                auto sum4 = [&](const float4 (&r)[4], const float4& w) {
+                    const float ws_[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x2 o01 = f32x2{r[t].x, r[t].y} + v01, o23 = f32x2{r[t].z, r[t].w} + v23;
+                        const f32x2 w2 = {ws_[t], ws_[t]};
+                        a01 = __builtin_elementwise_fma(w2, f32x2{fmaxf(o01[0], 0.f), fmaxf(o01[1], 0.f)}, a01);
+                        a23 = __builtin_elementwise_fma(w2, f32x2{fmaxf(o23[0], 0.f), fmaxf(o23[1], 0.f)}, a23);
+                    }
+                };
+                issue(0, ra, wa);
+                for (int k0 = 0; k0 < kmax; k0 += 8) {
+                    issue(k0 + 4, rb, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sum4(ra, wa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(k0 + 8, ra, wa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    sum4(rb, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // out0 = relu(H0[x] + t) ; Z2 = out0 + nagg1: this pair's two rows of the block, in place of t and v
+                const float4 o0 = make_float4(fmaxf(qd.s0.x + tt.x, 0.f), fmaxf(qd.s0.y + tt.y, 0.f), fmaxf(qd.s0.z + tt.z, 0.f),
+                                              fmaxf(qd.s0.w + tt.w, 0.f));
+                *reinterpret_cast<float4*>(rowT) = o0;
+                *reinterpret_cast<float4*>(rowT + D) = make_float4(a01[0] + o0.x, a01[1] + o0.y, a23[0] + o0.z, a23[1] + o0.w);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- out2 = relu(Z2 A1 + a1) ; item = M0[x] + m + out0 Wm1 + out2 Wm2 (+ bm, in m) ; score ----
+            {
+                f32x4 zb[4], o2[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) zb[nt] = *reinterpret_cast<const f32x4*>(sUV + c * kAggUvLd + D + 16 * nt + 4 * g);
+                bias4(a.a1, o2);
+                if (!(a.dbg & 2)) prod(a.A1, zb, o2);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    o2[nt] = f32x4{fmaxf(o2[nt][0], 0.f), fmaxf(o2[nt][1], 0.f), fmaxf(o2[nt][2], 0.f), fmaxf(o2[nt][3], 0.f)};
+                if (!(a.dbg & 2)) prod(a.Wm2, o2, qm);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) zb[nt] = *reinterpret_cast<const f32x4*>(sUV + c * kAggUvLd + 16 * nt + 4 * g);
+                if (!(a.dbg & 2)) prod(a.Wm1, zb, qm);
+                float part = 0.f;
+#pragma unroll
+                for (int ntp = 0; ntp < 4; ++ntp) {
+                    const f32x4 m0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.M0) + (size_t)x0u * (D * 4) + 64 * ntp + (size_t)boff);
+                    const f32x4 uo = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.user_o) + 64 * ntp + (size_t)roff);
+                    const f32x4 it4 = qm[ntp] + m0;
+                    if (a.item_emb && cvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.item_emb) + 64 * ntp + (size_t)roff) = it4;
+                    part += it4[0] * uo[0] + it4[1] * uo[1] + it4[2] * uo[2] + it4[3] * uo[3];
+                }
+                part = xor32_sum(xor16_sum(part));       // the four groups' quarters of pair c's row
+                if (g == 0 && cvalid) {
+                    a.scores[pr] = part;
+                    if (a.sig) a.sig[pr] = 1.f / (1.f + expf(-part));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next batch's block waits for this batch's reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    };
+    if (fast) run(std::true_type{});
+    else run(std::false_type{});
+}
+
+template <int K>
+static hipError_t launch_fold_k(const FoldArgs& a, hipStream_t st) {
+    const size_t lds = fused_agg_lds_bytes(a.nR, K);
+    static thread_local int per_cu = 0;
+    if (per_cu == 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(score_l2_folded_kernel<K>), kAggWaves * 64, lds) != hipSuccess || v < 1)
+            v = 4;
+        per_cu = v > 8 ? 8 : v;
+    }
+    const int64_t nbatch = (a.B + 15) >> 4;
+    const int64_t want = (nbatch + kAggWaves - 1) / kAggWaves;
+    const int64_t cap = 256 * (int64_t)per_cu;           // persistent grid
+    score_l2_folded_kernel<K><<<(int)(want < cap ? want : cap), kAggWaves * 64, lds, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32_t* adj_e, const int32_t* adj_r, const int32_t* items, int pid_stride,
+                                  const float* t1, const float* q, const float* user_o, const float* Wq, const float* bq, const float* Wv,
+                                  const float* bv, const float* Wqm, const float* A1, const float* a1, const float* Wm1, const float* Wm2,
+                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int nR, int n_entity,
+                                  hipStream_t st) {
+    FoldArgs f{};
+    f.agg = agg, f.M0 = M0, f.adj_e = adj_e, f.adj_r = adj_r, f.items = items, f.pid_stride = pid_stride, f.t1 = t1, f.q = q, f.user_o = user_o;
+    f.Wq = Wq, f.bq = bq, f.Wv = Wv, f.bv = bv, f.Wqm = Wqm, f.A1 = A1, f.a1 = a1, f.Wm1 = Wm1, f.Wm2 = Wm2, f.bm = bm;
+    f.item_emb = item_emb, f.scores = scores, f.sig = sig, f.B = B, f.K = K, f.nR = nR, f.max_id = (unsigned)(n_entity - 1);
+    f.table_bytes = (uint64_t)n_entity * 64 * 4, f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    static const char* dbg = getenv("MVIN_FOLD_DBG");
+    f.dbg = dbg ? atoi(dbg) : 0;
+    switch (K) {
+        case 16: return launch_fold_k<16>(f, st);
+        case 32: return launch_fold_k<32>(f, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 bool fused_agg_supported(int D, int K) { return D == 64 && (K == 16 || K == 32); }
@@ -390,21 +706,92 @@ bool fused_agg_applies(const FusedL2Args& a, int D) {
 }
 
 template <int K>
-static hipError_t launch_entity_aggregates_k(const FusedL2Args& a, hipStream_t st) {
+static hipError_t launch_entity_aggregates_k(const EntityAggArgs& a, hipStream_t st) {
     const size_t lds = ((size_t)((a.nR + 3) & ~3) + (size_t)kAggWaves * agg_list_words(K)) * sizeof(float);
-    const int64_t nquad = ((int64_t)a.max_id + 4) >> 2;
+    const int64_t nquad = ((int64_t)a.n_entity + 3) >> 2;
     const int64_t want = (nquad + kAggWaves - 1) / kAggWaves;
     const int64_t cap = 256 * 8;
     entity_aggregates_kernel<K><<<(int)(want < cap ? want : cap), kAggWaves * 64, lds, st>>>(a);
     return hipGetLastError();
 }
 
-hipError_t launch_entity_aggregates(const FusedL2Args& a, hipStream_t st) {
+hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st) {
     switch (a.K) {
         case 16: return launch_entity_aggregates_k<16>(a, st);
         case 32: return launch_entity_aggregates_k<32>(a, st);
         default: return hipErrorInvalidValue;
     }
+}
+
+// ---- folded-tail form: the per-call parameter block behind its four tables and two aggregates (mvin_fold_tables) ----
+//   Wstack [4][D][D] = W1.A0 | W2.A0 | W0.A0 | W0.Wm0     (the B operands of the table build: TA1 | TA2 | T0A | M0)
+//   Wv [D][D] = (W1 + c W2).A0      bv [D] = (b1 + c b2).A0 + a0        (the children's query term, as in the projected-tables form)
+//   Wq [D][D] = (W0 + c W1).A0      bq [D] = (b0 + c b1).A0 + a0        ((ev0 + nagg0) A0 + a0 = H0[x] + q Wq + bq)
+//   bm [D]    = bmix + b0.Wm0                                           (ev0 Wm0 = M0[x] + q W0.Wm0 + b0.Wm0)
+// Wm0 = the first D rows of the mix-hop combiner Wmix [3 D, D].  Block i < D: row i of the five products; block D: the biases.
+// Behind them, for the single-launch kernel (D = 64): Wperm [6][D][D] = Wq | Wv | Wqm | A1 | Wm1 | Wm2 with the columns of a row
+// regrouped, Wperm[k][c][ntp] = W[k][16 ntp + c] -- the four A values a lane needs for one k (one per 16-column tile) in ONE 16-byte load.
+__global__ void fold_prepare_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
+                                    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                    const float* __restrict__ A0, const float* __restrict__ a0, const float* __restrict__ Wmix,
+                                    const float* __restrict__ bmix, const float* __restrict__ A1, float c, int D, float* __restrict__ blk) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    float* Wstack = blk;
+    float* Wv = blk + (size_t)4 * D * D;
+    float* Wq = Wv + (size_t)D * D;
+    float* bv = Wq + (size_t)D * D;
+    float* bq = bv + D;
+    float* bm = bq + D;
+    if (j >= D) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, sm = 0.f;
+    for (int k0 = 0; k0 < D; k0 += 8) {                  // (eight steps' operands loaded before their FMAs)
+        float av[8], mv[8], x0[8], x1[8], x2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            av[k] = A0[(size_t)(k0 + k) * D + j];
+            mv[k] = Wmix[(size_t)(k0 + k) * D + j];
+            x0[k] = i < D ? W0[(size_t)i * D + k0 + k] : (b0 ? b0[k0 + k] : 0.f);
+            x1[k] = i < D ? W1[(size_t)i * D + k0 + k] : (b1 ? b1[k0 + k] : 0.f);
+            x2[k] = i < D ? W2[(size_t)i * D + k0 + k] : (b2 ? b2[k0 + k] : 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s0 = fmaf(x0[k], av[k], s0);
+            s1 = fmaf(x1[k], av[k], s1);
+            s2 = fmaf(x2[k], av[k], s2);
+            sm = fmaf(x0[k], mv[k], sm);
+        }
+    }
+    if (i < D) {
+        Wstack[(size_t)i * D + j] = s1;
+        Wstack[(size_t)D * D + (size_t)i * D + j] = s2;
+        Wstack[(size_t)2 * D * D + (size_t)i * D + j] = s0;
+        Wstack[(size_t)3 * D * D + (size_t)i * D + j] = sm;
+        Wv[(size_t)i * D + j] = fmaf(c, s2, s1);
+        Wq[(size_t)i * D + j] = fmaf(c, s1, s0);
+        if (D == 64) {
+            float* Wperm = bm + D;
+            const size_t o = (size_t)i * D + (size_t)(j & 15) * 4 + (size_t)(j >> 4);
+            const size_t DD = (size_t)D * D;
+            Wperm[o] = fmaf(c, s1, s0);
+            Wperm[DD + o] = fmaf(c, s2, s1);
+            Wperm[2 * DD + o] = sm;
+            Wperm[3 * DD + o] = A1[(size_t)i * D + j];
+            Wperm[4 * DD + o] = Wmix[DD + (size_t)i * D + j];
+            Wperm[5 * DD + o] = Wmix[2 * DD + (size_t)i * D + j];
+        }
+    } else {
+        const float av0 = a0 ? a0[j] : 0.f;
+        bv[j] = fmaf(c, s2, s1) + av0;
+        bq[j] = fmaf(c, s1, s0) + av0;
+        bm[j] = (bmix ? bmix[j] : 0.f) + sm;
+    }
+}
+
+hipError_t launch_fold_prepare(const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
+                               const float* a0, const float* Wmix, const float* bmix, const float* A1, float c, int D, float* blk, hipStream_t st) {
+    fold_prepare_kernel<<<D + 1, D < 64 ? 64 : D, 0, st>>>(W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, c, D, blk);
+    return hipGetLastError();
 }
 
 template <int K>

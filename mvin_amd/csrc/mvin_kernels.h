@@ -168,6 +168,43 @@ struct TailArgs {
     int dbg;                   // MVIN_TAIL_DBG (measurement only; results wrong): 1 no nagg / user_o loads, 2 one LDS read per product, 4 no stores
 };
 
+// entity_aggregates_kernel (mvin_fused_agg.hip): outS[e] = (selfS[e] +) sum_k w(e)_k tabS[y_ek], outG[e] = selfG[e] + sum_k w(e)_k tabG[y_ek]
+struct EntityAggArgs {
+    const float* tabS;         // [nE, 64] rows summed into outS (T1; folded-tail form: TA1)
+    const float* tabG;         // [nE, 64] rows summed into outG (TA2)
+    const float* selfS;        // [nE, 64] or NULL (folded-tail form: T0A)
+    const float* selfG;        // [nE, 64] (TA1)
+    const int32_t* adj_e;      // duplicate-slot encoding
+    const int32_t* adj_r;
+    const float* t0;           // [nR] relation logits of aggregator (0,.) or NULL (plain mean)
+    float* outS;               // [nE, 64]
+    float* outG;               // [nE, 64]
+    int n_entity, K, nR;
+    uint64_t table_bytes, adj_bytes;
+};
+
+// l2_tail_fold_kernel (mvin_tail.hip): the part of aggregate_delta_whole above the folded pair kernel
+//   out2 = relu(z2 A1 + a1) ;  item = M0[item] + q Wqm + out0 Wm1 + out2 Wm2 + bm ;  score = <user_o, item>
+struct TailFoldArgs {
+    const float* M0;           // [nE, 64] = E W0 Wm0 (per-call table)
+    const int64_t* items64;
+    const int32_t* items32;
+    const float* q;            // [B, 64]
+    const float* user_o;       // [B, 64]
+    const float* out0;         // [B, 64] from the folded pair kernel
+    const float* z2;           // [B, 64] out0 + nagg1
+    const float* Wqm;          // [64, 64] = W0 Wm0
+    const float* A1;
+    const float* a1;
+    const float* Wmix;         // [3 * 64, 64]: rows 64.. are Wm1 | Wm2
+    const float* bm;           // [64] = bmix + b0 Wm0
+    float* item_emb;           // [B, 64] or NULL
+    float* scores;
+    float* sig;
+    int64_t B;
+    int n_entity;
+};
+
 struct GatherMixArgs {
     const void* table;         // [nE, D] fp32 or bf16
     const int32_t* adj_e;      // [nE, K]
@@ -211,6 +248,8 @@ struct FusedL2Args {
     float* agg;                  // per-entity aggregates form (mvin_fused_agg.hip), or NULL: [2][nE][64] fp32, S0 | G -- written by
                                  // entity_aggregates_kernel from the projected tables (`table`) and the adjacency, read by
                                  // gather_attn_l2_agg_kernel in place of the tables
+    int fold;                    // gather_attn_l2_agg_kernel, folded-tail form (mvin_score_l2_folded_fwd): agg = H0 | G, W1 / b1 = Wq / bq;
+                                 // nagg0 <- out0 = relu(H0[x] + q Wq + bq), nagg1 <- out0 + sum_c (p1_c / K) relu(G[x_c] + v)
     int prj;                     // packed kernel over PROJECTED tables (mvin_gather_attn_l2_prj_fwd): `table` = [3][nE][D] fp32
                                  // (E.W1 | E.W1.A0 | E.W2.A0); W1 / b1 and W2 / b2 (= the combined (W1 + c W2).A0 and its bias)
                                  // project the PARENTS' queries only; A0 / a0 unused
@@ -399,7 +438,15 @@ bool fused_wpp_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_wpp(const FusedL2Args& a, hipStream_t st);
 bool fused_agg_supported(int D, int K);                       // per-entity aggregates S0 | G of the projected tables, dim 64 (mvin_fused_agg.hip)
 bool fused_agg_applies(const FusedL2Args& a, int D);
-hipError_t launch_entity_aggregates(const FusedL2Args& a, hipStream_t st);      // a.table (T1 | TA1 | TA2), a.adj_e / adj_r (encoding), a.t0 -> a.agg
+hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st);
+hipError_t launch_fold_prepare(const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
+                               const float* a0, const float* Wmix, const float* bmix, const float* A1, float c, int D, float* blk, hipStream_t st);   // mvin_fused_agg.hip
+hipError_t launch_l2_tail_fold(const TailFoldArgs& a, hipStream_t st);          // mvin_tail.hip (dim 64)
+hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32_t* adj_e, const int32_t* adj_r, const int32_t* items, int pid_stride,
+                                  const float* t1, const float* q, const float* user_o, const float* Wq, const float* bq, const float* Wv,
+                                  const float* bv, const float* Wqm, const float* A1, const float* a1, const float* Wm1, const float* Wm2,
+                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int nR, int n_entity,
+                                  hipStream_t st);                              // mvin_fused_agg.hip: the folded-tail form in one launch
 hipError_t launch_gather_attn_l2_agg(const FusedL2Args& a, hipStream_t st);     // a.agg, the encoding, a.t1, the query terms -> nagg0 / nagg1
 hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded = false);   // encoded: adj_e / adj_r = the duplicate-slot encoding
 bool fused_d16_supported(int D, int K);        // wave-per-parent variant for D = 16, K <= 16 (mvin_fused_d16.hip)

@@ -220,6 +220,153 @@ __global__ __launch_bounds__((D / 16) * 64) void l2_tail_kernel(TailArgs a) {
     }
 }
 
+// ---- folded-tail form (mvin_score_l2_folded_fwd), dim 64: the pair kernel (mvin_fused_agg.hip) has already left out0 = relu((ev0 +
+//      nagg0) A0 + a0) and Z2 = out0 + nagg1 -- through per-entity tables both are a gathered row plus a product of the query -- and
+//      ev0 itself only enters the combiner, where it is a gathered row plus a product of the query too:
+//        out2 = relu(Z2 A1 + a1) ;  item = M0[x] + q Wqm + out0 Wm1 + out2 Wm2 + bm            (M0 = E W0 Wm0, Wqm = W0 Wm0)
+//      FOUR products per pair instead of six, two barriers per tile instead of four; the tile machinery is l2_tail_kernel<64>'s
+//      (XOR-swizzled images, B fragments resident, every global read issued one tile ahead).
+__global__ __launch_bounds__(256) void l2_tail_fold_kernel(TailFoldArgs a) {
+    constexpr int D = 64, NT = 4, KS = 16, LD = 64, TM = 32, NTHR = 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sQ = smem;                   // [TM][LD]  q
+    float* sZ2 = sQ + TM * LD;          // Z2
+    float* sO0 = sZ2 + TM * LD;         // out0
+    float* sO2 = sO0 + TM * LD;         // out2
+    float* sSc = sO2 + TM * LD;         // [NT][TM] per-slab partial scores
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q16 = lane >> 4, l16 = lane & 15;
+    const int col = 16 * wave + l16;
+    auto at = [&](int row, int k) -> int { return row * LD + ((((k >> 2) ^ row) & 15) << 2) + (k & 3); };
+    auto hslot = [&](int j) -> int { return (12 * (q16 & 1)) ^ (4 * (q16 >> 1)) ^ j; };
+    float bQm[KS], bA1[KS], bC1[KS], bC2[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int kk = 4 * hslot(s >> 2) + (s & 3);
+        const size_t o = (size_t)kk * D + col;
+        bQm[s] = a.Wqm[o];
+        bA1[s] = a.A1[o];
+        bC1[s] = a.Wmix[(size_t)D * D + o];
+        bC2[s] = a.Wmix[(size_t)2 * D * D + o];
+    }
+    const float a1v = a.a1 ? a.a1[col] : 0.f;
+    const float bmv = a.bm[col];
+    auto mma = [&](const float* src, const float (&bf)[KS], f32x4 (&acc)[2]) {
+#pragma unroll
+        for (int s = 0; s < KS; s += 4) {
+            float4 av[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const float4*>(src + (16 * m + l16) * LD + ((hslot(s >> 2) ^ l16) << 2));
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].x, bf[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].x, bf[s], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].y, bf[s + 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].y, bf[s + 1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].z, bf[s + 2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].z, bf[s + 2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0].w, bf[s + 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1].w, bf[s + 3], acc[1], 0, 0, 0);
+        }
+    };
+    const int64_t ntiles = (a.B + TM - 1) / TM;
+    constexpr int XPT = TM * (D / 4) / NTHR;                // row chunks (4 floats) per thread and image: 2
+    // (plain arrays, copied element by element: as members of one struct the three float4 arrays stayed in scratch memory)
+    f32x4 nq[XPT], nz[XPT], no[XPT];      // (native vectors: arrays of HIP's float4 struct stayed in scratch memory here)
+    float nm0[2][4], nuo[2][4];
+    auto load_tile = [&](int64_t tile) {
+        const int64_t r0 = tile * TM;
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx / (D / 4), c = idx - row * (D / 4);
+            const int64_t r = min(r0 + row, a.B - 1);       // (rows past B: the last row again, never stored)
+            nq[i] = reinterpret_cast<const f32x4*>(a.q + r * D)[c];
+            nz[i] = reinterpret_cast<const f32x4*>(a.z2 + r * D)[c];
+            no[i] = reinterpret_cast<const f32x4*>(a.out0 + r * D)[c];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gr = min(r0 + 16 * m + 4 * q16 + r, a.B - 1);
+                int64_t it = a.items64 ? a.items64[gr] : (int64_t)a.items32[gr];
+                it = (int64_t)min((uint64_t)it, (uint64_t)(a.n_entity - 1));      // clamped into the table
+                nm0[m][r] = a.M0[it * D + col];
+                nuo[m][r] = a.user_o[gr * D + col];
+            }
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) load_tile(blockIdx.x);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * TM;
+        f32x4 cq[XPT], cz[XPT], co[XPT];
+        float cm0[2][4], cuo[2][4];
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) cq[i] = nq[i], cz[i] = nz[i], co[i] = no[i];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cm0[m][r] = nm0[m][r], cuo[m][r] = nuo[m][r];
+        }
+        __syncthreads();                                    // previous tile's buffers consumed
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int row = idx / (D / 4), c = idx - row * (D / 4);
+            *reinterpret_cast<f32x4*>(sQ + at(row, 4 * c)) = cq[i];
+            *reinterpret_cast<f32x4*>(sZ2 + at(row, 4 * c)) = cz[i];
+            *reinterpret_cast<f32x4*>(sO0 + at(row, 4 * c)) = co[i];
+        }
+        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);          // in flight under this tile's phases
+        __syncthreads();
+        // ---- out2 = relu(Z2 A1 + a1) ; the first two blocks of the combiner meanwhile (they do not need it) ----
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        {
+            f32x4 a2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mma(sZ2, bA1, a2);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sO2[at(16 * m + 4 * q16 + r, col)] = fmaxf(a2[m][r] + a1v, 0.f);
+            }
+            mma(sQ, bQm, acc);
+            mma(sO0, bC1, acc);
+        }
+        __syncthreads();
+        // ---- item = M0[x] + q Wqm + out0 Wm1 + out2 Wm2 + bm ; score ----
+        mma(sO2, bC2, acc);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * m + 4 * q16 + r;
+                const int64_t gr = r0 + row;
+                const float v = acc[m][r] + cm0[m][r] + bmv;
+                if (gr < a.B && a.item_emb) a.item_emb[gr * D + col] = v;
+                float part = cuo[m][r] * v;                     // (rows past B: never stored)
+                part = group_sum(part, 4);                      // the slab's 16 columns of this row
+                if (l16 == 0) sSc[wave * TM + row] = part;
+            }
+        }
+        __syncthreads();
+        if (tid < TM && r0 + tid < a.B) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT; ++w) s += sSc[w * TM + tid];      // fixed order: deterministic
+            a.scores[r0 + tid] = s;
+            if (a.sig) a.sig[r0 + tid] = 1.f / (1.f + expf(-s));
+        }
+    }
+}
+
+hipError_t launch_l2_tail_fold(const TailFoldArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(4 * 32 * 64 + 4 * 32) * 4;
+    const int64_t ntiles = (a.B + 31) / 32;
+    const int64_t cap = 256 * 4;
+    l2_tail_fold_kernel<<<(int)(ntiles < cap ? ntiles : cap), 256, lds, st>>>(a);
+    return hipGetLastError();
+}
+
 bool l2_tail_supported(int D) { return D == 16 || D == 32 || D == 64; }
 
 template <int D>

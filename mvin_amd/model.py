@@ -271,6 +271,9 @@ class MVIN(object):
         # kernels take (MVIN_L2_AGG=0 / 1 overrides: 0 answers through the library too)
         self.agg = {"0": False, "1": True}.get(os.environ.get("MVIN_L2_AGG", ""), None)
         self._agg_tables = {}                # per stream: workspace of mvin_entity_aggregates_elems floats, rewritten by every call
+        # folded-tail form of the native call (_fold_for): None = whenever the aggregates form is taken (MVIN_L2_FOLD=0 / 1 overrides)
+        self.fold = {"0": False, "1": True}.get(os.environ.get("MVIN_L2_FOLD", ""), None)
+        self._fold_ws = {}                   # per stream: workspace of mvin_fold_tables_elems floats, rewritten by every call
         # gathered form of the grouped key addressing (mvin_key_addressing_grouped_er_fwd, _ka_er_for): on request only
         self.ka_er = os.environ.get("MVIN_KA_ER", "0") == "1"
         self._ka_er_ws = {}                  # per stream: workspace of mvin_project_relations_elems floats, rewritten by every call
@@ -939,6 +942,12 @@ class MVIN(object):
             c = self._agg_ok_cache = (key, ops.gather_attn_l2_agg_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation))
         return c[1]
 
+    def _fold_for(self, enc):
+        """Folded-tail form of the native call (mvin_fold_tables -> mvin_score_l2_folded_fwd: the aggregates form with nagg0 and ev0
+        folded into per-entity tables too -- six products per pair instead of eight) wherever the aggregates form is taken by
+        mvin_score_l2_fwd (depth-2 trees, User_orient on).  ``self.fold`` False (MVIN_L2_FOLD=0) keeps aggregates + mvin_l2_tail_fwd."""
+        return self.fold is not False and bool(self.args.User_orient) and self._agg_for(enc)
+
     def _prj_plain_ok(self):
         """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
         where the library takes THAT kernel for this model's tables (mvin_gather_attn_l2_prj_supported: its LDS copy of the
@@ -1028,7 +1037,8 @@ class MVIN(object):
         # from the current parameters -- worth it when the batch's distinct children outnumber the entities (the per-entity
         # products cost ~n_entity rows of work, the per-child products they replace ~B K / 4)
         prj = (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B)
-        if prj:
+        fold = bool(prj and self._fold_for(enc))           # (its own workspace holds its own tables)
+        if prj and not fold:
             pt = self._prj_tables.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_project_tables_elems(self.n_entity, D)
             if pt is None or pt.numel() != n_ws:
@@ -1036,8 +1046,14 @@ class MVIN(object):
             s.prj_tables = pt.data_ptr()
         else:
             s.prj_tables = None
-        s.agg_tables = None
-        if prj and self._agg_for(enc):
+        s.agg_tables = s.fold_ws = None
+        if fold:
+            fw = self._fold_ws.get(stream.cuda_stream)
+            n_ws = _lib.load().mvin_fold_tables_elems(self.n_entity, D)
+            if fw is None or fw.numel() != n_ws:
+                fw = self._fold_ws[stream.cuda_stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+            s.fold_ws = fw.data_ptr()
+        elif prj and self._agg_for(enc):
             at = self._agg_tables.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_entity_aggregates_elems(self.n_entity, D)
             if at is None or at.numel() != n_ws:

@@ -47,3 +47,19 @@ us, a = timed(lambda: ops.gather_attn_l2_agg(ws, agg, enc_e, enc_r, items, t0, t
 print(f"aggregates form, as given:        {us:8.1f} us   max |diff| {float((a[0] - ref[0]).abs().max()):.2e} {float((a[1] - ref[1]).abs().max()):.2e}")
 us, a = timed(lambda: ops.gather_attn_l2_agg(ws, agg, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, nE, order=order))
 print(f"aggregates form, item order:      {us:8.1f} us   max |diff| {float((a[0] - ref[0]).abs().max()):.2e} {float((a[1] - ref[1]).abs().max()):.2e}")
+
+# ---- folded-tail form against aggregates + tail kernel (everything above key addressing) ----
+W0 = (torch.rand((D, D), device=dev, generator=g) - 0.5) / 8
+A1 = (torch.rand((D, D), device=dev, generator=g) - 0.5) / 8
+Wmix = (torch.rand((3 * D, D), device=dev, generator=g) - 0.5) / 8
+uo = torch.rand((B, D), device=dev, generator=g) - 0.5
+fw = ops.fold_tables(E, enc_e, enc_r, t0, W0, b[0], W[0], b[0], W[1], b[1], W[2], b[2], Wmix, b[0], A1, K, nR)
+us, _ = timed(lambda: ops.fold_tables(E, enc_e, enc_r, t0, W0, b[0], W[0], b[0], W[1], b[1], W[2], b[2], Wmix, b[0], A1, K, nR, out=fw))
+print(f"fold_tables (4 tables + H0 | G):  {us:8.1f} us")
+us, fo = timed(lambda: ops.score_l2_folded(fw, enc_e, enc_r, items, t0, t1, q, uo, A1, b[1], Wmix, K, D, nR, nE))
+print(f"score_l2_folded (2 launches):     {us:8.1f} us")
+def unfolded():
+    n0, n1 = ops.gather_attn_l2_agg(ws, agg, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, nE)
+    return ops.l2_tail(E, items, q, uo, n0, n1, W0, b[0], W[2], b[2], A1, b[1], Wmix, b[0])
+us, un = timed(unfolded)
+print(f"aggregates launch + l2_tail:      {us:8.1f} us   max |score diff| {float((fo[1] - un[1]).abs().max()):.2e} of {float(un[1].abs().max()):.2e}")

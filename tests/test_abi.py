@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in header_functions():
         assert hasattr(hip_lib, name), f"{name} declared in include/mvin_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in mvin_amd/_lib.py"
-    assert hip_lib.mvin_abi_version() == _lib.ABI_VERSION == 11
+    assert hip_lib.mvin_abi_version() == _lib.ABI_VERSION == 12
 
 
 def test_dynamic_symbol_table_is_exactly_the_header(hip_lib):

@@ -31,7 +31,12 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
     assert took_prj == (name in ("C3", "C2")), f"{name}: projected-tables form taken = {took_prj}"
     got = model.forward_users(users, items, uts)
     torch.cuda.synchronize()
-    if took_prj:          # the workspace mvin_score_l2_fwd wrote the three projected tables into exists: the form really ran
+    took_agg = bool(took_prj and model._agg_for(model._enc_for_l2(n_parents=B)))
+    assert took_agg == (name == "C3"), f"{name}: per-entity aggregates form taken = {took_agg}"
+    if took_agg:          # ... in its folded-tail form (mvin_fold_tables -> mvin_score_l2_folded_fwd): the workspace of that call exists
+        assert model._fold_for(model._enc_for_l2(n_parents=B)) and any(t is not None for t in model._fold_ws.values()), \
+            "mvin_fold_tables was not called"
+    elif took_prj:        # the workspace mvin_score_l2_fwd wrote the three projected tables into exists: the form really ran
         assert any(t is not None for t in model._prj_tables.values()), "mvin_project_tables was not called"
     if name == "C3":
         assert model._uts_records is not None, "static per-user records were expected at C3"
@@ -72,6 +77,21 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
         torch.cuda.synchronize()
         assert_close(s_users, other.scores.cpu().numpy(), f"{name}: projected tables vs per-row projection over {B} pairs")
         model.prj = None
+    if took_agg:
+        # (d') the per-entity aggregates of the projected tables against the wave-per-parent kernel over the tables themselves, whole batch
+        model.agg = False
+        other = model.forward_users(users, items, uts)
+        torch.cuda.synchronize()
+        assert_close(s_users, other.scores.cpu().numpy(), f"{name}: per-entity aggregates vs the kernel over the projected tables, {B} pairs")
+        model.agg = None
+        # (d'') the folded-tail form the rule took against aggregates + mvin_l2_tail_fwd, whole batch, scores and item embeddings
+        model.fold = False
+        other = model.forward_users(users, items, uts)
+        torch.cuda.synchronize()
+        assert any(t is not None for t in model._agg_tables.values()), "mvin_entity_aggregates was not called"
+        assert_close(s_users, other.scores.cpu().numpy(), f"{name}: folded tail vs aggregates + tail kernel, {B} pairs")
+        assert_close(got.item_embeddings[:4096].cpu().numpy(), other.item_embeddings[:4096].cpu().numpy(), f"{name}: item embeddings, folded tail")
+        model.fold = None
     if name == "C3":
         # (e) the other forms of the grouped key addressing, whole batch: the kernel over the static records + the MLP launch, and its
         #     gathered form (R_KGE[r] . E[h] per (relation, entity), rebuilt per call) -- against the flash form the automatic rule took

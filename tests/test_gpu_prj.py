@@ -454,6 +454,62 @@ def test_entity_aggregates_form_every_distinct_count(K, hip_lib):
     assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1, K parents per pair", rtol=3e-5, atol=6e-6)
 
 
+@pytest.mark.parametrize("K", [16, 32])
+def test_folded_tail_form_matches_aggregates_plus_tail(K, hip_lib):
+    """mvin_fold_tables -> mvin_score_l2_folded_fwd (H0 | G aggregates, M0 table, four products in the tail) against mvin_project_tables ->
+    mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd -> mvin_l2_tail_fwd on the same parameters: every distinct-children count, ragged
+    batches (tiles of 32 and quads of 4 partly filled), int64 and int32 items, with and without attention / biases."""
+    D, nR, n_entity = 64, 7, 603
+    rng = np.random.default_rng(K + 200)
+    adj_e = np.zeros((n_entity, K), dtype=np.int64)
+    adj_r = np.zeros((n_entity, K), dtype=np.int64)
+    for x in range(n_entity):
+        nd = x % K + 1
+        ne = rng.choice(n_entity, nd, replace=False)
+        nr = rng.integers(0, nR, nd)
+        pick = np.concatenate([np.arange(nd), rng.integers(0, nd, K - nd)])
+        rng.shuffle(pick)
+        adj_e[x], adj_r[x] = ne[pick], nr[pick]
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    E = f(n_entity, D)
+    ae, ar = torch.from_numpy(adj_e.astype(np.int32)).to(dev), torch.from_numpy(adj_r.astype(np.int32)).to(dev)
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    assert ops.score_l2_folded_supported(D, K, n_entity, nR)
+    W0, W1, W2, A0, A1, Wmix = f(D, D), f(D, D), f(D, D), f(D, D), f(D, D), f(3 * D, D)
+    for B, att, bias, i64 in ((4 * K + 37, 1.0, True, True), (1, 1.0, True, False), (33, 130.0, True, True), (95, False, False, False)):
+        b0, b1, b2, a0, a1, bmix = (f(D) if bias else None for _ in range(6))
+        items = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64 if i64 else np.int32)).to(dev)
+        q, user_o = f(B, D), f(B, D)
+        t0 = f(nR) * att if att else None
+        t1 = f(nR) * att if att else None
+        ws = ops.fold_tables(E, enc_e, enc_r, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, K, nR)
+        item, scores, sig = ops.score_l2_folded(ws, enc_e, enc_r, items, t0, t1, q, user_o, A1, a1, Wmix, K, D, nR, n_entity)
+        torch.cuda.synchronize()
+        pt = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, bool(att))
+        agg = ops.entity_aggregates(pt, enc_e, enc_r, t0, K, D, nR, n_entity)
+        n0, n1 = ops.gather_attn_l2_agg(pt, agg, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, n_entity)
+        want_item, want_scores, want_sig = ops.l2_tail(E, items, q, user_o, n0, n1, W0, b0, A0, a0, A1, a1, Wmix, bmix)
+        torch.cuda.synchronize()
+        assert_close(item.cpu().numpy(), want_item.cpu().numpy(), f"item_emb B={B}", rtol=3e-5, atol=3e-5)
+        assert_close(scores.cpu().numpy(), want_scores.cpu().numpy(), f"scores B={B}", rtol=3e-5, atol=3e-5)
+        assert_close(sig.cpu().numpy(), want_sig.cpu().numpy(), f"sigmoid B={B}", rtol=3e-5, atol=1e-5)
+        # the definitions of H0 and M0 (float64)
+        if B > 100:
+            tab = n_entity * D
+            T = ws[: 6 * tab].view(6, n_entity, D).double()
+            c = (1.0 / K) if att else 1.0
+            lg = t0.double()[ar.long()] if att else torch.zeros((n_entity, K), dtype=torch.float64, device=dev)
+            w = torch.softmax(lg, dim=1) / K if att else torch.full_like(lg, 1.0 / K)
+            Ed = E.double()
+            TA1 = Ed @ W1.double() @ A0.double()
+            H0 = Ed @ W0.double() @ A0.double() + (w[:, :, None] * TA1[ae.long()]).sum(1)
+            M0 = Ed @ W0.double() @ Wmix[:D].double()
+            assert_close(T[4].cpu().numpy(), H0.cpu().numpy(), "H0", rtol=2e-5, atol=5e-6)
+            assert_close(T[3].cpu().numpy(), M0.cpu().numpy(), "M0", rtol=2e-5, atol=5e-6)
+            assert c > 0
+
+
 def test_order_by_key_is_a_bucket_partition(hip_lib):
     """mvin_order_by_key: a permutation in which the keys' buckets (low 14 bits) are contiguous and ascending; any key skew, both widths."""
     dev = "cuda:0"
