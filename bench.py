@@ -868,8 +868,15 @@ def main():
         prj_now = (used_l2 and not hoisted and (enc is not None or model._prj_plain_ok())
                    and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2)))
         agg_now = bool(prj_now and model._agg_for(enc))
+        fold_now = bool(agg_now and L == 2 and model._fold_for(enc))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
+                 else "linear_mfma_kernel + entity_aggregates_kernel<%d> + score_l2_folded_kernel<%d> (mvin_fold_tables -> mvin_score_l2_folded_fwd: "
+                      "EVERYTHING above key addressing -- four per-entity tables E.W1.A0 | E.W2.A0 | E.W0.A0 | E.W0.Wm0 and the aggregates H0 | G, all "
+                      "rebuilt inside every step from the current parameters, then ONE launch that takes a pair from its item id and query row to "
+                      "its score: six 64 x 64 products on the matrix cores around the gather of its distinct children's G rows; the same sums in "
+                      "another association)" % (a.fanout, a.fanout)
+                 if fold_now
                  else "entity_aggregates_kernel<%d> + gather_attn_l2_agg_kernel<%d> (mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd: per-entity "
                       "aggregates S0 | G of the projected tables E.W1 | E.W1.A0 | E.W2.A0, all rebuilt inside every step from the current parameters; a "
                       "pair then gathers its distinct children's G rows and one S0 row -- the same sums in another association)" % (a.fanout, a.fanout)
@@ -931,6 +938,13 @@ def main():
                 adj_rows = 1.0
                 per_entity = float(((2 * cnt.double() + 1) * a.dim * 4 + K_ * 8 + 2 * a.dim * 4).sum()) / Bl
                 loaded_bpp = rows_loaded * a.dim * 4 + K_ * 8 + 3 * a.dim * 4 + per_entity
+                if fold_now:
+                    # folded tail, one launch: per pair H0[x], M0[x] and its distinct children's G rows, its adjacency row, its query and
+                    # user_o rows, the item embedding written, the score; per ENTITY and step E[e] read and four table rows written (table
+                    # build), then the aggregates kernel as above with one more self row (T0A[e])
+                    rows_loaded = float((2 + cnt[it].double()).mean())
+                    per_entity = float(((2 * cnt.double() + 2) * a.dim * 4 + K_ * 8 + 2 * a.dim * 4 + 5 * a.dim * 4).sum()) / Bl
+                    loaded_bpp = rows_loaded * a.dim * 4 + K_ * 8 + 3 * a.dim * 4 + 8 + per_entity
                 timed["aggregates_build_bytes_per_step"] = per_entity * Bl
             else:
                 loaded_bpp = rows_loaded * a.dim * s_ + adj_rows * K_ * 8 + a.dim * 4 + 4
@@ -939,6 +953,9 @@ def main():
                           "rows_per_pair_faithful": 1 + K_ + K_ * K_, "rows_per_pair_loaded": rows_loaded,
                           "adjacency_rows_per_pair_loaded": adj_rows,
                           "distinct_slots_per_adjacency_row": frac_distinct * K_,
+                          "folded_note": ("folded-tail form: `avg_launch_ms` covers mvin_fold_tables (parameter block, four-table build, aggregates) AND "
+                                          "the scoring launch -- everything above key addressing, mvin_l2_tail_fwd's work included; MVIN_L2_FOLD=0 "
+                                          "times aggregates + tail kernel, MVIN_L2_AGG=0 the kernel over the projected tables") if fold_now else None,
                           "aggregates_note": ("aggregates form: `avg_launch_ms` covers BOTH launches (aggregates over all %d entities + the per-pair "
                                               "gather); a pair's rows come from the 27 MB G table, not from its grandchildren's rows of three tables "
                                               "(rows_per_pair_loaded ~ 1 + its distinct children; the wave-per-parent kernel over the tables loaded "
@@ -1062,7 +1079,10 @@ def main():
                                                                              if (model._item_order_for(Bl) and not agg_now) else ")") if enc is not None
                                                                             else " over the plain adjacency)")
                                            + ("; per-entity aggregates S0 | G of those tables rebuilt inside every timed step too: mvin_entity_aggregates + "
-                                              "mvin_gather_attn_l2_agg_fwd in place of mvin_gather_attn_l2_prj_fwd" if agg_now else "")) if prj_now else
+                                              "mvin_gather_attn_l2_agg_fwd in place of mvin_gather_attn_l2_prj_fwd" if (agg_now and not fold_now) else "")
+                                           if not fold_now else
+                                           "folded tail over per-entity aggregates (E.W1.A0 | E.W2.A0 | E.W0.A0 | E.W0.Wm0 and H0 | G rebuilt inside every "
+                                           "timed step: mvin_fold_tables; then mvin_score_l2_folded_fwd, one launch from item id to score)") if prj_now else
                                           "encoded adjacency" if enc is not None else "plain adjacency"),
                        "entity_table_dtype": a.table_dtype, "arithmetic": "f32", "entity_table_mode": a.hoist,
                        "feed_mode": "pairs" if (a.feed == "pairs" or scorer is not None) else "users",

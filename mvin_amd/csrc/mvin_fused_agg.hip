@@ -499,6 +499,16 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
                         for (int ntp = 0; ntp < 4; ++ntp) acc[ntp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][ntp], b[nt][r], acc[ntp], 0, 0, 0);
                     }
                 };
+                if (a.dbg & 16) {                        // (measurement: half the A loads)
+                    stage(0, wa);
+                    stage(1, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(0, wa);
+                    mm(1, wb);
+                    mm(2, wa);
+                    mm(3, wb);
+                    return;
+                }
                 stage(0, wa);
                 stage(1, wb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            const int nquad = (int)((min((int64_t)16, a.B - p_base) + 3) >> 2);
+            const int nquad = (a.dbg & 8) ? 0 : (int)((min((int64_t)16, a.B - p_base) + 3) >> 2);
             struct Quad {
                 unsigned ce[SPL], cr[SPL];
                 float4 s0;

@@ -650,8 +650,31 @@ class MVIN(object):
             uo = self.args.User_orient
             enc = self._enc_for_l2(want_probs, n_parents=B * K ** (L - 2))
             tabs = None
+            prj_now = not want_probs and (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B, B * K ** (L - 2))
+            if prj_now and use_tail and self._fold_for(enc) and self.entity_emb_matrix.dtype == torch.float32:
+                # folded-tail form (mvin_fold_tables -> mvin_score_l2_folded_fwd): tables and aggregates from the current parameters,
+                # then everything above key addressing in one launch -- what mvin_score_l2_fwd runs for this call
+                Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
+                cs = torch.cuda.current_stream().cuda_stream
+                n_ws = ops._lib.load().mvin_fold_tables_elems(self.n_entity, D)
+                fw = self._fold_ws.get(cs)
+                if fw is None or fw.numel() != n_ws:
+                    fw = self._fold_ws[cs] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
+                t0 = a0.relation_scores() if a0.User_orient_rela else None
+                t1 = a1.relation_scores() if a1.User_orient_rela else None
+                if self._profile is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                ops.fold_tables(self.entity_emb_matrix, enc[0], enc[1], t0, Wp[0], bp[0], Wp[1], bp[1], Wp[2], bp[2], a0.weights, a0.bias,
+                                self.enti_transfer_matrix_list[0], self.enti_transfer_bias_list[0], a1.weights, K, self.n_relation, out=fw)
+                item_emb, scores, sig = ops.score_l2_folded(fw, enc[0], enc[1], item32, t0, t1, q, user_o, a1.weights, a1.bias,
+                                                            self.enti_transfer_matrix_list[0], K, D, self.n_relation, self.n_entity)
+                if self._profile is not None:
+                    e1.record()
+                    self._profile.append((e0, e1))
+                return item_emb, scores, sig, []
             # (the projected-tables kernels write no attention outputs: a want_probs pass keeps the form that does)
-            if not want_probs and (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B, B * K ** (L - 2)):
+            if prj_now:
                 # projected-tables form (mvin_gather_attn_l2_prj_fwd): E.W1 | E.W1.A0 | E.W2.A0 from the current parameters, per call
                 Wp, bp = self.transfer_matrix_list, self.transfer_matrix_bias
                 tabs = ops.project_tables(self.entity_emb_matrix, Wp[L - 1], Wp[L], bp[L - 1], bp[L], a0.weights, a0.bias, K,
