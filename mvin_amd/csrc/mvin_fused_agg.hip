@@ -431,7 +431,7 @@ struct FoldArgs {
     uint64_t table_bytes, adj_bytes;
     int K, nR, pid_stride;
     unsigned max_id;
-    int dbg;                     // MVIN_FOLD_DBG (measurement only; results wrong): 1 no G rows, 2 no products behind the gather, 4 none before it
+    int dbg;                     // MVIN_FOLD_DBG (measurement only; results wrong): 1 no G rows, 2 no products behind the gather, 4 none before it, 8 no gather steps
 };
 
 template <int K>
@@ -499,16 +499,6 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
                         for (int ntp = 0; ntp < 4; ++ntp) acc[ntp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][ntp], b[nt][r], acc[ntp], 0, 0, 0);
                     }
                 };
-                if (a.dbg & 16) {                        // (measurement: half the A loads)
-                    stage(0, wa);
-                    stage(1, wb);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mm(0, wa);
-                    mm(1, wb);
-                    mm(2, wa);
-                    mm(3, wb);
-                    return;
-                }
                 stage(0, wa);
                 stage(1, wb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -675,6 +665,7 @@ static hipError_t launch_fold_k(const FoldArgs& a, hipStream_t st) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(score_l2_folded_kernel<K>), kAggWaves * 64, lds) != hipSuccess || v < 1)
             v = 4;
         per_cu = v > 8 ? 8 : v;
+        if (const char* e = getenv("MVIN_FOLD_WGS")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;      // (measurement: workgroups per CU)
     }
     const int64_t nbatch = (a.B + 15) >> 4;
     const int64_t want = (nbatch + kAggWaves - 1) / kAggWaves;

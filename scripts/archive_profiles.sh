@@ -24,4 +24,16 @@ done
 cp $g/bench_variants.jsonl $d/${p}_bench_variants.jsonl
 cp $g/bench_default_$tag.json $d/${p}_default_bench.json
 cp $g/dma_probe_$tag.txt $d/${p}_gather_ceiling_dma_probe.txt
+# round 6: the flash key-addressing kernel, the folded-tail kernel and the forms of the two deepest levels (scripts/collect_r6.sh)
+cp $g/pmc_${tag}_flash/counters.json $d/${p}_flash_keyaddr_sq_tcc_counters.json 2>/dev/null
+f=$(ls $g/pmc_${tag}_flash/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $d/${p}_flash_keyaddr_kernel_stats.csv
+cp $g/pmc_${tag}_fold/counters.json $d/${p}_folded_kernel_sq_tcc_counters.json 2>/dev/null
+f=$(ls $g/pmc_${tag}_fold/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $d/${p}_two_level_forms_kernel_stats.csv
+cp $g/bench_agg_$tag.txt $d/${p}_two_level_forms_microbench.txt 2>/dev/null
+cp $g/fold_phases_$tag.txt $d/${p}_folded_kernel_phase_ablation.txt 2>/dev/null
+cp $g/bench_ka_flash_$tag.txt $d/${p}_keyaddr_forms_microbench.txt 2>/dev/null
+cp $g/trace_flash_$tag.txt $d/${p}_flash_keyaddr_stage_trace.txt 2>/dev/null
+for b in b512 b4096; do
+  [ -f $g/kt_${tag}_${b}_kernel_stats.csv ] && cp $g/kt_${tag}_${b}_kernel_stats.csv $d/${p}_train_${b}_kernel_stats.csv
+done
 ls -la $d | grep " ${p}_"
