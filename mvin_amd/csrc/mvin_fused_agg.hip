@@ -435,7 +435,7 @@ struct FoldArgs {
 };
 
 template <int K>
-__global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(FoldArgs a) {
+__global__ __launch_bounds__(kAggWaves * 64, 3) void score_l2_folded_kernel(FoldArgs a) {
     constexpr int D = 64, SPL = K / 16;
     static_assert(K == 16 || K == 32, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -478,40 +478,41 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
             unsigned boff = (unsigned)g * 16u;
             unsigned roff = (unsigned)pr * (unsigned)(D * 4) + (unsigned)g * 16u;     // floats [4 g, 4 g + 4) of row `pr` of a [B][64] array
             asm volatile("" : "+v"(woff), "+v"(boff));   // (loop-invariant loads are not to be hoisted out of the batch loop)
-            // acc[ntp] (+)= sum over the k tiles of W[k][16 ntp + c] b[nt] -- 64 MFMAs.  A from the regrouped copy of the block (Wperm: the
-            // four tiles' values of a lane's k in one 16-byte load -- buffer loads, so that they are known not to alias the LDS traffic
-            // around them), the loads of k tile nt + 1 in flight under the MFMAs of tile nt
-            auto prod = [&](const float* Wp, const f32x4 (&b)[4], f32x4 (&acc)[4]) {
-                asm volatile("" : "+s"(Wp));             // (the descriptor is not to be kept in SGPRs across the batch loop: six of them and their k-tile bases were 1100 spills)
-                const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, D * D * 4, 0x00020000);
-                f32x4 wa[4], wb[4];
-                auto stage = [&](int nt, f32x4 (&w)[4]) {
+            // THREE products as one chain of 12 k tiles, acc_j[ntp] += sum over k of W_j[k][16 ntp + c] b_j[nt] (64 MFMAs each).  A from the
+            // regrouped copies of the blocks (Wperm: the four column tiles' values of a lane's k in one 16-byte load -- buffer loads, so that
+            // they are known not to alias the LDS traffic around them) through a ring of three register buffers: the loads of k tiles
+            // s + 1 and s + 2 are in flight under the MFMAs of tile s, across the products' boundaries.  `between(j)` runs behind product j.
+            auto chain3 = [&](const float* W0p, const float* W1p, const float* W2p, const f32x4 (&b0)[4], const f32x4 (&b1)[4], const f32x4 (&b2)[4],
+                              f32x4 (&acc0)[4], f32x4 (&acc1)[4], f32x4 (&acc2)[4], auto&& between) {
+                asm volatile("" : "+s"(W0p), "+s"(W1p), "+s"(W2p));      // (descriptors and k-tile bases are not to live in SGPRs across the batch loop: 1 100 spills)
+                const __amdgpu_buffer_rsrc_t wr[3] = {__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W0p), 0, D * D * 4, 0x00020000),
+                                                      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W1p), 0, D * D * 4, 0x00020000),
+                                                      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W2p), 0, D * D * 4, 0x00020000)};
+                f32x4 ring[3][4];
+                auto load = [&](auto s_) {
+                    constexpr int s = decltype(s_)::value, j = s / 4, nt = s % 4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr, woff + (unsigned)(r * D * 4), nt * 16 * D * 4, 0);
-                        w[r] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wr[j], woff + (unsigned)(r * D * 4), nt * 16 * D * 4, 0);
+                        ring[s % 3][r] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
                     }
                 };
-                auto mm = [&](int nt, const f32x4 (&w)[4]) {
+                load(std::integral_constant<int, 0>{});
+                load(std::integral_constant<int, 1>{});
+                static_for<12>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value, j = s / 4, nt = s % 4;
+                    if constexpr (s + 2 < 12) load(std::integral_constant<int, s + 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    const f32x4 (&b)[4] = j == 0 ? b0 : j == 1 ? b1 : b2;
+                    f32x4 (&acc)[4] = j == 0 ? acc0 : j == 1 ? acc1 : acc2;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int ntp = 0; ntp < 4; ++ntp) acc[ntp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][ntp], b[nt][r], acc[ntp], 0, 0, 0);
+                        for (int ntp = 0; ntp < 4; ++ntp) acc[ntp] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[s % 3][r][ntp], b[nt][r], acc[ntp], 0, 0, 0);
                     }
-                };
-                stage(0, wa);
-                stage(1, wb);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(0, wa);
-                __builtin_amdgcn_sched_barrier(0);
-                stage(2, wa);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(1, wb);
-                __builtin_amdgcn_sched_barrier(0);
-                stage(3, wb);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(2, wa);
-                mm(3, wb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (nt == 3) between(std::integral_constant<int, j>{});
+                });
             };
             auto bias4 = [&](const float* bp, f32x4 (&acc)[4]) {
                 const char* bias = reinterpret_cast<const char*>(bp);
@@ -519,22 +520,24 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
                 for (int ntp = 0; ntp < 4; ++ntp)
                     acc[ntp] = bias ? *reinterpret_cast<const f32x4*>(bias + 64 * ntp + (size_t)boff) : f32x4{0.f, 0.f, 0.f, 0.f};
             };
-            f32x4 qm[4];
+            f32x4 qm[4], qb[4];
             {
-                f32x4 qb[4];
                 const char* qbase = reinterpret_cast<const char*>(a.q);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) qb[nt] = *reinterpret_cast<const f32x4*>(qbase + 64 * nt + (size_t)roff);
-#pragma unroll
-                for (int mat = 0; mat < 2; ++mat) {
-                    f32x4 acc[4];
-                    bias4(mat == 0 ? a.bq : a.bv, acc);
-                    if (!(a.dbg & 4)) prod(mat == 0 ? a.Wq : a.Wv, qb, acc);
-#pragma unroll
-                    for (int ntp = 0; ntp < 4; ++ntp) *reinterpret_cast<f32x4*>(sUV + c * kAggUvLd + mat * D + 16 * ntp + 4 * g) = acc[ntp];
-                }
+                f32x4 at[4], av[4];
+                bias4(a.bq, at);
+                bias4(a.bv, av);
                 bias4(a.bm, qm);
-                if (!(a.dbg & 4)) prod(a.Wqm, qb, qm);
+                if (!(a.dbg & 4))
+                    chain3(a.Wq, a.Wv, a.Wqm, qb, qb, qb, at, av, qm, [&](auto j_) {
+                        constexpr int j = decltype(j_)::value;
+                        if constexpr (j < 2) {           // t, then v: into the pairs' LDS rows
+                            const f32x4 (&acc)[4] = j == 0 ? at : av;
+#pragma unroll
+                            for (int ntp = 0; ntp < 4; ++ntp) *reinterpret_cast<f32x4*>(sUV + c * kAggUvLd + j * D + 16 * ntp + 4 * g) = acc[ntp];
+                        }
+                    });
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -620,23 +623,27 @@ __global__ __launch_bounds__(kAggWaves * 64, 4) void score_l2_folded_kernel(Fold
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- out2 = relu(Z2 A1 + a1) ; item = M0[x] + m + out0 Wm1 + out2 Wm2 (+ bm, in m) ; score ----
             {
-                f32x4 zb[4], o2[4];
+                f32x4 zb[4], ob[4], o2[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) zb[nt] = *reinterpret_cast<const f32x4*>(sUV + c * kAggUvLd + D + 16 * nt + 4 * g);
                 bias4(a.a1, o2);
-                if (!(a.dbg & 2)) prod(a.A1, zb, o2);
+                // Z2 A1 -> out2 (its accumulators, through the ReLU, are the third product's B operand); out0 Wm1 and out2 Wm2 into the item row
+                if (!(a.dbg & 2))
+                    chain3(a.A1, a.Wm1, a.Wm2, zb, ob, o2, o2, qm, qm, [&](auto j_) {
+                        if constexpr (decltype(j_)::value == 0) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    o2[nt] = f32x4{fmaxf(o2[nt][0], 0.f), fmaxf(o2[nt][1], 0.f), fmaxf(o2[nt][2], 0.f), fmaxf(o2[nt][3], 0.f)};
-                if (!(a.dbg & 2)) prod(a.Wm2, o2, qm);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) zb[nt] = *reinterpret_cast<const f32x4*>(sUV + c * kAggUvLd + 16 * nt + 4 * g);
-                if (!(a.dbg & 2)) prod(a.Wm1, zb, qm);
+                            for (int nt = 0; nt < 4; ++nt) {
+                                o2[nt] = f32x4{fmaxf(o2[nt][0], 0.f), fmaxf(o2[nt][1], 0.f), fmaxf(o2[nt][2], 0.f), fmaxf(o2[nt][3], 0.f)};
+                                ob[nt] = *reinterpret_cast<const f32x4*>(sUV + c * kAggUvLd + 16 * nt + 4 * g);      // out0: the second product's B operand
+                            }
+                        }
+                    });
+                const bool uo_is_q = a.user_o == a.q;     // (default wiring: the query IS user_o -- its rows are in registers since the batch's top)
                 float part = 0.f;
 #pragma unroll
                 for (int ntp = 0; ntp < 4; ++ntp) {
                     const f32x4 m0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.M0) + (size_t)x0u * (D * 4) + 64 * ntp + (size_t)boff);
-                    const f32x4 uo = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.user_o) + 64 * ntp + (size_t)roff);
+                    const f32x4 uo = uo_is_q ? qb[ntp] : *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.user_o) + 64 * ntp + (size_t)roff);
                     const f32x4 it4 = qm[ntp] + m0;
                     if (a.item_emb && cvalid) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.item_emb) + 64 * ntp + (size_t)roff) = it4;
                     part += it4[0] * uo[0] + it4[1] * uo[1] + it4[2] * uo[2] + it4[3] * uo[3];
