@@ -244,7 +244,7 @@ static int gather_attn_l2_impl(const void* table, const int32_t* adj_entity, con
         f.agg = const_cast<float*>(agg);
         f.order = order;
         if (!(prj && encoded && mvin::fused_agg_applies(f, D) && (!order || parents_per_pair == 1)))
-            return fail(-3, "mvin_gather_attn_l2_agg_fwd: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency and outputs < 2 GiB "
+            return fail(-3, "mvin_gather_attn_l2_agg_fwd: D = 64, K in {16, 32, 64}, n_entity <= 2^24, tables < 1 GiB, adjacency and outputs < 2 GiB "
                             "(a parent order: one parent per pair)");
         return hip_result(mvin::launch_gather_attn_l2_agg(f, (hipStream_t)stream), "mvin_gather_attn_l2_agg_fwd");
     }
@@ -435,7 +435,7 @@ int mvin_entity_aggregates(const float* ws, const int32_t* enc_entity, const int
     const char* who = "mvin_entity_aggregates";
     if (!ws || !enc_entity || !enc_relation || !agg) return fail(-1, "%s: null pointer", who);
     if (!agg_applies(D, K, n_entity, nR, 1))
-        return fail(-3, "%s: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
+        return fail(-3, "%s: D = 64, K in {16, 32, 64}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
                     who, D, K, n_entity, nR);
     mvin::EntityAggArgs f{};
     const size_t tab = (size_t)n_entity * D;
@@ -483,7 +483,7 @@ int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const i
     const char* who = "mvin_fold_tables";
     if (!entity_emb || !enc_entity || !enc_relation || !W0 || !W1 || !W2 || !A0 || !Wmix || !A1 || !ws) return fail(-1, "%s: null pointer", who);
     if (!agg_applies(D, K, n_entity, nR, 1))
-        return fail(-3, "%s: D = 64, K in {16, 32}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
+        return fail(-3, "%s: D = 64, K in {16, 32, 64}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
                     who, D, K, n_entity, nR);
     const size_t tab = (size_t)n_entity * D;
     float* blk = ws + 6 * tab;

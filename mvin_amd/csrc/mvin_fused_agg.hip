@@ -118,10 +118,16 @@ __device__ __forceinline__ void agg_load_slots(__amdgpu_buffer_rsrc_t adjE, __am
     if constexpr (SPL == 1) {
         ce[0] = __builtin_amdgcn_raw_buffer_load_b32(adjE, co, 0, 0);
         cr[0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, co, 0, 0);
-    } else {
+    } else if constexpr (SPL == 2) {
         const u32x2 e2 = __builtin_amdgcn_raw_buffer_load_b64(adjE, co, 0, 0);
         const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(adjR, co, 0, 0);
         ce[0] = e2[0], ce[1] = e2[1], cr[0] = r2[0], cr[1] = r2[1];
+    } else {
+        static_assert(SPL == 4, "SPL");
+        const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, co, 0, 0);
+        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, co, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ce[i] = e4[i], cr[i] = r4[i];
     }
 }
 
@@ -135,7 +141,7 @@ __device__ __forceinline__ float4 agg_row4(__amdgpu_buffer_rsrc_t tab, unsigned 
 template <int K>
 __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(EntityAggArgs a) {
     constexpr int D = 64, SPL = K / 16;
-    static_assert(K == 16 || K == 32, "K");
+    static_assert(K == 16 || K == 32 || K == 64, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nRp = (a.nR + 3) & ~3;
     float* sT = smem;                                    // [nRp] relation logits of aggregator (0,.), or exp(logit - max) of them
@@ -223,9 +229,9 @@ __global__ __launch_bounds__(kAggWaves * 64) void entity_aggregates_kernel(Entit
 // ---- nagg0 = S0[x] + c0 u1, nagg1 = sum_c (p1_c / K) relu(G[x_c] + v) per parent: sixteen parents' query terms per wave and batch
 //      on the matrix cores, then four parents at a time, one per 16-lane group ----
 template <int K>
-__global__ __launch_bounds__(kAggWaves * 64, 4) void gather_attn_l2_agg_kernel(FusedL2Args a) {
+__global__ __launch_bounds__(kAggWaves * 64, K == 64 ? 3 : 4) void gather_attn_l2_agg_kernel(FusedL2Args a) {
     constexpr int D = 64, SPL = K / 16;
-    static_assert(K == 16 || K == 32, "K");
+    static_assert(K == 16 || K == 32 || K == 64, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nRp = (a.nR + 3) & ~3;
     float* sT = smem;                                    // [nRp] relation logits of aggregator (1,.), or exp(logit - max) of them
@@ -437,7 +443,7 @@ struct FoldArgs {
 template <int K>
 __global__ __launch_bounds__(kAggWaves * 64, 3) void score_l2_folded_kernel(FoldArgs a) {
     constexpr int D = 64, SPL = K / 16;
-    static_assert(K == 16 || K == 32, "K");
+    static_assert(K == 16 || K == 32 || K == 64, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nRp = (a.nR + 3) & ~3;
     float* sT = smem;                                    // [nRp] relation logits of aggregator (1,.), or exp(logit - max) of them
@@ -696,11 +702,12 @@ hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32
     switch (K) {
         case 16: return launch_fold_k<16>(f, st);
         case 32: return launch_fold_k<32>(f, st);
+        case 64: return launch_fold_k<64>(f, st);
         default: return hipErrorInvalidValue;
     }
 }
 
-bool fused_agg_supported(int D, int K) { return D == 64 && (K == 16 || K == 32); }
+bool fused_agg_supported(int D, int K) { return D == 64 && (K == 16 || K == 32 || K == 64); }
 
 size_t fused_agg_lds_bytes(int nR, int K) {
     return ((size_t)((nR + 3) & ~3) + (size_t)kAggWaves * (16 * kAggUvLd + agg_list_words(K))) * sizeof(float);
@@ -727,6 +734,7 @@ hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st) {
     switch (a.K) {
         case 16: return launch_entity_aggregates_k<16>(a, st);
         case 32: return launch_entity_aggregates_k<32>(a, st);
+        case 64: return launch_entity_aggregates_k<64>(a, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -823,6 +831,7 @@ hipError_t launch_gather_attn_l2_agg(const FusedL2Args& a, hipStream_t st) {
     switch (a.K) {
         case 16: return launch_agg_k<16>(a, st);
         case 32: return launch_agg_k<32>(a, st);
+        case 64: return launch_agg_k<64>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

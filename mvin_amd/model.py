@@ -955,10 +955,14 @@ class MVIN(object):
         """Per-entity aggregates form of the two deepest levels (mvin_project_tables -> mvin_entity_aggregates ->
         mvin_gather_attn_l2_agg_fwd) for a call that takes the projected-tables form?  The aggregates cost ~17 gathered rows per
         entity and save a parent ~100 of its ~120 (C3): whenever the tables themselves pay (_prj_for_l2's rule is the stricter one),
-        on the shapes the kernels take (D = 64, K in {16, 32}, encoded adjacency).  ``self.agg`` False (MVIN_L2_AGG=0) keeps the kernels
+        on the shapes the kernels take (D = 64, K in {16, 32, 64}, encoded adjacency).  ``self.agg`` False (MVIN_L2_AGG=0) keeps the kernels
         over the tables."""
         if enc is None or self.agg is False:
             return False
+        return self._agg_shape_ok()
+
+    def _agg_shape_ok(self):
+        """mvin_gather_attn_l2_agg_supported for this model's tables (D = 64, K in {16, 32, 64}, sizes within 32-bit offsets)."""
         key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
         c = getattr(self, "_agg_ok_cache", None)
         if c is None or c[0] != key:
@@ -995,7 +999,9 @@ class MVIN(object):
         if want is None:
             # D <= 64, K <= 32: the other instances of the kernel are at their register budget already (K = 64: the second self row
             # costs 18 spilled registers in the front role's id pipeline) and measured no faster (C4) -- on request only
-            want = self.dim <= 64 and self.n_neighbor <= 32 and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
+            # (K = 64 takes it where the per-entity aggregates exist, D = 64: there the tables are only the aggregates' input)
+            k_ok = self.n_neighbor <= 32 or (self.n_neighbor == 64 and self.agg is not False and self._agg_shape_ok())
+            want = self.dim <= 64 and k_ok and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
         return bool(want)
 
     def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):

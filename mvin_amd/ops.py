@@ -382,7 +382,7 @@ def gather_attn_l2_prj(ws, enc_entity, enc_relation, parent_ids, t0, t1, q, B, p
 
 
 def gather_attn_l2_agg_supported(D, K, n_entity, nR):
-    """mvin_gather_attn_l2_agg_supported: does the per-entity aggregates form take these tables?  (D = 64, K in {16, 32}.)"""
+    """mvin_gather_attn_l2_agg_supported: does the per-entity aggregates form take these tables?  (D = 64, K in {16, 32, 64}.)"""
     return bool(_lib.load().mvin_gather_attn_l2_agg_supported(D, K, n_entity, nR))
 
 
@@ -428,7 +428,7 @@ def gather_attn_l2_agg(ws, agg, enc_entity, enc_relation, parent_ids, t0, t1, q,
 
 
 def score_l2_folded_supported(D, K, n_entity, nR):
-    """mvin_score_l2_folded_supported: does the folded-tail form take these tables?  (D = 64, K in {16, 32}.)"""
+    """mvin_score_l2_folded_supported: does the folded-tail form take these tables?  (D = 64, K in {16, 32, 64}.)"""
     return bool(_lib.load().mvin_score_l2_folded_supported(D, K, n_entity, nR))
 
 

@@ -28,11 +28,12 @@ def test_bench_scale_parity(name, B, n_ref, hip_lib):
     uts = torch.from_numpy(case.user_triplet_set).to(dev)
     assert model.prj is None and model.dedup is None, "this module runs the automatic rules (tests/conftest.py must not pin a form)"
     took_prj = (model._enc_for_l2(n_parents=B) is not None or model._prj_plain_ok()) and model._prj_for_l2(B)
-    assert took_prj == (name in ("C3", "C2")), f"{name}: projected-tables form taken = {took_prj}"
+    # (C4 -- K = 64 -- takes the tables as the input of the per-entity aggregates; its 39 relations keep key addressing on the records kernel)
+    assert took_prj, f"{name}: projected-tables form taken = {took_prj}"
     got = model.forward_users(users, items, uts)
     torch.cuda.synchronize()
     took_agg = bool(took_prj and model._agg_for(model._enc_for_l2(n_parents=B)))
-    assert took_agg == (name == "C3"), f"{name}: per-entity aggregates form taken = {took_agg}"
+    assert took_agg == (name in ("C3", "C4")), f"{name}: per-entity aggregates form taken = {took_agg}"
     if took_agg:          # ... in its folded-tail form (mvin_fold_tables -> mvin_score_l2_folded_fwd): the workspace of that call exists
         assert model._fold_for(model._enc_for_l2(n_parents=B)) and any(t is not None for t in model._fold_ws.values()), \
             "mvin_fold_tables was not called"

@@ -385,7 +385,7 @@ def test_wave_per_parent_kernel_every_distinct_count(K, hip_lib):
             assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1 vs the packed-tile kernel", rtol=3e-5, atol=6e-6)
 
 
-@pytest.mark.parametrize("K", [16, 32])
+@pytest.mark.parametrize("K", [16, 32, 64])
 def test_entity_aggregates_form_every_distinct_count(K, hip_lib):
     """The per-entity aggregates form (mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd, mvin_fused_agg.hip): S0 | G against their
     float64 definitions over the projected tables, then the launch -- every distinct-children count 1 .. K as parent and as child,
@@ -454,7 +454,7 @@ def test_entity_aggregates_form_every_distinct_count(K, hip_lib):
     assert_close(got1.cpu().numpy(), want1.cpu().numpy(), "nagg1, K parents per pair", rtol=3e-5, atol=6e-6)
 
 
-@pytest.mark.parametrize("K", [16, 32])
+@pytest.mark.parametrize("K", [16, 32, 64])
 def test_folded_tail_form_matches_aggregates_plus_tail(K, hip_lib):
     """mvin_fold_tables -> mvin_score_l2_folded_fwd (H0 | G aggregates, M0 table, four products in the tail) against mvin_project_tables ->
     mvin_entity_aggregates -> mvin_gather_attn_l2_agg_fwd -> mvin_l2_tail_fwd on the same parameters: every distinct-children count, ragged
