@@ -1000,8 +1000,12 @@ class MVIN(object):
             # D <= 64, K <= 32: the other instances of the kernel are at their register budget already (K = 64: the second self row
             # costs 18 spilled registers in the front role's id pipeline) and measured no faster (C4) -- on request only
             # (K = 64 takes it where the per-entity aggregates exist, D = 64: there the tables are only the aggregates' input)
-            k_ok = self.n_neighbor <= 32 or (self.n_neighbor == 64 and self.agg is not False and self._agg_shape_ok())
-            want = self.dim <= 64 and k_ok and (n_parents or B) * self.n_neighbor >= 16 * self.n_entity
+            # With the aggregates / the folded tail behind the tables the form pays earlier -- measured break-even (pairs per step, one GPU):
+            # C3 (K = 32) ~32 768 = 10 n_entity / K, C4 (K = 64) ~8 192 = 4.6 n_entity / K; the kernels over the tables themselves: 16
+            aggs = self.agg is not False and self.dim == 64 and self._agg_shape_ok()
+            k_ok = self.n_neighbor <= 32 or (self.n_neighbor == 64 and aggs)
+            factor = (5 if self.n_neighbor == 64 else 10) if aggs else 16
+            want = self.dim <= 64 and k_ok and (n_parents or B) * self.n_neighbor >= factor * self.n_entity
         return bool(want)
 
     def _score_l2_native(self, item, mem_h, mem_r, mem_t, uts=None, users=None, grouped=False):

@@ -155,14 +155,19 @@ def test_projected_tables_depth3(hip_lib):
 
 
 def test_auto_rule_and_refusals(hip_lib):
-    """Automatic: only when the batch's children outnumber the entities (B K >= 16 n_entity); never for a bf16 table or
+    """Automatic: only when the batch's children outnumber the entities (B K >= 16 n_entity; 10 / 5 n_entity at K <= 32 / K = 64 where the
+    per-entity aggregates exist); never for a bf16 table or
     without the projection; the entry point refuses what it cannot do."""
     args = make_args(**_shape(64, 32, B=8))
     case = synth.small_case(args, n_user=8, n_entity=500, n_relation=6, seed=5, repeats=True)
     params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=6)
     model = _model(args, case, params, None)
-    assert not model._prj_for_l2(8) and not model._prj_for_l2(249)
-    assert model._prj_for_l2(250) and model._prj_for_l2(4, n_parents=250)
+    # (D = 64, K = 32: the aggregates stand behind the tables -> 10 n_entity; the kernels over the tables themselves -> 16 n_entity)
+    assert not model._prj_for_l2(8) and not model._prj_for_l2(156)
+    assert model._prj_for_l2(157) and model._prj_for_l2(4, n_parents=157)
+    model.agg = False
+    assert not model._prj_for_l2(249) and model._prj_for_l2(250) and model._prj_for_l2(4, n_parents=250)
+    model.agg = None
     model.prj = False
     assert not model._prj_for_l2(1 << 20)
     bf = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params,
