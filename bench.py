@@ -113,9 +113,11 @@ def parse():
                     help="builder-side projection on ONE GPU: score rank 0's share of the global batch as one of W ranks "
                          "would (user-sorted split, row-shard exchange of the whole table per step); the line is marked "
                          "`emulated_world` and its `value` is per-rank pairs/s x W -- never a measurement of W GPUs")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=0,
                     help="independent steps are enqueued round-robin on this many HIP streams (single GPU, tables replicated, no "
-                         "hipGraph replay): the drain of one step's kernels overlaps the ramp of the next one's; 1 = one stream")
+                         "hipGraph replay): the drain of one step's kernels overlaps the ramp of the next one's; 1 = one stream; "
+                         "0 (default) = what mvin_amd.harness.ctr_eval_device takes for this batch size (harness.eval_streams: two for "
+                         "the single-launch pass, three for the multi-launch schedule)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--ablation", default="all",
                     help="the reference's --ablation preset (parameter_ablation.py); anything but 'all' is a different workload, "
@@ -754,6 +756,9 @@ def main():
     # runner in its pipelined form takes exactly two: step i scores working table i % 2 on stream i % 2 while the exchange for step
     # i + 1 fills the other table on the runner's side stream (the buffer's ready / free events order the three streams); its
     # serialised form (--no-overlap: one working table) keeps one.
+    if a.streams <= 0:
+        from mvin_amd.harness import eval_streams
+        a.streams = eval_streams(model, Bl)
     nstreams = a.streams if (a.streams > 1 and scorer is None and (not rowshard or overlap)) else 1
     if rowshard and nstreams > 1:
         nstreams = 2

@@ -31,16 +31,18 @@ def capture_without_gc():
             gc.enable()
 
 
-def scoring_streams(device, n=2):
-    """The process's ``n`` streams for independent scoring passes, created ONCE per device.  HIP maps streams onto a handful
-    of hardware queues round-robin and two streams that share a queue serialise: a pair of streams created late in a process
-    that already holds several landed on one queue (the two-stream rate at 512 pairs was 36 us instead of 24).  Callers that
-    pipeline independent batches (mvin_amd.harness.ctr_eval_device, bench.py) take their streams from here."""
+def scoring_streams(device, n=3):
+    """The process's first ``n`` streams for independent scoring passes, from ONE pool per device that only grows.  HIP maps streams
+    onto a handful of hardware queues round-robin and two streams that share a queue serialise: a pair of streams created late in a
+    process that already holds several landed on one queue (the two-stream rate at 512 pairs was 36 us instead of 24).  Callers that
+    pipeline independent batches (mvin_amd.harness.ctr_eval_device, bench.py) take their streams from here; asking for two and later
+    for three returns the same first two."""
     dev = torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), n)
-    if key not in _STREAMS:
-        _STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
-    return _STREAMS[key]
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    pool = _STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 class GraphedScorer(object):

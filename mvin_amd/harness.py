@@ -189,17 +189,26 @@ def ctr_eval(args, model, data, user_triplet_set, batch_size, sess=None):
     return aucs, accs, f1s, float(np.mean(aucs)), float(np.mean(accs)), float(np.mean(f1s))
 
 
-def ctr_eval_device(feeder, data, batch_size, streams=2, window=16):
+def eval_streams(model, batch_size):
+    """How many HIP streams the independent batches of an evaluation go round-robin to (measured at C3): TWO where a pass is the
+    single launch (<= MVIN.small_max_batch pairs: 24.3 us per 512-pair batch against 36.0 on one stream and 28.8 on three), THREE
+    for the multi-launch schedule (4 096 pairs: 71 vs 76 us on two; 524 288: 1.058 vs 1.082 ms; four: 1.097)."""
+    return 2 if batch_size <= int(getattr(model, "small_max_batch", 0) or 0) else 3
+
+
+def ctr_eval_device(feeder, data, batch_size, streams=None, window=16):
     """Same numbers as ctr_eval, feeds assembled on the device.  The batches of an evaluation are independent: they are
-    enqueued round-robin on ``streams`` HIP streams (at the reference's batch sizes a scoring pass is one launch that walks a
-    dependent chain of loads -- two passes in flight overlap their waits: 24 vs 36 us per 512-pair batch at C3), ``window``
-    batches ahead of the host-side metrics; ``streams=1`` scores and reads back one batch at a time."""
+    enqueued round-robin on ``streams`` HIP streams (None: ``eval_streams`` -- at the reference's batch sizes a scoring pass is one
+    launch that walks a dependent chain of loads, two passes in flight overlap their waits: 24 vs 36 us per 512-pair batch at C3),
+    ``window`` batches ahead of the host-side metrics; ``streams=1`` scores and reads back one batch at a time."""
     import torch
     from sklearn.metrics import f1_score, roc_auc_score
     aucs, accs, f1s = [], [], []
     starts = list(range(0, data.shape[0] - batch_size + 1, batch_size))
     dev = feeder.model.device
     from .graph import scoring_streams
+    if streams is None:
+        streams = eval_streams(feeder.model, batch_size)
     lanes = scoring_streams(dev, streams) if streams > 1 else None
     if lanes:
         # everything the forward builds lazily and CACHES (relation-logit tables dropped by invalidate() after a training epoch,
