@@ -872,8 +872,8 @@ def main():
         enc = model._enc_for_l2(n_parents=Bl * a.fanout ** (L - 2)) if (used_l2 and not hoisted) else None
         prj_now = (used_l2 and not hoisted and (enc is not None or model._prj_plain_ok())
                    and model._prj_for_l2(Bl, Bl * a.fanout ** (L - 2)))
-        agg_now = bool(prj_now and model._agg_for(enc))
-        fold_now = bool(agg_now and L == 2 and model._fold_for(enc))
+        fold_now = bool(prj_now and L == 2 and model._fold_for(enc))
+        agg_now = bool(fold_now or (prj_now and model._agg_for(enc)))
         kname = (("gather_mix_kernel (mvin_gather_mix_fwd) + per-entity table build/lookups "
                   "[entity-table mode: its own bytes per pair, not SURVEY 8(d)'s]") if hoisted
                  else "linear_mfma_kernel + entity_aggregates_kernel<%d> + score_l2_folded_kernel<%d> (mvin_fold_tables -> mvin_score_l2_folded_fwd: "

@@ -468,6 +468,17 @@ int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, const int32_t
                                nullptr, 0, stream, true, true, order, agg);
 }
 
+// does the folded-tail form run for these tables?  (dim 64 like the aggregates form, and dim 32)
+static bool fold_applies(int D, int K, int n_entity, int nR, int64_t B) {
+    if (D == 64) return agg_applies(D, K, n_entity, nR, B);
+    static const char* e = getenv("MVIN_L2_AGG");
+    if (e && e[0] == '0') return false;
+    if (n_entity <= 0 || nR <= 0 || nR > 4096 || !mvin::fused_fold_supported(D, K)) return false;
+    const uint64_t tb = (uint64_t)n_entity * (uint64_t)D * 4, ab = (uint64_t)n_entity * (uint64_t)K * 4;
+    return tb < (1ull << 30) && ab < (1ull << 31) && n_entity <= (1 << 24) && (B <= 0 || (uint64_t)B * D * 4 < (1ull << 31)) &&
+           mvin::fused_fold_lds_bytes(D, nR, K) <= 64 * 1024;
+}
+
 // ---- folded-tail form: tables TA1 | TA2 | T0A | M0, aggregates H0 | G, parameter block ----
 static size_t fold_blk_elems(int D) { return (size_t)12 * D * D + (size_t)3 * D; }      // Wstack[4] | Wv | Wq | bv | bq | bm | Wperm[6]
 
@@ -475,16 +486,16 @@ size_t mvin_fold_tables_elems(int n_entity, int D) {
     return n_entity > 0 && D > 0 ? (size_t)6 * n_entity * D + fold_blk_elems(D) : 0;
 }
 
-int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR) { return agg_applies(D, K, n_entity, nR, 1) ? 1 : 0; }
+int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR) { return fold_applies(D, K, n_entity, nR, 1) ? 1 : 0; }
 
 int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
                      const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0, const float* a0,
                      const float* Wmix, const float* bmix, const float* A1, int K, int D, int n_entity, int nR, float* ws, void* stream) {
     const char* who = "mvin_fold_tables";
     if (!entity_emb || !enc_entity || !enc_relation || !W0 || !W1 || !W2 || !A0 || !Wmix || !A1 || !ws) return fail(-1, "%s: null pointer", who);
-    if (!agg_applies(D, K, n_entity, nR, 1))
-        return fail(-3, "%s: D = 64, K in {16, 32, 64}, n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 (D=%d K=%d n_entity=%d nR=%d)",
-                    who, D, K, n_entity, nR);
+    if (!fold_applies(D, K, n_entity, nR, 1))
+        return fail(-3, "%s: D = 64 with K in {16, 32, 64} or D = 32 with K in {16, 32}; n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 "
+                        "(D=%d K=%d n_entity=%d nR=%d)", who, D, K, n_entity, nR);
     const size_t tab = (size_t)n_entity * D;
     float* blk = ws + 6 * tab;
     const float c = t0 ? 1.f / (float)K : 1.f;            // sum of a row's slot weights over K  (aggregators.py:139-152)
@@ -515,6 +526,7 @@ int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const i
     f.outG = ws + 5 * tab;
     f.n_entity = n_entity;
     f.K = K;
+    f.D = D;
     f.nR = nR;
     f.table_bytes = (uint64_t)tab * 4;
     f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
@@ -529,7 +541,7 @@ int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const i
     if (!ws || !enc_entity || !enc_relation || !q || !user_o || !A1 || !Wmix || !out0 || !z2 || !scores) return fail(-1, "%s: null pointer", who);
     if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
     if (B <= 0 || B >= (int64_t(1) << 31)) return fail(-2, "%s: B=%lld", who, (long long)B);
-    if (!agg_applies(D, K, n_entity, nR, B)) return fail(-3, "%s: unsupported shape / sizes D=%d K=%d n_entity=%d nR=%d B=%lld", who, D, K, n_entity, nR, (long long)B);
+    if (!fold_applies(D, K, n_entity, nR, B)) return fail(-3, "%s: unsupported shape / sizes D=%d K=%d n_entity=%d nR=%d B=%lld", who, D, K, n_entity, nR, (long long)B);
     const size_t tab = (size_t)n_entity * D;
     const float* blk = ws + 6 * tab;
     const float* Wv = blk + (size_t)4 * D * D;
@@ -538,14 +550,14 @@ int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const i
     const float* bq = bv + D;
     const float* bm = bq + D;
     static const bool two = getenv("MVIN_L2_FOLD_TWO") && atoi(getenv("MVIN_L2_FOLD_TWO")) != 0;
-    if (!two)                                 // ONE launch: pair kernel and tail on the same batches of 16 pairs (out0 / z2 stay unused)
+    if (!two || D != 64)                      // ONE launch: pair kernel and tail on the same batches of 16 pairs (out0 / z2 stay unused)
     {       // (the regrouped copies Wperm of the six blocks -- of the CURRENT A1 / Wmix too: mvin_fold_tables wrote them)
         const float* Wp = bm + D;
         const size_t DD = (size_t)D * D;
         return hip_result(mvin::launch_score_l2_folded(ws + 4 * tab, ws + 3 * tab, enc_entity, enc_relation,
                                                        items_i64 ? reinterpret_cast<const int32_t*>(items_i64) : items_i32, items_i64 ? 2 : 1, t1, q,
                                                        user_o, Wp, bq, Wp + DD, bv, Wp + 2 * DD, Wp + 3 * DD, a1, Wp + 4 * DD, Wp + 5 * DD, bm,
-                                                       item_emb, scores, sig, B, K, nR, n_entity, (hipStream_t)stream),
+                                                       item_emb, scores, sig, B, K, D, nR, n_entity, (hipStream_t)stream),
                           who);
     }
     // MVIN_L2_FOLD_TWO=1 (A/B): the pair kernel writes out0 and Z2, the tile kernel of mvin_tail.hip takes them from there
@@ -895,7 +907,7 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     }
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
-    if (a->fold_ws && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 && agg_applies(D, a->K, a->n_entity, nR, a->B)) {
+    if (a->fold_ws && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 && fold_applies(D, a->K, a->n_entity, nR, a->B)) {
         // folded-tail form: four per-entity tables + the aggregates H0 | G from the CURRENT parameters, then two launches per batch
         rc = mvin_fold_tables(reinterpret_cast<const float*>(a->entity_emb), a->enc_entity, a->enc_relation, a->t0, a->W0, a->b0, a->W1, a->b1,
                               a->W2, a->b2, a->A0, a->a0, a->Wmix, a->bmix, a->A1, a->K, D, a->n_entity, nR, a->fold_ws, stream);

@@ -19,122 +19,9 @@
 // Lanes = 4 groups x 16 column chunks in both kernels; a group owns one entity (its row: K / 16 slots per lane, softmax by DPP inside
 // the 16-lane row; the (row offset, weight) list of its distinct slots through LDS, read back as broadcasts) -- no exchange between
 // groups, full-wave stores.
-#include <cstdlib>
-#include <type_traits>
-
-#include "mvin_kernels.h"
+#include "mvin_fused_agg.h"
 
 namespace mvin {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kAggWaves = 4;
-constexpr int kAggUvLd = 132;         // floats per parent of the u1 | v block in LDS (128 + 4: sixteen lanes, sixteen bank groups)
-constexpr int kAggPad = 4;            // list entries of padding behind a group's K slots (the half round issued ahead of the last one)
-constexpr unsigned kAggOob = 0xFFFFFFF0u;       // a byte offset beyond every buffer: the load returns zeros, no memory access
-constexpr unsigned kAggPadRow = 0xFFFFFE00u;    // ... that stays beyond them (and below 2^32) with a lane's column offset added
-constexpr int agg_list_words(int K) { return 4 * 2 * (K + kAggPad); }      // per wave: 4 groups x (K + padding) x (offset, weight)
-size_t fused_agg_lds_bytes(int nR, int K);
-
-__device__ __forceinline__ int agg_xor16_imax(int v) {
-    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    return max((int)a[0], (int)a[1]);
-}
-__device__ __forceinline__ int agg_xor32_imax(int v) {
-    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    return max((int)a[0], (int)a[1]);
-}
-
-// The relation logits `t` [nR] (or NULL: no attention) as the table the softmaxes read: exp(t[r] - max over ALL relations) when the
-// logits allow it -- softmax is shift invariant, so one table serves every row, without a maximum per row or an exp per slot; a row
-// whose own logits all lie far below the global maximum would lose its weights to underflow, so a spread above 60 (exp(-60) = 9e-27:
-// sums of K of them stay normal) keeps the logits and the per-row form.  Returns whether the table holds exponentials; the caller
-// puts the workgroup barrier behind it.
-__device__ __forceinline__ bool agg_logit_table(const float* t, int nR, float* sT, int tid, int lane) {
-    float mx = -INFINITY, mn = INFINITY;
-    if (t)
-        for (int i = lane; i < nR; i += 64) {
-            const float l = t[i];
-            mx = fmaxf(mx, l), mn = fminf(mn, l);
-        }
-    else
-        mx = mn = 0.f;
-    mx = wave_max(mx), mn = -wave_max(-mn);
-    const bool fast = __builtin_amdgcn_readfirstlane((mx - mn <= 60.f) ? 1 : 0) != 0;      // (NaN logits: per-row form)
-    for (int i = tid; i < nR; i += kAggWaves * 64) {
-        const float l = t ? t[i] : 0.f;
-        sT[i] = fast ? lean_exp(fminf(l - mx, 0.f)) : l;
-    }
-    return fast;
-}
-
-// weights of a row's slots (SPL per lane of the 16-lane group that holds it; cr = relation | multiplicity << 16 | ...): multiplicity x
-// softmax over the distinct slots, over K (aggregators.py:118-146); a padding slot (multiplicity 0) weighs 0
-template <int SPL, bool FAST>
-__device__ __forceinline__ void agg_row_weights(const unsigned (&cr)[SPL], bool att, const float* sT, float invK, float (&wk)[SPL]) {
-    float lg[SPL];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-        const float mu = (float)((cr[i] >> 16) & 0xFFu);
-        const float l = att ? sT[cr[i] & 0xFFFFu] : (FAST ? 1.f : 0.f);
-        if constexpr (FAST) {
-            wk[i] = mu * l;                              // l = exp(logit - global max)
-        } else {
-            wk[i] = mu;
-            mx = fmaxf(mx, mu > 0.f ? l : -INFINITY);
-            lg[i] = l;
-        }
-    }
-    if (att) {
-        float z = 0.f;
-        if constexpr (FAST) {
-#pragma unroll
-            for (int i = 0; i < SPL; ++i) z += wk[i];
-        } else {
-            mx = group_max(mx, 4);
-#pragma unroll
-            for (int i = 0; i < SPL; ++i) {
-                wk[i] *= lean_exp(fminf(lg[i] - mx, 0.f));
-                z += wk[i];
-            }
-        }
-        z = group_sum(z, 4);
-        const float rz = z > 0.f ? invK * __builtin_amdgcn_rcpf(z) : 0.f;
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) wk[i] *= rz;
-    } else {
-#pragma unroll
-        for (int i = 0; i < SPL; ++i) wk[i] *= invK;
-    }
-}
-
-template <int SPL>
-__device__ __forceinline__ void agg_load_slots(__amdgpu_buffer_rsrc_t adjE, __amdgpu_buffer_rsrc_t adjR, unsigned co, unsigned (&ce)[SPL],
-                                               unsigned (&cr)[SPL]) {
-    if constexpr (SPL == 1) {
-        ce[0] = __builtin_amdgcn_raw_buffer_load_b32(adjE, co, 0, 0);
-        cr[0] = __builtin_amdgcn_raw_buffer_load_b32(adjR, co, 0, 0);
-    } else if constexpr (SPL == 2) {
-        const u32x2 e2 = __builtin_amdgcn_raw_buffer_load_b64(adjE, co, 0, 0);
-        const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(adjR, co, 0, 0);
-        ce[0] = e2[0], ce[1] = e2[1], cr[0] = r2[0], cr[1] = r2[1];
-    } else {
-        static_assert(SPL == 4, "SPL");
-        const u32x4 e4 = __builtin_amdgcn_raw_buffer_load_b128(adjE, co, 0, 0);
-        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(adjR, co, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ce[i] = e4[i], cr[i] = r4[i];
-    }
-}
-
-__device__ __forceinline__ float4 agg_row4(__amdgpu_buffer_rsrc_t tab, unsigned off) {
-    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(tab, off, 0, 0);
-    return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
-}
 
 // ---- outS | outG over all entities (four entities per wave and step): the aggregates form S0 | G (tabS = T1, no selfS), the
 //      folded-tail form H0 | G (tabS = TA1, selfS = T0A) ----
@@ -420,26 +307,6 @@ __global__ __launch_bounds__(kAggWaves * 64, K == 64 ? 3 : 4) void gather_attn_l
 //        t = q Wq + bq ; v = q Wv + bv ; m = q Wqm                                        (matrix cores; t, v -> LDS, m stays in registers)
 //        out0 = relu(H0[x] + t) ; Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + v)           (four pairs at a time, one per 16-lane group)
 //        out2 = relu(Z2 A1 + a1) ; item = M0[x] + m + out0 Wm1 + out2 Wm2 + bm ; score = <user_o, item>       (matrix cores)
-struct FoldArgs {
-    const float* agg;            // [2][nE][64] H0 | G
-    const float* M0;             // [nE][64]
-    const int32_t* adj_e;        // duplicate-slot encoding
-    const int32_t* adj_r;
-    const int32_t* items;        // [B] (stride pid_stride words)
-    const float* t1;             // [nR] relation logits of aggregator (1,.) or NULL
-    const float* q;              // [B][64]
-    const float* user_o;         // [B][64]
-    const float *Wq, *bq, *Wv, *bv, *Wqm, *A1, *a1, *Wm1, *Wm2, *bm;
-    float* item_emb;             // [B][64] or NULL
-    float* scores;
-    float* sig;                  // or NULL
-    int64_t B;
-    uint64_t table_bytes, adj_bytes;
-    int K, nR, pid_stride;
-    unsigned max_id;
-    int dbg;                     // MVIN_FOLD_DBG (measurement only; results wrong): 1 no G rows, 2 no products behind the gather, 4 none before it, 8 no gather steps
-};
-
 template <int K>
 __global__ __launch_bounds__(kAggWaves * 64, 3) void score_l2_folded_kernel(FoldArgs a) {
     constexpr int D = 64, SPL = K / 16;
@@ -690,15 +557,16 @@ static hipError_t launch_fold_k(const FoldArgs& a, hipStream_t st) {
 hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32_t* adj_e, const int32_t* adj_r, const int32_t* items, int pid_stride,
                                   const float* t1, const float* q, const float* user_o, const float* Wq, const float* bq, const float* Wv,
                                   const float* bv, const float* Wqm, const float* A1, const float* a1, const float* Wm1, const float* Wm2,
-                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int nR, int n_entity,
+                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int D, int nR, int n_entity,
                                   hipStream_t st) {
     FoldArgs f{};
     f.agg = agg, f.M0 = M0, f.adj_e = adj_e, f.adj_r = adj_r, f.items = items, f.pid_stride = pid_stride, f.t1 = t1, f.q = q, f.user_o = user_o;
     f.Wq = Wq, f.bq = bq, f.Wv = Wv, f.bv = bv, f.Wqm = Wqm, f.A1 = A1, f.a1 = a1, f.Wm1 = Wm1, f.Wm2 = Wm2, f.bm = bm;
     f.item_emb = item_emb, f.scores = scores, f.sig = sig, f.B = B, f.K = K, f.nR = nR, f.max_id = (unsigned)(n_entity - 1);
-    f.table_bytes = (uint64_t)n_entity * 64 * 4, f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    f.table_bytes = (uint64_t)n_entity * (uint64_t)D * 4, f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
     static const char* dbg = getenv("MVIN_FOLD_DBG");
     f.dbg = dbg ? atoi(dbg) : 0;
+    if (D == 32) return launch_score_l2_folded_d32(f, st);
     switch (K) {
         case 16: return launch_fold_k<16>(f, st);
         case 32: return launch_fold_k<32>(f, st);
@@ -708,6 +576,9 @@ hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32
 }
 
 bool fused_agg_supported(int D, int K) { return D == 64 && (K == 16 || K == 32 || K == 64); }
+bool fused_fold_supported(int D, int K) { return fused_agg_supported(D, K) || (D == 32 && (K == 16 || K == 32)); }
+size_t fused_fold_d32_lds_bytes(int nR, int K);
+size_t fused_fold_lds_bytes(int D, int nR, int K) { return D == 32 ? fused_fold_d32_lds_bytes(nR, K) : fused_agg_lds_bytes(nR, K); }
 
 size_t fused_agg_lds_bytes(int nR, int K) {
     return ((size_t)((nR + 3) & ~3) + (size_t)kAggWaves * (16 * kAggUvLd + agg_list_words(K))) * sizeof(float);
@@ -731,6 +602,7 @@ static hipError_t launch_entity_aggregates_k(const EntityAggArgs& a, hipStream_t
 }
 
 hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st) {
+    if (a.D == 32) return launch_entity_aggregates_d32(a, st);
     switch (a.K) {
         case 16: return launch_entity_aggregates_k<16>(a, st);
         case 32: return launch_entity_aggregates_k<32>(a, st);
@@ -745,8 +617,8 @@ hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st) {
 //   Wq [D][D] = (W0 + c W1).A0      bq [D] = (b0 + c b1).A0 + a0        ((ev0 + nagg0) A0 + a0 = H0[x] + q Wq + bq)
 //   bm [D]    = bmix + b0.Wm0                                           (ev0 Wm0 = M0[x] + q W0.Wm0 + b0.Wm0)
 // Wm0 = the first D rows of the mix-hop combiner Wmix [3 D, D].  Block i < D: row i of the five products; block D: the biases.
-// Behind them, for the single-launch kernel (D = 64): Wperm [6][D][D] = Wq | Wv | Wqm | A1 | Wm1 | Wm2 with the columns of a row
-// regrouped, Wperm[k][c][ntp] = W[k][16 ntp + c] -- the four A values a lane needs for one k (one per 16-column tile) in ONE 16-byte load.
+// Behind them, for the single-launch kernels (D = 64 / 32): Wperm [6][D][D] = Wq | Wv | Wqm | A1 | Wm1 | Wm2 with the columns of a row
+// regrouped, Wperm[k][c][ntp] = W[k][16 ntp + c] -- the A values a lane needs for one k (one per 16-column tile) in ONE 16- / 8-byte load.
 __global__ void fold_prepare_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                                     const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                                     const float* __restrict__ A0, const float* __restrict__ a0, const float* __restrict__ Wmix,
@@ -785,9 +657,9 @@ __global__ void fold_prepare_kernel(const float* __restrict__ W0, const float* _
         Wstack[(size_t)3 * D * D + (size_t)i * D + j] = sm;
         Wv[(size_t)i * D + j] = fmaf(c, s2, s1);
         Wq[(size_t)i * D + j] = fmaf(c, s1, s0);
-        if (D == 64) {
+        if (D == 64 || D == 32) {
             float* Wperm = bm + D;
-            const size_t o = (size_t)i * D + (size_t)(j & 15) * 4 + (size_t)(j >> 4);
+            const size_t o = (size_t)i * D + (size_t)(j & 15) * (D / 16) + (size_t)(j >> 4);
             const size_t DD = (size_t)D * D;
             Wperm[o] = fmaf(c, s1, s0);
             Wperm[DD + o] = fmaf(c, s2, s1);

@@ -181,6 +181,7 @@ struct EntityAggArgs {
     float* outG;               // [nE, 64]
     int n_entity, K, nR;
     uint64_t table_bytes, adj_bytes;
+    int D;                     // 64 (0: 64) or 32 (mvin_fused_agg32.hip)
 };
 
 // l2_tail_fold_kernel (mvin_tail.hip): the part of aggregate_delta_whole above the folded pair kernel
@@ -437,6 +438,8 @@ bool fused_wpp_supported(int D, int K);                       // wave-per-parent
 bool fused_wpp_applies(const FusedL2Args& a, int D);
 hipError_t launch_gather_attn_l2_wpp(const FusedL2Args& a, hipStream_t st);
 bool fused_agg_supported(int D, int K);                       // per-entity aggregates S0 | G of the projected tables, dim 64 (mvin_fused_agg.hip)
+bool fused_fold_supported(int D, int K);                      // folded-tail form: dim 64 (K 16 / 32 / 64) and dim 32 (K 16 / 32: mvin_fused_agg32.hip)
+size_t fused_fold_lds_bytes(int D, int nR, int K);
 bool fused_agg_applies(const FusedL2Args& a, int D);
 hipError_t launch_entity_aggregates(const EntityAggArgs& a, hipStream_t st);
 hipError_t launch_fold_prepare(const float* W0, const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
@@ -445,8 +448,8 @@ hipError_t launch_l2_tail_fold(const TailFoldArgs& a, hipStream_t st);          
 hipError_t launch_score_l2_folded(const float* agg, const float* M0, const int32_t* adj_e, const int32_t* adj_r, const int32_t* items, int pid_stride,
                                   const float* t1, const float* q, const float* user_o, const float* Wq, const float* bq, const float* Wv,
                                   const float* bv, const float* Wqm, const float* A1, const float* a1, const float* Wm1, const float* Wm2,
-                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int nR, int n_entity,
-                                  hipStream_t st);                              // mvin_fused_agg.hip: the folded-tail form in one launch
+                                  const float* bm, float* item_emb, float* scores, float* sig, int64_t B, int K, int D, int nR, int n_entity,
+                                  hipStream_t st);                              // mvin_fused_agg.hip / mvin_fused_agg32.hip: the folded-tail form in one launch
 hipError_t launch_gather_attn_l2_agg(const FusedL2Args& a, hipStream_t st);     // a.agg, the encoding, a.t1, the query terms -> nagg0 / nagg1
 hipError_t launch_gather_attn_l2_d32(const FusedL2Args& a, int table_bf16, hipStream_t st, bool encoded = false);   // encoded: adj_e / adj_r = the duplicate-slot encoding
 bool fused_d16_supported(int D, int K);        // wave-per-parent variant for D = 16, K <= 16 (mvin_fused_d16.hip)

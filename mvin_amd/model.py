@@ -186,7 +186,12 @@ class MVIN(object):
             return None
         if mode != "1":
             # measured (scripts/ab_enc.sh): the wave-per-parent kernel keeps D = 32, K <= 16 (BASELINE C2: 1.53 vs 1.88 ms)
-            if self.dim == 32 and self.n_neighbor <= 16:
+            # ... unless the call takes the folded tail over per-entity aggregates, which reads the encoding (C2 at bench size)
+            if self.dim == 32 and self.n_neighbor <= 16 and not (
+                    n_parents is not None and self.n_mix_hop * self.h_hop == 2 and self.args.User_orient and self.fold is not False
+                    and self.agg is not False and self.prj is not False and self.entity_emb_matrix.dtype == torch.float32
+                    and n_parents * self.n_neighbor >= 10 * self.n_entity
+                    and ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation)):
                 return None
             if n_parents is not None and n_parents < self.ENC_AUTO_MIN_PARENTS:
                 return None
@@ -973,7 +978,13 @@ class MVIN(object):
         """Folded-tail form of the native call (mvin_fold_tables -> mvin_score_l2_folded_fwd: the aggregates form with nagg0 and ev0
         folded into per-entity tables too -- six products per pair instead of eight) wherever the aggregates form is taken by
         mvin_score_l2_fwd (depth-2 trees, User_orient on).  ``self.fold`` False (MVIN_L2_FOLD=0) keeps aggregates + mvin_l2_tail_fwd."""
-        return self.fold is not False and bool(self.args.User_orient) and self._agg_for(enc)
+        if enc is None or self.fold is False or self.agg is False or not self.args.User_orient:
+            return False
+        key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
+        c = getattr(self, "_fold_ok_cache", None)
+        if c is None or c[0] != key:      # (dim 64 with K in {16, 32, 64} like the aggregates form, and dim 32 with K in {16, 32})
+            c = self._fold_ok_cache = (key, ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation))
+        return c[1]
 
     def _prj_plain_ok(self):
         """The projected-tables form over the PLAIN adjacency: the wave-per-parent kernel of D = 32, K in {8, 16} (BASELINE C2) --
@@ -1002,7 +1013,9 @@ class MVIN(object):
             # (K = 64 takes it where the per-entity aggregates exist, D = 64: there the tables are only the aggregates' input)
             # With the aggregates / the folded tail behind the tables the form pays earlier -- measured break-even (pairs per step, one GPU):
             # C3 (K = 32) ~32 768 = 10 n_entity / K, C4 (K = 64) ~8 192 = 4.6 n_entity / K; the kernels over the tables themselves: 16
-            aggs = self.agg is not False and self.dim == 64 and self._agg_shape_ok()
+            aggs = self.agg is not False and ((self.dim == 64 and self._agg_shape_ok())
+                                              or (self.dim == 32 and self.n_mix_hop * self.h_hop == 2 and self.fold is not False
+                                                  and ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation)))
             k_ok = self.n_neighbor <= 32 or (self.n_neighbor == 64 and aggs)
             factor = (5 if self.n_neighbor == 64 else 10) if aggs else 16
             want = self.dim <= 64 and k_ok and (n_parents or B) * self.n_neighbor >= factor * self.n_entity

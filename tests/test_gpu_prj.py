@@ -515,6 +515,61 @@ def test_folded_tail_form_matches_aggregates_plus_tail(K, hip_lib):
             assert c > 0
 
 
+@pytest.mark.parametrize("K", [16, 32])
+def test_folded_tail_form_dim32(K, hip_lib):
+    """The folded-tail form at dim 32 (mvin_fused_agg32.hip: eight rows per wave, two-tile products) against mvin_project_tables ->
+    mvin_gather_attn_l2_prj_fwd (the wave-per-parent kernel of dim 32 where it exists, the packed-tile kernel otherwise) -> mvin_l2_tail_fwd on the
+    same parameters, and H0 | G | M0 against their float64 definitions: every distinct-children count, ragged batches, both id widths,
+    with and without attention / biases."""
+    D, nR, n_entity = 32, 7, 611
+    rng = np.random.default_rng(K + 300)
+    adj_e = np.zeros((n_entity, K), dtype=np.int64)
+    adj_r = np.zeros((n_entity, K), dtype=np.int64)
+    for x in range(n_entity):
+        nd = x % K + 1
+        ne = rng.choice(n_entity, nd, replace=False)
+        nr = rng.integers(0, nR, nd)
+        pick = np.concatenate([np.arange(nd), rng.integers(0, nd, K - nd)])
+        rng.shuffle(pick)
+        adj_e[x], adj_r[x] = ne[pick], nr[pick]
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    E = f(n_entity, D)
+    ae, ar = torch.from_numpy(adj_e.astype(np.int32)).to(dev), torch.from_numpy(adj_r.astype(np.int32)).to(dev)
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    assert ops.score_l2_folded_supported(D, K, n_entity, nR) and not ops.gather_attn_l2_agg_supported(D, K, n_entity, nR)
+    W0, W1, W2, A0, A1, Wmix = f(D, D), f(D, D), f(D, D), f(D, D), f(D, D), f(3 * D, D)
+    for B, att, bias, i64 in ((4 * K + 37, 1.0, True, True), (1, 1.0, True, False), (9, 130.0, True, True), (95, False, False, False)):
+        b0, b1, b2, a0, a1, bmix = (f(D) if bias else None for _ in range(6))
+        items = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64 if i64 else np.int32)).to(dev)
+        q, user_o = f(B, D), f(B, D)
+        t0 = f(nR) * att if att else None
+        t1 = f(nR) * att if att else None
+        ws = ops.fold_tables(E, enc_e, enc_r, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, K, nR)
+        item, scores, sig = ops.score_l2_folded(ws, enc_e, enc_r, items, t0, t1, q, user_o, A1, a1, Wmix, K, D, nR, n_entity)
+        torch.cuda.synchronize()
+        pt = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, bool(att))
+        n0, n1 = ops.gather_attn_l2_prj(pt, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, n_entity)
+        want_item, want_scores, want_sig = ops.l2_tail(E, items, q, user_o, n0, n1, W0, b0, A0, a0, A1, a1, Wmix, bmix)
+        torch.cuda.synchronize()
+        assert_close(item.cpu().numpy(), want_item.cpu().numpy(), f"item_emb B={B}", rtol=3e-5, atol=3e-5)
+        assert_close(scores.cpu().numpy(), want_scores.cpu().numpy(), f"scores B={B}", rtol=3e-5, atol=3e-5)
+        assert_close(sig.cpu().numpy(), want_sig.cpu().numpy(), f"sigmoid B={B}", rtol=3e-5, atol=1e-5)
+        if B > 100:
+            T = ws[: 6 * n_entity * D].view(6, n_entity, D).double()
+            lg = t0.double()[ar.long()] if att else torch.zeros((n_entity, K), dtype=torch.float64, device=dev)
+            w = torch.softmax(lg, dim=1) / K if att else torch.full_like(lg, 1.0 / K)
+            Ed = E.double()
+            TA1 = Ed @ W1.double() @ A0.double()
+            TA2 = Ed @ W2.double() @ A0.double()
+            H0 = Ed @ W0.double() @ A0.double() + (w[:, :, None] * TA1[ae.long()]).sum(1)
+            G = TA1 + (w[:, :, None] * TA2[ae.long()]).sum(1)
+            M0 = Ed @ W0.double() @ Wmix[:D].double()
+            assert_close(T[4].cpu().numpy(), H0.cpu().numpy(), "H0", rtol=2e-5, atol=5e-6)
+            assert_close(T[5].cpu().numpy(), G.cpu().numpy(), "G", rtol=2e-5, atol=5e-6)
+            assert_close(T[3].cpu().numpy(), M0.cpu().numpy(), "M0", rtol=2e-5, atol=5e-6)
+
+
 def test_order_by_key_is_a_bucket_partition(hip_lib):
     """mvin_order_by_key: a permutation in which the keys' buckets (low 14 bits) are contiguous and ascending; any key skew, both widths."""
     dev = "cuda:0"

@@ -129,7 +129,8 @@ def test_hot_kernels_match_reference_graph(path, hip_lib):
                 # the forms above the tables, where the shape has them (D = 64, K in {16, 32}, encoded adjacency): the folded tail over
                 # per-entity aggregates in one launch (the default), aggregates + the tail kernel, the kernels over the tables themselves
                 enc_now = m._enc_for_l2(n_parents=items.shape[0])
-                forms = (("folded", None, None), ("aggregates", None, False), ("tables", False, None)) if m._agg_for(enc_now) else (("tables", None, None),)
+                forms = ((("folded", None, None), ("aggregates", None, False), ("tables", False, None)) if m._agg_for(enc_now) else
+                         (("folded", None, None), ("tables", False, None)) if m._fold_for(enc_now) else (("tables", None, None),))      # (dim 32: no aggregates + tail-kernel form)
                 for form, agg, fold in forms:
                     m.agg, m.fold = agg, fold
                     m._prj_tables.clear(), m._agg_tables.clear(), m._fold_ws.clear()
