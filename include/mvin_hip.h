@@ -233,7 +233,8 @@ MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, cons
                                 const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
                                 float* nagg1, void* stream);
 /* FOLDED-TAIL form of everything above key addressing for n_mix_hop = 1, h_hop = 2, User_orient on (mvin_l2_tail_fwd's formulas
- * over the aggregates above; D = 64, K in {16, 32, 64}).  nagg0 only ever enters through (ev0 + nagg0) A0 + a0, and ev0 through that and
+ * over the aggregates above; D = 64, K in {16, 32, 64} -- and D = 32, K in {16, 32}, where the aggregates exist as this form's H0 | G only).
+ * nagg0 only ever enters through (ev0 + nagg0) A0 + a0, and ev0 through that and
  * the combiner, so with c = the sum of a row's slot weights over K (1/K with attention, 1 without):
  *     (ev0 + nagg0) A0 + a0 = H0[x] + q Wq + bq        H0[e] = E[e] W0 A0 + sum_k w(e)_k TA1[y_ek],  Wq = (W0 + c W1) A0,
  *                                                       bq = (b0 + c b1) A0 + a0                      (S0[e] A0 = sum_k w(e)_k TA1[y_ek])
