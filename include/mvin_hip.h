@@ -212,7 +212,8 @@ MVIN_API int mvin_gather_attn_l2_prj_ordered_fwd(const float* ws, const int32_t*
                                 const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
                                 const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
                                 float* nagg1, void* stream);
-/* PER-ENTITY AGGREGATES of the projected tables (D = 64, K in {16, 32, 64}, encoded adjacency).  With one logit per relation
+/* PER-ENTITY AGGREGATES of the projected tables (D = 64, K in {16, 32, 64}, encoded adjacency): the two deepest levels of
+ * MVIN.aggregate_delta_whole (model.py:267-283 + :295-305, aggregators.py:98-146) once more re-associated.  With one logit per relation
  * (aggregators.py:118-146: User_orient_rela scores a relation, not a user) the softmax weights w(e)_k of entity e's slots under
  * aggregator (0,.) belong to the ENTITY, and so does everything of the formulas above that does not carry the query:
  *     G[e]  = TA1[e] + sum_k w(e)_k TA2[y_ek]          S0[e] = sum_k w(e)_k T1[y_ek]            (once per ENTITY and call)
@@ -232,7 +233,8 @@ MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, cons
                                 const void* parent_ids, int parent_ids_i64, const int32_t* order, const float* t0, const float* t1,
                                 const float* q, int B, int parents_per_pair, int K, int D, int n_entity, int nR, float* nagg0,
                                 float* nagg1, void* stream);
-/* FOLDED-TAIL form of everything above key addressing for n_mix_hop = 1, h_hop = 2, User_orient on (mvin_l2_tail_fwd's formulas
+/* FOLDED-TAIL form of everything above key addressing for n_mix_hop = 1, h_hop = 2, User_orient on -- MVIN.aggregate_delta_whole,
+ * model.py:259-324, with SumAggregator_urh_matrix._call, aggregators.py:98-146, and the score of model.py:158-159 (mvin_l2_tail_fwd's formulas
  * over the aggregates above; D = 64, K in {16, 32, 64} -- and D = 32, K in {16, 32}, where the aggregates exist as this form's H0 | G only).
  * nagg0 only ever enters through (ev0 + nagg0) A0 + a0, and ev0 through that and
  * the combiner, so with c = the sum of a row's slot weights over K (1/K with attention, 1 without):
