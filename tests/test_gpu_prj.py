@@ -6,6 +6,8 @@ E.W2 (built once per call, per ENTITY) and adds q.W1 + b1 / q.W2 + b2 (once per 
 multiplying every distinct child by W1 and W2; round 5's final form folds the aggregator's matrix A0 in as well (E.W1 | E.W1.A0 | E.W2.A0:
 mvin_project_tables), so no product per distinct child is left.  Same ids, same rows per pair; results equal to fp32 round-off -- checked here against the
 faithful encoded kernel, the fp32 mirror of the reference graph and the float64 equations."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -568,6 +570,56 @@ def test_folded_tail_form_dim32(K, hip_lib):
             assert_close(T[4].cpu().numpy(), H0.cpu().numpy(), "H0", rtol=2e-5, atol=5e-6)
             assert_close(T[5].cpu().numpy(), G.cpu().numpy(), "G", rtol=2e-5, atol=5e-6)
             assert_close(T[3].cpu().numpy(), M0.cpu().numpy(), "M0", rtol=2e-5, atol=5e-6)
+
+
+FOLD_PRESETS = ["all", "no_sw", "no_kg_eh_uo", "no_uor", "no_uor_and_no_kg_eh_uo", "no_ps_o_ft", "ho_only", "ho_only_uo_kg_eh", "no_uor_ho_only"]
+
+
+@pytest.mark.parametrize("i", range(int(os.environ.get("MVIN_FUZZ_OFFSET", "0")), int(os.environ.get("MVIN_FUZZ_OFFSET", "0")) + 36))
+def test_random_configuration_in_folded_form(i, hip_lib):
+    """Seeded random sweep over what the folded-tail form can meet -- dim 32 / 64, its fan-outs, ripple hops and memories, 2 .. 130 relations,
+    ragged batches from one pair on, every ablation preset that keeps User_orient and the wide-and-deep combiner (a query that is NOT user_o,
+    no relation attention, user embeddings instead of preference sets, ...), the three feeds, int32 ids -- through the model (forced: the
+    automatic rule needs bench-size batches), against the fp32 mirror and the fp64 equations."""
+    rng = np.random.default_rng(77000 + i)
+    D = int(rng.choice([32, 64]))
+    K = int(rng.choice([16, 32] if D == 32 else [16, 32, 64]))
+    P, Nm = int(rng.choice([1, 2, 2, 3])), int(rng.choice([4, 8, 16, 32, 64]))
+    nR = int(rng.choice([2, 5, 9, 39, 130]))
+    B = int(rng.choice([1, 7, 33, 64, 129, 300]))
+    n_user = int(rng.choice([1, 3, 17, 200]))
+    abl = str(rng.choice(FOLD_PRESETS))
+    feed = str(rng.choice(["pairs", "users", "users_grouped"]))
+    ids32 = bool(rng.random() < 0.3)
+    args = make_args(dim=D, neighbor_sample_size=K, h_hop=2, n_mix_hop=1, p_hop=P, n_memory=Nm, batch_size=B, ablation=abl)
+    case = synth.small_case(args, n_user=n_user, n_entity=150 + 41 * (i % 7), n_relation=nR, seed=77100 + i, zero_rows=3, repeats=True)
+    params = init_params(args, case.n_user, case.n_entity, case.n_relation, seed=77200 + i, random_agg_bias=True)
+    uts = synth.ripple_sets(case.n_user, case.n_entity, case.n_relation, max(1, P), Nm, seed=77300 + i)
+    if feed != "pairs":
+        case.memories_h, case.memories_r, case.memories_t = synth.memories_for(uts, case.users)
+    m, e = run_oracles(args, case, params)
+    model = MVIN(args, case.n_user, case.n_entity, case.n_relation, case.adj_entity, case.adj_relation, params=params, device="cuda:0")
+    model.prj, model.dedup = True, True
+    dev = model.device
+    u_d, i_d = torch.from_numpy(case.users).to(dev), torch.from_numpy(case.items).to(dev)
+    if ids32:
+        u_d, i_d = u_d.to(torch.int32), i_d.to(torch.int32)
+    mem = [[torch.from_numpy(x).to(dev) for x in lst] for lst in (case.memories_h, case.memories_r, case.memories_t)]
+    if feed == "pairs":
+        out = model.forward_device(u_d, i_d, *mem)
+    else:
+        model.group_min_pairs_per_user = 0 if feed == "users_grouped" else 10 ** 9
+        out = model.forward_users(u_d, i_d, torch.from_numpy(uts).to(dev))
+    torch.cuda.synchronize()
+    what = f"case {i}: D={D} K={K} P={P} Nm={Nm} nR={nR} B={B} users={n_user} {abl} {feed} ids32={ids32}"
+    enc = model._enc_for_l2(n_parents=B)
+    assert enc is not None and model._fold_for(enc), what
+    assert any(t is not None for t in model._fold_ws.values()), f"the folded-tail form did not run, {what}"
+    got = out.scores.cpu().numpy()
+    assert_close(got, m.scores.numpy(), f"scores vs fp32 mirror, {what}", rtol=1e-5, atol=1e-6)
+    assert_close(out.item_embeddings.cpu().numpy(), m.item_embeddings.numpy(), f"item_embeddings, {what}", rtol=1e-5, atol=1e-6)
+    err_hip, err_mir = np.abs(got - e.scores).max(), np.abs(m.scores.numpy() - e.scores).max()
+    assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
 
 
 def test_order_by_key_is_a_bucket_partition(hip_lib):
