@@ -65,18 +65,27 @@ __device__ __forceinline__ void block_scan2(int c, int s, int* sC, int* sS, int&
 // scan, then it walks the chunk again writing the segment table; offs[] leaves LDS coalesced.  (It was a loop of
 // n_user/1024 workgroup scans with three barriers each: 37 us for 23 553 users; walking the chunks straight from global
 // memory is a chain of uncoalesced load latencies: ~20 us there, 85 us for amazon-book's 70 585.)
-constexpr int kScanTile = 32768;
+constexpr int kScanTile = 16384;      // two LDS arrays per tile: the counters / offsets and the segment numbers (128 KB)
 __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t* __restrict__ count, int n_user, int64_t B,
                                                           int32_t* __restrict__ offs, int32_t* __restrict__ seg_user,
                                                           int32_t* __restrict__ seg_ptr, int32_t* __restrict__ nseg) {
     extern __shared__ int sCnt[];
+    int* sSeg = sCnt + min(n_user, kScanTile);           // segment number of every user of the tile that occurs, -1 otherwise
     __shared__ int sC[16], sS[16];
     const int tid = threadIdx.x;
     int carryC = 0, carryS = 0;
     for (int t0 = 0; t0 < n_user; t0 += kScanTile) {
         const int n = min(kScanTile, n_user - t0);
         __syncthreads();                                      // previous tile written out; sC / sS free again
-        for (int u = tid; u < n; u += 1024) sCnt[u] = count[t0 + u];
+        // (eight loads in flight per thread: one load -> LDS store per trip was a chain of n / 1024 memory latencies, 23 in a row at last-fm)
+        for (int u0 = tid; u0 < n; u0 += 8 * 1024) {
+            int v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = u0 + j * 1024 < n ? count[t0 + u0 + j * 1024] : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (u0 + j * 1024 < n) sCnt[u0 + j * 1024] = v[j];
+        }
         __syncthreads();
         const int per = ((n + 1023) / 1024) | 1;              // odd: lane t reads word t*per + j -- no LDS bank conflicts
         const int u0 = min(tid * per, n), u1 = min(u0 + per, n);
@@ -93,17 +102,23 @@ __global__ __launch_bounds__(1024) void group_scan_kernel(const int32_t* __restr
         for (int u = u0; u < u1; ++u) {
             const int v = sCnt[u];
             sCnt[u] = ec;
-            if (v > 0) {
-                seg_user[es] = t0 + u;
-                seg_ptr[es] = ec;
-                ++es;
-            }
+            sSeg[u] = v > 0 ? es : -1;
+            es += v > 0 ? 1 : 0;
             ec += v;
         }
         carryC += totC;
         carryS += totS;
         __syncthreads();
-        for (int u = tid; u < n; u += 1024) offs[t0 + u] = sCnt[u];
+        // the segment table leaves LDS with consecutive lanes on consecutive users (written from the chunk walk above, a lane's 23 segments
+        // apart from its neighbour's, it was 47 k single-word write transactions from one workgroup: 2/3 of the kernel's 27 us)
+        for (int u = tid; u < n; u += 1024) {
+            const int o = sCnt[u], sg = sSeg[u];
+            offs[t0 + u] = o;
+            if (sg >= 0) {
+                seg_user[sg] = t0 + u;
+                seg_ptr[sg] = o;
+            }
+        }
     }
     if (tid == 0) {
         nseg[0] = carryS;
@@ -211,10 +226,10 @@ hipError_t launch_group_pairs(const int64_t* u64, const int32_t* u32, int64_t B,
     const int blocks = (int)((B + 255) / 256 < 2048 ? (B + 255) / 256 : 2048);
     group_count_kernel<<<blocks, 256, 0, st>>>(u64, u32, B, n_user, count, rank);
     {
-        const size_t scan_lds = (size_t)(n_user < kScanTile ? n_user : kScanTile) * sizeof(int32_t);
+        const size_t scan_lds = (size_t)2 * (n_user < kScanTile ? n_user : kScanTile) * sizeof(int32_t);
         if (scan_lds > 48 * 1024) {
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(group_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(kScanTile * sizeof(int32_t)));
+                                    (int)(2 * kScanTile * sizeof(int32_t)));
             if (e != hipSuccess) return e;
         }
         group_scan_kernel<<<1, 1024, scan_lds, st>>>(count, n_user, B, offs, seg_user, seg_ptr, nseg);
