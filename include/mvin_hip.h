@@ -247,7 +247,8 @@ MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, cons
  *     out0 = relu(H0[x] + q Wq + bq) ;  Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + q Wv + bv)            (the pair kernel; out0, z2 [B, D] scratch)
  *     out2 = relu(Z2 A1 + a1) ;  item_emb = M0[x] + q Wqm + out0 Wm1 + out2 Wm2 + bmix + b0 Wm0 ;  scores = <user_o, item_emb>
  * -- six D x D products per pair instead of eight, the same sums in another association (agreement to rounding).  item_emb / sig may
- * be NULL.  _supported: as mvin_gather_attn_l2_agg_supported. */
+ * be NULL; so may out0 / z2 ([B, D] scratch rows): only the two-launch A/B variant (MVIN_L2_FOLD_TWO=1 in the environment: pair kernel +
+ * four-product tile kernel) writes them, the default is ONE launch that keeps them in LDS.  _supported: the shapes above. */
 MVIN_API int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR);
 MVIN_API size_t mvin_fold_tables_elems(int n_entity, int D);
 MVIN_API int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,

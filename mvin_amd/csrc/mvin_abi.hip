@@ -538,7 +538,7 @@ int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const i
                              const float* a1, const float* Wmix, int64_t B, int K, int D, int n_entity, int nR, float* out0, float* z2,
                              float* item_emb, float* scores, float* sig, void* stream) {
     const char* who = "mvin_score_l2_folded_fwd";
-    if (!ws || !enc_entity || !enc_relation || !q || !user_o || !A1 || !Wmix || !out0 || !z2 || !scores) return fail(-1, "%s: null pointer", who);
+    if (!ws || !enc_entity || !enc_relation || !q || !user_o || !A1 || !Wmix || !scores) return fail(-1, "%s: null pointer", who);
     if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
     if (B <= 0 || B >= (int64_t(1) << 31)) return fail(-2, "%s: B=%lld", who, (long long)B);
     if (!fold_applies(D, K, n_entity, nR, B)) return fail(-3, "%s: unsupported shape / sizes D=%d K=%d n_entity=%d nR=%d B=%lld", who, D, K, n_entity, nR, (long long)B);
@@ -561,6 +561,7 @@ int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const i
                           who);
     }
     // MVIN_L2_FOLD_TWO=1 (A/B): the pair kernel writes out0 and Z2, the tile kernel of mvin_tail.hip takes them from there
+    if (!out0 || !z2) return fail(-1, "%s: the two-launch variant (MVIN_L2_FOLD_TWO=1) needs the out0 / z2 scratch rows", who);
     mvin::FusedL2Args f{};
     f.table = ws;
     f.agg = const_cast<float*>(ws + 4 * tab);     // H0 | G

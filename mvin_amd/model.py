@@ -190,8 +190,7 @@ class MVIN(object):
             if self.dim == 32 and self.n_neighbor <= 16 and not (
                     n_parents is not None and self.n_mix_hop * self.h_hop == 2 and self.args.User_orient and self.fold is not False
                     and self.agg is not False and self.prj is not False and self.entity_emb_matrix.dtype == torch.float32
-                    and n_parents * self.n_neighbor >= 10 * self.n_entity
-                    and ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation)):
+                    and n_parents * self.n_neighbor >= 10 * self.n_entity and self._fold_shape_ok()):
                 return None
             if n_parents is not None and n_parents < self.ENC_AUTO_MIN_PARENTS:
                 return None
@@ -980,9 +979,13 @@ class MVIN(object):
         mvin_score_l2_fwd (depth-2 trees, User_orient on).  ``self.fold`` False (MVIN_L2_FOLD=0) keeps aggregates + mvin_l2_tail_fwd."""
         if enc is None or self.fold is False or self.agg is False or not self.args.User_orient:
             return False
+        return self._fold_shape_ok()
+
+    def _fold_shape_ok(self):
+        """mvin_score_l2_folded_supported for this model's tables (dim 64 with K in {16, 32, 64} like the aggregates form, dim 32 with K in {16, 32})."""
         key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
         c = getattr(self, "_fold_ok_cache", None)
-        if c is None or c[0] != key:      # (dim 64 with K in {16, 32, 64} like the aggregates form, and dim 32 with K in {16, 32})
+        if c is None or c[0] != key:
             c = self._fold_ok_cache = (key, ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation))
         return c[1]
 
@@ -1015,7 +1018,7 @@ class MVIN(object):
             # C3 (K = 32) ~32 768 = 10 n_entity / K, C4 (K = 64) ~8 192 = 4.6 n_entity / K; the kernels over the tables themselves: 16
             aggs = self.agg is not False and ((self.dim == 64 and self._agg_shape_ok())
                                               or (self.dim == 32 and self.n_mix_hop * self.h_hop == 2 and self.fold is not False
-                                                  and ops.score_l2_folded_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation)))
+                                                  and self._fold_shape_ok()))
             k_ok = self.n_neighbor <= 32 or (self.n_neighbor == 64 and aggs)
             factor = (5 if self.n_neighbor == 64 else 10) if aggs else 16
             want = self.dim <= 64 and k_ok and (n_parents or B) * self.n_neighbor >= factor * self.n_entity

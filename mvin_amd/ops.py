@@ -462,8 +462,9 @@ def score_l2_folded(ws, enc_entity, enc_relation, items, t0, t1, q, user_o, A1, 
     B = items.shape[0]
     if ws.numel() != lib.mvin_fold_tables_elems(n_entity, D) or tuple(q.shape) != (B, D) or tuple(user_o.shape) != (B, D):
         raise ValueError("score_l2_folded: the workspace of fold_tables(n_entity, D) and q, user_o [B, D] expected")
-    out0 = torch.empty((B, D), dtype=F32, device=ws.device)
-    z2 = torch.empty((B, D), dtype=F32, device=ws.device)
+    two = os.environ.get("MVIN_L2_FOLD_TWO", "0") not in ("", "0")      # (the two-launch A/B variant needs scratch rows for out0 / Z2)
+    out0 = torch.empty((B, D), dtype=F32, device=ws.device) if two else None
+    z2 = torch.empty((B, D), dtype=F32, device=ws.device) if two else None
     item_emb = torch.empty((B, D), dtype=F32, device=ws.device) if want_item_emb else None
     scores = torch.empty((B,), dtype=F32, device=ws.device)
     sig = torch.empty((B,), dtype=F32, device=ws.device)
