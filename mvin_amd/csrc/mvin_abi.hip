@@ -476,7 +476,7 @@ static bool fold_applies(int D, int K, int n_entity, int nR, int64_t B) {
     if (n_entity <= 0 || nR <= 0 || nR > 4096 || !mvin::fused_fold_supported(D, K)) return false;
     const uint64_t tb = (uint64_t)n_entity * (uint64_t)D * 4, ab = (uint64_t)n_entity * (uint64_t)K * 4;
     return tb < (1ull << 30) && ab < (1ull << 31) && n_entity <= (1 << 24) && (B <= 0 || (uint64_t)B * D * 4 < (1ull << 31)) &&
-           mvin::fused_fold_lds_bytes(D, nR, K) <= 64 * 1024;
+           mvin::fused_fold_lds_bytes(D, nR, K) <= 48 * 1024;
 }
 
 // ---- folded-tail form: tables TA1 | TA2 | T0A | M0, aggregates H0 | G, parameter block ----

@@ -588,7 +588,7 @@ size_t fused_agg_lds_bytes(int nR, int K) {
 bool fused_agg_applies(const FusedL2Args& a, int D) {
     return a.prj && fused_agg_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_r && a.adj_bytes > 0 &&
            a.adj_bytes < (1ull << 31) && a.table_bytes > 0 && a.table_bytes < (1ull << 30) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
-           a.max_id < (1u << 24) && a.nR > 0 && fused_agg_lds_bytes(a.nR, a.K) <= 64 * 1024;
+           a.max_id < (1u << 24) && a.nR > 0 && fused_agg_lds_bytes(a.nR, a.K) <= 48 * 1024;      // (dynamic LDS above 48 KB needs a function attribute: such relation counts keep the other kernels)
 }
 
 template <int K>

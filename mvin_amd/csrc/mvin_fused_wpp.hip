@@ -384,7 +384,7 @@ bool fused_wpp_applies(const FusedL2Args& a, int D) {
     if (e && e[0] == '0') return false;                  // A/B: the packed-tile kernel
     return a.prj && fused_wpp_supported(D, a.K) && !a.probs_parent && !a.probs_child && a.adj_r && a.adj_bytes > 0 &&
            a.adj_bytes < (1ull << 31) && a.table_bytes > 0 && a.table_bytes < (1ull << 30) && (uint64_t)a.P * D * 4 < (1ull << 31) &&
-           a.max_id < (1u << 24) && a.W1 && a.W2 && a.q && fused_wpp_lds_bytes(a.nR, a.K) <= 64 * 1024;
+           a.max_id < (1u << 24) && a.W1 && a.W2 && a.q && fused_wpp_lds_bytes(a.nR, a.K) <= 48 * 1024;      // (dynamic LDS above 48 KB would need a function attribute)
 }
 
 template <int K>

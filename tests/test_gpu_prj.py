@@ -622,6 +622,35 @@ def test_random_configuration_in_folded_form(i, hip_lib):
     assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
 
 
+def test_folded_form_with_thousands_of_relations(hip_lib):
+    """The relation logits live in LDS next to the kernels' per-wave blocks: up to the 48 KB a launch gets without a function attribute
+    (2 600 relations at K = 32) the folded form runs, beyond it the _supported queries say no and the callers keep the other kernels."""
+    D, K, n_entity = 64, 32, 300
+    assert ops.score_l2_folded_supported(D, K, n_entity, 2600) and not ops.score_l2_folded_supported(D, K, n_entity, 2800)
+    assert not ops.gather_attn_l2_agg_supported(D, 64, n_entity, 1700) and ops.gather_attn_l2_agg_supported(D, 64, n_entity, 1600)
+    nR = 2600
+    rng = np.random.default_rng(5)
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    ae = torch.from_numpy(rng.integers(0, n_entity, (n_entity, K)).astype(np.int32)).to(dev)
+    ar = torch.from_numpy(rng.integers(0, nR, (n_entity, K)).astype(np.int32)).to(dev)
+    ae[:, K // 2:] = ae[:, : K // 2]                     # repeated slots
+    ar[:, K // 2:] = ar[:, : K // 2]
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    E, W0, W1, W2, A0, A1, Wmix = f(n_entity, D), f(D, D), f(D, D), f(D, D), f(D, D), f(D, D), f(3 * D, D)
+    B = 77
+    items = torch.from_numpy(rng.integers(0, n_entity, B).astype(np.int64)).to(dev)
+    q, t0, t1 = f(B, D), f(nR), f(nR)
+    ws = ops.fold_tables(E, enc_e, enc_r, t0, W0, None, W1, None, W2, None, A0, None, Wmix, None, A1, K, nR)
+    item, scores, sig = ops.score_l2_folded(ws, enc_e, enc_r, items, t0, t1, q, q, A1, None, Wmix, K, D, nR, n_entity)
+    pt = ops.project_tables(E, W1, W2, None, None, A0, None, K, True)
+    n0, n1 = ops.gather_attn_l2_prj(pt, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, n_entity)
+    want_item, want_scores, _ = ops.l2_tail(E, items, q, q, n0, n1, W0, None, A0, None, A1, None, Wmix, None)
+    torch.cuda.synchronize()
+    assert_close(scores.cpu().numpy(), want_scores.cpu().numpy(), "scores, 2 600 relations", rtol=3e-5, atol=3e-5)
+    assert_close(item.cpu().numpy(), want_item.cpu().numpy(), "item_emb, 2 600 relations", rtol=3e-5, atol=3e-5)
+
+
 def test_order_by_key_is_a_bucket_partition(hip_lib):
     """mvin_order_by_key: a permutation in which the keys' buckets (low 14 bits) are contiguous and ascending; any key skew, both widths."""
     dev = "cuda:0"
