@@ -811,6 +811,22 @@ def main():
         barrier()
         faithful = ((time.perf_counter() - t1) / a.steps, float((out_f.scores - out.scores).abs().max()))
         model.prj = None
+    # ... and with every pair gathering its own rows: the kernels over the projected tables themselves (no per-entity aggregates), on the
+    # SAME streams as the timed region.  SURVEY 7.3-c asks for the per-entity route to be a separate, labelled mode: this is the other one.
+    gather_mode = None
+    if scorer is None and not rowshard and model.agg is None and model.prj is None:
+        enc_g = model._enc_for_l2(n_parents=Bl * a.fanout ** (a.hop * a.mix - 2))
+        if model._prj_for_l2(Bl, Bl * a.fanout ** (a.hop * a.mix - 2)) and (model._fold_for(enc_g) or model._agg_for(enc_g)):
+            model.agg = False
+            for i in range(max(3, nstreams)):
+                step_on(i)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(a.steps):
+                out_g = step_on(i)
+            barrier()
+            gather_mode = ((time.perf_counter() - t1) / a.steps, float((out_g.scores - out.scores).abs().max()))
+            model.agg = None
     if one_call:
         model._profile = []
         model._ka_profile = []
@@ -1073,6 +1089,11 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.table_dtype, "data": "synthetic",
+            "mode": ("per-entity aggregates (SURVEY 7.3-c route 2b, exact; every table rebuilt inside every timed step, nothing cached): the "
+                     "pair-independent sums of the two deepest levels are taken per ENTITY, a pair gathers ~9 rows; the mode in which every "
+                     "pair gathers its own rows is other_modes.every_pair_gathers_its_rows, and `roofline` is THAT mode's kernel"
+                     if agg_now else "every pair gathers its own rows") if (used_l2 and not hoisted) else
+                    ("entity-table mode (--hoist)" if hoisted else "per-level kernels"),
             "config": {"workload": f"{a.dataset}-shaped tables (nE={case.n_entity}, nU={case.n_user}, "
                                    f"nR={case.n_relation}), dim={a.dim} hop={a.hop} n_mix_hop={a.mix} "
                                    f"fan-out={a.fanout} p_hop={d['p_hop']} n_memory={d['n_memory']}, "
@@ -1143,6 +1164,14 @@ def main():
                 "value": (Bl if emulated else a.batch) / single_stream, "unit": "pairs/s", "ms_per_step": 1e3 * single_stream,
                 "note": "the same K steps enqueued on ONE stream (how rounds 1-4 ran the line): every kernel waits for the last workgroup "
                         "of the one before; with `config.streams` streams the independent steps' kernels fill those drains"}
+        if gather_mode is not None:
+            rec.setdefault("other_modes", {})["every_pair_gathers_its_rows"] = {
+                "value": (Bl if emulated else a.batch) / gather_mode[0], "unit": "pairs/s", "ms_per_step": 1e3 * gather_mode[0], "streams": nstreams,
+                "max_abs_diff_vs_timed_scores": gather_mode[1],
+                "note": "the same K steps on the same streams with MVIN.agg = False (MVIN_L2_AGG=0): the two deepest levels as the gather kernel "
+                        "over the projected tables (mvin_gather_attn_l2_prj_fwd: every pair gathers the rows of its own distinct children and "
+                        "grandchildren -- the kernel of `roofline`) + mvin_l2_tail_fwd, i.e. WITHOUT the per-entity sums of SURVEY 7.3-c's route "
+                        "2b that `value` takes"}
         if faithful is not None:
             rec.setdefault("other_modes", {})["unprojected_two_level"] = {
                 "value": (Bl if emulated else a.batch) / faithful[0], "unit": "pairs/s", "ms_per_step": 1e3 * faithful[0], "streams": 1,
