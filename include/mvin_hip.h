@@ -255,6 +255,20 @@ MVIN_API int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity
                               const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
                               const float* a0, const float* Wmix, const float* bmix, const float* A1, int K, int D, int n_entity, int nR,
                               float* ws, void* stream);
+/* The same with EVERY PAIR GATHERING ITS OWN ROWS (D = 64, K in {16, 32}): no per-entity sums -- mvin_fold_tables_ex with aggregates = 0
+ * builds the four per-row tables only (SURVEY 7.3-c's route 2: the matrices moved to the tables, the same rows gathered), and
+ * mvin_score_l2_folded_gather_fwd walks a pair's distinct children and grandchildren like mvin_gather_attn_l2_prj_ordered_fwd
+ * (nagg0 A0 = sum_c (p0_c / K) TA1[x_c]: one T1 row per child less) and finishes the pair in the same launch.  `order`: as there.
+ * MVIN_L2_FOLD_GATHER=0 in the environment makes _supported answer 0 (A/B: wave-per-parent kernel + mvin_l2_tail_fwd). */
+MVIN_API int mvin_fold_tables_ex(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
+                                 const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0,
+                                 const float* a0, const float* Wmix, const float* bmix, const float* A1, int aggregates, int K, int D,
+                                 int n_entity, int nR, float* ws, void* stream);
+MVIN_API int mvin_score_l2_folded_gather_supported(int D, int K, int n_entity, int nR);
+MVIN_API int mvin_score_l2_folded_gather_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const int64_t* items_i64,
+                                             const int32_t* items_i32, const int32_t* order, const float* t0, const float* t1, const float* q,
+                                             const float* user_o, const float* A1, const float* a1, const float* Wmix, int64_t B, int K, int D,
+                                             int n_entity, int nR, float* item_emb, float* scores, float* sig, void* stream);
 MVIN_API int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const int64_t* items_i64,
                                       const int32_t* items_i32, const float* t0, const float* t1, const float* q, const float* user_o,
                                       const float* A1, const float* a1, const float* Wmix, int64_t B, int K, int D, int n_entity, int nR,
@@ -529,6 +543,8 @@ typedef struct {
                                       adjacency, User_orient on, an fp32 table and a shape mvin_score_l2_folded_supported takes, everything
                                       above key addressing runs as mvin_fold_tables -> mvin_score_l2_folded_fwd (nagg0 / nagg1 are its
                                       scratch rows); takes precedence over prj_tables / agg_tables.  Rewritten by every call */
+    int fold_gather;               /* with fold_ws: 1 = the form in which every pair gathers its own rows (mvin_fold_tables_ex without
+                                      aggregates -> mvin_score_l2_folded_gather_fwd, in item order when item_order_ws is given) */
 } mvin_score_l2_args;
 MVIN_API int mvin_score_l2_fwd(const mvin_score_l2_args* args, void* stream);
 

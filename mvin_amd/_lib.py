@@ -71,7 +71,7 @@ class ScoreL2Args(C.Structure):
         ("B", C.c_int64)] + [(n, C.c_int) for n in ("D", "K", "P", "Nm", "n_entity", "n_relation", "table_bf16", "n_user")] + [
         ("enc_entity", C.c_void_p), ("enc_relation", C.c_void_p), ("group_ws", C.c_void_p),
         ("user_records", C.c_void_p), ("depth", C.c_int), ("prj_tables", C.c_void_p), ("ka_er", C.c_void_p),
-        ("ka_flash", C.c_void_p), ("item_order_ws", C.c_void_p), ("agg_tables", C.c_void_p), ("fold_ws", C.c_void_p)]
+        ("ka_flash", C.c_void_p), ("item_order_ws", C.c_void_p), ("agg_tables", C.c_void_p), ("fold_ws", C.c_void_p), ("fold_gather", C.c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/mvin_hip.h one to one.
@@ -99,6 +99,9 @@ SIGNATURES = {
     "mvin_score_l2_folded_supported": (C.c_int, [C.c_int] * 4),
     "mvin_fold_tables_elems": (C.c_size_t, [C.c_int] * 2),
     "mvin_fold_tables": (C.c_int, [C.c_void_p] * 15 + [C.c_int] * 4 + [C.c_void_p] * 2),
+    "mvin_fold_tables_ex": (C.c_int, [C.c_void_p] * 15 + [C.c_int] * 5 + [C.c_void_p] * 2),
+    "mvin_score_l2_folded_gather_supported": (C.c_int, [C.c_int] * 4),
+    "mvin_score_l2_folded_gather_fwd": (C.c_int, [C.c_void_p] * 13 + [C.c_int64] + [C.c_int] * 4 + [C.c_void_p] * 4),
     "mvin_score_l2_folded_fwd": (C.c_int, [C.c_void_p] * 12 + [C.c_int64] + [C.c_int] * 4 + [C.c_void_p] * 6),
     "mvin_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mvin_scatter_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

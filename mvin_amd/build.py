@@ -18,7 +18,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG_DIR), "include")
 LIB_PATH = os.path.join(PKG_DIR, "libmvin_hip.so")
 STAMP_PATH = LIB_PATH + ".stamp"
 OBJ_DIR = os.path.join(PKG_DIR, "_build")
-SOURCES = ["mvin_kernels.hip", "mvin_fused.hip", "mvin_fused_split.hip", "mvin_fused_packed.hip", "mvin_fused_wpp.hip", "mvin_fused_agg.hip", "mvin_fused_agg32.hip", "mvin_fused_d16.hip", "mvin_fused_d32.hip", "mvin_tail.hip", "mvin_tail_flash.hip", "mvin_score_small.hip", "mvin_keyaddr.hip", "mvin_keyaddr_stream.hip", "mvin_keyaddr_grouped.hip", "mvin_keyaddr_dense.hip", "mvin_keyaddr_static.hip", "mvin_keyaddr_flash.hip", "mvin_keyaddr_wave.hip", "mvin_hoist.hip", "mvin_probe.hip", "mvin_group.hip", "mvin_order.hip", "mvin_prep.hip", "mvin_linear_mfma.hip", "mvin_bwd.hip", "mvin_abi.hip"]
+SOURCES = ["mvin_kernels.hip", "mvin_fused.hip", "mvin_fused_split.hip", "mvin_fused_packed.hip", "mvin_fused_wpp.hip", "mvin_fused_agg.hip", "mvin_fused_agg32.hip", "mvin_fused_wpp_fold.hip", "mvin_fused_d16.hip", "mvin_fused_d32.hip", "mvin_tail.hip", "mvin_tail_flash.hip", "mvin_score_small.hip", "mvin_keyaddr.hip", "mvin_keyaddr_stream.hip", "mvin_keyaddr_grouped.hip", "mvin_keyaddr_dense.hip", "mvin_keyaddr_static.hip", "mvin_keyaddr_flash.hip", "mvin_keyaddr_wave.hip", "mvin_hoist.hip", "mvin_probe.hip", "mvin_group.hip", "mvin_order.hip", "mvin_prep.hip", "mvin_linear_mfma.hip", "mvin_bwd.hip", "mvin_abi.hip"]
 HEADERS = ["mvin_common.h", "mvin_kernels.h", "mvin_fused_agg.h"]
 VERSION_SCRIPT = os.path.join(CSRC, "libmvin_hip.map")
 ARCH = "gfx950"

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "mvin_kernels.h"
+#include "mvin_fused_agg.h"
 
 namespace {
 
@@ -468,6 +469,8 @@ int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, const int32_t
                                nullptr, 0, stream, true, true, order, agg);
 }
 
+static bool fold_gather_applies(int D, int K, int n_entity, int nR, int64_t B);
+
 // does the folded-tail form run for these tables?  (dim 64 like the aggregates form, and dim 32)
 static bool fold_applies(int D, int K, int n_entity, int nR, int64_t B) {
     if (D == 64) return agg_applies(D, K, n_entity, nR, B);
@@ -491,9 +494,17 @@ int mvin_score_l2_folded_supported(int D, int K, int n_entity, int nR) { return 
 int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
                      const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0, const float* a0,
                      const float* Wmix, const float* bmix, const float* A1, int K, int D, int n_entity, int nR, float* ws, void* stream) {
+    return mvin_fold_tables_ex(entity_emb, enc_entity, enc_relation, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, 1, K, D, n_entity, nR, ws,
+                               stream);
+}
+
+int mvin_fold_tables_ex(const float* entity_emb, const int32_t* enc_entity, const int32_t* enc_relation, const float* t0, const float* W0,
+                        const float* b0, const float* W1, const float* b1, const float* W2, const float* b2, const float* A0, const float* a0,
+                        const float* Wmix, const float* bmix, const float* A1, int aggregates, int K, int D, int n_entity, int nR, float* ws,
+                        void* stream) {
     const char* who = "mvin_fold_tables";
     if (!entity_emb || !enc_entity || !enc_relation || !W0 || !W1 || !W2 || !A0 || !Wmix || !A1 || !ws) return fail(-1, "%s: null pointer", who);
-    if (!fold_applies(D, K, n_entity, nR, 1))
+    if (!(aggregates ? fold_applies(D, K, n_entity, nR, 1) : fold_gather_applies(D, K, n_entity, nR, 1)))
         return fail(-3, "%s: D = 64 with K in {16, 32, 64} or D = 32 with K in {16, 32}; n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB, nR <= 4096 "
                         "(D=%d K=%d n_entity=%d nR=%d)", who, D, K, n_entity, nR);
     const size_t tab = (size_t)n_entity * D;
@@ -514,6 +525,7 @@ int mvin_fold_tables(const float* entity_emb, const int32_t* enc_entity, const i
     l.nz = 4;
     l.out_zstride = (int64_t)n_entity * D;
     if (int rc = mvin_linear_fwd(&l, stream)) return rc;
+    if (!aggregates) return 0;                // (the gather form: per-row tables only, every pair walks its own children)
     mvin::EntityAggArgs f{};
     f.tabS = ws;                              // H0[e] = T0A[e] + sum_k w_k TA1[y_k]
     f.selfS = ws + 2 * tab;
@@ -607,6 +619,56 @@ int mvin_score_l2_folded_fwd(const float* ws, const int32_t* enc_entity, const i
     t.B = B;
     t.n_entity = n_entity;
     return hip_result(mvin::launch_l2_tail_fold(t, (hipStream_t)stream), who);
+}
+
+// the folded tail with every pair gathering its own rows (no per-entity sums): dim 64, K in {16, 32}
+static bool fold_gather_applies(int D, int K, int n_entity, int nR, int64_t B) {
+    if (D != 64 || (K != 16 && K != 32) || n_entity <= 0 || nR <= 0 || nR > 4096) return false;
+    static const char* e = getenv("MVIN_L2_FOLD_GATHER");
+    if (e && e[0] == '0') return false;                   // A/B: wave-per-parent kernel + mvin_l2_tail_fwd
+    const uint64_t tb = (uint64_t)n_entity * (uint64_t)D * 4, ab = (uint64_t)n_entity * (uint64_t)K * 4;
+    return tb < (1ull << 30) && ab < (1ull << 31) && n_entity <= (1 << 24) && (B <= 0 || (uint64_t)B * D * 4 < (1ull << 31)) &&
+           mvin::fused_wppfold_lds_bytes(nR, K) <= 48 * 1024;
+}
+
+int mvin_score_l2_folded_gather_supported(int D, int K, int n_entity, int nR) { return fold_gather_applies(D, K, n_entity, nR, 1) ? 1 : 0; }
+
+int mvin_score_l2_folded_gather_fwd(const float* ws, const int32_t* enc_entity, const int32_t* enc_relation, const int64_t* items_i64,
+                                    const int32_t* items_i32, const int32_t* order, const float* t0, const float* t1, const float* q,
+                                    const float* user_o, const float* A1, const float* a1, const float* Wmix, int64_t B, int K, int D,
+                                    int n_entity, int nR, float* item_emb, float* scores, float* sig, void* stream) {
+    const char* who = "mvin_score_l2_folded_gather_fwd";
+    if (!ws || !enc_entity || !enc_relation || !q || !user_o || !A1 || !Wmix || !scores) return fail(-1, "%s: null pointer", who);
+    if ((items_i64 == nullptr) == (items_i32 == nullptr)) return fail(-1, "%s: exactly one of items_i64 / items_i32", who);
+    if (B <= 0 || B >= (int64_t(1) << 31)) return fail(-2, "%s: B=%lld", who, (long long)B);
+    if (!fold_gather_applies(D, K, n_entity, nR, B))
+        return fail(-3, "%s: D = 64, K in {16, 32}; n_entity <= 2^24, tables < 1 GiB, adjacency < 2 GiB (D=%d K=%d n_entity=%d nR=%d B=%lld)", who, D, K,
+                    n_entity, nR, (long long)B);
+    const size_t tab = (size_t)n_entity * D, DD = (size_t)D * D;
+    const float* blk = ws + 6 * tab;
+    const float* bv = blk + 6 * DD;
+    const float* bq = bv + D;
+    const float* bm = bq + D;
+    const float* Wp = bm + D;                 // the regrouped copies of the six blocks: Wq | Wv | Wqm | A1 | Wm1 | Wm2
+    mvin::FoldArgs f{};
+    f.tables = ws;                            // TA1 | TA2 | T0A
+    f.M0 = ws + 3 * tab;
+    f.adj_e = enc_entity;
+    f.adj_r = enc_relation;
+    f.items = items_i64 ? reinterpret_cast<const int32_t*>(items_i64) : items_i32;
+    f.pid_stride = items_i64 ? 2 : 1;
+    f.order = order;
+    f.t0 = t0;
+    f.t1 = t1;
+    f.q = q;
+    f.user_o = user_o;
+    f.Wq = Wp, f.bq = bq, f.Wv = Wp + DD, f.bv = bv, f.Wqm = Wp + 2 * DD, f.A1 = Wp + 3 * DD, f.a1 = a1, f.Wm1 = Wp + 4 * DD, f.Wm2 = Wp + 5 * DD, f.bm = bm;
+    f.item_emb = item_emb, f.scores = scores, f.sig = sig;
+    f.B = B, f.K = K, f.nR = nR;
+    f.max_id = (unsigned)(n_entity - 1);
+    f.table_bytes = (uint64_t)tab * 4;
+    f.adj_bytes = (uint64_t)n_entity * (uint64_t)K * 4;
+    return hip_result(mvin::launch_score_l2_folded_gather(f, (hipStream_t)stream), who);
 }
 
 int mvin_encode_adjacency(const int32_t* adj_entity, const int32_t* adj_relation, int n_entity, int K, int32_t* cnt,
@@ -908,7 +970,24 @@ int mvin_score_l2_fwd(const mvin_score_l2_args* a, void* stream) {
     if (rc) return rc;
     }
     // the parents of a depth-2 tree are the items themselves: the kernel reads the int64 ids in place (no expand launch)
-    if (a->fold_ws && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 && fold_applies(D, a->K, a->n_entity, nR, a->B)) {
+    if (a->fold_ws && a->fold_gather && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 &&
+        fold_gather_applies(D, a->K, a->n_entity, nR, a->B)) {
+        // folded tail, every pair gathering its own rows: the four per-row tables (no aggregates), parents in item order, one launch
+        rc = mvin_fold_tables_ex(reinterpret_cast<const float*>(a->entity_emb), a->enc_entity, a->enc_relation, a->t0, a->W0, a->b0, a->W1, a->b1,
+                                 a->W2, a->b2, a->A0, a->a0, a->Wmix, a->bmix, a->A1, 0, a->K, D, a->n_entity, nR, a->fold_ws, stream);
+        if (rc) return rc;
+        const int32_t* order = nullptr;
+        if (a->item_order_ws) {
+            int32_t* ord = a->item_order_ws + mvin::order_ws_elems(a->B);
+            rc = mvin_order_by_key(a->items, nullptr, a->B, a->item_order_ws, ord, stream);
+            if (rc) return rc;
+            order = ord;
+        }
+        return mvin_score_l2_folded_gather_fwd(a->fold_ws, a->enc_entity, a->enc_relation, a->items, nullptr, order, a->t0, a->t1, a->user_o,
+                                               a->user_o, a->A1, a->a1, a->Wmix, a->B, a->K, D, a->n_entity, nR, a->item_emb, a->scores, a->sig,
+                                               stream);
+    }
+    if (a->fold_ws && !a->fold_gather && a->enc_entity && a->enc_relation && a->W0 && a->W1 && a->W2 && !a->table_bf16 && fold_applies(D, a->K, a->n_entity, nR, a->B)) {
         // folded-tail form: four per-entity tables + the aggregates H0 | G from the CURRENT parameters, then two launches per batch
         rc = mvin_fold_tables(reinterpret_cast<const float*>(a->entity_emb), a->enc_entity, a->enc_relation, a->t0, a->W0, a->b0, a->W1, a->b1,
                               a->W2, a->b2, a->A0, a->a0, a->Wmix, a->bmix, a->A1, a->K, D, a->n_entity, nR, a->fold_ws, stream);

@@ -137,9 +137,15 @@ struct FoldArgs {
     int K, nR, pid_stride;
     unsigned max_id;
     int dbg;                     // MVIN_FOLD_DBG (measurement only; results wrong): 1 no G rows, 2 no products behind the gather, 4 none before it, 8 no gather steps
+    // the gather form (mvin_fused_wpp_fold.hip): no aggregates -- every pair walks its own children and grandchildren
+    const float* tables;         // [3][nE][64] TA1 | TA2 | T0A
+    const float* t0;             // [nR] relation logits of aggregator (0,.) or NULL
+    const int32_t* order;        // [B] or NULL: slot i of the launch works on pair order[i]
 };
 
 hipError_t launch_entity_aggregates_d32(const EntityAggArgs& a, hipStream_t st);      // mvin_fused_agg32.hip
 hipError_t launch_score_l2_folded_d32(const FoldArgs& f, hipStream_t st);
+hipError_t launch_score_l2_folded_gather(const FoldArgs& f, hipStream_t st);           // mvin_fused_wpp_fold.hip
+size_t fused_wppfold_lds_bytes(int nR, int K);
 
 }  // namespace mvin

@@ -981,6 +981,14 @@ class MVIN(object):
             return False
         return self._fold_shape_ok()
 
+    def _fold_gather_ok(self):
+        """mvin_score_l2_folded_gather_supported for this model's tables (dim 64, K in {16, 32}; MVIN_L2_FOLD_GATHER=0 says no)."""
+        key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
+        c = getattr(self, "_fold_gather_cache", None)
+        if c is None or c[0] != key:
+            c = self._fold_gather_cache = (key, ops.score_l2_folded_gather_supported(self.dim, self.n_neighbor, self.n_entity, self.n_relation))
+        return c[1]
+
     def _fold_shape_ok(self):
         """mvin_score_l2_folded_supported for this model's tables (dim 64 with K in {16, 32, 64} like the aggregates form, dim 32 with K in {16, 32})."""
         key = (self.n_entity, self.n_relation, self.dim, self.n_neighbor)
@@ -1087,7 +1095,10 @@ class MVIN(object):
         # products cost ~n_entity rows of work, the per-child products they replace ~B K / 4)
         prj = (enc is not None or self._prj_plain_ok()) and self._prj_for_l2(B)
         fold = bool(prj and self._fold_for(enc))           # (its own workspace holds its own tables)
-        if prj and not fold:
+        # MVIN.agg = False ("every pair gathers its own rows"): the folded tail still applies, in its gather form -- per-row tables only
+        gfold = bool(prj and not fold and enc is not None and self.agg is False and self.fold is not False and self.args.User_orient
+                     and self.n_mix_hop * self.h_hop == 2 and self._fold_gather_ok())
+        if prj and not fold and not gfold:
             pt = self._prj_tables.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_project_tables_elems(self.n_entity, D)
             if pt is None or pt.numel() != n_ws:
@@ -1096,12 +1107,14 @@ class MVIN(object):
         else:
             s.prj_tables = None
         s.agg_tables = s.fold_ws = None
-        if fold:
+        s.fold_gather = 0
+        if fold or gfold:
             fw = self._fold_ws.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_fold_tables_elems(self.n_entity, D)
             if fw is None or fw.numel() != n_ws:
                 fw = self._fold_ws[stream.cuda_stream] = torch.empty((n_ws,), dtype=torch.float32, device=self.device)
             s.fold_ws = fw.data_ptr()
+            s.fold_gather = 1 if gfold else 0
         elif prj and self._agg_for(enc):
             at = self._agg_tables.get(stream.cuda_stream)
             n_ws = _lib.load().mvin_entity_aggregates_elems(self.n_entity, D)
@@ -1134,7 +1147,7 @@ class MVIN(object):
         s.V, s.o_cat, s.parents, s.nagg0, s.nagg1, s.group_ws = (w.data_ptr() if w is not None else None for w in ws[:6])
         s.item_order_ws = None
         # (the aggregates form gathers ~12 rows of a 27 MB table per pair: item order buys it nothing -- measured 235 vs 252 us at C3)
-        if prj and enc is not None and s.agg_tables is None and self._item_order_for(B):
+        if prj and enc is not None and s.agg_tables is None and (s.fold_ws is None or gfold) and self._item_order_for(B):
             if ws[6] is None:
                 ws = self._native_l2_ws[wkey] = ws[:6] + (torch.empty(_lib.load().mvin_order_by_key_ws_elems(B) + B, dtype=torch.int32,
                                                                       device=self.device),)

@@ -432,7 +432,7 @@ def score_l2_folded_supported(D, K, n_entity, nR):
     return bool(_lib.load().mvin_score_l2_folded_supported(D, K, n_entity, nR))
 
 
-def fold_tables(entity_emb, enc_entity, enc_relation, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, K, nR, out=None):
+def fold_tables(entity_emb, enc_entity, enc_relation, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, K, nR, out=None, aggregates=True):
     """mvin_fold_tables: the workspace of the folded-tail form -- TA1 | TA2 | T0A | M0, the aggregates H0 | G and the parameter
     block -- from the CURRENT parameters, the encoded adjacency and the relation logits t0 of aggregator (0,.) (None: plain mean)."""
     lib = _lib.load()
@@ -447,9 +447,41 @@ def fold_tables(entity_emb, enc_entity, enc_relation, t0, W0, b0, W1, b1, W2, b2
         out = torch.empty((n,), dtype=F32, device=entity_emb.device)
     elif out.numel() != n or out.dtype != F32 or not out.is_contiguous():
         raise ValueError("fold_tables: workspace of mvin_fold_tables_elems floats expected")
-    _lib.check(lib.mvin_fold_tables(_p(entity_emb), _p(enc_entity), _p(enc_relation), _p(t0), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2),
-                                    _p(A0), _p(a0), _p(Wmix), _p(bmix), _p(A1), K, D, nE, nR, _p(out), _stream()), "mvin_fold_tables")
+    # (aggregates=False: the four per-row tables only -- the workspace of score_l2_folded_gather, where every pair gathers its own rows)
+    _lib.check(lib.mvin_fold_tables_ex(_p(entity_emb), _p(enc_entity), _p(enc_relation), _p(t0), _p(W0), _p(b0), _p(W1), _p(b1), _p(W2), _p(b2),
+                                       _p(A0), _p(a0), _p(Wmix), _p(bmix), _p(A1), 1 if aggregates else 0, K, D, nE, nR, _p(out), _stream()),
+               "mvin_fold_tables")
     return out
+
+
+def score_l2_folded_gather_supported(D, K, n_entity, nR):
+    """mvin_score_l2_folded_gather_supported: the folded tail with every pair gathering its own rows (D = 64, K in {16, 32})."""
+    return bool(_lib.load().mvin_score_l2_folded_gather_supported(D, K, n_entity, nR))
+
+
+def score_l2_folded_gather(ws, enc_entity, enc_relation, items, t0, t1, q, user_o, A1, a1, Wmix, K, D, nR, n_entity, order=None,
+                           want_item_emb=True):
+    """mvin_score_l2_folded_gather_fwd over the workspace of ``fold_tables(..., aggregates=False)``: (item_emb [B,D] or None, scores [B],
+    sigmoid(scores) [B]).  ``order``: a permutation of the pairs (order_by_key over the items) or None."""
+    lib = _lib.load()
+    for t, dt, nm in ((ws, F32, "ws"), (enc_entity, I32, "enc_entity"), (enc_relation, I32, "enc_relation"),
+                      (items, torch.int64 if items.dtype == torch.int64 else I32, "items"), (t0, F32, "t0"), (t1, F32, "t1"), (q, F32, "q"),
+                      (user_o, F32, "user_o"), (A1, F32, "A1"), (a1, F32, "a1"), (Wmix, F32, "Wmix"), (order, I32, "order")):
+        _chk(t, dt, nm)
+    B = items.shape[0]
+    if ws.numel() != lib.mvin_fold_tables_elems(n_entity, D) or tuple(q.shape) != (B, D) or tuple(user_o.shape) != (B, D):
+        raise ValueError("score_l2_folded_gather: the workspace of fold_tables(n_entity, D) and q, user_o [B, D] expected")
+    if order is not None and order.numel() != B:
+        raise ValueError("score_l2_folded_gather: order must be a permutation of the pairs")
+    item_emb = torch.empty((B, D), dtype=F32, device=ws.device) if want_item_emb else None
+    scores = torch.empty((B,), dtype=F32, device=ws.device)
+    sig = torch.empty((B,), dtype=F32, device=ws.device)
+    i64 = items.dtype == torch.int64
+    _lib.check(lib.mvin_score_l2_folded_gather_fwd(_p(ws), _p(enc_entity), _p(enc_relation), _p(items) if i64 else None,
+                                                   None if i64 else _p(items), _p(order), _p(t0), _p(t1), _p(q), _p(user_o), _p(A1), _p(a1),
+                                                   _p(Wmix), B, K, D, n_entity, nR, _p(item_emb), _p(scores), _p(sig), _stream()),
+               "mvin_score_l2_folded_gather_fwd")
+    return item_emb, scores, sig
 
 
 def score_l2_folded(ws, enc_entity, enc_relation, items, t0, t1, q, user_o, A1, a1, Wmix, K, D, nR, n_entity, want_item_emb=True):

@@ -622,6 +622,48 @@ def test_random_configuration_in_folded_form(i, hip_lib):
     assert err_hip <= 4 * err_mir + 2e-6, f"HIP-vs-fp64 {err_hip:.3e} > 4x mirror-vs-fp64 {err_mir:.3e}, {what}"
 
 
+@pytest.mark.parametrize("K", [16, 32])
+def test_folded_tail_gather_form(K, hip_lib):
+    """mvin_fold_tables_ex(aggregates = 0) -> mvin_score_l2_folded_gather_fwd (every pair gathers its own rows; the tail in the same launch)
+    against mvin_project_tables -> mvin_gather_attn_l2_prj_fwd -> mvin_l2_tail_fwd: every distinct-children count as parent and as child,
+    ragged batches, parents as given / in key order / reversed, both softmax forms, with and without attention / biases."""
+    D, nR, n_entity = 64, 7, 603
+    rng = np.random.default_rng(K + 400)
+    adj_e = np.zeros((n_entity, K), dtype=np.int64)
+    adj_r = np.zeros((n_entity, K), dtype=np.int64)
+    for x in range(n_entity):
+        nd = x % K + 1
+        ne = rng.choice(n_entity, nd, replace=False)
+        nr = rng.integers(0, nR, nd)
+        pick = np.concatenate([np.arange(nd), rng.integers(0, nd, K - nd)])
+        rng.shuffle(pick)
+        adj_e[x], adj_r[x] = ne[pick], nr[pick]
+    dev = "cuda:0"
+    f = lambda *s: torch.from_numpy(rng.normal(size=s).astype(np.float32) * 0.3).to(dev)      # noqa: E731
+    E = f(n_entity, D)
+    ae, ar = torch.from_numpy(adj_e.astype(np.int32)).to(dev), torch.from_numpy(adj_r.astype(np.int32)).to(dev)
+    enc_e, enc_r, cnt = ops.encode_adjacency(ae, ar)
+    assert ops.score_l2_folded_gather_supported(D, K, n_entity, nR) and not ops.score_l2_folded_gather_supported(D, 64, n_entity, nR)
+    W0, W1, W2, A0, A1, Wmix = f(D, D), f(D, D), f(D, D), f(D, D), f(D, D), f(3 * D, D)
+    for B, att, bias, i64 in ((4 * K + 37, 1.0, True, True), (1, 1.0, True, False), (33, 130.0, True, True), (95, False, False, False)):
+        b0, b1, b2, a0, a1, bmix = (f(D) if bias else None for _ in range(6))
+        items = torch.from_numpy((np.arange(B) * 7 % n_entity).astype(np.int64 if i64 else np.int32)).to(dev)
+        q, user_o = f(B, D), f(B, D)
+        t0 = f(nR) * att if att else None
+        t1 = f(nR) * att if att else None
+        ws = ops.fold_tables(E, enc_e, enc_r, t0, W0, b0, W1, b1, W2, b2, A0, a0, Wmix, bmix, A1, K, nR, aggregates=False)
+        pt = ops.project_tables(E, W1, W2, b1, b2, A0, a0, K, bool(att))
+        n0, n1 = ops.gather_attn_l2_prj(pt, enc_e, enc_r, items, t0, t1, q, B, 1, K, D, nR, n_entity)
+        want_item, want_scores, want_sig = ops.l2_tail(E, items, q, user_o, n0, n1, W0, b0, A0, a0, A1, a1, Wmix, bmix)
+        orders = (None,) if B == 1 else (None, ops.order_by_key(items), torch.flip(torch.arange(B, dtype=torch.int32, device=dev), dims=[0]))
+        for order in orders:
+            item, scores, sig = ops.score_l2_folded_gather(ws, enc_e, enc_r, items, t0, t1, q, user_o, A1, a1, Wmix, K, D, nR, n_entity, order=order)
+            torch.cuda.synchronize()
+            assert_close(item.cpu().numpy(), want_item.cpu().numpy(), f"item_emb B={B}", rtol=3e-5, atol=3e-5)
+            assert_close(scores.cpu().numpy(), want_scores.cpu().numpy(), f"scores B={B}", rtol=3e-5, atol=3e-5)
+            assert_close(sig.cpu().numpy(), want_sig.cpu().numpy(), f"sigmoid B={B}", rtol=3e-5, atol=1e-5)
+
+
 def test_folded_form_with_thousands_of_relations(hip_lib):
     """The relation logits live in LDS next to the kernels' per-wave blocks: up to the 48 KB a launch gets without a function attribute
     (2 600 relations at K = 32) the folded form runs, beyond it the _supported queries say no and the callers keep the other kernels."""

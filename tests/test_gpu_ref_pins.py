@@ -129,14 +129,18 @@ def test_hot_kernels_match_reference_graph(path, hip_lib):
                 # the forms above the tables, where the shape has them (D = 64, K in {16, 32}, encoded adjacency): the folded tail over
                 # per-entity aggregates in one launch (the default), aggregates + the tail kernel, the kernels over the tables themselves
                 enc_now = m._enc_for_l2(n_parents=items.shape[0])
-                forms = ((("folded", None, None), ("aggregates", None, False), ("tables", False, None)) if m._agg_for(enc_now) else
+                # (agg False = every pair gathers its own rows: with the tail folded into the gather launch where that kernel exists --
+                #  dim 64, K <= 32 --, as gather kernel + tail kernel otherwise / with fold False)
+                gf = m._fold_gather_ok() and enc_now is not None and D == 64
+                forms = ((("folded", None, None), ("aggregates", None, False), ("gather-folded" if gf else "tables", False, None), ("tables", False, False))
+                         if m._agg_for(enc_now) else
                          (("folded", None, None), ("tables", False, None)) if m._fold_for(enc_now) else (("tables", None, None),))      # (dim 32: no aggregates + tail-kernel form)
                 for form, agg, fold in forms:
                     m.agg, m.fold = agg, fold
                     m._prj_tables.clear(), m._agg_tables.clear(), m._fold_ws.clear()
                     check(m.forward_device(users, items, *mem), f"{what}, {form}: per-pair feed")
                     check(m.forward_users(users, items, uts_d), f"{what}, {form}: users feed")
-                    ws_of = {"folded": m._fold_ws, "aggregates": m._agg_tables, "tables": m._prj_tables}[form]
+                    ws_of = {"folded": m._fold_ws, "gather-folded": m._fold_ws, "aggregates": m._agg_tables, "tables": m._prj_tables}[form]
                     assert any(t is not None for t in ws_of.values()), f"the workspace of the {form} form was not written: another form ran"
                 if ka_er and m._ka_er_for(uts_d, m._uts_records[3] if m._uts_records else None):
                     assert any(t is not None for t in m._ka_er_ws.values()), "mvin_project_relations was not called"
