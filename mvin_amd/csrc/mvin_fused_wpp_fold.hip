@@ -23,7 +23,7 @@ __device__ __forceinline__ float wppf_bperm(float v, int src_lane) {
 __device__ __forceinline__ int wppf_bperm(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
 template <int K>
-__global__ __launch_bounds__(kWppWaves * 64, 3) void score_l2_wppfold_kernel(FoldArgs a) {
+__global__ __launch_bounds__(kWppWaves * 64, 4) void score_l2_wppfold_kernel(FoldArgs a) {
     constexpr int D = 64, SPL = K / 16;                  // slots of a child's row per lane of its group
     static_assert(K == 16 || K == 32, "K");
     extern __shared__ __attribute__((aligned(16))) float smem[];
