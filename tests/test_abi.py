@@ -75,6 +75,38 @@ def test_argument_errors_are_reported_not_thrown(hip_lib):
         _lib.check(rc, "mvin_ripple_attn_fwd")
 
 
+def test_round6_entry_points_validate_before_launching(hip_lib):
+    """The aggregates / folded-tail entry points (ABI 12): sizes and shape support are plain host arithmetic, null pointers and
+    unsupported shapes come back as error codes before anything is launched."""
+    one = C.c_void_p(16)
+    nE, nR = 1000, 9
+    assert hip_lib.mvin_entity_aggregates_elems(nE, 64) == 2 * nE * 64
+    assert hip_lib.mvin_fold_tables_elems(nE, 64) == 6 * nE * 64 + 12 * 64 * 64 + 3 * 64
+    assert hip_lib.mvin_order_by_key_ws_elems(1000) > 1000
+    # which shapes the forms take: aggregates dim 64 only; folded tail dim 64 and dim 32; the gather form dim 64, K <= 32
+    assert hip_lib.mvin_gather_attn_l2_agg_supported(64, 32, nE, nR) == 1 and hip_lib.mvin_gather_attn_l2_agg_supported(64, 64, nE, nR) == 1
+    assert hip_lib.mvin_gather_attn_l2_agg_supported(32, 16, nE, nR) == 0 and hip_lib.mvin_gather_attn_l2_agg_supported(64, 128, nE, nR) == 0
+    assert hip_lib.mvin_score_l2_folded_supported(32, 16, nE, nR) == 1 and hip_lib.mvin_score_l2_folded_supported(32, 64, nE, nR) == 0
+    assert hip_lib.mvin_score_l2_folded_supported(128, 32, nE, nR) == 0 and hip_lib.mvin_score_l2_folded_supported(64, 32, 1 << 25, nR) == 0
+    assert hip_lib.mvin_score_l2_folded_gather_supported(64, 32, nE, nR) == 1 and hip_lib.mvin_score_l2_folded_gather_supported(64, 64, nE, nR) == 0
+    assert hip_lib.mvin_score_l2_folded_supported(64, 32, nE, 5000) == 0          # more relation logits than the kernels keep in LDS
+    # null pointers
+    assert hip_lib.mvin_entity_aggregates(None, one, one, None, 32, 64, nE, nR, one, None) == -1
+    assert hip_lib.mvin_fold_tables(one, one, one, None, None, None, one, None, one, None, one, None, one, None, one, 32, 64, nE, nR, one, None) == -1
+    assert hip_lib.mvin_score_l2_folded_fwd(None, one, one, one, None, None, None, one, one, one, None, one, 8, 32, 64, nE, nR, None, None, None,
+                                            one, None, None) == -1
+    # both / neither id width
+    assert hip_lib.mvin_score_l2_folded_fwd(one, one, one, one, one, None, None, one, one, one, None, one, 8, 32, 64, nE, nR, None, None, None,
+                                            one, None, None) == -1
+    assert hip_lib.mvin_order_by_key(None, None, 8, one, one, None) == -1
+    # a shape no kernel takes: -3, with the reason in the error string
+    rc = hip_lib.mvin_fold_tables(one, one, one, None, one, None, one, None, one, None, one, None, one, None, one, 128, 64, nE, nR, one, None)
+    assert rc == -3 and b"K in {16, 32, 64}" in hip_lib.mvin_last_error()
+    rc = hip_lib.mvin_score_l2_folded_gather_fwd(one, one, one, one, None, None, None, None, one, one, one, None, one, 8, 64, 64, nE, nR, None,
+                                                 one, None, None)
+    assert rc == -3
+
+
 def test_ops_refuse_cpu_tensors(hip_lib):
     import torch
     from mvin_amd import _lib, ops
