@@ -243,8 +243,8 @@ MVIN_API int mvin_gather_attn_l2_agg_fwd(const float* ws, const float* agg, cons
  *     ev0 Wm0               = M0[x] + q Wqm + b0 Wm0    M0 = E W0 Wm0,  Wqm = W0 Wm0   (Wm0 | Wm1 | Wm2 = the row blocks of Wmix)
  * mvin_fold_tables builds, per call and from the current parameters, TA1 | TA2 | T0A = E W0 A0 | M0 (one four-matrix table build),
  * H0 | G (mvin_entity_aggregates' kernel) and the parameter block into `ws` (mvin_fold_tables_elems floats).
- * mvin_score_l2_folded_fwd then scores B pairs in two launches:
- *     out0 = relu(H0[x] + q Wq + bq) ;  Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + q Wv + bv)            (the pair kernel; out0, z2 [B, D] scratch)
+ * mvin_score_l2_folded_fwd then scores B pairs in ONE launch (a batch of 16 pairs per wave from item id and query row to score):
+ *     out0 = relu(H0[x] + q Wq + bq) ;  Z2 = out0 + sum_c (p1_c / K) relu(G[x_c] + q Wv + bv)            (kept in LDS)
  *     out2 = relu(Z2 A1 + a1) ;  item_emb = M0[x] + q Wqm + out0 Wm1 + out2 Wm2 + bmix + b0 Wm0 ;  scores = <user_o, item_emb>
  * -- six D x D products per pair instead of eight, the same sums in another association (agreement to rounding).  item_emb / sig may
  * be NULL; so may out0 / z2 ([B, D] scratch rows): only the two-launch A/B variant (MVIN_L2_FOLD_TWO=1 in the environment: pair kernel +
